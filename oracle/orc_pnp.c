@@ -1,0 +1,809 @@
+/*
+ * orc_pnp.c -- CPU ORACLE (test infrastructure, NOT product code).  PARITY UNPINNED, see
+ * vo_oracle.h.
+ *
+ * Restates cv::solvePnPRansac as the reference calls it (src/visualOdometry.cpp:161-178:
+ * useExtrinsicGuess=true, 500 iters, 0.5 px, conf 0.999f, SOLVEPNP_ITERATIVE, zero distortion)
+ * following OpenCV 4.5.x:
+ *   calib3d/src/solvepnp.cpp   solvePnPRansac, PnPRansacCallback, solvePnPGeneric
+ *   calib3d/src/ptsetreg.cpp   RANSACPointSetRegistrator::run/getSubset/findInliers,
+ *                              RANSACUpdateNumIters
+ *   calib3d/src/epnp.cpp       epnp::compute_pose and helpers
+ *   calib3d/src/calibration.cpp cvFindExtrinsicCameraParams2 (useExtrinsicGuess branch)
+ *   calib3d/src/compat_ptsetreg.cpp CvLevMarq
+ * SURVEY.md App. A4.  Compiled with -ffp-contract=off.
+ */
+#include "orc_internal.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+/* ======================================= EPnP =========================================== */
+typedef struct {
+    double uc, vc, fu, fv;
+    int n;
+    const double *pws, *us;
+    double *alphas, *pcs;
+    double cws[4][3], ccs[4][3];
+} Epnp;
+
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double dist2(const double *p1, const double *p2)
+{
+    return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) +
+           (p1[2] - p2[2]) * (p1[2] - p2[2]);
+}
+
+/* cvMulTransposed(src, dst, 1): dst = src^T src, upper triangle by sequential sums, mirrored */
+static void mul_transposed(const double *src, int rows, int cols, double *dst)
+{
+    for (int i = 0; i < cols; i++)
+        for (int j = i; j < cols; j++) {
+            double s = 0;
+            for (int k = 0; k < rows; k++)
+                s += src[k * cols + i] * src[k * cols + j];
+            dst[i * cols + j] = s;
+        }
+    for (int i = 0; i < cols; i++)
+        for (int j = 0; j < i; j++)
+            dst[i * cols + j] = dst[j * cols + i];
+}
+
+static void choose_control_points(Epnp *e)
+{
+    int n = e->n;
+    e->cws[0][0] = e->cws[0][1] = e->cws[0][2] = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++)
+            e->cws[0][j] += e->pws[3 * i + j];
+    for (int j = 0; j < 3; j++)
+        e->cws[0][j] /= n;
+
+    double *PW0 = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    double pw0tpw0[9], dc[3], uct[9], vt[9];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++)
+            PW0[3 * i + j] = e->pws[3 * i + j] - e->cws[0][j];
+    mul_transposed(PW0, n, 3, pw0tpw0);
+    free(PW0);
+    /* cvSVD(&PW0tPW0, &DC, &UCt, 0, CV_SVD_MODIFY_A | CV_SVD_U_T): At := A^T, rows -> U^T */
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            uct[i * 3 + k] = pw0tpw0[k * 3 + i];
+    orc_jacobi_svd(uct, 3, dc, vt, 3, 3, 3, 3);
+    for (int i = 1; i < 4; i++) {
+        double k = sqrt(dc[i - 1] / n);
+        for (int j = 0; j < 3; j++)
+            e->cws[i][j] = e->cws[0][j] + k * uct[3 * (i - 1) + j];
+    }
+}
+
+static void compute_barycentric_coordinates(Epnp *e)
+{
+    double cc[9], cc_inv[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 1; j < 4; j++)
+            cc[3 * i + j - 1] = e->cws[j][i] - e->cws[0][i];
+    orc_invert_svd(cc, 3, cc_inv);
+    const double *ci = cc_inv;
+    for (int i = 0; i < e->n; i++) {
+        const double *pi = e->pws + 3 * i;
+        double *a = e->alphas + 4 * i;
+        for (int j = 0; j < 3; j++)
+            a[1 + j] = ci[3 * j] * (pi[0] - e->cws[0][0]) + ci[3 * j + 1] * (pi[1] - e->cws[0][1]) +
+                       ci[3 * j + 2] * (pi[2] - e->cws[0][2]);
+        a[0] = 1.0f - a[1] - a[2] - a[3];
+    }
+}
+
+static void fill_M(const Epnp *e, double *M, int row, const double *as, double u, double v)
+{
+    double *M1 = M + row * 12, *M2 = M1 + 12;
+    for (int i = 0; i < 4; i++) {
+        M1[3 * i] = as[i] * e->fu;
+        M1[3 * i + 1] = 0.0;
+        M1[3 * i + 2] = as[i] * (e->uc - u);
+        M2[3 * i] = 0.0;
+        M2[3 * i + 1] = as[i] * e->fv;
+        M2[3 * i + 2] = as[i] * (e->vc - v);
+    }
+}
+
+static void compute_L_6x10(const double *ut, double *l_6x10)
+{
+    const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+            dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+            dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+            b++;
+            if (b > 3) {
+                a++;
+                b = a + 1;
+            }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double *row = l_6x10 + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+}
+
+static void compute_rho(const Epnp *e, double *rho)
+{
+    rho[0] = dist2(e->cws[0], e->cws[1]);
+    rho[1] = dist2(e->cws[0], e->cws[2]);
+    rho[2] = dist2(e->cws[0], e->cws[3]);
+    rho[3] = dist2(e->cws[1], e->cws[2]);
+    rho[4] = dist2(e->cws[1], e->cws[3]);
+    rho[5] = dist2(e->cws[2], e->cws[3]);
+}
+
+/* betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]; approx_1 uses [B11 B12 B13 B14] */
+static void find_betas_approx_1(const double *L, const double *rho, double *betas)
+{
+    double l_6x4[24], b4[4];
+    for (int i = 0; i < 6; i++) {
+        l_6x4[i * 4 + 0] = L[i * 10 + 0];
+        l_6x4[i * 4 + 1] = L[i * 10 + 1];
+        l_6x4[i * 4 + 2] = L[i * 10 + 3];
+        l_6x4[i * 4 + 3] = L[i * 10 + 6];
+    }
+    orc_solve_svd(l_6x4, 6, 4, rho, b4);
+    if (b4[0] < 0) {
+        betas[0] = sqrt(-b4[0]);
+        betas[1] = -b4[1] / betas[0];
+        betas[2] = -b4[2] / betas[0];
+        betas[3] = -b4[3] / betas[0];
+    } else {
+        betas[0] = sqrt(b4[0]);
+        betas[1] = b4[1] / betas[0];
+        betas[2] = b4[2] / betas[0];
+        betas[3] = b4[3] / betas[0];
+    }
+}
+
+/* approx_2 uses [B11 B12 B22] */
+static void find_betas_approx_2(const double *L, const double *rho, double *betas)
+{
+    double l_6x3[18], b3[3];
+    for (int i = 0; i < 6; i++) {
+        l_6x3[i * 3 + 0] = L[i * 10 + 0];
+        l_6x3[i * 3 + 1] = L[i * 10 + 1];
+        l_6x3[i * 3 + 2] = L[i * 10 + 2];
+    }
+    orc_solve_svd(l_6x3, 6, 3, rho, b3);
+    if (b3[0] < 0) {
+        betas[0] = sqrt(-b3[0]);
+        betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+    } else {
+        betas[0] = sqrt(b3[0]);
+        betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+    }
+    if (b3[1] < 0)
+        betas[0] = -betas[0];
+    betas[2] = 0.0;
+    betas[3] = 0.0;
+}
+
+/* approx_3 uses [B11 B12 B22 B13 B23] */
+static void find_betas_approx_3(const double *L, const double *rho, double *betas)
+{
+    double l_6x5[30], b5[5];
+    for (int i = 0; i < 6; i++) {
+        l_6x5[i * 5 + 0] = L[i * 10 + 0];
+        l_6x5[i * 5 + 1] = L[i * 10 + 1];
+        l_6x5[i * 5 + 2] = L[i * 10 + 2];
+        l_6x5[i * 5 + 3] = L[i * 10 + 3];
+        l_6x5[i * 5 + 4] = L[i * 10 + 4];
+    }
+    orc_solve_svd(l_6x5, 6, 5, rho, b5);
+    if (b5[0] < 0) {
+        betas[0] = sqrt(-b5[0]);
+        betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+    } else {
+        betas[0] = sqrt(b5[0]);
+        betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+    }
+    if (b5[1] < 0)
+        betas[0] = -betas[0];
+    betas[2] = b5[3] / betas[0];
+    betas[3] = 0.0;
+}
+
+static void compute_A_and_b_gauss_newton(const double *l_6x10, const double *rho,
+                                         const double betas[4], double *A, double *b)
+{
+    for (int i = 0; i < 6; i++) {
+        const double *rowL = l_6x10 + i * 10;
+        double *rowA = A + i * 4;
+        rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+        rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+        rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+        rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+        b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] +
+                         rowL[2] * betas[1] * betas[1] + rowL[3] * betas[0] * betas[2] +
+                         rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                         rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] +
+                         rowL[8] * betas[2] * betas[3] + rowL[9] * betas[3] * betas[3]);
+    }
+}
+
+/* epnp::qr_solve (Householder, including its row-scan quirk in the eta loop) */
+static void qr_solve(double *pA, int nr, int nc, double *pb, double *pX)
+{
+    double A1[8], A2[8];
+    double *ppAkk = pA;
+    for (int k = 0; k < nc; k++) {
+        double *ppAik1 = ppAkk, eta = fabs(*ppAik1);
+        for (int i = k + 1; i < nr; i++) {
+            double elt = fabs(*ppAik1);
+            if (eta < elt)
+                eta = elt;
+            ppAik1 += nc;
+        }
+        if (eta == 0) {
+            A1[k] = A2[k] = 0.0;
+            return;
+        } else {
+            double *ppAik2 = ppAkk, sum2 = 0.0, inv_eta = 1. / eta;
+            for (int i = k; i < nr; i++) {
+                *ppAik2 *= inv_eta;
+                sum2 += *ppAik2 * *ppAik2;
+                ppAik2 += nc;
+            }
+            double sigma = sqrt(sum2);
+            if (*ppAkk < 0)
+                sigma = -sigma;
+            *ppAkk += sigma;
+            A1[k] = sigma * *ppAkk;
+            A2[k] = -eta * sigma;
+            for (int j = k + 1; j < nc; j++) {
+                double *ppAik = ppAkk, sum = 0;
+                for (int i = k; i < nr; i++) {
+                    sum += *ppAik * ppAik[j - k];
+                    ppAik += nc;
+                }
+                double tau = sum / A1[k];
+                ppAik = ppAkk;
+                for (int i = k; i < nr; i++) {
+                    ppAik[j - k] -= tau * *ppAik;
+                    ppAik += nc;
+                }
+            }
+        }
+        ppAkk += nc + 1;
+    }
+    /* b <- Qt b */
+    double *ppAjj = pA;
+    for (int j = 0; j < nc; j++) {
+        double *ppAij = ppAjj, tau = 0;
+        for (int i = j; i < nr; i++) {
+            tau += *ppAij * pb[i];
+            ppAij += nc;
+        }
+        tau /= A1[j];
+        ppAij = ppAjj;
+        for (int i = j; i < nr; i++) {
+            pb[i] -= tau * *ppAij;
+            ppAij += nc;
+        }
+        ppAjj += nc + 1;
+    }
+    /* X = R-1 b */
+    pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        double *ppAij = pA + i * nc + (i + 1), sum = 0;
+        for (int j = i + 1; j < nc; j++) {
+            sum += *ppAij * pX[j];
+            ppAij++;
+        }
+        pX[i] = (pb[i] - sum) / A2[i];
+    }
+}
+
+static void gauss_newton(const double *L, const double *rho, double betas[4])
+{
+    double a[24], b[6], x[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 5; k++) {
+        compute_A_and_b_gauss_newton(L, rho, betas, a, b);
+        qr_solve(a, 6, 4, b, x);
+        for (int i = 0; i < 4; i++)
+            betas[i] += x[i];
+    }
+}
+
+static void compute_ccs(Epnp *e, const double *betas, const double *ut)
+{
+    for (int i = 0; i < 4; i++)
+        e->ccs[i][0] = e->ccs[i][1] = e->ccs[i][2] = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        const double *v = ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++)
+                e->ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+}
+
+static void compute_pcs(Epnp *e)
+{
+    for (int i = 0; i < e->n; i++) {
+        const double *a = e->alphas + 4 * i;
+        double *pc = e->pcs + 3 * i;
+        for (int j = 0; j < 3; j++)
+            pc[j] = a[0] * e->ccs[0][j] + a[1] * e->ccs[1][j] + a[2] * e->ccs[2][j] + a[3] * e->ccs[3][j];
+    }
+}
+
+static void solve_for_sign(Epnp *e)
+{
+    if (e->pcs[2] < 0.0) {
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 3; j++)
+                e->ccs[i][j] = -e->ccs[i][j];
+        for (int i = 0; i < e->n; i++) {
+            e->pcs[3 * i] = -e->pcs[3 * i];
+            e->pcs[3 * i + 1] = -e->pcs[3 * i + 1];
+            e->pcs[3 * i + 2] = -e->pcs[3 * i + 2];
+        }
+    }
+}
+
+static void estimate_R_and_t(Epnp *e, double R[3][3], double t[3])
+{
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    int n = e->n;
+    for (int i = 0; i < n; i++) {
+        const double *pc = e->pcs + 3 * i, *pw = e->pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            pc0[j] += pc[j];
+            pw0[j] += pw[j];
+        }
+    }
+    for (int j = 0; j < 3; j++) {
+        pc0[j] /= n;
+        pw0[j] /= n;
+    }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, abt_d[3], abt_u[9], abt_vt[9];
+    for (int i = 0; i < n; i++) {
+        const double *pc = e->pcs + 3 * i, *pw = e->pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    /* cvSVD(&ABt, &ABt_D, &ABt_U, &ABt_V, CV_SVD_MODIFY_A): U and V (not transposed) */
+    orc_svd(abt, 3, 3, abt_d, abt_u, abt_vt);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) /* dot(abt_u + 3*i, abt_v + 3*j), abt_v[j][k] = vt[k][j] */
+            R[i][j] = abt_u[3 * i] * abt_vt[0 * 3 + j] + abt_u[3 * i + 1] * abt_vt[1 * 3 + j] +
+                      abt_u[3 * i + 2] * abt_vt[2 * 3 + j];
+    const double det = R[0][0] * R[1][1] * R[2][2] + R[0][1] * R[1][2] * R[2][0] +
+                       R[0][2] * R[1][0] * R[2][1] - R[0][2] * R[1][1] * R[2][0] -
+                       R[0][1] * R[1][0] * R[2][2] - R[0][0] * R[1][2] * R[2][1];
+    if (det < 0) {
+        R[2][0] = -R[2][0];
+        R[2][1] = -R[2][1];
+        R[2][2] = -R[2][2];
+    }
+    t[0] = pc0[0] - dot3(R[0], pw0);
+    t[1] = pc0[1] - dot3(R[1], pw0);
+    t[2] = pc0[2] - dot3(R[2], pw0);
+}
+
+static double reprojection_error(const Epnp *e, double R[3][3], const double t[3])
+{
+    double sum2 = 0.0;
+    for (int i = 0; i < e->n; i++) {
+        const double *pw = e->pws + 3 * i;
+        double Xc = dot3(R[0], pw) + t[0];
+        double Yc = dot3(R[1], pw) + t[1];
+        double inv_Zc = 1.0 / (dot3(R[2], pw) + t[2]);
+        double ue = e->uc + e->fu * Xc * inv_Zc;
+        double ve = e->vc + e->fv * Yc * inv_Zc;
+        double u = e->us[2 * i], v = e->us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / e->n;
+}
+
+static double compute_R_and_t(Epnp *e, const double *ut, const double *betas, double R[3][3],
+                              double t[3])
+{
+    compute_ccs(e, betas, ut);
+    compute_pcs(e);
+    solve_for_sign(e);
+    estimate_R_and_t(e, R, t);
+    return reprojection_error(e, R, t);
+}
+
+void orc_epnp_d(const double *pws, const double *us, int n, double fu, double fv, double uc,
+                double vc, double Rout[3][3], double tout[3])
+{
+    Epnp e;
+    e.uc = uc;
+    e.vc = vc;
+    e.fu = fu;
+    e.fv = fv;
+    e.n = n;
+    e.pws = pws;
+    e.us = us;
+    e.alphas = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+    e.pcs = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+
+    choose_control_points(&e);
+    compute_barycentric_coordinates(&e);
+
+    double *M = (double *)malloc(sizeof(double) * 2 * (size_t)n * 12);
+    for (int i = 0; i < n; i++)
+        fill_M(&e, M, 2 * i, e.alphas + 4 * i, us[2 * i], us[2 * i + 1]);
+    double mtm[144], d[12], ut[144], vt[144];
+    mul_transposed(M, 2 * n, 12, mtm);
+    free(M);
+    /* cvSVD(&MtM, &D, &Ut, 0, CV_SVD_MODIFY_A | CV_SVD_U_T) */
+    for (int i = 0; i < 12; i++)
+        for (int k = 0; k < 12; k++)
+            ut[i * 12 + k] = mtm[k * 12 + i];
+    orc_jacobi_svd(ut, 12, d, vt, 12, 12, 12, 12);
+
+    double l_6x10[60], rho[6];
+    compute_L_6x10(ut, l_6x10);
+    compute_rho(&e, rho);
+
+    double Betas[4][4], rep_errors[4];
+    double Rs[4][3][3], ts[4][3];
+    memset(Betas, 0, sizeof(Betas));
+
+    find_betas_approx_1(l_6x10, rho, Betas[1]);
+    gauss_newton(l_6x10, rho, Betas[1]);
+    rep_errors[1] = compute_R_and_t(&e, ut, Betas[1], Rs[1], ts[1]);
+
+    find_betas_approx_2(l_6x10, rho, Betas[2]);
+    gauss_newton(l_6x10, rho, Betas[2]);
+    rep_errors[2] = compute_R_and_t(&e, ut, Betas[2], Rs[2], ts[2]);
+
+    find_betas_approx_3(l_6x10, rho, Betas[3]);
+    gauss_newton(l_6x10, rho, Betas[3]);
+    rep_errors[3] = compute_R_and_t(&e, ut, Betas[3], Rs[3], ts[3]);
+
+    int N = 1;
+    if (rep_errors[2] < rep_errors[1])
+        N = 2;
+    if (rep_errors[3] < rep_errors[N])
+        N = 3;
+    memcpy(Rout, Rs[N], sizeof(double) * 9);
+    memcpy(tout, ts[N], sizeof(double) * 3);
+    free(e.alphas);
+    free(e.pcs);
+}
+
+/* solvePnPGeneric(..., SOLVEPNP_EPNP): undistortPoints (K, dist=0) to f32 normalised coords,
+ * then epnp(cameraMatrix, opoints, undistorted) re-applies fu/uc in double (solvepnp.cpp,
+ * epnp.h init_points) */
+static void epnp_from_f32(const float *xyz, const float *uv, int n, const float *K, double R[3][3],
+                          double t[3])
+{
+    double fx = (double)K[0], fy = (double)K[4], cx = (double)K[2], cy = (double)K[5];
+    double ifx = 1. / fx, ify = 1. / fy;
+    double *pws = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    double *us = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        /* cvUndistortPointsInternal: x = (u - cx)*ifx; zero distortion => fixed point */
+        double x = ((double)uv[2 * i] - cx) * ifx, y = ((double)uv[2 * i + 1] - cy) * ify;
+        float xn = (float)x, yn = (float)y;
+        pws[3 * i] = xyz[3 * i];
+        pws[3 * i + 1] = xyz[3 * i + 1];
+        pws[3 * i + 2] = xyz[3 * i + 2];
+        us[2 * i] = xn * fx + cx;
+        us[2 * i + 1] = yn * fy + cy;
+    }
+    orc_epnp_d(pws, us, n, fx, fy, cx, cy, R, t);
+    free(pws);
+    free(us);
+}
+
+void orc_epnp(const float *xyz, const float *uv, int n, const float *K, double *R, double *t)
+{
+    double Rm[3][3], tv[3];
+    epnp_from_f32(xyz, uv, n, K, Rm, tv);
+    memcpy(R, Rm, sizeof(Rm));
+    memcpy(t, tv, sizeof(tv));
+}
+
+/* ======================================= RANSAC ========================================= */
+/* ptsetreg.cpp RANSACUpdateNumIters */
+static int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.;
+    p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.;
+    ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN)
+        return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
+}
+
+/* getSubset: modelPoints distinct indices from rng.uniform(0,count) */
+static void get_subset(uint64_t *rng, int count, int modelPoints, int32_t *idx)
+{
+    for (int i = 0; i < modelPoints; i++) {
+        int idx_i;
+        for (;;) {
+            idx_i = (int)(orc_rng_next(rng) % (unsigned)count);
+            int dup = 0;
+            for (int k = 0; k < i; k++)
+                if (idx[k] == idx_i)
+                    dup = 1;
+            if (!dup)
+                break;
+        }
+        idx[i] = idx_i;
+    }
+}
+
+void orc_ransac_subsets(int count, int iters, int32_t *idx)
+{
+    uint64_t rng = (uint64_t)-1;
+    for (int it = 0; it < iters; it++)
+        get_subset(&rng, count, 5, idx + 5 * it);
+}
+
+/* ================================ CvLevMarq + extrinsics ================================ */
+enum { LM_DONE = 0, LM_STARTED = 1, LM_CALC_J = 2, LM_CHECK_ERR = 3 };
+
+typedef struct {
+    double prevParam[6], param[6], JtJ[36], JtErr[6];
+    double prevErrNorm, errNorm;
+    int lambdaLg10, max_iter, state, iters;
+    double epsilon;
+} LevMarq;
+
+static void lm_step(LevMarq *s)
+{
+    const double LOG10 = log(10.);
+    double lambda = exp(s->lambdaLg10 * LOG10);
+    double JtJN[36], x[6];
+    memcpy(JtJN, s->JtJ, sizeof(JtJN)); /* mask is all ones; err != NULL => no completeSymm */
+    for (int i = 0; i < 6; i++)
+        JtJN[i * 6 + i] *= 1. + lambda;
+    orc_solve_svd(JtJN, 6, 6, s->JtErr, x);
+    for (int i = 0; i < 6; i++)
+        s->param[i] = s->prevParam[i] - x[i];
+}
+
+static double norm_l2(const double *v, int n)
+{
+    double s = 0;
+    for (int i = 0; i < n; i++)
+        s += v[i] * v[i];
+    return sqrt(s);
+}
+
+/* cvFindExtrinsicCameraParams2(..., useExtrinsicGuess = 1): LM on pixel reprojection error.
+ * M [n*3], m [n*2] doubles; A4 = fx fy cx cy; rt[6] in/out.  Returns LM outer iterations. */
+static int find_extrinsic_lm(const double *M, const double *m, int n, const double *A4, double *rt)
+{
+    LevMarq s;
+    memset(&s, 0, sizeof(s));
+    s.prevErrNorm = s.errNorm = DBL_MAX;
+    s.lambdaLg10 = -3;
+    s.max_iter = 20;
+    s.epsilon = FLT_EPSILON;
+    s.state = LM_STARTED;
+    memcpy(s.param, rt, sizeof(double) * 6);
+
+    double *J = (double *)malloc(sizeof(double) * 2 * (size_t)n * 6);
+    double *err = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+
+    for (;;) {
+        int want_J = 0, want_err = 0, proceed;
+        /* ---- CvLevMarq::update ---- */
+        if (s.state == LM_DONE) {
+            proceed = 0;
+        } else if (s.state == LM_STARTED) {
+            want_J = want_err = 1;
+            s.state = LM_CALC_J;
+            proceed = 1;
+        } else if (s.state == LM_CALC_J) {
+            /* cvMulTransposed(J, JtJ, 1); cvGEMM(J, err, 1, 0, 0, JtErr, CV_GEMM_A_T) */
+            for (int i = 0; i < 6; i++)
+                for (int j = i; j < 6; j++) {
+                    double a = 0;
+                    for (int k = 0; k < 2 * n; k++)
+                        a += J[k * 6 + i] * J[k * 6 + j];
+                    s.JtJ[i * 6 + j] = a;
+                }
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < i; j++)
+                    s.JtJ[i * 6 + j] = s.JtJ[j * 6 + i];
+            for (int i = 0; i < 6; i++) {
+                double a = 0;
+                for (int k = 0; k < 2 * n; k++)
+                    a += J[k * 6 + i] * err[k];
+                s.JtErr[i] = a;
+            }
+            memcpy(s.prevParam, s.param, sizeof(s.param));
+            lm_step(&s);
+            if (s.iters == 0)
+                s.prevErrNorm = norm_l2(err, 2 * n);
+            want_err = 1;
+            s.state = LM_CHECK_ERR;
+            proceed = 1;
+        } else { /* LM_CHECK_ERR */
+            s.errNorm = norm_l2(err, 2 * n);
+            int handled = 0;
+            if (s.errNorm > s.prevErrNorm) {
+                if (++s.lambdaLg10 <= 16) {
+                    lm_step(&s);
+                    want_err = 1;
+                    s.state = LM_CHECK_ERR;
+                    proceed = 1;
+                    handled = 1;
+                }
+            }
+            if (!handled) {
+                s.lambdaLg10 = s.lambdaLg10 - 1 > -16 ? s.lambdaLg10 - 1 : -16;
+                double dn[6];
+                for (int i = 0; i < 6; i++)
+                    dn[i] = s.param[i] - s.prevParam[i];
+                if (++s.iters >= s.max_iter ||
+                    norm_l2(dn, 6) / (norm_l2(s.prevParam, 6) + DBL_EPSILON) < s.epsilon) {
+                    s.state = LM_DONE;
+                    proceed = 1; /* returns true with _err == 0 -> caller breaks */
+                } else {
+                    s.prevErrNorm = s.errNorm;
+                    want_J = want_err = 1;
+                    s.state = LM_CALC_J;
+                    proceed = 1;
+                }
+            }
+        }
+        /* ---- caller loop body ---- */
+        if (!proceed || !want_err)
+            break;
+        if (want_J)
+            orc_project_points_d(M, n, s.param, s.param + 3, A4, err, J, J + 3, 6);
+        else
+            orc_project_points_d(M, n, s.param, s.param + 3, A4, err, NULL, NULL, 0);
+        for (int k = 0; k < 2 * n; k++)
+            err[k] = err[k] - m[k];
+    }
+    memcpy(rt, s.param, sizeof(double) * 6);
+    int iters = s.iters;
+    free(J);
+    free(err);
+    return iters;
+}
+
+/* ==================================== solvePnPRansac ==================================== */
+int orc_solve_pnp_ransac(const float *xyz, const float *uv, int n, const float *K, double *rvec,
+                         double *tvec, int iterations_count, float reprojection_error,
+                         double confidence, int32_t *inliers, int *n_inliers, double *dbg)
+{
+    const int model_points = 5;
+    if (n_inliers)
+        *n_inliers = 0;
+    if (n < 4)
+        return -1; /* CV_Assert(npoints >= 4) */
+    if (n == 4)
+        return -2; /* P3P kernel: never reached by the reference in practice, not restated */
+    if (n == model_points) {
+        /* solvePnP(opoints, ipoints, ..., ransac_kernel_method) on all points */
+        double R[3][3], t[3];
+        epnp_from_f32(xyz, uv, n, K, R, t);
+        orc_rodrigues_mat2vec(&R[0][0], rvec);
+        memcpy(tvec, t, sizeof(t));
+        if (inliers)
+            for (int i = 0; i < n; i++)
+                inliers[i] = i;
+        if (n_inliers)
+            *n_inliers = n;
+        return 1;
+    }
+
+    uint8_t *mask = (uint8_t *)malloc((size_t)n), *bestMask = (uint8_t *)malloc((size_t)n);
+    float *proj = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+    double bestModel[6] = {0, 0, 0, 0, 0, 0};
+    int niters = iterations_count > 1 ? iterations_count : 1, maxGoodCount = 0, bestIter = -1, iter;
+    const double threshold = (double)reprojection_error;
+    const float t2 = (float)(threshold * threshold);
+    uint64_t rng = (uint64_t)-1;
+
+    for (iter = 0; iter < niters; iter++) {
+        int32_t idx[5];
+        float ms1[15], ms2[10];
+        get_subset(&rng, n, model_points, idx);
+        for (int i = 0; i < 5; i++) {
+            memcpy(ms1 + 3 * i, xyz + 3 * idx[i], sizeof(float) * 3);
+            memcpy(ms2 + 2 * i, uv + 2 * idx[i], sizeof(float) * 2);
+        }
+        /* PnPRansacCallback::runKernel: solvePnP(EPNP) writes the shared rvec/tvec buffers */
+        double R[3][3], t[3];
+        epnp_from_f32(ms1, ms2, 5, K, R, t);
+        orc_rodrigues_mat2vec(&R[0][0], rvec);
+        memcpy(tvec, t, sizeof(t));
+        /* computeError: projectPoints (f64 -> f32), squared distance accumulated in f32 */
+        orc_project_points(xyz, n, rvec, tvec, K, proj);
+        int goodCount = 0;
+        for (int i = 0; i < n; i++) {
+            float dx = uv[2 * i] - proj[2 * i], dy = uv[2 * i + 1] - proj[2 * i + 1];
+            float e = dx * dx + dy * dy;
+            int f = e <= t2;
+            mask[i] = (uint8_t)f;
+            goodCount += f;
+        }
+        if (goodCount > (maxGoodCount > model_points - 1 ? maxGoodCount : model_points - 1)) {
+            uint8_t *tmp = mask;
+            mask = bestMask;
+            bestMask = tmp;
+            memcpy(bestModel, rvec, sizeof(double) * 3);
+            memcpy(bestModel + 3, tvec, sizeof(double) * 3);
+            maxGoodCount = goodCount;
+            bestIter = iter;
+            niters = ransac_update_num_iters(confidence, (double)(n - goodCount) / n, model_points,
+                                             niters);
+        }
+    }
+    if (dbg) {
+        dbg[0] = iter;
+        dbg[1] = bestIter;
+        dbg[2] = maxGoodCount;
+        dbg[3] = 0;
+    }
+    int ret;
+    if (maxGoodCount <= 0) {
+        /* rvec/tvec keep the last hypothesis; inliers released */
+        ret = 0;
+    } else {
+        /* compress inliers (f64) and refine: solvePnP(ITERATIVE, useExtrinsicGuess=true) starts
+         * from the shared rvec/tvec = pose of the LAST evaluated hypothesis */
+        double *M = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+        double *m = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+        int n1 = 0;
+        for (int i = 0; i < n; i++)
+            if (bestMask[i]) {
+                M[3 * n1] = xyz[3 * i];
+                M[3 * n1 + 1] = xyz[3 * i + 1];
+                M[3 * n1 + 2] = xyz[3 * i + 2];
+                m[2 * n1] = uv[2 * i];
+                m[2 * n1 + 1] = uv[2 * i + 1];
+                if (inliers)
+                    inliers[n1] = i;
+                n1++;
+            }
+        double A4[4] = {(double)K[0], (double)K[4], (double)K[2], (double)K[5]};
+        double rt[6] = {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]};
+        int lm_iters = find_extrinsic_lm(M, m, n1, A4, rt);
+        memcpy(rvec, rt, sizeof(double) * 3);
+        memcpy(tvec, rt + 3, sizeof(double) * 3);
+        if (n_inliers)
+            *n_inliers = n1;
+        if (dbg)
+            dbg[3] = lm_iters;
+        free(M);
+        free(m);
+        ret = 1;
+    }
+    free(mask);
+    free(bestMask);
+    free(proj);
+    return ret;
+}

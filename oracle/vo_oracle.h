@@ -1,0 +1,111 @@
+/*
+ * vo_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's hot path
+ *   circularMatching() -> triangulatePoints() -> solvePnPRansac()
+ * (ZhenghaoFei/visual_odom: src/feature.cpp:118-148, src/main.cpp:169-171,
+ *  src/visualOdometry.cpp:132-193) including the OpenCV 4.5.x CPU algorithms
+ * those call sites dispatch to (calcOpticalFlowPyrLK, triangulatePoints,
+ * convertPointsFromHomogeneous, solvePnPRansac/EPnP/LevMarq, Rodrigues).
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors and OpenCV is
+ * not installed in the authoring container, so this restatement could not be
+ * diffed against the real library.  It is pinned instead by analytic ground
+ * truth and independent numpy re-derivations (tests/test_oracle_*.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call anything declared here.  The product (visual_odom_amd/, libvo_hip)
+ * never does.
+ */
+#ifndef VO_ORACLE_H
+#define VO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- image pyramid / derivative (OpenCV imgproc pyrDown, video lkpyramid) ---- */
+/* dst must hold ((w+1)/2)*((h+1)/2) bytes. 5-tap [1 4 6 4 1]^2, REFLECT_101, (v+128)>>8 */
+void orc_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst);
+/* dst: h*w*2 int16, interleaved (Ix,Iy); Scharr 3x3 unnormalised, REFLECT_101 */
+void orc_scharr(const uint8_t *src, int w, int h, int16_t *dst);
+
+/* ---------- cv::calcOpticalFlowPyrLK (feature.cpp:136-139 call sites) ---------------- */
+/* accum_mode: 0 = exact int64 accumulators (determinism recipe, default);
+ *             1 = float accumulators in scalar pixel order (x86 non-SIMD OpenCV build) */
+int orc_calc_optical_flow_pyr_lk(const uint8_t *prev, const uint8_t *next, int w, int h,
+                                 const float *prev_pts, int n, float *next_pts,
+                                 uint8_t *status, float *err,
+                                 int win, int max_level, int max_count, double eps,
+                                 double min_eig_threshold, int accum_mode, int nthreads);
+/* number of LK inner iterations executed by the last call, summed over points/levels (bench) */
+long long orc_lk_last_iteration_count(void);
+
+/* ---------- feature.cpp:76-148 : circularMatching + deleteUnmatchFeaturesCircle ------- */
+/* pts_l0 [n*2] in; outputs sized n*2 floats each; ages [n_ages] in/out (ages += 1, then
+ * compacted together with the points, feature.cpp:83-86,111).  Returns survivors M.
+ * status4 (optional, 4*n) receives the raw per-hop LK status before compaction.
+ * keep_idx (optional, n) receives original indices of the survivors. */
+int orc_circular_matching(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
+                          const uint8_t *r1, int w, int h, float *pts_l0, int n,
+                          float *pts_r0, float *pts_r1, float *pts_l1, float *pts_l0_ret,
+                          int *ages, int *n_ages, uint8_t *status4, int *keep_idx,
+                          int nthreads);
+
+/* visualOdometry.cpp:44-77,119-125 : checkValidMatch(thr) + removeInvalidPoints x4.
+ * Compacts the four arrays in place, returns K.  valid (optional, m) gets the mask. */
+int orc_check_valid_and_remove(float *pts_l0, float *pts_r0, float *pts_l1, float *pts_r1,
+                               const float *pts_l0_ret, int m, int threshold, uint8_t *valid);
+
+/* ---------- main.cpp:169-171 : triangulatePoints + convertPointsFromHomogeneous ------ */
+void orc_triangulate_points(const float *P_l, const float *P_r, const float *pts_l,
+                            const float *pts_r, int n, float *points4d /* 4 x n row-major */);
+void orc_convert_points_from_homogeneous(const float *points4d_t /* n x 4 */, int n,
+                                         float *points3d /* n x 3 */);
+/* both in one call: xyz [n*3] */
+void orc_triangulate(const float *P_l, const float *P_r, const float *pts_l,
+                     const float *pts_r, int n, float *xyz);
+
+/* ---------- visualOdometry.cpp:161-189 : solvePnPRansac + Rodrigues ------------------ */
+/* xyz [n*3] f32, uv [n*2] f32, K [9] f32 row-major, rvec/tvec in/out (f64, used as shared
+ * buffers exactly like OpenCV does with useExtrinsicGuess=true).  Returns 1 on success,
+ * 0 on RANSAC failure, <0 on bad input.  inliers (optional, n) / n_inliers out.
+ * dbg (optional, 8 doubles): [0]=niters executed, [1]=best hypothesis index,
+ * [2]=maxGoodCount, [3]=LM iterations. */
+int orc_solve_pnp_ransac(const float *xyz, const float *uv, int n, const float *K,
+                         double *rvec, double *tvec, int iterations_count,
+                         float reprojection_error, double confidence, int32_t *inliers,
+                         int *n_inliers, double *dbg);
+void orc_rodrigues_vec2mat(const double *rvec, double *R /*9*/, double *dRdr /*27 or NULL*/);
+void orc_rodrigues_mat2vec(const double *R, double *rvec);
+/* EPnP on n>=4 correspondences; K as f32 3x3; uv already in pixels (f32) */
+void orc_epnp(const float *xyz, const float *uv, int n, const float *K, double *R, double *t);
+/* cv::projectPoints, zero distortion; uv_out f32 [n*2] */
+void orc_project_points(const float *xyz, int n, const double *rvec, const double *tvec,
+                        const float *K, float *uv_out);
+/* the cv::RNG(0xffffffffffffffff) 5-subset stream RANSAC consumes: idx[iters*5] */
+void orc_ransac_subsets(int count, int iters, int32_t *idx);
+
+/* generic one-sided Jacobi SVD (core/lapack.cpp JacobiSVDImpl_<double>), exposed for tests.
+ * A is m x n row-major (m >= n).  w[n], u[m*n] (columns = left vectors), vt[n*n]. */
+void orc_svd(const double *A, int m, int n, double *w, double *u, double *vt);
+
+/* ---------- host glue restated for full-sequence replay ("next" rows f1/f3) ---------- */
+/* feature.cpp:206-253 + bucket.cpp:14-51 (quirks B1-B3 reproduced).  points/ages in/out,
+ * capacity cap entries each; n_points/n_ages in/out. */
+int orc_bucketing_features(int rows, int cols, float *points, int *ages, int *n_points,
+                           int *n_ages, int cap, int bucket_size, int features_per_bucket);
+/* cv::FAST(img, thr, nonmax=true) TYPE_9_16; pts [cap*2] f32 in row-major scan order */
+int orc_fast_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, float *pts,
+                    int cap);
+/* utils.cpp:57-131 */
+void orc_rotation_matrix_to_euler(const double *R, float *euler3);
+int orc_integrate_odometry_stereo(double *frame_pose /*4x4*/, const double *R,
+                                  const double *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
