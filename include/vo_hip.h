@@ -1,0 +1,146 @@
+/*
+ * vo_hip.h -- C ABI of libvo_hip.so: the MI355X (gfx950) stereo visual-odometry front end.
+ *
+ * The reference (ZhenghaoFei/visual_odom) has no plugin / FFI layer: its hot path is reached
+ * through plain C++ free functions.  Every entry point below names the reference interface it
+ * replaces (file:line into the reference tree); INTEGRATION.md shows the C++ adapter a maintainer
+ * adds so that circularMatching() / trackingFrame2Frame() call these instead of OpenCV.
+ *
+ * Conventions: plain pointers and sizes, no exceptions, no torch types.  Return value 0 = VO_OK or
+ * a negative VO_ERR_* code (vo_last_error() gives text).  Caller allocates every output; the
+ * library owns all device memory and its HIP stream inside vo_ctx.  One vo_ctx per host thread per
+ * GPU; a ctx is not thread-safe.  Points are interleaved float32 (x, y) like cv::Point2f, images
+ * are 8-bit gray row-major with a byte stride, like the continuous CV_8UC1 cv::Mat the reference
+ * passes around (utils.cpp:179).
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK 0
+#define VO_ERR_ARG (-1)      /* bad argument / size beyond the capacity given to vo_create */
+#define VO_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define VO_ERR_STATE (-3)    /* call order violated (e.g. run before configure) */
+#define VO_ERR_TOO_FEW (-4)  /* fewer than 5 correspondences reached PnP (OpenCV would CV_Assert) */
+
+typedef struct vo_ctx vo_ctx;
+
+/* LK / RANSAC parameters; vo_default_params() fills the reference's literals
+ * (feature.cpp:127-128,136: win 21 (fixed), maxLevel 3, COUNT+EPS 30 / 0.01, minEig 1e-3;
+ *  visualOdometry.cpp:168-172: 500 iterations, 0.5 px, confidence 0.999f;
+ *  visualOdometry.cpp:120: circular-consistency threshold 0). */
+typedef struct vo_params {
+    int lk_max_level;
+    int lk_max_count;
+    double lk_epsilon;
+    double lk_min_eig_threshold;
+    int consistency_threshold;
+    int ransac_iterations;
+    float ransac_reproj_error;
+    double ransac_confidence;
+} vo_params;
+
+void vo_default_params(vo_params *p);
+
+/* device: HIP device ordinal.  max_w/max_h: largest image.  max_pts: per-frame point capacity.
+ * max_frames: largest batch for the vo_batch_* API (1 is enough for the drop-in calls).
+ * Returns NULL on failure (no HIP device, out of memory). */
+vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames);
+void vo_destroy(vo_ctx *ctx);
+const char *vo_last_error(const vo_ctx *ctx);
+int vo_set_params(vo_ctx *ctx, const vo_params *p);
+int vo_get_params(const vo_ctx *ctx, vo_params *p);
+
+/* ------------------------------------------------------------------------------------------
+ * Drop-in calls (host buffers in, host buffers out, synchronous).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces circularMatching() -- feature.h:61-65 / feature.cpp:118-148 -- i.e. the four
+ * cv::calcOpticalFlowPyrLK calls plus deleteUnmatchFeaturesCircle() (feature.cpp:76-116).
+ * pts_l0_xy [2n].  out_* [2n] each, compacted to *n_out survivors in input order.
+ * status4 (optional, [4][n]): raw LK status of the 4 hops before compaction.
+ * keep_idx (optional, [n]): input index of each survivor (the adapter compacts `ages` with it).
+ * apply_consistency != 0 additionally applies checkValidMatch(thr) + removeInvalidPoints
+ * (visualOdometry.cpp:44-77,119-125) so the outputs are the K points that reach triangulation. */
+int vo_circular_match(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
+                      const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
+                      float *out_l0, float *out_r0, float *out_r1, float *out_l1, float *out_l0_ret,
+                      uint8_t *status4, int32_t *keep_idx, int *n_out, int apply_consistency);
+
+/* Replaces cv::triangulatePoints + cv::convertPointsFromHomogeneous -- main.cpp:169-171.
+ * P_l / P_r: 3x4 float32 row-major (main.cpp:73-74).  xyz_out [3n] float32 (N x 1 CV_32FC3). */
+int vo_triangulate(vo_ctx *ctx, const float *P_l, const float *P_r, const float *pts_l_xy,
+                   const float *pts_r_xy, int n, float *xyz_out);
+
+/* Replaces cv::solvePnPRansac(..., useExtrinsicGuess=true, SOLVEPNP_ITERATIVE) + cv::Rodrigues --
+ * visualOdometry.cpp:161-189.  K: 3x3 float32 row-major.  rvec_io / tvec_io: f64[3]; on success
+ * they receive the refined pose (on VO_ERR_TOO_FEW they are left untouched).  R_out (optional,
+ * f64[9] row-major) = Rodrigues(rvec).  inliers (optional, int32[n]) / n_inliers as cv::Mat
+ * inliers.  Iterations / threshold / confidence come from vo_params.
+ * Returns VO_OK when a model was found, 1 when RANSAC found none (OpenCV returns false). */
+int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
+                  double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers);
+
+/* The whole per-frame hot path in one call: circularMatching + consistency filter + triangulation
+ * + PnP/RANSAC (matchingFeatures' tail visualOdometry.cpp:116-127, main.cpp:169-181), one upload,
+ * one download.  out_l0/out_r0/out_l1/out_r1 [2n] and xyz_out [3n] are compacted to *n_out (= K).
+ * keep_idx (optional, [n]) -> input index of each of the K points; keep_idx_circ/n_circ (optional)
+ * -> survivors of deleteUnmatchFeaturesCircle alone (what `ages` is compacted with, quirk B3). */
+int vo_track_frame(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
+                   const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
+                   const float *P_l, const float *P_r, float *out_l0, float *out_r0, float *out_l1,
+                   float *out_r1, float *xyz_out, int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ,
+                   int *n_circ, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
+                   int *n_inliers);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched, device-resident API (throughput mode: many independent frames per launch so that a
+ * 256-CU part is filled; inputs stay in HBM between calls).
+ *   image table: n_images pyramids; frame f = quad of image indices (l0, r0, l1, r1).
+ * ------------------------------------------------------------------------------------------ */
+#define VO_STAGE_PYRAMID 1
+#define VO_STAGE_LK 2
+#define VO_STAGE_FILTER 4
+#define VO_STAGE_TRIANGULATE 8
+#define VO_STAGE_PNP 16
+#define VO_STAGE_ALL 31
+#define VO_NUM_STAGES 5
+
+int vo_batch_configure(vo_ctx *ctx, int n_images, int w, int h, int n_frames);
+/* host -> device copy of one level-0 image */
+int vo_batch_upload_image(vo_ctx *ctx, int image_idx, const uint8_t *host_pixels, int stride);
+/* device -> device copy (e.g. from a torch uint8 tensor's data_ptr()) */
+int vo_batch_upload_image_dev(vo_ctx *ctx, int image_idx, const void *dev_pixels, int stride);
+/* quads4 [n_frames][4] = (l0, r0, l1, r1) image indices */
+int vo_batch_set_quads(vo_ctx *ctx, const int32_t *quads4, int n_frames);
+int vo_batch_set_points(vo_ctx *ctx, int frame, const float *pts_l0_xy, int n);
+int vo_batch_set_projection(vo_ctx *ctx, const float *P_l, const float *P_r);
+/* enqueue the selected stages for all frames on the ctx stream (asynchronous) */
+int vo_batch_run(vo_ctx *ctx, int stages);
+/* same, bracketed per stage by HIP events on the ctx stream; blocks; ms_per_stage[VO_NUM_STAGES]
+ * in the order PYRAMID, LK, FILTER, TRIANGULATE, PNP */
+int vo_batch_run_timed(vo_ctx *ctx, int stages, float *ms_per_stage);
+int vo_batch_sync(vo_ctx *ctx);
+/* results of one frame (after vo_batch_sync); any pointer may be NULL */
+int vo_batch_get_tracks(vo_ctx *ctx, int frame, float *r0, float *r1, float *l1, float *l0_ret,
+                        uint8_t *status4, int n);
+int vo_batch_get_filtered(vo_ctx *ctx, int frame, float *l0, float *r0, float *l1, float *r1, float *xyz,
+                          int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ);
+int vo_batch_get_pose(vo_ctx *ctx, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
+                      int *n_inliers, int *status, int32_t *dbg4 /* niters, best, max_good, lm_iters */);
+/* one pyramid level of one image back to the host (tests): out must hold w_l*h_l bytes */
+int vo_batch_get_pyramid_level(vo_ctx *ctx, int image_idx, int level, uint8_t *out, int *w_l, int *h_l);
+
+/* algorithmic HBM bytes of one frame at the current configuration:
+ * bytes[0] = pyramid, [1] = LK, [2] = post (filter + triangulation + PnP), for n points */
+int vo_model_bytes(const vo_ctx *ctx, int w, int h, int n_points, double *bytes3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+"""ctypes binding of libvo_hip.so (the C ABI in include/vo_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, fails to load, or no GPU is present,
+`load()` / `Context()` raise -- the product path never routes through the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libvo_hip.so")
+
+VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW = 0, -1, -2, -3, -4
+STAGE_PYRAMID, STAGE_LK, STAGE_FILTER, STAGE_TRIANGULATE, STAGE_PNP, STAGE_ALL = 1, 2, 4, 8, 16, 31
+STAGE_NAMES = ("pyramid", "lk", "filter", "triangulate", "pnp")
+
+# every symbol include/vo_hip.h declares (checked by the CPU test-suite against the built .so)
+EXPORTS = (
+    "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
+    "vo_circular_match", "vo_triangulate", "vo_pnp_ransac", "vo_track_frame",
+    "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
+    "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed",
+    "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
+    "vo_batch_get_pyramid_level", "vo_model_bytes",
+)
+
+
+class VoParams(C.Structure):
+    _fields_ = [("lk_max_level", C.c_int), ("lk_max_count", C.c_int), ("lk_epsilon", C.c_double),
+                ("lk_min_eig_threshold", C.c_double), ("consistency_threshold", C.c_int),
+                ("ransac_iterations", C.c_int), ("ransac_reproj_error", C.c_float),
+                ("ransac_confidence", C.c_double)]
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libvo_hip.so; raises if it has not been built (python -m visual_odom_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("libvo_hip.so not built: run `python -m visual_odom_amd.build` "
+                           "(there is no CPU fallback)")
+    lib = C.CDLL(SO_PATH)
+    lib.vo_create.restype = C.c_void_p
+    lib.vo_create.argtypes = [C.c_int] * 5
+    lib.vo_destroy.argtypes = [C.c_void_p]
+    lib.vo_destroy.restype = None
+    lib.vo_last_error.restype = C.c_char_p
+    lib.vo_last_error.argtypes = [C.c_void_p]
+    lib.vo_default_params.argtypes = [C.POINTER(VoParams)]
+    lib.vo_default_params.restype = None
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """One vo_ctx: owns device buffers + a HIP stream on `device`."""
+
+    def __init__(self, device=0, max_w=1241, max_h=376, max_pts=4096, max_frames=1):
+        self.lib = load()
+        self.h = self.lib.vo_create(device, max_w, max_h, max_pts, max_frames)
+        if not self.h:
+            raise RuntimeError("vo_create failed: no HIP device %d or out of memory" % device)
+        self.h = C.c_void_p(self.h)
+        self.max_pts, self.max_frames = max_pts, max_frames
+        self.n_frames = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != VO_OK and rc not in allow:
+            raise VoError(rc, (self.lib.vo_last_error(self.h) or b"").decode())
+        return rc
+
+    # ---- parameters ---------------------------------------------------------------------
+    def get_params(self):
+        p = VoParams()
+        self._chk(self.lib.vo_get_params(self.h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        self._chk(self.lib.vo_set_params(self.h, C.byref(p)))
+
+    # ---- drop-in calls ------------------------------------------------------------------
+    def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):
+        imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
+        h, w = imgs[0].shape
+        pts = _f32(pts_l0, (-1, 2))
+        n = pts.shape[0]
+        outs = [np.zeros((max(n, 1), 2), np.float32) for _ in range(5)]
+        st = np.zeros((4, max(n, 1)), np.uint8)
+        keep = np.zeros(max(n, 1), np.int32)
+        n_out = C.c_int(0)
+        st_flat = np.zeros(4 * max(n, 1), np.uint8)
+        self._chk(self.lib.vo_circular_match(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
+                                             w, h, w, _p(pts), n, _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                                             _p(outs[3]), _p(outs[4]), _p(st_flat), _p(keep),
+                                             C.byref(n_out), int(apply_consistency)))
+        m = n_out.value
+        st = st_flat[:4 * n].reshape(4, n) if n else st[:, :0]
+        return dict(l0=outs[0][:m].copy(), r0=outs[1][:m].copy(), r1=outs[2][:m].copy(),
+                    l1=outs[3][:m].copy(), l0_ret=outs[4][:m].copy(), status4=st.copy(),
+                    keep_idx=keep[:m].copy(), n_out=m)
+
+    def triangulate(self, P_l, P_r, pts_l, pts_r):
+        P_l, P_r = _f32(P_l, (3, 4)), _f32(P_r, (3, 4))
+        pl, pr = _f32(pts_l, (-1, 2)), _f32(pts_r, (-1, 2))
+        n = pl.shape[0]
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        self._chk(self.lib.vo_triangulate(self.h, _p(P_l), _p(P_r), _p(pl), _p(pr), n, _p(xyz)))
+        return xyz[:n].copy()
+
+    def pnp_ransac(self, xyz, uv, K, rvec=None, tvec=None):
+        """returns (found, rvec, tvec, R, inliers)"""
+        xyz, uv, K = _f32(xyz, (-1, 3)), _f32(uv, (-1, 2)), _f32(K, (3, 3))
+        n = xyz.shape[0]
+        rv = np.zeros(3) if rvec is None else np.array(rvec, np.float64).reshape(3).copy()
+        tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3).copy()
+        R = np.zeros((3, 3))
+        inl = np.zeros(max(n, 1), np.int32)
+        ninl = C.c_int(0)
+        rc = self._chk(self.lib.vo_pnp_ransac(self.h, _p(xyz), _p(uv), n, _p(K), _p(rv), _p(tv), _p(R),
+                                              _p(inl), C.byref(ninl)), allow=(1,))
+        return rc == VO_OK, rv, tv, R, inl[:ninl.value].copy()
+
+    def track_frame(self, l0, r0, l1, r1, pts_l0, P_l, P_r, rvec=None, tvec=None):
+        imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
+        h, w = imgs[0].shape
+        pts = _f32(pts_l0, (-1, 2))
+        n = pts.shape[0]
+        P_l, P_r = _f32(P_l, (3, 4)), _f32(P_r, (3, 4))
+        o = [np.zeros((max(n, 1), 2), np.float32) for _ in range(4)]
+        xyz = np.zeros((max(n, 1), 3), np.float32)
+        keep, keepc, inl = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        n_out, n_circ, ninl = C.c_int(0), C.c_int(0), C.c_int(0)
+        rv = np.zeros(3) if rvec is None else np.array(rvec, np.float64).reshape(3).copy()
+        tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3).copy()
+        R = np.zeros((3, 3))
+        rc = self._chk(self.lib.vo_track_frame(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
+                                               w, h, w, _p(pts), n, _p(P_l), _p(P_r), _p(o[0]), _p(o[1]),
+                                               _p(o[2]), _p(o[3]), _p(xyz), _p(keep), C.byref(n_out),
+                                               _p(keepc), C.byref(n_circ), _p(rv), _p(tv), _p(R), _p(inl),
+                                               C.byref(ninl)), allow=(1, VO_ERR_TOO_FEW))
+        k = n_out.value
+        return dict(rc=rc, l0=o[0][:k].copy(), r0=o[1][:k].copy(), l1=o[2][:k].copy(), r1=o[3][:k].copy(),
+                    xyz=xyz[:k].copy(), keep_idx=keep[:k].copy(), keep_idx_circ=keepc[:n_circ.value].copy(),
+                    rvec=rv, tvec=tv, R=R, inliers=inl[:ninl.value].copy())
+
+    # ---- batched device-resident API ------------------------------------------------------
+    def batch_configure(self, n_images, w, h, n_frames):
+        self._chk(self.lib.vo_batch_configure(self.h, n_images, w, h, n_frames))
+        self.n_frames = n_frames
+
+    def batch_upload_image(self, idx, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        self._chk(self.lib.vo_batch_upload_image(self.h, idx, _p(img), img.shape[1]))
+
+    def batch_upload_image_dev(self, idx, dev_ptr, stride):
+        self._chk(self.lib.vo_batch_upload_image_dev(self.h, idx, C.c_void_p(dev_ptr), stride))
+
+    def batch_set_quads(self, quads):
+        q = np.ascontiguousarray(quads, np.int32).reshape(-1, 4)
+        self._chk(self.lib.vo_batch_set_quads(self.h, _p(q), q.shape[0]))
+
+    def batch_set_points(self, frame, pts):
+        pts = _f32(pts, (-1, 2))
+        self._chk(self.lib.vo_batch_set_points(self.h, frame, _p(pts), pts.shape[0]))
+
+    def batch_set_projection(self, P_l, P_r):
+        self._chk(self.lib.vo_batch_set_projection(self.h, _p(_f32(P_l, (3, 4))), _p(_f32(P_r, (3, 4)))))
+
+    def batch_run(self, stages=STAGE_ALL):
+        self._chk(self.lib.vo_batch_run(self.h, stages))
+
+    def batch_run_timed(self, stages=STAGE_ALL):
+        ms = np.zeros(5, np.float32)
+        self._chk(self.lib.vo_batch_run_timed(self.h, stages, _p(ms)))
+        return ms
+
+    def batch_sync(self):
+        self._chk(self.lib.vo_batch_sync(self.h))
+
+    def batch_get_tracks(self, frame, n):
+        o = [np.zeros((max(n, 1), 2), np.float32) for _ in range(4)]
+        st = np.zeros(4 * max(n, 1), np.uint8)
+        self._chk(self.lib.vo_batch_get_tracks(self.h, frame, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(st), n))
+        return dict(r0=o[0][:n], r1=o[1][:n], l1=o[2][:n], l0_ret=o[3][:n], status4=st[:4 * n].reshape(4, n))
+
+    def batch_get_filtered(self, frame):
+        cap = self.max_pts
+        o = [np.zeros((cap, 2), np.float32) for _ in range(4)]
+        xyz = np.zeros((cap, 3), np.float32)
+        keep, keepc = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        k, m = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.vo_batch_get_filtered(self.h, frame, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(xyz),
+                                                 _p(keep), C.byref(k), _p(keepc), C.byref(m)))
+        k, m = k.value, m.value
+        return dict(l0=o[0][:k].copy(), r0=o[1][:k].copy(), l1=o[2][:k].copy(), r1=o[3][:k].copy(),
+                    xyz=xyz[:k].copy(), keep_idx=keep[:k].copy(), keep_idx_circ=keepc[:m].copy())
+
+    def batch_get_pose(self, frame):
+        rv, tv, R = np.zeros(3), np.zeros(3), np.zeros((3, 3))
+        inl = np.zeros(self.max_pts, np.int32)
+        ninl, status = C.c_int(0), C.c_int(0)
+        dbg = np.zeros(4, np.int32)
+        self._chk(self.lib.vo_batch_get_pose(self.h, frame, _p(rv), _p(tv), _p(R), _p(inl), C.byref(ninl),
+                                             C.byref(status), _p(dbg)))
+        return dict(rvec=rv, tvec=tv, R=R, inliers=inl[:ninl.value].copy(), status=status.value,
+                    niters=int(dbg[0]), best_iter=int(dbg[1]), max_good=int(dbg[2]), lm_iters=int(dbg[3]))
+
+    def batch_get_pyramid_level(self, idx, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.vo_batch_get_pyramid_level(self.h, idx, level, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._chk(self.lib.vo_batch_get_pyramid_level(self.h, idx, level, _p(out), C.byref(w), C.byref(h)))
+        return out
+
+    def model_bytes(self, w, h, n_points):
+        b = np.zeros(3, np.float64)
+        self._chk(self.lib.vo_model_bytes(self.h, w, h, n_points, _p(b)))
+        return b

@@ -1,0 +1,743 @@
+// capi.hip -- host side of libvo_hip.so: context, device memory, stream, and the C ABI declared
+// in include/vo_hip.h.  No exceptions cross the ABI; every HIP failure becomes VO_ERR_HIP with a
+// message retrievable through vo_last_error().
+#include "../../include/vo_hip.h"
+#include "vo_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace vo;
+
+struct vo_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
+    vo_params prm;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[VO_NUM_STAGES + 1] = {};
+    std::string err;
+
+    // batch configuration
+    int n_images = 0, n_frames = 0, w = 0, h = 0, levels = 0; // levels = max_level + 1 actually built
+    int lw[VO_MAX_LEVELS] = {}, lh[VO_MAX_LEVELS] = {}, lstride[VO_MAX_LEVELS] = {};
+    size_t loff[VO_MAX_LEVELS] = {}, img_bytes = 0;
+    int max_pts_set = 0; // largest n over the frames of the batch
+
+    // device memory
+    uint8_t *d_pix = nullptr; // all pyramids, image i at d_pix + i * img_bytes
+    size_t pix_capacity = 0;
+    PyrImage *d_imgs = nullptr;
+    Quad *d_quads = nullptr;
+    float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr, *d_outB = nullptr;
+    uint8_t *d_status = nullptr;
+    int *d_npts = nullptr, *d_nA = nullptr, *d_nB = nullptr, *d_idxA = nullptr, *d_idxB = nullptr;
+    float *d_xyz = nullptr, *d_P = nullptr; // d_P: P_l (12) then P_r (12)
+    int32_t *d_subsets = nullptr, *d_inliers = nullptr;
+    double *d_models = nullptr;
+    int *d_counts = nullptr;
+    PnpResult *d_results = nullptr;
+    int ransac_cap = 0;
+    float h_P[24] = {};
+    bool have_P = false;
+    std::vector<int> h_npts;
+};
+
+namespace {
+
+#define VO_HIP_TRY(ctx, call)                                                                         \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return VO_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+int fail(vo_ctx *ctx, int code, const char *msg)
+{
+    ctx->err = msg;
+    return code;
+}
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// pyramid geometry exactly as buildOpticalFlowPyramid: stop when the next level would not be
+// larger than the 21 x 21 window
+int plan_levels(vo_ctx *c, int w, int h)
+{
+    int cw = w, ch = h, l = 0;
+    size_t off = 0;
+    for (;; l++) {
+        c->lw[l] = cw;
+        c->lh[l] = ch;
+        c->lstride[l] = align_up(cw, 16);
+        c->loff[l] = off;
+        off += (size_t)c->lstride[l] * ch;
+        off = (off + 255) / 256 * 256;
+        int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+        if (l == c->prm.lk_max_level || l + 1 >= VO_MAX_LEVELS || nw <= 21 || nh <= 21)
+            break;
+        cw = nw;
+        ch = nh;
+    }
+    c->levels = l + 1;
+    c->img_bytes = off;
+    return 0;
+}
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t n)
+{
+    return hipMalloc((void **)p, n * sizeof(T));
+}
+
+} // namespace
+
+extern "C" {
+
+void vo_default_params(vo_params *p)
+{
+    p->lk_max_level = 3;
+    p->lk_max_count = 30;
+    p->lk_epsilon = 0.01;
+    p->lk_min_eig_threshold = 0.001;
+    p->consistency_threshold = 0;
+    p->ransac_iterations = 500;
+    p->ransac_reproj_error = 0.5f;
+    p->ransac_confidence = (double)0.999f; // `float confidence = 0.999` in the reference
+}
+
+const char *vo_last_error(const vo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+void vo_destroy(vo_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = {c->d_pix,    c->d_imgs,  c->d_quads,   c->d_pts,      c->d_trk,    c->d_outA,
+                    c->d_outB,   c->d_status, c->d_npts,   c->d_nA,       c->d_nB,     c->d_idxA,
+                    c->d_idxB,   c->d_xyz,   c->d_P,       c->d_subsets,  c->d_inliers, c->d_models,
+                    c->d_counts, c->d_results};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    for (auto &e : c->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
+{
+    if (max_w < 32 || max_h < 32 || max_pts < 1 || max_frames < 1)
+        return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return nullptr;
+    if (hipSetDevice(device) != hipSuccess)
+        return nullptr;
+    vo_ctx *c = new vo_ctx();
+    c->device = device;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->cap = max_pts;
+    c->max_frames = max_frames;
+    c->max_images = 4 * max_frames;
+    vo_default_params(&c->prm);
+    c->ransac_cap = 1000;
+    const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : c->ev)
+        ok = ok && hipEventCreate(&e) == hipSuccess;
+    // worst case pyramid bytes per image (5 levels, padded strides)
+    {
+        size_t per = 0;
+        int cw = max_w, ch = max_h;
+        for (int l = 0; l < VO_MAX_LEVELS; l++) {
+            per += (size_t)align_up(cw, 16) * ch + 256;
+            cw = (cw + 1) / 2;
+            ch = (ch + 1) / 2;
+        }
+        c->pix_capacity = per * (size_t)c->max_images;
+    }
+    ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
+    ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
+    ok = ok && dmalloc(&c->d_quads, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_pts, B * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_trk, B * 4 * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_outA, B * 5 * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_outB, B * 4 * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_status, B * 4 * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_npts, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_nA, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_nB, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_idxA, B * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_idxB, B * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_xyz, B * cap * 3) == hipSuccess;
+    ok = ok && dmalloc(&c->d_P, (size_t)24) == hipSuccess;
+    ok = ok && dmalloc(&c->d_subsets, B * c->ransac_cap * 5) == hipSuccess;
+    ok = ok && dmalloc(&c->d_inliers, B * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_models, B * c->ransac_cap * 6) == hipSuccess;
+    ok = ok && dmalloc(&c->d_counts, B * c->ransac_cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_results, B) == hipSuccess;
+    if (ok) {
+        ok = hipMemset(c->d_npts, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_nB, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_nA, 0, B * sizeof(int)) == hipSuccess;
+    }
+    if (!ok) {
+        vo_destroy(c);
+        return nullptr;
+    }
+    c->h_npts.assign(B, 0);
+    return c;
+}
+
+int vo_set_params(vo_ctx *c, const vo_params *p)
+{
+    if (!c || !p)
+        return VO_ERR_ARG;
+    if (p->lk_max_level < 0 || p->lk_max_level >= VO_MAX_LEVELS || p->ransac_iterations < 1 ||
+        p->ransac_iterations > c->ransac_cap || !(p->ransac_confidence > 0 && p->ransac_confidence < 1))
+        return fail(c, VO_ERR_ARG, "vo_set_params: parameter out of range");
+    c->prm = *p;
+    c->n_images = 0; // pyramid plan depends on lk_max_level: force re-configure
+    return VO_OK;
+}
+
+int vo_get_params(const vo_ctx *c, vo_params *p)
+{
+    if (!c || !p)
+        return VO_ERR_ARG;
+    *p = c->prm;
+    return VO_OK;
+}
+
+int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (n_images < 1 || n_images > c->max_images || n_frames < 1 || n_frames > c->max_frames || w < 32 ||
+        h < 32 || w > c->max_w || h > c->max_h)
+        return fail(c, VO_ERR_ARG, "vo_batch_configure: size beyond the capacity given to vo_create");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_images == n_images && c->w == w && c->h == h && c->n_frames == n_frames)
+        return VO_OK;
+    plan_levels(c, w, h);
+    if (c->img_bytes * (size_t)n_images > c->pix_capacity)
+        return fail(c, VO_ERR_ARG, "vo_batch_configure: pyramid storage exceeds capacity");
+    std::vector<PyrImage> tab((size_t)n_images);
+    for (int i = 0; i < n_images; i++) {
+        memset(&tab[i], 0, sizeof(PyrImage));
+        for (int l = 0; l < c->levels; l++) {
+            tab[i].lvl[l] = c->d_pix + (size_t)i * c->img_bytes + c->loff[l];
+            tab[i].w[l] = c->lw[l];
+            tab[i].h[l] = c->lh[l];
+            tab[i].stride[l] = c->lstride[l];
+        }
+    }
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_imgs, tab.data(), sizeof(PyrImage) * n_images, hipMemcpyHostToDevice,
+                                 c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_images = n_images;
+    c->n_frames = n_frames;
+    c->w = w;
+    c->h = h;
+    c->max_pts_set = 0;
+    std::fill(c->h_npts.begin(), c->h_npts.end(), 0);
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_npts, 0, sizeof(int) * c->max_frames, c->stream));
+    return VO_OK;
+}
+
+static int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (c->n_images == 0)
+        return fail(c, VO_ERR_STATE, "upload before vo_batch_configure");
+    if (idx < 0 || idx >= c->n_images || !src || stride < c->w)
+        return fail(c, VO_ERR_ARG, "vo_batch_upload_image: bad index / stride");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0];
+    VO_HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->lstride[0], src, (size_t)stride, (size_t)c->w, (size_t)c->h,
+                                   kind, c->stream));
+    return VO_OK;
+}
+
+int vo_batch_upload_image(vo_ctx *c, int idx, const uint8_t *host, int stride)
+{
+    int rc = upload_image(c, idx, host, stride, hipMemcpyHostToDevice);
+    if (rc == VO_OK) // pageable host memory: make the call safe to return from
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return rc;
+}
+
+int vo_batch_upload_image_dev(vo_ctx *c, int idx, const void *dev, int stride)
+{
+    return upload_image(c, idx, dev, stride, hipMemcpyDeviceToDevice);
+}
+
+int vo_batch_set_quads(vo_ctx *c, const int32_t *quads4, int n_frames)
+{
+    if (!c || !quads4)
+        return VO_ERR_ARG;
+    if (c->n_images == 0 || n_frames != c->n_frames)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_quads: configure first / frame count mismatch");
+    for (int i = 0; i < 4 * n_frames; i++)
+        if (quads4[i] < 0 || quads4[i] >= c->n_images)
+            return fail(c, VO_ERR_ARG, "vo_batch_set_quads: image index out of range");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_quads, quads4, sizeof(Quad) * n_frames, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_batch_set_points(vo_ctx *c, int frame, const float *pts, int n)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames || n < 0 || n > c->cap || (n > 0 && !pts))
+        return fail(c, VO_ERR_ARG, "vo_batch_set_points: bad frame / more points than max_pts");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    if (n > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts + (size_t)frame * c->cap, pts, sizeof(float2) * n,
+                                     hipMemcpyHostToDevice, c->stream));
+    c->h_npts[frame] = n;
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_npts + frame, &c->h_npts[frame], sizeof(int), hipMemcpyHostToDevice,
+                                 c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->max_pts_set = 0;
+    for (int f = 0; f < c->n_frames; f++)
+        c->max_pts_set = c->h_npts[f] > c->max_pts_set ? c->h_npts[f] : c->max_pts_set;
+    return VO_OK;
+}
+
+int vo_batch_set_projection(vo_ctx *c, const float *P_l, const float *P_r)
+{
+    if (!c || !P_l || !P_r)
+        return VO_ERR_ARG;
+    memcpy(c->h_P, P_l, 12 * sizeof(float));
+    memcpy(c->h_P + 12, P_r, 12 * sizeof(float));
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_P, c->h_P, 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_P = true;
+    return VO_OK;
+}
+
+static int run_stages(vo_ctx *c, int stages, bool timed)
+{
+    if (c->n_images == 0)
+        return fail(c, VO_ERR_STATE, "vo_batch_run before vo_batch_configure");
+    if ((stages & (VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) && !c->have_P)
+        return fail(c, VO_ERR_STATE, "vo_batch_run: projection matrices not set");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    const int B = c->n_frames, cap = c->cap;
+    int e = 0;
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_PYRAMID)
+        for (int l = 0; l + 1 < c->levels; l++)
+            launch_pyr_down(c->d_imgs, c->n_images, l, c->lw[l + 1], c->lh[l + 1], c->stream);
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_LK) {
+        LkParams lp;
+        lp.max_level = c->levels - 1;
+        int mc = c->prm.lk_max_count;
+        lp.max_count = mc < 0 ? 0 : mc > 100 ? 100 : mc;
+        double eps = c->prm.lk_epsilon;
+        eps = eps < 0. ? 0. : eps > 10. ? 10. : eps;
+        lp.epsilon = eps * eps;
+        lp.min_eig = (float)c->prm.lk_min_eig_threshold;
+        launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk,
+                           c->d_status, lp, c->stream);
+    }
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_FILTER)
+        launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
+                       c->d_idxA, c->d_nA, c->d_outB, c->d_idxB, c->d_nB, B, c->stream);
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_TRIANGULATE) // stage-B rows: 0 = l0, 1 = r0, 2 = l1, 3 = r1
+        launch_triangulate(c->d_P, c->d_P + 12, c->d_outB, c->d_outB + cap, (size_t)4 * cap, c->d_nB, cap,
+                           c->max_pts_set, B, c->d_xyz, c->stream);
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_PNP) {
+        PnpParams pp;
+        pp.iters = c->prm.ransac_iterations;
+        pp.reproj = c->prm.ransac_reproj_error;
+        pp.confidence = c->prm.ransac_confidence;
+        // intrinsic_matrix = projMatrl(0:3, 0:3) (visualOdometry.cpp:163-165)
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++)
+                pp.K[r * 3 + k] = c->h_P[r * 4 + k];
+        launch_pnp(c->d_xyz, c->d_outB + 2 * cap, (size_t)4 * cap, c->d_nB, cap, B, pp, c->d_subsets,
+                   c->d_models, c->d_counts, c->d_inliers, c->d_results, c->stream);
+    }
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+    VO_HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_batch_run(vo_ctx *c, int stages)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    return run_stages(c, stages, false);
+}
+
+int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
+{
+    if (!c || !ms)
+        return VO_ERR_ARG;
+    int rc = run_stages(c, stages, true);
+    if (rc != VO_OK)
+        return rc;
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < VO_NUM_STAGES; s++)
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s], c->ev[s + 1]));
+    return VO_OK;
+}
+
+int vo_batch_sync(vo_ctx *c)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+#define D2H(dst, src, bytes)                                                                           \
+    do {                                                                                              \
+        if ((dst) && (bytes) > 0)                                                                      \
+            VO_HIP_TRY(c, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, c->stream));   \
+    } while (0)
+
+int vo_batch_get_tracks(vo_ctx *c, int frame, float *r0, float *r1, float *l1, float *l0_ret, uint8_t *status4,
+                        int n)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames || n < 0 || n > c->cap)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_tracks: bad frame / n");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cap = c->cap;
+    const float2 *t = c->d_trk + (size_t)frame * 4 * cap;
+    D2H(r0, t, sizeof(float2) * n);
+    D2H(r1, t + cap, sizeof(float2) * n);
+    D2H(l1, t + 2 * cap, sizeof(float2) * n);
+    D2H(l0_ret, t + 3 * cap, sizeof(float2) * n);
+    if (status4)
+        for (int hop = 0; hop < 4; hop++)
+            D2H(status4 + (size_t)hop * n, c->d_status + ((size_t)frame * 4 + hop) * cap, (size_t)n);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_batch_get_filtered(vo_ctx *c, int frame, float *l0, float *r0, float *l1, float *r1, float *xyz,
+                          int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_filtered: bad frame");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int nAB[2] = {0, 0};
+    VO_HIP_TRY(c, hipMemcpyAsync(&nAB[0], c->d_nA + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(&nAB[1], c->d_nB + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t cap = c->cap;
+    const int K = nAB[1], M = nAB[0];
+    const float2 *b = c->d_outB + (size_t)frame * 4 * cap;
+    D2H(l0, b, sizeof(float2) * K);
+    D2H(r0, b + cap, sizeof(float2) * K);
+    D2H(l1, b + 2 * cap, sizeof(float2) * K);
+    D2H(r1, b + 3 * cap, sizeof(float2) * K);
+    D2H(xyz, c->d_xyz + (size_t)frame * cap * 3, sizeof(float) * 3 * K);
+    D2H(keep_idx, c->d_idxB + (size_t)frame * cap, sizeof(int32_t) * K);
+    D2H(keep_idx_circ, c->d_idxA + (size_t)frame * cap, sizeof(int32_t) * M);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_out)
+        *n_out = K;
+    if (n_circ)
+        *n_circ = M;
+    return VO_OK;
+}
+
+// stage-A arrays (deleteUnmatchFeaturesCircle output) of one frame
+static int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, float *l1, float *l0r,
+                       int32_t *keep_idx, int *n_out)
+{
+    int M = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(&M, c->d_nA + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t cap = c->cap;
+    const float2 *a = c->d_outA + (size_t)frame * 5 * cap;
+    D2H(l0, a, sizeof(float2) * M);
+    D2H(r0, a + cap, sizeof(float2) * M);
+    D2H(r1, a + 2 * cap, sizeof(float2) * M);
+    D2H(l1, a + 3 * cap, sizeof(float2) * M);
+    D2H(l0r, a + 4 * cap, sizeof(float2) * M);
+    D2H(keep_idx, c->d_idxA + (size_t)frame * cap, sizeof(int32_t) * M);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = M;
+    return VO_OK;
+}
+
+int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
+                      int *n_inliers, int *status, int32_t *dbg4)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_pose: bad frame");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    PnpResult r;
+    VO_HIP_TRY(c, hipMemcpyAsync(&r, c->d_results + frame, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (r.status >= 0) {
+        if (rvec)
+            memcpy(rvec, r.rvec, sizeof(r.rvec));
+        if (tvec)
+            memcpy(tvec, r.tvec, sizeof(r.tvec));
+        if (R)
+            memcpy(R, r.R, sizeof(r.R));
+    }
+    if (inliers && r.n_inliers > 0) {
+        D2H(inliers, c->d_inliers + (size_t)frame * c->cap, sizeof(int32_t) * r.n_inliers);
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (n_inliers)
+        *n_inliers = r.n_inliers;
+    if (status)
+        *status = r.status;
+    if (dbg4) {
+        dbg4[0] = r.niters;
+        dbg4[1] = r.best_iter;
+        dbg4[2] = r.max_good;
+        dbg4[3] = r.lm_iters;
+    }
+    return VO_OK;
+}
+
+int vo_batch_get_pyramid_level(vo_ctx *c, int idx, int level, uint8_t *out, int *w_l, int *h_l)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (idx < 0 || idx >= c->n_images || level < 0 || level >= c->levels)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_pyramid_level: bad image / level");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    if (w_l)
+        *w_l = c->lw[level];
+    if (h_l)
+        *h_l = c->lh[level];
+    if (out) {
+        VO_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)c->lw[level],
+                                       c->d_pix + (size_t)idx * c->img_bytes + c->loff[level],
+                                       (size_t)c->lstride[level], (size_t)c->lw[level], (size_t)c->lh[level],
+                                       hipMemcpyDeviceToHost, c->stream));
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return VO_OK;
+}
+
+int vo_model_bytes(const vo_ctx *c, int w, int h, int n_points, double *b)
+{
+    if (!c || !b || w < 1 || h < 1 || n_points < 0)
+        return VO_ERR_ARG;
+    // B_pyr = 4 images x (read sum_{l<L} S_l + write sum_{l>=1} S_l)
+    int L = c->prm.lk_max_level, cw = w, ch = h;
+    double rd = 0, wr = 0;
+    int lv = 0;
+    for (int l = 0; l <= L; l++) {
+        double S = (double)cw * ch;
+        if (l < L)
+            rd += S;
+        if (l >= 1)
+            wr += S;
+        lv = l;
+        int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+        if (nw <= 21 || nh <= 21)
+            break;
+        cw = nw;
+        ch = nh;
+    }
+    (void)lv;
+    b[0] = 4.0 * (rd + wr);
+    // B_lk = 4 hops x N x [(L+1) x ((win+3)^2 + (win+1)^2) + 8 + 8 + 1]
+    b[1] = 4.0 * n_points * ((L + 1) * (576.0 + 484.0) + 17.0);
+    b[2] = 48.0 * n_points + 48.0;
+    return VO_OK;
+}
+
+/* ---------------------------------- drop-in calls ---------------------------------------- */
+
+static int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
+                              const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
+{
+    if (!l0 || !r0 || !l1 || !r1 || n < 0 || (n > 0 && !pts))
+        return fail(c, VO_ERR_ARG, "null image / points");
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    int rc = vo_batch_configure(c, 4, w, h, 1);
+    if (rc != VO_OK)
+        return rc;
+    const uint8_t *imgs[4] = {l0, r0, l1, r1};
+    for (int i = 0; i < 4; i++) {
+        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice);
+        if (rc != VO_OK)
+            return rc;
+    }
+    const int32_t quad[4] = {0, 1, 2, 3};
+    rc = vo_batch_set_quads(c, quad, 1);
+    if (rc != VO_OK)
+        return rc;
+    return vo_batch_set_points(c, 0, pts, n);
+}
+
+int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1,
+                      int w, int h, int stride, const float *pts, int n, float *out_l0, float *out_r0,
+                      float *out_r1, float *out_l1, float *out_l0_ret, uint8_t *status4, int32_t *keep_idx,
+                      int *n_out, int apply_consistency)
+{
+    if (!c || !n_out)
+        return VO_ERR_ARG;
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    if (rc != VO_OK)
+        return rc;
+    rc = run_stages(c, VO_STAGE_PYRAMID | VO_STAGE_LK | VO_STAGE_FILTER, false);
+    if (rc != VO_OK)
+        return rc;
+    if (status4) {
+        rc = vo_batch_get_tracks(c, 0, nullptr, nullptr, nullptr, nullptr, status4, n);
+        if (rc != VO_OK)
+            return rc;
+    }
+    if (!apply_consistency)
+        return get_stage_a(c, 0, out_l0, out_r0, out_r1, out_l1, out_l0_ret, keep_idx, n_out);
+    // stage B drops l0_ret (removeInvalidPoints is not applied to it); fill it from stage A by index
+    int K = 0;
+    rc = vo_batch_get_filtered(c, 0, out_l0, out_r0, out_l1, out_r1, nullptr, keep_idx, &K, nullptr, nullptr);
+    if (rc != VO_OK)
+        return rc;
+    if (out_l0_ret && K > 0) {
+        std::vector<int32_t> idx((size_t)K);
+        std::vector<float> ret((size_t)2 * (n > 0 ? n : 1));
+        VO_HIP_TRY(c, hipMemcpy(idx.data(), c->d_idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+        VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk + (size_t)3 * c->cap, sizeof(float2) * n,
+                                hipMemcpyDeviceToHost));
+        for (int i = 0; i < K; i++) {
+            out_l0_ret[2 * i] = ret[2 * idx[i]];
+            out_l0_ret[2 * i + 1] = ret[2 * idx[i] + 1];
+        }
+    }
+    *n_out = K;
+    return VO_OK;
+}
+
+int vo_triangulate(vo_ctx *c, const float *P_l, const float *P_r, const float *pl, const float *pr, int n,
+                   float *xyz_out)
+{
+    if (!c || !P_l || !P_r || n < 0 || (n > 0 && (!pl || !pr || !xyz_out)))
+        return VO_ERR_ARG;
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    if (n == 0)
+        return VO_OK;
+    int rc = vo_batch_set_projection(c, P_l, P_r);
+    if (rc != VO_OK)
+        return rc;
+    // frame 0, stage-B rows 0 (left) and 1 (right)
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB, pl, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB + c->cap, pr, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_triangulate(c->d_P, c->d_P + 12, c->d_outB, c->d_outB + c->cap, (size_t)4 * c->cap, c->d_nB, c->cap,
+                       n, 1, c->d_xyz, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    VO_HIP_TRY(c, hipMemcpyAsync(xyz_out, c->d_xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+static int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
+                      int *n_inliers)
+{
+    int status = 0, ninl = 0;
+    int rc = vo_batch_get_pose(c, 0, rvec_io, tvec_io, R_out, inliers, &ninl, &status, nullptr);
+    if (rc != VO_OK)
+        return rc;
+    if (n_inliers)
+        *n_inliers = ninl;
+    if (status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached solvePnPRansac");
+    return status == 1 ? VO_OK : 1;
+}
+
+int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
+                  double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers)
+{
+    if (!c || !K || n < 0 || (n > 0 && (!xyz || !uv)))
+        return VO_ERR_ARG;
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    PnpParams pp;
+    pp.iters = c->prm.ransac_iterations;
+    pp.reproj = c->prm.ransac_reproj_error;
+    pp.confidence = c->prm.ransac_confidence;
+    memcpy(pp.K, K, sizeof(pp.K));
+    if (n > 0) {
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB + 2 * (size_t)c->cap, uv, sizeof(float2) * n,
+                                     hipMemcpyHostToDevice, c->stream));
+    }
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (c->n_frames < 1)
+        c->n_frames = 1;
+    launch_pnp(c->d_xyz, c->d_outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, c->d_nB, c->cap, 1, pp,
+               c->d_subsets, c->d_models, c->d_counts, c->d_inliers, c->d_results, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
+}
+
+int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w,
+                   int h, int stride, const float *pts, int n, const float *P_l, const float *P_r,
+                   float *out_l0, float *out_r0, float *out_l1, float *out_r1, float *xyz_out,
+                   int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ, double *rvec_io,
+                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers)
+{
+    if (!c || !P_l || !P_r)
+        return VO_ERR_ARG;
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    if (rc != VO_OK)
+        return rc;
+    rc = vo_batch_set_projection(c, P_l, P_r);
+    if (rc != VO_OK)
+        return rc;
+    rc = run_stages(c, VO_STAGE_ALL, false);
+    if (rc != VO_OK)
+        return rc;
+    rc = vo_batch_get_filtered(c, 0, out_l0, out_r0, out_l1, out_r1, xyz_out, keep_idx, n_out, keep_idx_circ,
+                               n_circ);
+    if (rc != VO_OK)
+        return rc;
+    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
+}
+
+} // extern "C"

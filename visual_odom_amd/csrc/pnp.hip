@@ -1,0 +1,439 @@
+// pnp.hip -- PnP + RANSAC pose solve on the device.
+//
+// Replaces cv::solvePnPRansac + cv::Rodrigues as called by trackingFrame2Frame()
+// (reference src/visualOdometry.cpp:161-189: useExtrinsicGuess = true, 500 iterations,
+// reprojection error 0.5 px, confidence 0.999f, SOLVEPNP_ITERATIVE, zero distortion).
+//
+// OpenCV's RANSAC loop is sequential with an adaptive iteration count.  Its random 5-subsets do
+// not depend on earlier hypotheses (cv::RNG(-1) stream, duplicates redrawn), so all hypotheses are
+// evaluated in parallel and the sequential control flow is replayed afterwards on the vote counts:
+//   1. ransac_subsets_kernel   one thread per frame replays the RNG stream -> [iters][5] indices
+//   2. epnp_kernel             one thread per hypothesis: 5-point EPnP (vo_epnp.h) -> rvec|tvec
+//   3. vote_kernel             one wavefront per hypothesis: project all K points (f64 -> f32),
+//                              squared error <= thr^2, ballot + popcount -> inlier count
+//   4. select_refine_kernel    one workgroup per frame: replays "keep first strictly better,
+//                              niters = RANSACUpdateNumIters(...)" to find the winning hypothesis
+//                              and the last one OpenCV would have evaluated (its pose is the start
+//                              of the final refinement because rvec/tvec are shared buffers),
+//                              rebuilds the inlier mask, runs the CvLevMarq state machine with
+//                              block-wide reductions of J^T J / J^T e, and converts rvec -> R.
+#include "vo_kernels.h"
+#include "vo_epnp.h"
+
+#include <float.h>
+
+namespace vo {
+
+// one thread per frame (the stream is strictly sequential); n_frames threads in total
+__global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters,
+                                       int32_t *__restrict__ subsets /* [B][iters][5] */)
+{
+    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= n_frames)
+        return;
+    const int count = n_pts[frame];
+    int32_t *out = subsets + (size_t)frame * iters * 5;
+    if (count < 5)
+        return;
+    if (count == 5) { // model_points == npoints: solvePnP on all points in order
+        for (int i = 0; i < 5; i++)
+            out[i] = i;
+        return;
+    }
+    uint64_t state = 0xffffffffffffffffull; // cv::RNG rng((uint64)-1)
+    for (int it = 0; it < iters; it++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            int idx_i;
+            for (;;) {
+                state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+                idx_i = (int)((uint32_t)state % (uint32_t)count);
+                bool dup = false;
+                for (int k = 0; k < i; k++)
+                    dup |= idx[k] == idx_i;
+                if (!dup)
+                    break;
+            }
+            idx[i] = idx_i;
+        }
+        for (int i = 0; i < 5; i++)
+            out[it * 5 + i] = idx[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
+                                                  const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
+                                                  size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                  const int32_t *__restrict__ subsets, PnpParams prm,
+                                                  double *__restrict__ models /* [B][iters][6] */)
+{
+    const int frame = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
+    const int count = n_pts[frame];
+    if (count < 5)
+        return;
+    const int nh = count == 5 ? 1 : prm.iters;
+    if (h >= nh)
+        return;
+    const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
+    float x5[15], u5[10];
+    for (int i = 0; i < 5; i++) {
+        const int k = idx[i];
+        const float *p = xyz + ((size_t)frame * cap + k) * 3;
+        x5[3 * i] = p[0];
+        x5[3 * i + 1] = p[1];
+        x5[3 * i + 2] = p[2];
+        const float2 q = uv[frame * uv_stride + k];
+        u5[2 * i] = q.x;
+        u5[2 * i + 1] = q.y;
+    }
+    double rv[3], tv[3];
+    epnp5_solve(x5, u5, prm.K, rv, tv);
+    double *m = models + ((size_t)frame * prm.iters + h) * 6;
+    m[0] = rv[0];
+    m[1] = rv[1];
+    m[2] = rv[2];
+    m[3] = tv[0];
+    m[4] = tv[1];
+    m[5] = tv[2];
+}
+
+// squared reprojection error exactly as PnPRansacCallback::computeError: projection in f64,
+// stored as f32, difference and squared norm in f32
+__device__ __forceinline__ bool is_inlier(const double *R, const double *t, double fx, double fy, double cx,
+                                          double cy, const float *p, float2 q, float thr2)
+{
+    double uvd[2];
+    project_point(R, t, nullptr, fx, fy, cx, cy, (double)p[0], (double)p[1], (double)p[2], uvd, nullptr,
+                  nullptr);
+    const float dx = q.x - (float)uvd[0], dy = q.y - (float)uvd[1];
+    const float e = dx * dx + dy * dy;
+    return e <= thr2;
+}
+
+__global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                  size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                  PnpParams prm, const double *__restrict__ models,
+                                                  int *__restrict__ counts /* [B][iters] */)
+{
+    const int frame = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+    const int count = n_pts[frame];
+    if (count <= 5)
+        return;
+    const double *m = models + ((size_t)frame * prm.iters + h) * 6;
+    double R[9], t[3] = {m[3], m[4], m[5]};
+    rodrigues_v2m(m, R, nullptr);
+    const double fx = prm.K[0], fy = prm.K[4], cx = prm.K[2], cy = prm.K[5];
+    const double thr = (double)prm.reproj;
+    const float thr2 = (float)(thr * thr);
+    int good = 0;
+    for (int i = lane; i < count; i += 64)
+        good += is_inlier(R, t, fx, fy, cx, cy, xyz + ((size_t)frame * cap + i) * 3, uv[frame * uv_stride + i],
+                          thr2);
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1)
+        good += __shfl_xor(good, mm, 64);
+    if (lane == 0)
+        counts[(size_t)frame * prm.iters + h] = good;
+}
+
+// calib3d/ptsetreg.cpp RANSACUpdateNumIters
+__device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.;
+    p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.;
+    ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN)
+        return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+constexpr int LM_NRED = 28; // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void select_refine_kernel(const float *__restrict__ xyz,
+                                                            const float2 *__restrict__ uv, size_t uv_stride,
+                                                            const int *__restrict__ n_pts, int cap,
+                                                            PnpParams prm, const double *__restrict__ models,
+                                                            const int *__restrict__ counts,
+                                                            int32_t *__restrict__ inliers /* [B][cap] */,
+                                                            PnpResult *__restrict__ results)
+{
+    __shared__ int s_best, s_last, s_niters, s_maxgood, s_ninl;
+    __shared__ int s_wave[4];
+    __shared__ double s_param[6];
+    __shared__ double s_red[4][LM_NRED];
+    __shared__ double s_sum[LM_NRED];
+    __shared__ int s_flags[2]; // [0] proceed & want_err, [1] want_J
+
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int count = n_pts[frame];
+    PnpResult &res = results[frame];
+    if (count < 5) {
+        if (tid == 0) {
+            res.status = count == 4 ? -2 : -1; // CV_Assert(npoints >= 4) / P3P path not provided
+            res.n_inliers = 0;
+            res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
+        }
+        return;
+    }
+    const double *mf = models + (size_t)frame * prm.iters * 6;
+    const float *X = xyz + (size_t)frame * cap * 3;
+    const float2 *U = uv + frame * uv_stride;
+    int32_t *inl = inliers + (size_t)frame * cap;
+
+    if (count == 5) { // direct solvePnP(EPNP) on the 5 points, all inliers, no refinement
+        if (tid < 5)
+            inl[tid] = tid;
+        if (tid == 0) {
+            for (int k = 0; k < 3; k++) {
+                res.rvec[k] = mf[k];
+                res.tvec[k] = mf[3 + k];
+            }
+            rodrigues_v2m(res.rvec, res.R, nullptr);
+            res.n_inliers = 5;
+            res.status = 1;
+            res.niters = 1;
+            res.best_iter = 0;
+            res.max_good = 5;
+            res.lm_iters = 0;
+        }
+        return;
+    }
+
+    // ---- replay RANSACPointSetRegistrator::run on the vote counts ----
+    if (tid == 0) {
+        const int *cf = counts + (size_t)frame * prm.iters;
+        int niters = prm.iters > 1 ? prm.iters : 1, maxGood = 0, best = -1, it;
+        for (it = 0; it < niters; it++) {
+            const int good = cf[it];
+            if (good > (maxGood > 4 ? maxGood : 4)) {
+                maxGood = good;
+                best = it;
+                niters = ransac_update_num_iters(prm.confidence, (double)(count - good) / count, 5, niters);
+            }
+        }
+        s_best = best;
+        s_last = it - 1;
+        s_niters = it;
+        s_maxgood = maxGood;
+        s_ninl = 0;
+    }
+    __syncthreads();
+    const int best = s_best, last = s_last;
+    const double fx = prm.K[0], fy = prm.K[4], cx = prm.K[2], cy = prm.K[5];
+
+    if (best < 0) { // no model: rvec/tvec hold the last evaluated hypothesis, inliers released
+        if (tid == 0) {
+            for (int k = 0; k < 3; k++) {
+                res.rvec[k] = mf[last * 6 + k];
+                res.tvec[k] = mf[last * 6 + 3 + k];
+            }
+            rodrigues_v2m(res.rvec, res.R, nullptr);
+            res.n_inliers = 0;
+            res.status = 0;
+            res.niters = s_niters;
+            res.best_iter = -1;
+            res.max_good = 0;
+            res.lm_iters = 0;
+        }
+        return;
+    }
+
+    // ---- inlier mask of the winning hypothesis, stable compaction into inl[] ----
+    {
+        double R[9], t[3] = {mf[best * 6 + 3], mf[best * 6 + 4], mf[best * 6 + 5]};
+        rodrigues_v2m(mf + best * 6, R, nullptr);
+        const double thr = (double)prm.reproj;
+        const float thr2 = (float)(thr * thr);
+        for (int start = 0; start < count; start += 256) {
+            const int i = start + tid;
+            const bool in = i < count && is_inlier(R, t, fx, fy, cx, cy, X + (size_t)i * 3, U[i], thr2);
+            const unsigned long long m = __ballot(in);
+            if (lane == 0)
+                s_wave[wv] = __popcll(m);
+            __syncthreads();
+            int off = s_ninl;
+            for (int w = 0; w < wv; w++)
+                off += s_wave[w];
+            if (in)
+                inl[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+            if (tid == 0)
+                s_ninl += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            __syncthreads();
+        }
+    }
+    const int n1 = s_ninl;
+
+    // ---- CvLevMarq (cvFindExtrinsicCameraParams2, useExtrinsicGuess) from the LAST hypothesis ----
+    enum { LM_DONE = 0, LM_STARTED = 1, LM_CALC_J = 2, LM_CHECK_ERR = 3 };
+    // thread-0 private solver state
+    double prevParam[6], JtJ[36], JtErr[6];
+    double prevErrNorm = DBL_MAX, errNorm = DBL_MAX;
+    int lambdaLg10 = -3, state = LM_STARTED, iters = 0;
+    const int max_iter = 20;
+    const double epsilon = (double)FLT_EPSILON;
+    if (tid == 0)
+        for (int k = 0; k < 6; k++)
+            s_param[k] = mf[last * 6 + k];
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) {
+            int want_J = 0, want_err = 0, proceed = 1;
+            auto lm_step = [&]() {
+                const double lambda = exp(lambdaLg10 * log(10.));
+                double A[36], x[6];
+                for (int k = 0; k < 36; k++)
+                    A[k] = JtJ[k];
+                for (int k = 0; k < 6; k++)
+                    A[k * 6 + k] *= 1. + lambda;
+                solve_svd<6, 6>(A, JtErr, x);
+                for (int k = 0; k < 6; k++)
+                    s_param[k] = prevParam[k] - x[k];
+            };
+            if (state == LM_DONE) {
+                proceed = 0;
+            } else if (state == LM_STARTED) {
+                want_J = want_err = 1;
+                state = LM_CALC_J;
+            } else if (state == LM_CALC_J) {
+                int q = 0;
+                for (int i = 0; i < 6; i++)
+                    for (int j = i; j < 6; j++) {
+                        JtJ[i * 6 + j] = s_sum[q];
+                        JtJ[j * 6 + i] = s_sum[q];
+                        q++;
+                    }
+                for (int k = 0; k < 6; k++) {
+                    JtErr[k] = s_sum[21 + k];
+                    prevParam[k] = s_param[k];
+                }
+                lm_step();
+                if (iters == 0)
+                    prevErrNorm = sqrt(s_sum[27]);
+                want_err = 1;
+                state = LM_CHECK_ERR;
+            } else { // LM_CHECK_ERR
+                errNorm = sqrt(s_sum[27]);
+                bool handled = false;
+                if (errNorm > prevErrNorm) {
+                    if (++lambdaLg10 <= 16) {
+                        lm_step();
+                        want_err = 1;
+                        state = LM_CHECK_ERR;
+                        handled = true;
+                    }
+                }
+                if (!handled) {
+                    lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+                    double dn = 0, pn = 0;
+                    for (int k = 0; k < 6; k++) {
+                        const double d = s_param[k] - prevParam[k];
+                        dn += d * d;
+                        pn += prevParam[k] * prevParam[k];
+                    }
+                    if (++iters >= max_iter || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < epsilon) {
+                        state = LM_DONE; // update() returns true with _err == 0 -> caller breaks
+                    } else {
+                        prevErrNorm = errNorm;
+                        want_J = want_err = 1;
+                        state = LM_CALC_J;
+                    }
+                }
+            }
+            s_flags[0] = proceed && want_err;
+            s_flags[1] = want_J;
+        }
+        __syncthreads();
+        if (!s_flags[0])
+            break;
+        const bool want_J = s_flags[1] != 0;
+
+        // ---- residuals (and Jacobian) of every inlier at s_param; block-wide reduction ----
+        double acc[LM_NRED];
+#pragma unroll
+        for (int k = 0; k < LM_NRED; k++)
+            acc[k] = 0;
+        {
+            double R[9], dRdr[27];
+            const double rv[3] = {s_param[0], s_param[1], s_param[2]};
+            const double t[3] = {s_param[3], s_param[4], s_param[5]};
+            rodrigues_v2m(rv, R, want_J ? dRdr : nullptr);
+            for (int k = tid; k < n1; k += 256) {
+                const int i = inl[k];
+                const float *p = X + (size_t)i * 3;
+                const float2 q = U[i];
+                double uvd[2], Ju[6], Jv[6];
+                project_point(R, t, dRdr, fx, fy, cx, cy, (double)p[0], (double)p[1], (double)p[2], uvd,
+                              want_J ? Ju : nullptr, want_J ? Jv : nullptr);
+                const double eu = uvd[0] - (double)q.x, ev = uvd[1] - (double)q.y;
+                acc[27] += eu * eu + ev * ev;
+                if (want_J) {
+                    int qq = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int b = a; b < 6; b++)
+                            acc[qq++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                        acc[21 + a] += Ju[a] * eu + Jv[a] * ev;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LM_NRED; k++) {
+            const double s = wave_sum_f64(acc[k]);
+            if (lane == 0)
+                s_red[wv][k] = s;
+        }
+        __syncthreads();
+        if (tid < LM_NRED)
+            s_sum[tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        for (int k = 0; k < 3; k++) {
+            res.rvec[k] = s_param[k];
+            res.tvec[k] = s_param[3 + k];
+        }
+        rodrigues_v2m(res.rvec, res.R, nullptr); // cv::Rodrigues(rvec, rotation), visualOdometry.cpp:188
+        res.n_inliers = n1;
+        res.status = 1;
+        res.niters = s_niters;
+        res.best_iter = best;
+        res.max_good = s_maxgood;
+        res.lm_iters = iters;
+    }
+}
+
+void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                const PnpParams &prm, int32_t *subsets, double *models, int *counts, int32_t *inliers,
+                PnpResult *results, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return;
+    hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
+                       prm.iters, subsets);
+    hipLaunchKernelGGL(epnp_kernel, dim3((prm.iters + 63) / 64, n_frames), dim3(64), 0, stream, xyz, uv,
+                       uv_stride, n_pts, cap, subsets, prm, models);
+    hipLaunchKernelGGL(vote_kernel, dim3(prm.iters, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
+                       cap, prm, models, counts);
+    hipLaunchKernelGGL(select_refine_kernel, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
+                       cap, prm, models, counts, inliers, results);
+}
+
+} // namespace vo

@@ -1,0 +1,149 @@
+// post.hip -- epilogue of circularMatching(): status / sign filter, circular-consistency check,
+// order-preserving compaction, and stereo triangulation.
+//
+// Replaces (reference file:line)
+//   deleteUnmatchFeaturesCircle   src/feature.cpp:76-116   (stage A: 5 arrays + ages by 4 statuses,
+//                                                           also drops x<0 || y<0 of pt0..pt3)
+//   checkValidMatch + removeInvalidPoints x4   src/visualOdometry.cpp:44-77,119-125 (stage B)
+//   cv::triangulatePoints + convertPointsFromHomogeneous   src/main.cpp:169-171
+// vector::erase semantics = stable compaction, done with a wave-ballot prefix sum per frame.
+#include "vo_kernels.h"
+#include "vo_tri.h"
+
+namespace vo {
+
+// one 256-thread workgroup per frame
+__global__ __launch_bounds__(256) void compact_kernel(const float2 *__restrict__ pts_in,   // [B][cap]
+                                                      const float2 *__restrict__ trk,      // [B][4][cap]
+                                                      const uint8_t *__restrict__ status,  // [B][4][cap]
+                                                      const int *__restrict__ n_pts, int cap, int threshold,
+                                                      float2 *__restrict__ outA,  // [B][5][cap] l0,r0,r1,l1,l0ret
+                                                      int *__restrict__ idxA,     // [B][cap]
+                                                      int *__restrict__ nA,       // [B]
+                                                      float2 *__restrict__ outB,  // [B][4][cap] l0,r0,l1,r1
+                                                      int *__restrict__ idxB,     // [B][cap]
+                                                      int *__restrict__ nB)       // [B]
+{
+    __shared__ int s_wave[2][4];
+    __shared__ int s_base[2];
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = n_pts[frame];
+    const float2 *p0 = pts_in + (size_t)frame * cap;
+    const float2 *t0 = trk + (size_t)frame * 4 * cap;
+    const uint8_t *s0 = status + (size_t)frame * 4 * cap;
+    if (tid < 2)
+        s_base[tid] = 0;
+    __syncthreads();
+
+    for (int start = 0; start < n; start += 256) {
+        const int i = start + tid;
+        bool ka = false, kb = false;
+        float2 l0 = {0, 0}, r0 = {0, 0}, r1 = {0, 0}, l1 = {0, 0}, lr = {0, 0};
+        if (i < n) {
+            l0 = p0[i];
+            r0 = t0[i];
+            r1 = t0[cap + i];
+            l1 = t0[2 * cap + i];
+            lr = t0[3 * cap + i];
+            bool bad = s0[3 * cap + i] == 0 || l1.x < 0 || l1.y < 0 || s0[2 * cap + i] == 0 || r1.x < 0 ||
+                       r1.y < 0 || s0[cap + i] == 0 || r0.x < 0 || r0.y < 0 || s0[i] == 0 || l0.x < 0 ||
+                       l0.y < 0;
+            ka = !bad;
+            // int offset = max(|dx|, |dy|) truncated; keep iff offset <= threshold
+            float ax = fabsf(l0.x - lr.x), ay = fabsf(l0.y - lr.y);
+            int offset = (int)(ax < ay ? ay : ax);
+            kb = ka && !(offset > threshold);
+        }
+        const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int ra = __popcll(ma & below), rb = __popcll(mb & below);
+        if (lane == 0) {
+            s_wave[0][wv] = __popcll(ma);
+            s_wave[1][wv] = __popcll(mb);
+        }
+        __syncthreads();
+        int offa = s_base[0], offb = s_base[1];
+        for (int w = 0; w < wv; w++) {
+            offa += s_wave[0][w];
+            offb += s_wave[1][w];
+        }
+        if (ka) {
+            const int o = offa + ra;
+            float2 *oa = outA + (size_t)frame * 5 * cap;
+            oa[o] = l0;
+            oa[cap + o] = r0;
+            oa[2 * cap + o] = r1;
+            oa[3 * cap + o] = l1;
+            oa[4 * cap + o] = lr;
+            idxA[(size_t)frame * cap + o] = i;
+        }
+        if (kb) {
+            const int o = offb + rb;
+            float2 *ob = outB + (size_t)frame * 4 * cap;
+            ob[o] = l0;
+            ob[cap + o] = r0;
+            ob[2 * cap + o] = l1;
+            ob[3 * cap + o] = r1;
+            idxB[(size_t)frame * cap + o] = i;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_base[0] += s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3];
+            s_base[1] += s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nA[frame] = s_base[0];
+        nB[frame] = s_base[1];
+    }
+}
+
+// thread per point; pl/pr are rows 0 and 1 of the stage-B arrays of each frame
+__global__ __launch_bounds__(256) void triangulate_kernel(const float *__restrict__ Pl,
+                                                          const float *__restrict__ Pr,
+                                                          const float2 *__restrict__ pl,
+                                                          const float2 *__restrict__ pr,
+                                                          size_t frame_stride /* float2 units */,
+                                                          const int *__restrict__ n_pts, int cap,
+                                                          float *__restrict__ xyz /* [B][cap][3] */)
+{
+    const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pts[frame])
+        return;
+    float P0[12], P1[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        P0[k] = Pl[k];
+        P1[k] = Pr[k];
+    }
+    const float2 a = pl[frame * frame_stride + i], b = pr[frame * frame_stride + i];
+    float out[3];
+    triangulate_one(P0, P1, a.x, a.y, b.x, b.y, out);
+    float *o = xyz + ((size_t)frame * cap + i) * 3;
+    o[0] = out[0];
+    o[1] = out[1];
+    o[2] = out[2];
+}
+
+void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
+                    int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
+                    int n_frames, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return;
+    hipLaunchKernelGGL(compact_kernel, dim3(n_frames), dim3(256), 0, stream, pts_in, trk, status, n_pts, cap,
+                       threshold, outA, idxA, nA, outB, idxB, nB);
+}
+
+void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, const float2 *pr,
+                        size_t frame_stride, const int *n_pts, int cap, int max_pts, int n_frames, float *xyz,
+                        hipStream_t stream)
+{
+    if (n_frames <= 0 || max_pts <= 0)
+        return;
+    hipLaunchKernelGGL(triangulate_kernel, dim3((max_pts + 255) / 256, n_frames), dim3(256), 0, stream, Pl, Pr,
+                       pl, pr, frame_stride, n_pts, cap, xyz);
+}
+
+} // namespace vo

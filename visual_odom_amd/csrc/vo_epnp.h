@@ -1,0 +1,404 @@
+// vo_epnp.h -- 5-point EPnP minimal solver used as the RANSAC hypothesis kernel.
+//
+// Drop-in for what cv::solvePnPRansac runs per iteration in the reference
+// (visualOdometry.cpp:176-178 -> PnPRansacCallback::runKernel -> solvePnP(SOLVEPNP_EPNP) on a
+// 5-point subset): control points by PCA, barycentric coordinates, 10x12 M, null space of M^T M,
+// three beta approximations each refined by 5 Gauss-Newton steps, Horn absolute orientation,
+// best-of-three by reprojection error; then R -> rvec.  VO_HD so tests/host_check can run the very
+// same code on the CPU (unit test only, never a product fallback).
+#pragma once
+
+#include "vo_linalg.h"
+
+namespace vo {
+
+struct Epnp5 {
+    double uc, vc, fu, fv;
+    double pws[15], us[10], alphas[20], pcs[15];
+    double cws[4][3], ccs[4][3];
+};
+
+VO_HD double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+VO_HD double dist2(const double *p1, const double *p2)
+{
+    return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) +
+           (p1[2] - p2[2]) * (p1[2] - p2[2]);
+}
+
+// Householder QR least squares, 6x4 (the EPnP authors' qr_solve incl. its pivot-scan behaviour)
+VO_HD void qr_solve_6x4(double *pA, double *pb, double *pX)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    for (int k = 0; k < nc; k++) {
+        double eta = fabs(pA[k * nc + k]);
+        for (int i = k + 1; i < nr; i++) { // scans rows k .. nr-2
+            double elt = fabs(pA[(i - 1) * nc + k]);
+            if (eta < elt)
+                eta = elt;
+        }
+        if (eta == 0) {
+            return;
+        }
+        double sum2 = 0.0, inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) {
+            pA[i * nc + k] *= inv_eta;
+            sum2 += pA[i * nc + k] * pA[i * nc + k];
+        }
+        double sigma = sqrt(sum2);
+        if (pA[k * nc + k] < 0)
+            sigma = -sigma;
+        pA[k * nc + k] += sigma;
+        A1[k] = sigma * pA[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double sum = 0;
+            for (int i = k; i < nr; i++)
+                sum += pA[i * nc + k] * pA[i * nc + j];
+            double tau = sum / A1[k];
+            for (int i = k; i < nr; i++)
+                pA[i * nc + j] -= tau * pA[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) { // b <- Qt b
+        double tau = 0;
+        for (int i = j; i < nr; i++)
+            tau += pA[i * nc + j] * pb[i];
+        tau /= A1[j];
+        for (int i = j; i < nr; i++)
+            pb[i] -= tau * pA[i * nc + j];
+    }
+    pX[nc - 1] = pb[nc - 1] / A2[nc - 1]; // X = R^-1 b
+    for (int i = nc - 2; i >= 0; i--) {
+        double sum = 0;
+        for (int j = i + 1; j < nc; j++)
+            sum += pA[i * nc + j] * pX[j];
+        pX[i] = (pb[i] - sum) / A2[i];
+    }
+}
+
+VO_HD void epnp_gauss_newton(const double *L, const double *rho, double *betas)
+{
+    double a[24], b[6], x[4] = {0, 0, 0, 0};
+    for (int it = 0; it < 5; it++) {
+        for (int i = 0; i < 6; i++) {
+            const double *rowL = L + i * 10;
+            double *rowA = a + i * 4;
+            rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+            rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+            rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+            rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+            b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] +
+                             rowL[2] * betas[1] * betas[1] + rowL[3] * betas[0] * betas[2] +
+                             rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                             rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] +
+                             rowL[8] * betas[2] * betas[3] + rowL[9] * betas[3] * betas[3]);
+        }
+        qr_solve_6x4(a, b, x);
+        for (int i = 0; i < 4; i++)
+            betas[i] += x[i];
+    }
+}
+
+// camera-frame control points from betas, point cloud, sign, Horn alignment, reprojection error
+VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *betas, double *R /*9*/,
+                                  double *t)
+{
+    const int n = 5;
+    for (int i = 0; i < 4; i++)
+        e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double *v = ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++)
+                e.ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+    for (int i = 0; i < n; i++) {
+        const double *a = e.alphas + 4 * i;
+        double *pc = e.pcs + 3 * i;
+        for (int j = 0; j < 3; j++)
+            pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
+    }
+    if (e.pcs[2] < 0.0) { // solve_for_sign
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 3; j++)
+                e.ccs[i][j] = -e.ccs[i][j];
+        for (int i = 0; i < 3 * n; i++)
+            e.pcs[i] = -e.pcs[i];
+    }
+    // estimate_R_and_t
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) {
+            pc0[j] += e.pcs[3 * i + j];
+            pw0[j] += e.pws[3 * i + j];
+        }
+    for (int j = 0; j < 3; j++) {
+        pc0[j] /= n;
+        pw0[j] /= n;
+    }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const double *pc = e.pcs + 3 * i, *pw = e.pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    double At[9], wd[3], vt[9];
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            At[i * 3 + k] = abt[k * 3 + i];
+    jacobi_svd<3, 3, true>(At, wd, vt);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) // (U V^T)[i][j], U[i][k] = At[k][i], V[j][k] = vt[k][j]
+            R[i * 3 + j] = At[0 * 3 + i] * vt[0 * 3 + j] + At[1 * 3 + i] * vt[1 * 3 + j] +
+                           At[2 * 3 + i] * vt[2 * 3 + j];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] -
+                       R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) {
+        R[6] = -R[6];
+        R[7] = -R[7];
+        R[8] = -R[8];
+    }
+    t[0] = pc0[0] - dot3(R + 0, pw0);
+    t[1] = pc0[1] - dot3(R + 3, pw0);
+    t[2] = pc0[2] - dot3(R + 6, pw0);
+    // reprojection_error
+    double sum2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double *pw = e.pws + 3 * i;
+        double Xc = dot3(R + 0, pw) + t[0];
+        double Yc = dot3(R + 3, pw) + t[1];
+        double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+        double ue = e.uc + e.fu * Xc * inv_Zc;
+        double ve = e.vc + e.fv * Yc * inv_Zc;
+        double u = e.us[2 * i], v = e.us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / n;
+}
+
+// xyz5[15], uv5[10]: the subset (f32, as RANSAC's getSubset copies them); Kf: 3x3 f32 row-major.
+// Outputs rvec[3], tvec[3] (f64).
+VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
+                                double *tvec)
+{
+    const int n = 5;
+    Epnp5 e;
+    e.fu = (double)Kf[0];
+    e.fv = (double)Kf[4];
+    e.uc = (double)Kf[2];
+    e.vc = (double)Kf[5];
+    const double ifx = 1. / e.fu, ify = 1. / e.fv;
+    for (int i = 0; i < n; i++) {
+        // undistortPoints (zero distortion) -> f32 normalised coords -> back to pixels in f64
+        double x = ((double)uv5[2 * i] - e.uc) * ifx, y = ((double)uv5[2 * i + 1] - e.vc) * ify;
+        float xn = (float)x, yn = (float)y;
+        e.pws[3 * i] = xyz5[3 * i];
+        e.pws[3 * i + 1] = xyz5[3 * i + 1];
+        e.pws[3 * i + 2] = xyz5[3 * i + 2];
+        e.us[2 * i] = xn * e.fu + e.uc;
+        e.us[2 * i + 1] = yn * e.fv + e.vc;
+    }
+    // ---- choose_control_points
+    e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++)
+            e.cws[0][j] += e.pws[3 * i + j];
+    for (int j = 0; j < 3; j++)
+        e.cws[0][j] /= n;
+    {
+        double PW0[15], ptp[9], dc[3], vt[9];
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < 3; j++)
+                PW0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < n; k++)
+                    s += PW0[k * 3 + i] * PW0[k * 3 + j];
+                ptp[i * 3 + j] = s;
+            }
+        ptp[3] = ptp[1];
+        ptp[6] = ptp[2];
+        ptp[7] = ptp[5];
+        // symmetric: At == A^T == A; rows of At after the SVD = U^T
+        jacobi_svd<3, 3, true>(ptp, dc, vt);
+        for (int i = 1; i < 4; i++) {
+            double k = sqrt(dc[i - 1] / n);
+            for (int j = 0; j < 3; j++)
+                e.cws[i][j] = e.cws[0][j] + k * ptp[3 * (i - 1) + j];
+        }
+    }
+    // ---- compute_barycentric_coordinates
+    {
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 1; j < 4; j++)
+                cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
+        invert_svd<3>(cc, ci);
+        for (int i = 0; i < n; i++) {
+            const double *pi = e.pws + 3 * i;
+            double *a = e.alphas + 4 * i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) +
+                           ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
+            a[0] = 1.0f - a[1] - a[2] - a[3];
+        }
+    }
+    // ---- M (10 x 12), M^T M, its eigen-basis through the SVD
+    double ut[144], d12[12];
+    {
+        double M[120];
+        for (int i = 0; i < n; i++) {
+            const double *as = e.alphas + 4 * i;
+            double u = e.us[2 * i], v = e.us[2 * i + 1];
+            double *M1 = M + (2 * i) * 12, *M2 = M1 + 12;
+            for (int q = 0; q < 4; q++) {
+                M1[3 * q] = as[q] * e.fu;
+                M1[3 * q + 1] = 0.0;
+                M1[3 * q + 2] = as[q] * (e.uc - u);
+                M2[3 * q] = 0.0;
+                M2[3 * q + 1] = as[q] * e.fv;
+                M2[3 * q + 2] = as[q] * (e.vc - v);
+            }
+        }
+        for (int i = 0; i < 12; i++)
+            for (int j = i; j < 12; j++) {
+                double s = 0;
+                for (int k = 0; k < 2 * n; k++)
+                    s += M[k * 12 + i] * M[k * 12 + j];
+                ut[i * 12 + j] = s;
+            }
+        for (int i = 0; i < 12; i++)
+            for (int j = 0; j < i; j++)
+                ut[i * 12 + j] = ut[j * 12 + i];
+    }
+    jacobi_svd<12, 12, false>(ut, d12, nullptr);
+
+    // ---- L_6x10, rho
+    double L[60], rho[6];
+    {
+        const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+                dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+                dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+                b++;
+                if (b > 3) {
+                    a++;
+                    b = a + 1;
+                }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double *row = L + 10 * i;
+            row[0] = dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+            row[2] = dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+            row[5] = dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+            row[9] = dot3(dv[3][i], dv[3][i]);
+        }
+        rho[0] = dist2(e.cws[0], e.cws[1]);
+        rho[1] = dist2(e.cws[0], e.cws[2]);
+        rho[2] = dist2(e.cws[0], e.cws[3]);
+        rho[3] = dist2(e.cws[1], e.cws[2]);
+        rho[4] = dist2(e.cws[1], e.cws[3]);
+        rho[5] = dist2(e.cws[2], e.cws[3]);
+    }
+
+    double Rs[3][9], ts[3][3], rep[3];
+    // ---- approximation 1: betas10 columns [B11 B12 B13 B14]
+    {
+        double l[24], b4[4], betas[4];
+        for (int i = 0; i < 6; i++) {
+            l[i * 4 + 0] = L[i * 10 + 0];
+            l[i * 4 + 1] = L[i * 10 + 1];
+            l[i * 4 + 2] = L[i * 10 + 3];
+            l[i * 4 + 3] = L[i * 10 + 6];
+        }
+        solve_svd<6, 4>(l, rho, b4);
+        if (b4[0] < 0) {
+            betas[0] = sqrt(-b4[0]);
+            betas[1] = -b4[1] / betas[0];
+            betas[2] = -b4[2] / betas[0];
+            betas[3] = -b4[3] / betas[0];
+        } else {
+            betas[0] = sqrt(b4[0]);
+            betas[1] = b4[1] / betas[0];
+            betas[2] = b4[2] / betas[0];
+            betas[3] = b4[3] / betas[0];
+        }
+        epnp_gauss_newton(L, rho, betas);
+        rep[0] = epnp_compute_R_and_t(e, ut, betas, Rs[0], ts[0]);
+    }
+    // ---- approximation 2: [B11 B12 B22]
+    {
+        double l[18], b3[3], betas[4];
+        for (int i = 0; i < 6; i++) {
+            l[i * 3 + 0] = L[i * 10 + 0];
+            l[i * 3 + 1] = L[i * 10 + 1];
+            l[i * 3 + 2] = L[i * 10 + 2];
+        }
+        solve_svd<6, 3>(l, rho, b3);
+        if (b3[0] < 0) {
+            betas[0] = sqrt(-b3[0]);
+            betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0;
+        } else {
+            betas[0] = sqrt(b3[0]);
+            betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0;
+        }
+        if (b3[1] < 0)
+            betas[0] = -betas[0];
+        betas[2] = 0.0;
+        betas[3] = 0.0;
+        epnp_gauss_newton(L, rho, betas);
+        rep[1] = epnp_compute_R_and_t(e, ut, betas, Rs[1], ts[1]);
+    }
+    // ---- approximation 3: [B11 B12 B22 B13 B23]
+    {
+        double l[30], b5[5], betas[4];
+        for (int i = 0; i < 6; i++) {
+            l[i * 5 + 0] = L[i * 10 + 0];
+            l[i * 5 + 1] = L[i * 10 + 1];
+            l[i * 5 + 2] = L[i * 10 + 2];
+            l[i * 5 + 3] = L[i * 10 + 3];
+            l[i * 5 + 4] = L[i * 10 + 4];
+        }
+        solve_svd<6, 5>(l, rho, b5);
+        if (b5[0] < 0) {
+            betas[0] = sqrt(-b5[0]);
+            betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0;
+        } else {
+            betas[0] = sqrt(b5[0]);
+            betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0;
+        }
+        if (b5[1] < 0)
+            betas[0] = -betas[0];
+        betas[2] = b5[3] / betas[0];
+        betas[3] = 0.0;
+        epnp_gauss_newton(L, rho, betas);
+        rep[2] = epnp_compute_R_and_t(e, ut, betas, Rs[2], ts[2]);
+    }
+    int N = 0;
+    if (rep[1] < rep[0])
+        N = 1;
+    if (rep[2] < rep[N])
+        N = 2;
+    rodrigues_m2v(Rs[N], rvec);
+    tvec[0] = ts[N][0];
+    tvec[1] = ts[N][1];
+    tvec[2] = ts[N][2];
+}
+
+} // namespace vo

@@ -1,0 +1,48 @@
+// vo_kernels.h -- parameter / result records and launch wrappers shared by the kernel
+// translation units (pyramid.hip, lk.hip, post.hip, pnp.hip) and the C-ABI host code (capi.hip).
+#pragma once
+
+#include "vo_dev.h"
+
+namespace vo {
+
+struct LkParams {
+    int max_level;   // 3 in the reference (feature.cpp:136) -> 4 pyramid levels
+    int max_count;   // 30
+    double epsilon;  // (0.01)^2 after OpenCV's sanitising
+    float min_eig;   // 1e-3
+};
+
+struct PnpParams {
+    int iters;          // 500   (visualOdometry.cpp:168)
+    float reproj;       // 0.5f  (visualOdometry.cpp:169)
+    double confidence;  // (double)0.999f (visualOdometry.cpp:170)
+    float K[9];         // intrinsic matrix, f32 row-major = projMatrl(0:3, 0:3)
+};
+
+// per-frame result record (all f64 like OpenCV's rvec / tvec / rotation)
+struct PnpResult {
+    double rvec[3], tvec[3], R[9];
+    int n_inliers;
+    int status;   // 1 ok, 0 RANSAC found no model, <0 bad input (fewer than 5 points)
+    int niters;   // RANSAC iterations OpenCV would have executed
+    int best_iter;
+    int max_good;
+    int lm_iters;
+};
+
+void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
+void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
+                        int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
+                        const LkParams &prm, hipStream_t stream);
+void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
+                    int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
+                    int n_frames, hipStream_t stream);
+void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, const float2 *pr,
+                        size_t frame_stride, const int *n_pts, int cap, int max_pts, int n_frames, float *xyz,
+                        hipStream_t stream);
+void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                const PnpParams &prm, int32_t *subsets, double *models, int *counts, int32_t *inliers,
+                PnpResult *results, hipStream_t stream);
+
+} // namespace vo
