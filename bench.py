@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- stereo frames/sec of the MI355X hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path (pyramids -> 4-hop LK -> filter -> triangulation ->
+PnP/RANSAC) over one batch of B independent KITTI-00-shaped (1241x376) stereo frame quadruples with
+~2000 bucketed keypoints each, all inputs already resident in HBM.  Multi-GPU = replicas: each
+rank runs its own batch on its own GPU, no data-path collective; value = frames of
+all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel = fused LK, HBM-bound model,
+algorithmic bytes of SURVEY.md 8d / launch duration from HIP events on the launch stream) and
+`cpu_baseline` (the oracle, a scalar C port with OpenMP, on a bounded sample of the same frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (width, height, per_bucket, lk_max_level, description)
+    "kitti2000": (1241, 376, 6, 3, "KITTI-00-shaped 1241x376 stereo, ~2000 bucketed keypoints/frame "
+                                   "(bucket=rows/10, 6 per bucket), maxLevel 3"),
+    "kitti374": (1241, 376, 1, 3, "KITTI-00-shaped 1241x376 stereo, reference-default bucketing "
+                                  "(1 per bucket, <=374 pts), maxLevel 3"),
+    "hd4000": (1920, 1080, 4, 3, "synthetic 1920x1080 stereo, ~4000 keypoints/frame, maxLevel 3"),
+}
+
+
+def build_inputs(workload, n_quads, seed):
+    from visual_odom_amd import synth
+    w, h, per_bucket, max_level, _ = WORKLOADS[workload]
+    if (w, h) == (synth.KITTI_W, synth.KITTI_H):
+        world = synth.StereoWorld(seed=seed)
+    else:
+        world = synth.StereoWorld(seed=seed, width=w, height=h, fx=synth.KITTI_FX * w / synth.KITTI_W,
+                                  cx=w / 2.0 - 0.5, cy=h / 2.0 - 0.5, bf=synth.KITTI_BF * w / synth.KITTI_W)
+    lefts, rights, poses, _ = world.render_sequence(n_quads + 1)
+    bucket = h // 10
+    pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads)]
+    return world, lefts, rights, pts, max_level
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frame quadruples per step per GPU")
+    ap.add_argument("--quads", type=int, default=8, help="distinct rendered quadruples cycled over the batch")
+    ap.add_argument("--workload", default="kitti2000", choices=sorted(WORKLOADS))
+    ap.add_argument("--stages", default="full", choices=["full", "lk"],
+                    help="full = BASELINE config 3 (LK+tri+PnP on device); lk = config 2 (circularMatching only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    args = ap.parse_args()
+
+    import torch
+    from visual_odom_amd import replicas
+    rank, local_rank, world_size = replicas.rank_info()
+    dist = replicas.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from visual_odom_amd import _lib
+    B, S = args.frames, min(args.quads, args.frames)
+    # every rank renders its own sequence (seed by rank) = independent sequences, one per GPU
+    world, lefts, rights, pts, max_level = build_inputs(args.workload, S, 20260925 + rank)
+    w, h = world.w, world.h
+    n_pts = [len(p) for p in pts]
+    ctx = _lib.Context(local_rank, w, h, 8192, B)
+    ctx.set_params(lk_max_level=max_level)
+    n_images = 2 * (S + 1)
+    ctx.batch_configure(n_images, w, h, B)
+    # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
+    keep = []
+    for k in range(S + 1):
+        for side, img in ((0, lefts[k]), (1, rights[k])):
+            t = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+            keep.append(t)
+            torch.cuda.synchronize()
+            ctx.batch_upload_image_dev(2 * k + side, t.data_ptr(), w)
+    ctx.batch_sync()
+    quads = [[2 * (b % S), 2 * (b % S) + 1, 2 * (b % S) + 2, 2 * (b % S) + 3] for b in range(B)]
+    ctx.batch_set_quads(quads)
+    for b in range(B):
+        ctx.batch_set_points(b, pts[b % S])
+    P_l, P_r = world.proj_matrices()
+    ctx.batch_set_projection(P_l, P_r)
+    stages = _lib.STAGE_ALL if args.stages == "full" else (_lib.STAGE_PYRAMID | _lib.STAGE_LK | _lib.STAGE_FILTER)
+
+    def barrier():
+        ctx.batch_sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.batch_run(stages)
+    barrier()
+    K = args.steps
+    t0 = time.perf_counter()
+    for k in range(K):
+        ctx.batch_run_slot(stages, k % _lib.EVENT_SLOTS)
+    ctx.batch_sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed, frames_total = replicas.aggregate(dist, elapsed, B * K, dev)
+    if dist is not None:
+        dist.barrier()
+
+    # per-stage kernel time from the HIP events recorded on the launch stream during the timed steps
+    stage_ms = np.mean([ctx.batch_slot_times(k % _lib.EVENT_SLOTS) for k in range(max(0, K - _lib.EVENT_SLOTS), K)],
+                       axis=0)
+    fps = frames_total / elapsed
+    pts_per_launch = sum(n_pts[b % S] for b in range(B))
+    lk_bytes = sum(ctx.model_bytes(w, h, n_pts[b % S])[1] for b in range(B))
+    frame_bytes = sum(ctx.model_bytes(w, h, n_pts[b % S]).sum() for b in range(B)) / B
+    lk_ms = float(stage_ms[1])
+    achieved = lk_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features",
+            "value": fps, "unit": "frames/s", "n_gpus": world_size, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload][4], "stages": args.stages,
+                       "frames_per_step_per_gpu": B, "points_per_frame": float(np.mean([n_pts[b % S] for b in range(B)])),
+                       "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,
+                       "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
+                       "model_bytes_per_frame": frame_bytes,
+                       "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
+            "roofline": {"bound": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(lefts, rights, pts, world, min(args.cpu_frames, S), args.stages)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return out
+
+
+def cpu_baseline(lefts, rights, pts, world, n_frames, stages):
+    """The oracle (scalar C port of the reference's OpenCV CPU path, OpenMP over features) timed on
+    this host's cores on a bounded sample of the same frames.  Checker code is only *timed* here."""
+    from oracle import oracle as orc
+    orc.build()
+    P_l, P_r = world.proj_matrices()
+    K = world.K()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+
+    def one_frame(k, threads):
+        r = orc.circular_matching(lefts[k], rights[k], lefts[k + 1], rights[k + 1], pts[k], nthreads=threads)
+        (l0, r0, l1, r1), _ = orc.check_valid_and_remove(r["l0"], r["r0"], r["l1"], r["r1"], r["l0_ret"])
+        if stages == "full" and len(l0) >= 5:
+            xyz = orc.triangulate(P_l, P_r, l0, r0)
+            orc.solve_pnp_ransac(xyz, l1, K)
+
+    # pick the OpenMP width that is fastest on this host (a cgroup may expose fewer cores than it lists)
+    best_t, best_dt = 1, None
+    for t in sorted({1, min(avail, 8), min(avail, 32), min(avail, 128), avail}):
+        one_frame(0, t)  # warm-up (first call pays library / thread-pool start-up)
+        t0 = time.perf_counter()
+        one_frame(0, t)
+        dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best_t, best_dt = t, dt
+    reps = max(1, min(200, int(10.0 / max(best_dt * n_frames, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for k in range(n_frames):
+            one_frame(k, best_t)
+    dt = time.perf_counter() - t0
+    return {"value": reps * n_frames / dt, "unit": "frames/s", "cores": best_t, "kind": "port",
+            "sample": "%d passes over %d frame quadruples of the same workload, %.1f s wall; oracle = scalar C "
+                      "restatement of the OpenCV CPU path (no SIMD), OpenMP over features, %d threads chosen as "
+                      "fastest of the widths tried (host lists %d CPUs)" % (reps, n_frames, dt, best_t, avail)}
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,13 @@ int vo_batch_run(vo_ctx *ctx, int stages);
 /* same, bracketed per stage by HIP events on the ctx stream; blocks; ms_per_stage[VO_NUM_STAGES]
  * in the order PYRAMID, LK, FILTER, TRIANGULATE, PNP */
 int vo_batch_run_timed(vo_ctx *ctx, int stages, float *ms_per_stage);
+/* asynchronous variant: like vo_batch_run, with the per-stage HIP events of ring slot `slot`
+ * (0 <= slot < VO_EVENT_SLOTS) recorded on the ctx stream; after vo_batch_sync,
+ * vo_batch_slot_times returns the stage durations of that slot.  Lets a benchmark time K
+ * back-to-back steps without a host round trip per step. */
+#define VO_EVENT_SLOTS 256
+int vo_batch_run_slot(vo_ctx *ctx, int stages, int slot);
+int vo_batch_slot_times(vo_ctx *ctx, int slot, float *ms_per_stage);
 int vo_batch_sync(vo_ctx *ctx);
 /* results of one frame (after vo_batch_sync); any pointer may be NULL */
 int vo_batch_get_tracks(vo_ctx *ctx, int frame, float *r0, float *r1, float *l1, float *l0_ret,

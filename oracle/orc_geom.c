@@ -22,6 +22,12 @@ uint32_t orc_rng_next(uint64_t *state)
     return (uint32_t)(*state);
 }
 
+/* OpenCV calls std::hypot here.  Its last-ulp behaviour is libm specific (glibc changed it in 2.35,
+ * device libms differ again), and EPnP's 5-point null space amplifies a 1-ulp difference in a
+ * Givens angle into ~1e-6 px hypothesis differences.  The restatement therefore pins the
+ * definition to three correctly rounded IEEE operations: sqrt(fma(a, a, b*b)). */
+static inline double orc_hypot(double a, double b) { return sqrt(fma(a, a, b * b)); }
+
 /* ---- JacobiSVDImpl_<double>(At, astep, W, Vt, vstep, m, n, n1, DBL_MIN, DBL_EPSILON*10) ---
  * At: n rows of length m (row i = column i of A). On exit rows of At are the left singular
  * vectors (first n1 rows normalised), W sorted descending, Vt rows = right singular vectors. */
@@ -56,7 +62,7 @@ void orc_jacobi_svd(double *At, int astep, double *_W, double *Vt, int vstep, in
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                double beta = a - b, gamma = orc_hypot(p, beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);

@@ -39,7 +39,14 @@ static inline int reflect101(int p, int len)
 void orc_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst)
 {
     int dw = (w + 1) / 2, dh = (h + 1) / 2;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
     int *rows = (int *)malloc(sizeof(int) * (size_t)dw * 5);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
     for (int y = 0; y < dh; y++) {
         for (int k = 0; k < 5; k++) {
             int sy = reflect101(2 * y - 2 + k, h);
@@ -59,13 +66,21 @@ void orc_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst)
         }
     }
     free(rows);
+    }
 }
 
 /* lkpyramid.cpp calcSharrDeriv: rows/cols clamped by REFLECT_101, no normalisation */
 void orc_scharr(const uint8_t *src, int w, int h, int16_t *dst)
 {
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
     int *t0 = (int *)malloc(sizeof(int) * (size_t)(w + 2));
     int *t1 = (int *)malloc(sizeof(int) * (size_t)(w + 2));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
     for (int y = 0; y < h; y++) {
         const uint8_t *s0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * w;
         const uint8_t *s1 = src + (size_t)y * w;
@@ -88,6 +103,7 @@ void orc_scharr(const uint8_t *src, int w, int h, int16_t *dst)
     }
     free(t0);
     free(t1);
+    }
 }
 
 /* one pyramid level stored with a `brd`-pixel border on every side, like OpenCV's buffers */
@@ -110,6 +126,9 @@ static void level_alloc(OrcLevel *L, int w, int h, int brd)
 /* copyMakeBorder(level, ..., BORDER_REFLECT_101) */
 static void level_fill(OrcLevel *L, const uint8_t *src /* w x h contiguous */)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int y = -L->brd; y < L->h + L->brd; y++) {
         int sy = reflect101(y, L->h);
         uint8_t *d = L->img + (ptrdiff_t)y * L->stride;
@@ -176,7 +195,7 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
     (void)nthreads;
 
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) reduction(+ : iters_total)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : iters_total)
 #endif
     for (int ptidx = 0; ptidx < n; ptidx++) {
         int16_t IWin[32 * 32], dIWin[32 * 32 * 2];

@@ -1,0 +1,85 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """the CPU oracle (checker) -- built on demand with gcc"""
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def small_world():
+    from visual_odom_amd import synth
+    return synth.StereoWorld(seed=11, width=480, height=160, fx=300.0, cx=239.5, cy=79.5, bf=-160.0,
+                             tex_size=1024)
+
+
+@pytest.fixture(scope="session")
+def small_seq(small_world):
+    """3 stereo frames (2 quadruples) of the small world + keypoints of frames 0 and 1"""
+    from visual_odom_amd import synth
+    lefts, rights, poses, depths = small_world.render_sequence(3)
+    pts = [synth.select_keypoints(lefts[k], bucket=16, per_bucket=2) for k in range(2)]
+    return dict(L=lefts, R=rights, poses=poses, depths=depths, pts=pts)
+
+
+@pytest.fixture(scope="session")
+def kitti_world():
+    from visual_odom_amd import synth
+    return synth.StereoWorld(seed=20260925)
+
+
+@pytest.fixture(scope="session")
+def kitti_seq(kitti_world):
+    from visual_odom_amd import synth
+    lefts, rights, poses, depths = kitti_world.render_sequence(2)
+    pts = synth.select_keypoints(lefts[0], bucket=37, per_bucket=6)
+    return dict(L=lefts, R=rights, poses=poses, depths=depths, pts=pts)
+
+
+@pytest.fixture(scope="session")
+def host_check():
+    """device-side math headers compiled for the host with g++ (unit test of the kernel code)"""
+    import ctypes
+    src = os.path.join(ROOT, "tests", "host_check", "host_check.cpp")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libhost_check.so")
+    deps = [src] + [os.path.join(ROOT, "visual_odom_amd", "csrc", f) for f in ("vo_linalg.h", "vo_epnp.h", "vo_tri.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def volib():
+    from visual_odom_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(volib):
+    """a vo_ctx on GPU 0; fails loudly (no skip, no fallback) when the HIP path cannot run"""
+    ctx = volib.Context(0, 1920, 1080, 8192, 8)
+    yield ctx
+    ctx.close()
+
+
+def vp(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.c_void_p)

@@ -13,6 +13,7 @@ SO_PATH = os.path.join(HERE, "libvo_hip.so")
 
 VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW = 0, -1, -2, -3, -4
 STAGE_PYRAMID, STAGE_LK, STAGE_FILTER, STAGE_TRIANGULATE, STAGE_PNP, STAGE_ALL = 1, 2, 4, 8, 16, 31
+EVENT_SLOTS = 256
 STAGE_NAMES = ("pyramid", "lk", "filter", "triangulate", "pnp")
 
 # every symbol include/vo_hip.h declares (checked by the CPU test-suite against the built .so)
@@ -20,7 +21,7 @@ EXPORTS = (
     "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
     "vo_circular_match", "vo_triangulate", "vo_pnp_ransac", "vo_track_frame",
     "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
-    "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed",
+    "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
     "vo_batch_get_pyramid_level", "vo_model_bytes",
 )
@@ -208,6 +209,14 @@ class Context:
     def batch_run_timed(self, stages=STAGE_ALL):
         ms = np.zeros(5, np.float32)
         self._chk(self.lib.vo_batch_run_timed(self.h, stages, _p(ms)))
+        return ms
+
+    def batch_run_slot(self, stages, slot):
+        self._chk(self.lib.vo_batch_run_slot(self.h, stages, slot))
+
+    def batch_slot_times(self, slot):
+        ms = np.zeros(5, np.float32)
+        self._chk(self.lib.vo_batch_slot_times(self.h, slot, _p(ms)))
         return ms
 
     def batch_sync(self):

@@ -19,6 +19,7 @@ struct vo_ctx {
     vo_params prm;
     hipStream_t stream = nullptr;
     hipEvent_t ev[VO_NUM_STAGES + 1] = {};
+    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 1) for vo_batch_run_slot
     std::string err;
 
     // batch configuration
@@ -128,6 +129,9 @@ void vo_destroy(vo_ctx *c)
     for (auto &e : c->ev)
         if (e)
             (void)hipEventDestroy(e);
+    for (auto &e : c->ring)
+        if (e)
+            (void)hipEventDestroy(e);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -154,6 +158,9 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     for (auto &e : c->ev)
+        ok = ok && hipEventCreate(&e) == hipSuccess;
+    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 1), nullptr);
+    for (auto &e : c->ring)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     // worst case pyramid bytes per image (5 levels, padded strides)
     {
@@ -331,8 +338,10 @@ int vo_batch_set_projection(vo_ctx *c, const float *P_l, const float *P_r)
     return VO_OK;
 }
 
-static int run_stages(vo_ctx *c, int stages, bool timed)
+static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr)
 {
+    if (!evs)
+        evs = c->ev;
     if (c->n_images == 0)
         return fail(c, VO_ERR_STATE, "vo_batch_run before vo_batch_configure");
     if ((stages & (VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) && !c->have_P)
@@ -341,13 +350,13 @@ static int run_stages(vo_ctx *c, int stages, bool timed)
     const int B = c->n_frames, cap = c->cap;
     int e = 0;
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_PYRAMID)
         for (int l = 0; l + 1 < c->levels; l++)
             launch_pyr_down(c->d_imgs, c->n_images, l, c->lw[l + 1], c->lh[l + 1], c->stream);
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_LK) {
         LkParams lp;
@@ -362,19 +371,19 @@ static int run_stages(vo_ctx *c, int stages, bool timed)
                            c->d_status, lp, c->stream);
     }
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_FILTER)
         launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
                        c->d_idxA, c->d_nA, c->d_outB, c->d_idxB, c->d_nB, B, c->stream);
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_TRIANGULATE) // stage-B rows: 0 = l0, 1 = r0, 2 = l1, 3 = r1
         launch_triangulate(c->d_P, c->d_P + 12, c->d_outB, c->d_outB + cap, (size_t)4 * cap, c->d_nB, cap,
                            c->max_pts_set, B, c->d_xyz, c->stream);
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_PNP) {
         PnpParams pp;
@@ -389,7 +398,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed)
                    c->d_models, c->d_counts, c->d_inliers, c->d_results, c->stream);
     }
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(c->ev[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     VO_HIP_TRY(c, hipGetLastError());
     return VO_OK;
 }
@@ -411,6 +420,24 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < VO_NUM_STAGES; s++)
         VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s], c->ev[s + 1]));
+    return VO_OK;
+}
+
+int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
+{
+    if (!c || slot < 0 || slot >= VO_EVENT_SLOTS)
+        return VO_ERR_ARG;
+    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 1)]);
+}
+
+int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
+{
+    if (!c || !ms || slot < 0 || slot >= VO_EVENT_SLOTS)
+        return VO_ERR_ARG;
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 1)];
+    for (int s = 0; s < VO_NUM_STAGES; s++)
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s], evs[s + 1]));
     return VO_OK;
 }
 

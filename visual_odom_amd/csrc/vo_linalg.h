@@ -27,6 +27,10 @@
 
 namespace vo {
 
+// sqrt(a^2 + b^2) from three correctly rounded IEEE operations (mul, fma, sqrt): bit-identical on
+// the host and on gfx950, unlike libm / ocml hypot whose last ulp is implementation specific.
+VO_HD double vo_hypot(double a, double b) { return sqrt(fma(a, a, b * b)); }
+
 // One-sided (Hestenes) Jacobi SVD of the M x N matrix whose COLUMNS are the rows of At
 // (At is N rows of length M, row stride M).  On return: W[N] descending singular values,
 // rows of At = left singular vectors (normalised), rows of Vt = right singular vectors.
@@ -64,7 +68,7 @@ VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                double beta = a - b, gamma = vo_hypot(p, beta);
                 double c, s;
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
