@@ -4,9 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path (pyramids -> 4-hop LK -> filter -> triangulation ->
-PnP/RANSAC) over one batch of B independent KITTI-00-shaped (1241x376) stereo frame quadruples with
-~2000 bucketed keypoints each, all inputs already resident in HBM.  Multi-GPU = replicas: each
+One "step" = one pass of the hot path (bordered pyramids + Scharr images of every stereo pair ->
+4-hop LK -> filter -> triangulation -> PnP/RANSAC) over one batch of B KITTI-00-shaped (1241x376)
+stereo frame quadruples with ~2000 bucketed keypoints each, all inputs already resident in HBM.  The
+batch is a SEQUENCE: B + 1 stereo pairs in the image table, frame b = (pair b, pair b + 1), so every
+step builds 2 (B + 1) pyramids -- two new images per frame, like a real sequence where the t1
+pyramids of one frame are the t0 pyramids of the next.  Multi-GPU = replicas: each
 rank runs its own batch on its own GPU, no data-path collective; value = frames of
 all ranks / max-over-ranks time.
 
@@ -47,7 +50,7 @@ def build_inputs(workload, n_quads, seed):
                                   cx=w / 2.0 - 0.5, cy=h / 2.0 - 0.5, bf=synth.KITTI_BF * w / synth.KITTI_W)
     lefts, rights, poses, _ = world.render_sequence(n_quads + 1)
     bucket = h // 10
-    pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads)]
+    pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads + 1)]
     return world, lefts, rights, pts, max_level
 
 
@@ -82,21 +85,27 @@ def main():
     n_pts = [len(p) for p in pts]
     ctx = _lib.Context(local_rank, w, h, 8192, B)
     ctx.set_params(lk_max_level=max_level)
-    n_images = 2 * (S + 1)
+    # table pair j shows rendered pair tri(j): the S + 1 rendered pairs are walked forwards then
+    # backwards, so consecutive table pairs are always consecutive rendered frames (real motion)
+    def tri(j):
+        m = j % (2 * S)
+        return m if m <= S else 2 * S - m
+
+    n_images = 2 * (B + 1)
     ctx.batch_configure(n_images, w, h, B)
     # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
-    keep = []
-    for k in range(S + 1):
-        for side, img in ((0, lefts[k]), (1, rights[k])):
-            t = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
-            keep.append(t)
-            torch.cuda.synchronize()
-            ctx.batch_upload_image_dev(2 * k + side, t.data_ptr(), w)
+    dev_imgs = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev),
+                 torch.from_numpy(np.ascontiguousarray(rights[k])).to(dev)) for k in range(S + 1)]
+    torch.cuda.synchronize()
+    for j in range(B + 1):
+        for side in (0, 1):
+            ctx.batch_upload_image_dev(2 * j + side, dev_imgs[tri(j)][side].data_ptr(), w)
     ctx.batch_sync()
-    quads = [[2 * (b % S), 2 * (b % S) + 1, 2 * (b % S) + 2, 2 * (b % S) + 3] for b in range(B)]
+    quads = [[2 * b, 2 * b + 1, 2 * b + 2, 2 * b + 3] for b in range(B)]
     ctx.batch_set_quads(quads)
+    frame_pts = [pts[tri(b)] for b in range(B)]
     for b in range(B):
-        ctx.batch_set_points(b, pts[b % S])
+        ctx.batch_set_points(b, frame_pts[b])
     P_l, P_r = world.proj_matrices()
     ctx.batch_set_projection(P_l, P_r)
     stages = _lib.STAGE_ALL if args.stages == "full" else (_lib.STAGE_PYRAMID | _lib.STAGE_LK | _lib.STAGE_FILTER)
@@ -125,9 +134,9 @@ def main():
     stage_ms = np.mean([ctx.batch_slot_times(k % _lib.EVENT_SLOTS) for k in range(max(0, K - _lib.EVENT_SLOTS), K)],
                        axis=0)
     fps = frames_total / elapsed
-    pts_per_launch = sum(n_pts[b % S] for b in range(B))
-    lk_bytes = sum(ctx.model_bytes(w, h, n_pts[b % S])[1] for b in range(B))
-    frame_bytes = sum(ctx.model_bytes(w, h, n_pts[b % S]).sum() for b in range(B)) / B
+    pts_per_launch = sum(len(p) for p in frame_pts)
+    lk_bytes = sum(ctx.model_bytes(w, h, len(p))[1] for p in frame_pts)
+    frame_bytes = sum(ctx.model_bytes(w, h, len(p)).sum() for p in frame_pts) / B
     lk_ms = float(stage_ms[1])
     achieved = lk_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
 
@@ -139,13 +148,15 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][4], "stages": args.stages,
-                       "frames_per_step_per_gpu": B, "points_per_frame": float(np.mean([n_pts[b % S] for b in range(B)])),
+                       "frames_per_step_per_gpu": B, "pyramids_per_step_per_gpu": n_images,
+                       "points_per_frame": float(np.mean([len(p) for p in frame_pts])),
                        "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes,
                        "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
             "roofline": {"bound": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": measured_traffic(args.workload, B),
                          "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch},
         }
         if not args.no_cpu_baseline and world_size == 1:
@@ -156,6 +167,21 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     return out
+
+
+def measured_traffic(workload, frames):
+    """HBM bytes per LK launch from the committed rocprofv3 PMC passes (profiles/lk_traffic.json,
+    written by tools/pmc_traffic.py from separate --pmc runs of this same command, with the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md); None when no pass matches this configuration."""
+    path = os.path.join(ROOT, "profiles", "lk_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload and rec.get("frames_per_step") == frames:
+            return rec.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(lefts, rights, pts, world, n_frames, stages):

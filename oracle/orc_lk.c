@@ -180,6 +180,18 @@ static inline int cv_floor_f(float v)
 
 static long long g_iter_count;
 long long orc_lk_last_iteration_count(void) { return g_iter_count; }
+/* histogram of the inner-iteration count of every (point, level) solve since the last reset:
+ * hist[k] = solves that executed k iterations (k = 0..100); used to size the GPU kernel's loops */
+static long long g_iter_hist[101];
+void orc_lk_iteration_histogram(long long *hist101, int reset)
+{
+    for (int i = 0; i <= 100; i++) {
+        if (hist101)
+            hist101[i] = g_iter_hist[i];
+        if (reset)
+            g_iter_hist[i] = 0;
+    }
+}
 
 /* LKTrackerInvoker::operator() for one pyramid level and a range of points */
 static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivBuf /* padded */,
@@ -283,6 +295,7 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
         nextX -= halfWin;
         nextY -= halfWin;
         float prevDX = 0, prevDY = 0;
+        int my_iters = 0;
         for (int j = 0; j < maxCount; j++) {
             int inx = cv_floor_f(nextX), iny = cv_floor_f(nextY);
             if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
@@ -291,6 +304,7 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
                 break;
             }
             iters_total++;
+            my_iters++;
             a = nextX - inx;
             b = nextY - iny;
             iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
@@ -341,6 +355,10 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
             prevDX = dx;
             prevDY = dy;
         }
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        g_iter_hist[my_iters]++;
 
         /* status[ptidx] && err && level == 0 && !(flags & OPTFLOW_LK_GET_MIN_EIGENVALS) */
         if (status[ptidx] && err && level == 0) {

@@ -42,6 +42,8 @@ int orc_calc_optical_flow_pyr_lk(const uint8_t *prev, const uint8_t *next, int w
                                  double min_eig_threshold, int accum_mode, int nthreads);
 /* number of LK inner iterations executed by the last call, summed over points/levels (bench) */
 long long orc_lk_last_iteration_count(void);
+/* hist101[k] = (point, level) solves that ran k inner iterations since the last reset */
+void orc_lk_iteration_histogram(long long *hist101, int reset);
 
 /* ---------- feature.cpp:76-148 : circularMatching + deleteUnmatchFeaturesCircle ------- */
 /* pts_l0 [n*2] in; outputs sized n*2 floats each; ages [n_ages] in/out (ages += 1, then

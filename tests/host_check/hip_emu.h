@@ -1,0 +1,206 @@
+// hip_emu.h -- TEST ONLY.  A tiny single-workgroup SIMT emulator so the CPU test-suite can execute
+// the *real* kernel sources (lk.hip, pyramid.hip) without a GPU: every work-item of one workgroup
+// is a ucontext coroutine; a cross-lane operation (DPP, readlane, readfirstlane) or a barrier
+// yields to a round-robin scheduler, so all lanes arrive before any proceeds -- which is the
+// lock-step the hardware provides inside a wavefront.  Control flow must be wave-uniform around
+// cross-lane operations (it is in these kernels).  Semantics of the DPP controls follow the CDNA3/4
+// ISA manual ("DPP_CTRL": quad_perm, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31 with
+// row_mask / bank_mask / bound_ctrl).  Not a product path: libvo_hip never includes this.
+#pragma once
+#define VO_HOST_EMUL 1
+
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct float2 {
+    float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct EmuIdx {
+    unsigned x, y, z;
+};
+typedef void *hipStream_t;
+
+namespace emu {
+
+struct Block {
+    int n = 0;
+    ucontext_t main;
+    std::vector<ucontext_t> ctx;
+    char *stacks = nullptr;
+    std::vector<char> done;
+    std::vector<uint64_t> xbuf;
+    int cur = 0;
+    std::function<void()> body;
+};
+inline Block *&current()
+{
+    static Block *b = nullptr;
+    return b;
+}
+inline EmuIdx &tidx()
+{
+    static EmuIdx t{0, 0, 0};
+    return t;
+}
+inline EmuIdx &bidx()
+{
+    static EmuIdx t{0, 0, 0};
+    return t;
+}
+inline EmuIdx &bdim()
+{
+    static EmuIdx t{1, 1, 1};
+    return t;
+}
+
+inline void yield()
+{
+    Block *b = current();
+    swapcontext(&b->ctx[b->cur], &b->main);
+}
+
+inline void trampoline()
+{
+    Block *b = current();
+    b->body();
+    b->done[b->cur] = 1;
+    swapcontext(&b->ctx[b->cur], &b->main);
+}
+
+// run `body` once per work-item of a workgroup of n threads (threadIdx.x = 0 .. n-1)
+inline void run_block(int n, unsigned bx, unsigned by, unsigned bz, const std::function<void()> &body)
+{
+    static const size_t STACK = 64 * 1024;
+    static std::vector<char> pool; // reused across blocks (no re-zeroing)
+    if (pool.size() < (size_t)n * STACK)
+        pool.resize((size_t)n * STACK);
+    Block blk;
+    blk.n = n;
+    blk.ctx.resize(n);
+    blk.stacks = pool.data();
+    blk.done.assign(n, 0);
+    blk.xbuf.assign(n, 0);
+    blk.body = body;
+    current() = &blk;
+    bidx() = EmuIdx{bx, by, bz};
+    bdim() = EmuIdx{(unsigned)n, 1, 1};
+    for (int i = 0; i < n; i++) {
+        getcontext(&blk.ctx[i]);
+        blk.ctx[i].uc_stack.ss_sp = blk.stacks + (size_t)i * STACK;
+        blk.ctx[i].uc_stack.ss_size = STACK;
+        blk.ctx[i].uc_link = &blk.main;
+        makecontext(&blk.ctx[i], (void (*)())trampoline, 0);
+    }
+    for (;;) {
+        bool any = false;
+        for (int i = 0; i < n; i++) {
+            if (blk.done[i])
+                continue;
+            any = true;
+            blk.cur = i;
+            tidx() = EmuIdx{(unsigned)i, 0, 0};
+            swapcontext(&blk.main, &blk.ctx[i]);
+        }
+        if (!any)
+            break;
+    }
+    current() = nullptr;
+}
+
+inline int lane_id() { return current()->cur; }
+
+// every lane publishes `v`, then reads the value lane `src` published (src < 0: returns `fallback`)
+inline uint32_t exchange(uint32_t v, int src, uint32_t fallback)
+{
+    Block *b = current();
+    b->xbuf[b->cur] = v;
+    yield();
+    uint32_t r = src >= 0 ? (uint32_t)b->xbuf[src] : fallback;
+    yield();
+    return r;
+}
+
+inline int dpp_source(int lane, int ctrl)
+{
+    const int row = lane & ~15, l16 = lane & 15;
+    if (ctrl >= 0 && ctrl <= 0xff)
+        return (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);
+    if (ctrl == 0x141)
+        return (lane & ~7) + (7 - (lane & 7));
+    if (ctrl == 0x140)
+        return row + (15 - l16);
+    if (ctrl == 0x142)
+        return row >= 16 ? row - 1 : -1;
+    if (ctrl == 0x143)
+        return (lane & 63) >= 32 ? (lane & ~63) + 31 : -1;
+    abort(); // control not modelled
+}
+
+} // namespace emu
+
+#define threadIdx (emu::tidx())
+#define blockIdx (emu::bidx())
+#define blockDim (emu::bdim())
+
+static inline void __syncthreads() { emu::yield(); }
+static inline int __float2int_rn(float v) { return (int)lrintf(v); }
+static inline int __float_as_int(float v)
+{
+    int i;
+    memcpy(&i, &v, 4);
+    return i;
+}
+static inline float __int_as_float(int i)
+{
+    float v;
+    memcpy(&v, &i, 4);
+    return v;
+}
+
+static inline int emu_readfirstlane(int v)
+{
+    const int wave0 = emu::lane_id() & ~63;
+    return (int)emu::exchange((uint32_t)v, wave0, 0);
+}
+static inline int emu_readlane(int v, int lane)
+{
+    const int wave0 = emu::lane_id() & ~63;
+    return (int)emu::exchange((uint32_t)v, wave0 + lane, 0);
+}
+static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    const int lane = emu::lane_id();
+    const int wl = lane & 63;
+    int s = emu::dpp_source(wl, ctrl);
+    const bool enabled = ((row_mask >> (wl >> 4)) & 1) && ((bank_mask >> ((wl & 15) >> 2)) & 1);
+    const uint32_t got = emu::exchange((uint32_t)src, s < 0 ? -1 : (lane & ~63) + s, 0);
+    if (!enabled)
+        return old;
+    if (s < 0)
+        return bound_ctrl ? 0 : old;
+    return (int)got;
+}
+static inline uint32_t emu_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> (8 * (sh & 3)));
+}

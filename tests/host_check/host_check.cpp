@@ -1,8 +1,12 @@
 // host_check.cpp -- TEST ONLY.  Compiles the VO_HD device-side math headers (vo_linalg.h,
-// vo_epnp.h, vo_tri.h) with g++ so the CPU test-suite can compare the *same source* the kernels
+// vo_epnp.h, vo_tri.h, vo_lkmath.h) with g++ so the CPU test-suite can compare the *same source* the kernels
 // run against the oracle without a GPU.  Not a product path: libvo_hip never links this.
+#include <stdint.h>
+#include <string.h>
+
 #include "../../visual_odom_amd/csrc/vo_epnp.h"
 #include "../../visual_odom_amd/csrc/vo_linalg.h"
+#include "../../visual_odom_amd/csrc/vo_lkmath.h"
 #include "../../visual_odom_amd/csrc/vo_tri.h"
 
 extern "C" {
@@ -18,4 +22,54 @@ void hc_triangulate(const float *Pl, const float *Pr, const float *pl, const flo
         vo::triangulate_one(Pl, Pr, pl[2 * i], pl[2 * i + 1], pr[2 * i], pr[2 * i + 1], xyz + 3 * i);
 }
 void hc_solve6(const double *A, const double *b, double *x) { vo::solve_svd<6, 6>(A, b, x); }
+
+// LK packed pixel arithmetic (vo_lkmath.h): n row segments, each 8 + 8 bytes / 8 + 8 Scharr dwords
+void hc_bilinear7_u8(const uint8_t *top8, const uint8_t *bot8, const int *w4, int n, int16_t *val7)
+{
+    for (int i = 0; i < n; i++) {
+        uint32_t t[2], b[2], out[4];
+        memcpy(t, top8 + 8 * i, 8);
+        memcpy(b, bot8 + 8 * i, 8);
+        const int *w = w4 + 4 * i;
+        vo::bilinear7_u8(t[0], t[1], b[0], b[1], vo::pack_w(w[0], w[1]), vo::pack_w(w[2], w[3]), out);
+        for (int k = 0; k < 7; k++)
+            val7[7 * i + k] = (int16_t)((out[k / 2] >> (16 * (k & 1))) & 0xffff);
+        val7[7 * i + 6] = (int16_t)(out[3] & 0xffff);
+        if ((out[3] >> 16) != 0)
+            val7[7 * i] = 0x7fff; // the unused 8th slot must stay zero
+    }
+}
+void hc_bilinear7_deriv(const uint32_t *dt8, const uint32_t *db8, const int *w4, int n, int16_t *ix7, int16_t *iy7)
+{
+    for (int i = 0; i < n; i++) {
+        uint32_t ix[4], iy[4];
+        const int *w = w4 + 4 * i;
+        vo::bilinear7_deriv(dt8 + 8 * i, db8 + 8 * i, vo::pack_w(w[0], w[1]), vo::pack_w(w[2], w[3]), ix, iy);
+        for (int k = 0; k < 7; k++) {
+            ix7[7 * i + k] = (int16_t)((ix[k / 2] >> (16 * (k & 1))) & 0xffff);
+            iy7[7 * i + k] = (int16_t)((iy[k / 2] >> (16 * (k & 1))) & 0xffff);
+        }
+        if ((ix[3] >> 16) != 0 || (iy[3] >> 16) != 0)
+            ix7[7 * i] = 0x7fff;
+    }
+}
+// b1 += diff * Ix over packed pairs, exactly as the kernel's inner loop
+void hc_diff_dot(const int16_t *val7, const int16_t *I7, const int16_t *ix7, int n, int *b1)
+{
+    for (int i = 0; i < n; i++) {
+        int acc = 0;
+        for (int m = 0; m < 4; m++) {
+            auto pk = [&](const int16_t *a) {
+                uint32_t lo = (uint16_t)a[7 * i + 2 * m], hi = 2 * m + 1 < 7 ? (uint16_t)a[7 * i + 2 * m + 1] : 0u;
+                return lo | (hi << 16);
+            };
+            acc = vo::sdot2(vo::pk_sub_i16(pk(val7), pk(I7)), pk(ix7), acc);
+        }
+        b1[i] = acc;
+    }
+}
+uint32_t hc_scharr4(const int *p8)
+{
+    return vo::scharr4_packed(p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]);
+}
 }

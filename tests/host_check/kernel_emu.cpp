@@ -1,0 +1,130 @@
+// kernel_emu.cpp -- TEST ONLY.  Executes the real kernel sources (pyramid.hip, lk.hip) on the CPU
+// through the coroutine SIMT emulator in hip_emu.h, so that the CPU test-suite can compare the
+// kernels' complete data path (bordered pyramid layout, Scharr images, lane mapping, packed pixel
+// arithmetic, DPP reductions, tile handling) with the oracle without a GPU.  Not a product path.
+#include "hip_emu.h"
+
+#include "../../visual_odom_amd/csrc/lk.hip"
+#include "../../visual_odom_amd/csrc/pyramid.hip"
+
+#include <vector>
+
+namespace {
+
+struct Plan {
+    int levels = 0;
+    int lw[VO_MAX_LEVELS], lh[VO_MAX_LEVELS], ls[VO_MAX_LEVELS];
+    size_t off[VO_MAX_LEVELS], total = 0;
+};
+
+// the geometry libvo_hip plans in capi.hip (plan_levels / level_stride)
+Plan plan(int w, int h, int max_level)
+{
+    Plan p;
+    int cw = w, ch = h, l = 0;
+    size_t off = 0;
+    for (;; l++) {
+        p.lw[l] = cw;
+        p.lh[l] = ch;
+        p.ls[l] = (VO_BX + cw + VO_BY + 15) / 16 * 16;
+        p.off[l] = off;
+        off += (size_t)p.ls[l] * (ch + 2 * VO_BY);
+        off = (off + 255) / 256 * 256;
+        int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+        if (l == max_level || l + 1 >= VO_MAX_LEVELS || nw <= 21 || nh <= 21)
+            break;
+        cw = nw;
+        ch = nh;
+    }
+    p.levels = l + 1;
+    p.total = off;
+    return p;
+}
+
+template <typename F>
+void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
+{
+    for (unsigned z = 0; z < gz; z++)
+        for (unsigned y = 0; y < gy; y++)
+            for (unsigned x = 0; x < gx; x++)
+                emu::run_block(threads, x, y, z, body);
+}
+
+} // namespace
+
+extern "C" {
+
+// imgs: n_img images of w x h (contiguous).  Builds every pyramid with the emulated kernels.
+// lvl_out / der_out (optional): interior of level `want_level` of image 0 (w_l*h_l bytes / dwords).
+// Then tracks pts [n][2] through the quad (0,1,2,3) with the emulated LK kernel.
+int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want_level, uint8_t *lvl_out,
+           uint32_t *der_out, int *lvl_w, int *lvl_h, const float *pts, int n, int max_count, double eps,
+           float min_eig, int aligned_lds, float *trk /* [4][n][2] */, uint8_t *status /* [4][n] */)
+{
+    using namespace vo;
+    Plan p = plan(w, h, max_level);
+    std::vector<uint8_t> pix(p.total * n_img, 0xA5); // poison: any read of unwritten border shows up
+    std::vector<uint32_t> der(p.total * n_img, 0);
+    std::vector<PyrImage> tab(n_img);
+    for (int i = 0; i < n_img; i++) {
+        memset(&tab[i], 0, sizeof(PyrImage));
+        for (int l = 0; l < p.levels; l++) {
+            size_t org = (size_t)i * p.total + p.off[l] + (size_t)VO_BY * p.ls[l] + VO_BX;
+            tab[i].lvl[l] = pix.data() + org;
+            tab[i].der[l] = der.data() + org;
+            tab[i].w[l] = p.lw[l];
+            tab[i].h[l] = p.lh[l];
+            tab[i].stride[l] = p.ls[l];
+        }
+        for (int y = 0; y < h; y++)
+            memcpy(tab[i].lvl[0] + (ptrdiff_t)y * p.ls[0], imgs + ((size_t)i * h + y) * w, w);
+    }
+    const PyrImage *d_imgs = tab.data();
+    auto fill = [&](int l) {
+        launch((p.ls[l] + 255) / 256, p.lh[l] + 2 * VO_BY, n_img, 256, [&] { border_fill_kernel(d_imgs, l); });
+    };
+    fill(0);
+    for (int l = 0; l + 1 < p.levels; l++) {
+        launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
+        fill(l + 1);
+    }
+    launch((w + 255) / 256, (h + 3) / 4, n_img * p.levels, 256, [&] { scharr_kernel(d_imgs, p.levels); });
+
+    if (want_level >= 0 && want_level < p.levels) {
+        const int l = want_level;
+        *lvl_w = p.lw[l];
+        *lvl_h = p.lh[l];
+        for (int y = 0; y < p.lh[l]; y++) {
+            if (lvl_out)
+                memcpy(lvl_out + (size_t)y * p.lw[l], tab[0].lvl[l] + (ptrdiff_t)y * p.ls[l], p.lw[l]);
+            if (der_out)
+                memcpy(der_out + (size_t)y * p.lw[l], tab[0].der[l] + (ptrdiff_t)y * p.ls[l], 4 * (size_t)p.lw[l]);
+        }
+    }
+    if (n <= 0 || n_img < 4)
+        return p.levels;
+
+    Quad quad{0, 1, 2, 3};
+    LkParams prm;
+    prm.max_level = p.levels - 1;
+    prm.max_count = max_count;
+    prm.epsilon = eps * eps;
+    prm.min_eig = min_eig;
+    std::vector<float2> out((size_t)4 * n);
+    const int cap = n, n_frames = 1, fpg = 1, parts = 8, ppp = (n + parts - 1) / parts;
+    for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
+        if (aligned_lds)
+            emu::run_block(64, b, 0, 0, [&] {
+                lk_circular_kernel<true>(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(),
+                                         status, prm);
+            });
+        else
+            emu::run_block(64, b, 0, 0, [&] {
+                lk_circular_kernel<false>(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(),
+                                          status, prm);
+            });
+    }
+    memcpy(trk, out.data(), sizeof(float2) * 4 * (size_t)n);
+    return p.levels;
+}
+}

@@ -48,3 +48,87 @@ def test_rodrigues_bit_identical(orc, host_check):
         back = np.zeros(3)
         host_check.hc_rodrigues_m2v(vp(R1), vp(back))
         assert np.array_equal(back, orc.rodrigues(R0))
+
+
+# ---------------------------------------------------------------------------------------------
+# vo_lkmath.h: the packed v_perm / v_dot2 pixel arithmetic of the LK kernel against the plain
+# DESCALE formulas of OpenCV's LKTrackerInvoker (lkpyramid.cpp), incl. the extreme operands
+def _weights(rng, n):
+    a, b = rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32)
+    a[:4], b[:4] = [0, 0, 1 - 2**-20, 0.5], [0, 1 - 2**-20, 0, 0.5]
+    one = np.float32(1)
+    s = np.float32(1 << 14)
+    w00 = np.rint((one - a) * (one - b) * s).astype(np.int32)
+    w01 = np.rint(a * (one - b) * s).astype(np.int32)
+    w10 = np.rint((one - a) * b * s).astype(np.int32)
+    w11 = (1 << 14) - w00 - w01 - w10
+    return np.ascontiguousarray(np.stack([w00, w01, w10, w11], 1).astype(np.int32))
+
+
+def _descale(x, n):
+    return (x + (1 << (n - 1))) >> n
+
+
+def test_lk_bilinear_u8_exact(host_check):
+    rng = np.random.default_rng(5)
+    n = 20000
+    top = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    bot = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    top[:8], bot[:8] = 255, 255
+    top[8:16], bot[8:16] = 0, 255
+    w = _weights(rng, n)
+    w[4:8] = [[16384, 0, 0, 0], [0, 16384, 0, 0], [0, 0, 16384, 0], [0, 0, 0, 16384]]
+    got = np.zeros((n, 7), np.int16)
+    host_check.hc_bilinear7_u8(vp(top), vp(bot), vp(w), n, vp(got))
+    t, b = top.astype(np.int64), bot.astype(np.int64)
+    ref = _descale(t[:, :7] * w[:, [0]] + t[:, 1:] * w[:, [1]] + b[:, :7] * w[:, [2]] + b[:, 1:] * w[:, [3]], 9)
+    assert np.array_equal(got, ref)
+    assert ref.max() == 8160
+
+
+def test_lk_bilinear_deriv_exact(host_check):
+    rng = np.random.default_rng(6)
+    n = 20000
+    # true Scharr samples are in [-4080, 4080]; stored pre-multiplied by 4
+    dx = rng.integers(-4080, 4081, (2, n, 8)).astype(np.int64)
+    dy = rng.integers(-4080, 4081, (2, n, 8)).astype(np.int64)
+    dx[:, :4], dy[:, :4] = 4080, -4080
+    dx[:, 4:8], dy[:, 4:8] = -4080, 4080
+    packed = (((dx * 4) & 0xffff) | (((dy * 4) & 0xffff) << 16)).astype(np.uint32)
+    w = _weights(rng, n)
+    ix, iy = np.zeros((n, 7), np.int16), np.zeros((n, 7), np.int16)
+    host_check.hc_bilinear7_deriv(vp(np.ascontiguousarray(packed[0])), vp(np.ascontiguousarray(packed[1])), vp(w), n,
+                                  vp(ix), vp(iy))
+    for got, d in ((ix, dx), (iy, dy)):
+        ref = _descale(d[0][:, :7] * w[:, [0]] + d[0][:, 1:] * w[:, [1]] + d[1][:, :7] * w[:, [2]] +
+                       d[1][:, 1:] * w[:, [3]], 14)
+        assert np.array_equal(got, ref)
+
+
+def test_lk_diff_dot_exact(host_check):
+    rng = np.random.default_rng(7)
+    n = 5000
+    val = rng.integers(0, 8161, (n, 7)).astype(np.int16)
+    I = rng.integers(0, 8161, (n, 7)).astype(np.int16)
+    ix = rng.integers(-4080, 4081, (n, 7)).astype(np.int16)
+    val[0], I[0], ix[0] = 8160, 0, 4080       # largest per-lane partial: 7 * 8160 * 4080 < 2^28
+    val[1], I[1], ix[1] = 0, 8160, 4080
+    b1 = np.zeros(n, np.int32)
+    host_check.hc_diff_dot(vp(val), vp(I), vp(ix), n, vp(b1))
+    ref = ((val.astype(np.int64) - I) * ix).sum(1)
+    assert np.array_equal(b1, ref) and abs(ref).max() < 2**28
+
+
+def test_scharr_packed_matches_oracle(orc, host_check):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    img[4, 5], img[3:6, 4], img[3:6, 6] = 0, 255, 0
+    d = orc.scharr(img).astype(np.int64)
+    host_check.hc_scharr4.restype = C.c_uint32
+    for y in range(1, 8):
+        for x in range(1, 10):
+            p = img[y - 1:y + 2, x - 1:x + 2].astype(np.int32)
+            p8 = np.ascontiguousarray([p[0, 0], p[0, 1], p[0, 2], p[1, 0], p[1, 2], p[2, 0], p[2, 1], p[2, 2]], np.int32)
+            v = host_check.hc_scharr4(vp(p8))
+            gx, gy = np.array([v & 0xffff, v >> 16], np.uint16).view(np.int16)
+            assert gx == 4 * d[y, x, 0] and gy == 4 * d[y, x, 1]

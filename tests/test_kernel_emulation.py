@@ -1,0 +1,110 @@
+"""The real kernel sources (pyramid.hip, lk.hip) executed on the CPU through the coroutine SIMT
+emulator of tests/host_check (hip_emu.h / kernel_emu.cpp) and compared with the oracle: bordered
+pyramid layout, Scharr images, lane mapping, packed pixel arithmetic, DPP reductions, search-tile
+handling -- everything of the LK data path except the silicon.  The -m gpu tests repeat the same
+comparisons on the MI355X through the C ABI; this file is what lets a kernel change be checked
+before any GPU time is spent.  Unit test of device code, not a product path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, vp
+
+
+@pytest.fixture(scope="module")
+def kemu():
+    src_dir = os.path.join(ROOT, "tests", "host_check")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libkernel_emu.so")
+    csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
+    deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
+    deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
+                               os.path.join(src_dir, "kernel_emu.cpp")])
+    lib = C.CDLL(so)
+    lib.ke_run.restype = C.c_int
+    return lib
+
+
+def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.01, min_eig=1e-3, aligned=0):
+    imgs = np.ascontiguousarray(np.stack(imgs), np.uint8)
+    n_img, h, w = imgs.shape
+    pts = np.zeros((0, 2), np.float32) if pts is None else np.ascontiguousarray(pts, np.float32)
+    n = len(pts)
+    lvl = np.zeros((h, w), np.uint8)
+    der = np.zeros((h, w), np.uint32)
+    lw, lh = C.c_int(0), C.c_int(0)
+    trk = np.zeros((4, max(n, 1), 2), np.float32)
+    st = np.zeros((4, max(n, 1)), np.uint8)
+    levels = lib.ke_run(vp(imgs), n_img, w, h, max_level, want_level, vp(lvl), vp(der), C.byref(lw), C.byref(lh),
+                        vp(pts), n, max_count, C.c_double(eps), C.c_float(min_eig), aligned, vp(trk), vp(st))
+    lw, lh = lw.value, lh.value
+    return dict(levels=levels, lvl=lvl.ravel()[:lw * lh].reshape(lh, lw), der=der.ravel()[:lw * lh].reshape(lh, lw),
+                trk=trk[:, :n], status=st[:, :n])
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(100, 200), (97, 131), (45, 53)])
+def test_emulated_pyramid_and_scharr_match_oracle(kemu, orc, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    ref = orc.build_pyramid(img, 3)
+    expect = 1
+    hh, ww = shape
+    while expect < 4 and (ww + 1) // 2 > 21 and (hh + 1) // 2 > 21:
+        ww, hh, expect = (ww + 1) // 2, (hh + 1) // 2, expect + 1
+    for l in range(expect):
+        r = ke_run(kemu, [img], want_level=l)
+        assert r["levels"] == expect
+        assert np.array_equal(r["lvl"], ref[l]), l
+        d = orc.scharr(ref[l]).astype(np.int64) * 4
+        packed = ((d[..., 0] & 0xffff) | ((d[..., 1] & 0xffff) << 16)).astype(np.uint32)
+        assert np.array_equal(r["der"], packed), l
+
+
+def _oracle_hops(orc, L0, R0, L1, R1, pts, **kw):
+    p1, s1, _ = orc.calc_optical_flow_pyr_lk(L0, R0, pts, **kw)
+    p2, s2, _ = orc.calc_optical_flow_pyr_lk(R0, R1, p1, **kw)
+    p3, s3, _ = orc.calc_optical_flow_pyr_lk(R1, L1, p2, **kw)
+    p4, s4, _ = orc.calc_optical_flow_pyr_lk(L1, L0, p3, **kw)
+    return np.stack([p1, p2, p3, p4]), np.stack([s1, s2, s3, s4])
+
+
+@pytest.mark.parametrize("aligned", [0, 1])
+def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq, aligned):
+    s = small_seq
+    imgs = [s["L"][0], s["R"][0], s["L"][1], s["R"][1]]
+    border = np.array([[0, 0], [479, 159], [2.5, 80.25], [476.2, 10.7], [240, 1.1], [250.4, 158.9],
+                       [-5, 50], [100, -3], [520, 100], [12.5, 12.5], [-25, 80], [240, 185]], np.float32)
+    pts = np.vstack([s["pts"][0][::6], border]).astype(np.float32)
+    r = ke_run(kemu, imgs, pts, aligned=aligned)
+    ref, st = _oracle_hops(orc, *imgs, pts)
+    assert np.array_equal(r["status"], st)
+    assert np.array_equal(bits(r["trk"]), bits(ref))
+    assert st[:, :len(pts) - len(border)].mean() > 0.5
+
+
+def test_emulated_lk_large_motion_and_params(kemu, orc):
+    """big flow (search tile re-fetched mid-iteration), fractional / out-of-image start points,
+    non-reference parameters"""
+    from test_oracle_images import smooth_image
+    w, h = 256, 128
+    imgs = [smooth_image(w, h, seed=9), smooth_image(w, h, 13.7, -9.2, seed=9), smooth_image(w, h, 20.1, 4.4, seed=9),
+            smooth_image(w, h, -6.3, 11.8, seed=9)]
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-10, w + 10, 40), rng.uniform(-10, h + 10, 40)], 1).astype(np.float32)
+    r = ke_run(kemu, imgs, pts)
+    ref, st = _oracle_hops(orc, *imgs, pts)
+    assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
+    r = ke_run(kemu, imgs, pts[:16], max_level=2, max_count=7, eps=0.03, min_eig=0.01)
+    ref, st = _oracle_hops(orc, *imgs, pts[:16], max_level=2, max_count=7, eps=0.03, min_eig=0.01)
+    assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))

@@ -29,8 +29,9 @@ struct vo_ctx {
     int max_pts_set = 0; // largest n over the frames of the batch
 
     // device memory
-    uint8_t *d_pix = nullptr; // all pyramids, image i at d_pix + i * img_bytes
-    size_t pix_capacity = 0;
+    uint8_t *d_pix = nullptr;  // all bordered pyramids, image i at d_pix + i * img_bytes
+    uint32_t *d_der = nullptr; // all Scharr pyramids (one dword per pixel), image i at d_der + i * img_bytes
+    size_t pix_capacity = 0;   // in pixels (bytes of d_pix, dwords of d_der)
     PyrImage *d_imgs = nullptr;
     Quad *d_quads = nullptr;
     float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr, *d_outB = nullptr;
@@ -65,6 +66,8 @@ int fail(vo_ctx *ctx, int code, const char *msg)
 }
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+// row pitch (pixels) of a bordered level: VO_BX left + w + at least VO_BY right, multiple of 16
+inline int level_stride(int w) { return align_up(VO_BX + w + VO_BY, 16); }
 
 // pyramid geometry exactly as buildOpticalFlowPyramid: stop when the next level would not be
 // larger than the 21 x 21 window
@@ -75,9 +78,9 @@ int plan_levels(vo_ctx *c, int w, int h)
     for (;; l++) {
         c->lw[l] = cw;
         c->lh[l] = ch;
-        c->lstride[l] = align_up(cw, 16);
+        c->lstride[l] = level_stride(cw);
         c->loff[l] = off;
-        off += (size_t)c->lstride[l] * ch;
+        off += (size_t)c->lstride[l] * (ch + 2 * VO_BY);
         off = (off + 255) / 256 * 256;
         int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
         if (l == c->prm.lk_max_level || l + 1 >= VO_MAX_LEVELS || nw <= 21 || nh <= 21)
@@ -119,7 +122,7 @@ void vo_destroy(vo_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_pix,    c->d_imgs,  c->d_quads,   c->d_pts,      c->d_trk,    c->d_outA,
+    void *ptrs[] = {c->d_der, c->d_pix,    c->d_imgs,  c->d_quads,   c->d_pts,      c->d_trk,    c->d_outA,
                     c->d_outB,   c->d_status, c->d_npts,   c->d_nA,       c->d_nB,     c->d_idxA,
                     c->d_idxB,   c->d_xyz,   c->d_P,       c->d_subsets,  c->d_inliers, c->d_models,
                     c->d_counts, c->d_results};
@@ -167,13 +170,14 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         size_t per = 0;
         int cw = max_w, ch = max_h;
         for (int l = 0; l < VO_MAX_LEVELS; l++) {
-            per += (size_t)align_up(cw, 16) * ch + 256;
+            per += (size_t)level_stride(cw) * (ch + 2 * VO_BY) + 256;
             cw = (cw + 1) / 2;
             ch = (ch + 1) / 2;
         }
         c->pix_capacity = per * (size_t)c->max_images;
     }
     ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
+    ok = ok && dmalloc(&c->d_der, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
     ok = ok && dmalloc(&c->d_quads, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_pts, B * cap) == hipSuccess;
@@ -243,7 +247,10 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     for (int i = 0; i < n_images; i++) {
         memset(&tab[i], 0, sizeof(PyrImage));
         for (int l = 0; l < c->levels; l++) {
-            tab[i].lvl[l] = c->d_pix + (size_t)i * c->img_bytes + c->loff[l];
+            // pointers address pixel (0, 0); VO_BY rows and VO_BX columns of border precede it
+            const size_t org = (size_t)i * c->img_bytes + c->loff[l] + (size_t)VO_BY * c->lstride[l] + VO_BX;
+            tab[i].lvl[l] = c->d_pix + org;
+            tab[i].der[l] = c->d_der + org;
             tab[i].w[l] = c->lw[l];
             tab[i].h[l] = c->lh[l];
             tab[i].stride[l] = c->lstride[l];
@@ -251,6 +258,8 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     }
     VO_HIP_TRY(c, hipMemcpyAsync(c->d_imgs, tab.data(), sizeof(PyrImage) * n_images, hipMemcpyHostToDevice,
                                  c->stream));
+    // the Scharr border is BORDER_CONSTANT 0 (and stays 0: scharr_kernel writes interiors only)
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_der, 0, sizeof(uint32_t) * c->img_bytes * (size_t)n_images, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_images = n_images;
     c->n_frames = n_frames;
@@ -271,7 +280,7 @@ static int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemc
     if (idx < 0 || idx >= c->n_images || !src || stride < c->w)
         return fail(c, VO_ERR_ARG, "vo_batch_upload_image: bad index / stride");
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0];
+    uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX;
     VO_HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->lstride[0], src, (size_t)stride, (size_t)c->w, (size_t)c->h,
                                    kind, c->stream));
     return VO_OK;
@@ -352,9 +361,14 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
-    if (stages & VO_STAGE_PYRAMID)
-        for (int l = 0; l + 1 < c->levels; l++)
+    if (stages & VO_STAGE_PYRAMID) {
+        launch_border_fill(c->d_imgs, c->n_images, 0, c->lstride[0], c->lh[0], c->stream);
+        for (int l = 0; l + 1 < c->levels; l++) {
             launch_pyr_down(c->d_imgs, c->n_images, l, c->lw[l + 1], c->lh[l + 1], c->stream);
+            launch_border_fill(c->d_imgs, c->n_images, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
+        }
+        launch_scharr(c->d_imgs, c->n_images, c->levels, c->lw[0], c->lh[0], c->stream);
+    }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
@@ -576,7 +590,8 @@ int vo_batch_get_pyramid_level(vo_ctx *c, int idx, int level, uint8_t *out, int 
         *h_l = c->lh[level];
     if (out) {
         VO_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)c->lw[level],
-                                       c->d_pix + (size_t)idx * c->img_bytes + c->loff[level],
+                                       c->d_pix + (size_t)idx * c->img_bytes + c->loff[level] +
+                                           (size_t)VO_BY * c->lstride[level] + VO_BX,
                                        (size_t)c->lstride[level], (size_t)c->lw[level], (size_t)c->lh[level],
                                        hipMemcpyDeviceToHost, c->stream));
         VO_HIP_TRY(c, hipStreamSynchronize(c->stream));

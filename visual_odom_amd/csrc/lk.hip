@@ -6,83 +6,79 @@
 // Semantics follow OpenCV's CPU LKTrackerInvoker: 14-bit fixed-point bilinear weights, int16
 // template (I*32, Scharr Ix/Iy), 2x2 structure tensor, min-eigenvalue test, <=30 Gauss-Newton
 // iterations with the eps^2 and oscillation stops, +-winSize admissibility window, final in-bounds
-// status check.  The five sums A11/A12/A22/b1/b2 are accumulated exactly (int32 per lane, int64
-// across the wave) so the result does not depend on reduction order; the 2x2 solve is plain f32
-// with contraction off.
+// status check.  The five sums A11/A12/A22/b1/b2 are accumulated exactly in integers (so the result
+// does not depend on reduction order) and rounded to f32 once; the 2x2 solve is plain f32 with
+// contraction off.
 //
 // Mapping (CDNA4): ONE WAVEFRONT PER FEATURE, one single-wave workgroup per feature.  A feature is
 // a serial chain (4 hops x 4 levels x <=30 iterations) but independent of every other feature, so
 // the wave keeps all per-feature state in registers and never synchronises with another wave.
-//   lane l -> window row r = l/3, column segment s = l%3 (7 px): 63 lanes cover the 21x21 window,
-//   each lane keeps its 7 template samples (I, Ix, Iy) in VGPRs for the whole level.
-//   LDS per wave: 24x32 u8 template source tile, 22x22 packed (Ix,Iy) Scharr tile, 40x48 u8 search
-//   tile of J that is re-fetched only when the window leaves it.  Tiles are filled with aligned
-//   dword loads (rows of the pyramid are 16-B aligned); tiles touching the image border take a
-//   byte path that applies REFLECT_101.
+//   lane l -> window row r = l/3, column segment s = l%3 (7 px): 63 lanes cover the 21x21 window.
+//   Template: each lane loads its 2 x 8 pixels and 2 x 8 Scharr samples straight from the bordered
+//   pyramid (no border path, no staging) and keeps the 7 samples of I, Ix, Iy packed two per VGPR
+//   (12 VGPRs) for the whole level.
+//   Search image J: a 40 x 48 byte tile in LDS (1920 B per wave), filled with 16-byte loads and
+//   re-fetched only when the window leaves it; one iteration reads two unaligned 8-byte rows.
+//   Pixel arithmetic: v_perm_b32 / v_dot2_u32_u16 / v_dot2_i32_i16 / v_pk_sub_i16 (vo_lkmath.h).
+//   Reductions: v_add_u32_dpp butterflies (vo_dev.h wave_sum_exact_f32), no LDS round trips.
+// Grid: blocks are numbered so that (dispatcher: block b -> XCD b % 8) all features of one frame
+// run on ONE XCD, i.e. the frame's four pyramids are pulled into one L2 only, eight frames at a time.
+// Batches of fewer than 8 frames split each frame's feature list into contiguous parts over 8/fpg XCDs.
 #include "vo_kernels.h"
+#include "vo_lkmath.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace vo {
 
 constexpr int LK_WIN = 21;
-constexpr int LK_IT_W = 32, LK_IT_H = 24, LK_IT_STRIDE = 36; // template source tile (bytes)
-constexpr int LK_D_W = 22;                                    // derivative tile 22 x 22 dwords
-constexpr int LK_JT_W = 48, LK_JT_H = 40, LK_JT_STRIDE = 52;  // search tile (bytes)
+constexpr int LK_JT_W = 48, LK_JT_H = 40; // search tile (bytes x rows), LDS row stride = LK_JT_W
 constexpr int LK_W_BITS = 14;
 
-__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+struct __attribute__((packed, aligned(1))) LkU2 {
+    uint32_t lo, hi;
+};
+struct __attribute__((packed, aligned(4))) LkU4 {
+    uint32_t a, b, c, d;
+};
 
-// fill a (rows x wbytes) u8 tile at LDS `dst` (row stride dstride) from image coords (x0, y0);
-// x0 must be a multiple of 4 when the aligned path is taken
-template <int WBYTES, int ROWS, int DSTRIDE>
-__device__ __forceinline__ void load_tile(uint8_t *dst, const uint8_t *__restrict__ img, int stride, int w,
-                                          int h, int x0, int y0, int lane)
-{
-    const bool interior = x0 >= 0 && x0 + WBYTES <= w && y0 >= 0 && y0 + ROWS <= h;
-    if (interior) {
-        constexpr int DW = WBYTES / 4;
-        const uint8_t *base = img + (size_t)y0 * stride + x0;
-        for (int i = lane; i < ROWS * DW; i += 64) {
-            int r = i / DW, c = i - r * DW;
-            uint32_t v = *reinterpret_cast<const uint32_t *>(base + (size_t)r * stride + 4 * c);
-            *reinterpret_cast<uint32_t *>(dst + r * DSTRIDE + 4 * c) = v;
-        }
-    } else {
-        for (int i = lane; i < ROWS * WBYTES; i += 64) {
-            int r = i / WBYTES, c = i - r * WBYTES;
-            int y = reflect101(y0 + r, h), x = reflect101(x0 + c, w);
-            dst[r * DSTRIDE + c] = img[(size_t)y * stride + x];
-        }
-    }
-}
-
+// ALIGNED_LDS = false: the two J rows are read as unaligned 8-byte LDS accesses (gfx950 supports
+// them; a misaligned access may take extra LDS cycles).  true: three aligned dwords per row +
+// v_alignbyte_b32.  Both are kept so the choice is a measured one (VO_LK_ALIGNED_LDS=1 selects true).
+template <bool ALIGNED_LDS>
 __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
                                                           const float2 *__restrict__ pts_in,
                                                           const int *__restrict__ n_pts, int cap,
+                                                          int n_frames, int fpg /* 1, 2, 4 or 8 */,
+                                                          int ppp /* features per part */,
                                                           float2 *__restrict__ trk,      // [B][4][cap]
                                                           uint8_t *__restrict__ status,  // [B][4][cap]
                                                           LkParams prm)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_it[LK_IT_H * LK_IT_STRIDE];
-    __shared__ __attribute__((aligned(16))) int s_d[LK_D_W * LK_D_W];
-    __shared__ __attribute__((aligned(16))) uint8_t s_jt[LK_JT_H * LK_JT_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_jt[LK_JT_H * LK_JT_W + 16];
 
-    const int frame = blockIdx.y, f = blockIdx.x;
-    if (f >= n_pts[frame])
+    // XCD-aware block numbering: block id b runs on XCD b % 8 (observed dispatcher behaviour, used
+    // for L2 affinity only): XCD x works on frames x, x + 8, x + 16, ... one frame after another
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int grp = slot / ppp, fi = slot - grp * ppp;
+    const int frame = grp * fpg + (xcd & (fpg - 1));
+    const int f = (xcd / fpg) * ppp + fi;
+    if (frame >= n_frames || f >= n_pts[frame])
         return;
     const int lane = threadIdx.x;
-    // lane -> (row, 7-pixel segment); lane 63 has no pixels (addresses clamped, contributions zeroed)
+    // lane -> (row, 7-pixel segment); lane 63 duplicates lane 62's addresses, contributions zeroed
     const bool live = lane < 63;
-    const int r = live ? lane / 3 : 20, seg = live ? lane - 3 * (lane / 3) : 0;
-    const int c0 = 7 * seg;
+    const int lr = live ? lane : 62;
+    const int r = lr / 3, c0 = 7 * (lr - 3 * r);
 
     const Quad q = quads[frame];
     const float halfWin = (LK_WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
 
-    float2 p = pts_in[(size_t)frame * cap + f];
+    const float2 p = pts_in[(size_t)frame * cap + f];
     float prevPtX = unif(p.x), prevPtY = unif(p.y);
 
     for (int hop = 0; hop < 4; hop++) {
@@ -111,6 +107,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             const int iw = I.w[level], ih = I.h[level], istride = I.stride[level];
             const int jw = J.w[level], jh = J.h[level], jstride = J.stride[level];
             const uint8_t *__restrict__ Iimg = I.lvl[level];
+            const uint32_t *__restrict__ Ider = I.der[level];
             const uint8_t *__restrict__ Jimg = J.lvl[level];
 
             prevX -= halfWin;
@@ -126,70 +123,37 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             int iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
             int iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
             int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            uint32_t wt = pack_w(iw00, iw01), wb = pack_w(iw10, iw11);
 
-            // ---- template source tile: image rows ipy-1 .. ipy+22, cols x0 .. x0+31 ----
-            const int tx0 = (ipx - 1) & ~3, ty0 = ipy - 1;
-            __syncthreads(); // previous level's readers of s_it / s_d / s_jt are done
-            load_tile<LK_IT_W, LK_IT_H, LK_IT_STRIDE>(s_it, Iimg, istride, iw, ih, tx0, ty0, lane);
-            __syncthreads();
-
-            // ---- Scharr derivative at the 22 x 22 integer positions (ipx+x, ipy+y) ----
-            // zero outside the image (derivative buffer has a CONSTANT border), reflected inside
-            for (int i = lane; i < LK_D_W * LK_D_W; i += 64) {
-                int y = i / LK_D_W, x = i - y * LK_D_W;
-                int gx = ipx + x, gy = ipy + y;
-                int packed = 0;
-                if (gx >= 0 && gx < iw && gy >= 0 && gy < ih) {
-                    const uint8_t *c = &s_it[(y + 1) * LK_IT_STRIDE + (gx - tx0)];
-                    int p00 = c[-LK_IT_STRIDE - 1], p01 = c[-LK_IT_STRIDE], p02 = c[-LK_IT_STRIDE + 1];
-                    int p10 = c[-1], p12 = c[1];
-                    int p20 = c[LK_IT_STRIDE - 1], p21 = c[LK_IT_STRIDE], p22 = c[LK_IT_STRIDE + 1];
-                    // t0(x) = (row-1 + row+1)*3 + row*10 ; t1(x) = row+1 - row-1
-                    int ix = ((p02 + p22) * 3 + p12 * 10) - ((p00 + p20) * 3 + p10 * 10);
-                    int iy = ((p22 - p02) + (p20 - p00)) * 3 + (p21 - p01) * 10;
-                    packed = (ix & 0xffff) | (iy << 16);
-                }
-                s_d[i] = packed;
-            }
-            __syncthreads();
-
-            // ---- 21 x 21 template (registers) + structure tensor ----
-            int Ival[7], Ixv[7], Iyv[7];
+            // ---- 21 x 21 template straight from the bordered pyramid (registers) + structure tensor --
+            // lane: pixels (ipx + c0 .. + 7, ipy + r) and the row below; the bordered layout makes
+            // every admissible window an in-bounds read (reflected pixels, zero derivatives)
+            uint32_t Ip[4], Ixp[4], Iyp[4];
             int a11 = 0, a12 = 0, a22 = 0;
             {
-                const uint8_t *row0 = &s_it[(r + 1) * LK_IT_STRIDE + (ipx - tx0) + c0];
-                const uint8_t *row1 = row0 + LK_IT_STRIDE;
-                const int *d0 = &s_d[r * LK_D_W + c0], *d1 = d0 + LK_D_W;
-                int pa = row0[0], pb = row1[0];
-                int da = d0[0], db = d1[0];
+                const ptrdiff_t o = (ptrdiff_t)(ipy + r) * istride + ipx + c0;
+                const LkU2 t = *reinterpret_cast<const LkU2 *>(Iimg + o);
+                const LkU2 u = *reinterpret_cast<const LkU2 *>(Iimg + o + istride);
+                const LkU4 dt0 = *reinterpret_cast<const LkU4 *>(Ider + o);
+                const LkU4 dt1 = *reinterpret_cast<const LkU4 *>(Ider + o + 4);
+                const LkU4 db0 = *reinterpret_cast<const LkU4 *>(Ider + o + istride);
+                const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + o + istride + 4);
+                const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
+                const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
+                bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Ip);
+                bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);
 #pragma unroll
-                for (int j = 0; j < 7; j++) {
-                    int pa1 = row0[j + 1], pb1 = row1[j + 1];
-                    int da1 = d0[j + 1], db1 = d1[j + 1];
-                    int ival = descale(pa * iw00 + pa1 * iw01 + pb * iw10 + pb1 * iw11, LK_W_BITS - 5);
-                    int ixval = descale((short)da * iw00 + (short)da1 * iw01 + (short)db * iw10 +
-                                            (short)db1 * iw11,
-                                        LK_W_BITS);
-                    int iyval = descale((da >> 16) * iw00 + (da1 >> 16) * iw01 + (db >> 16) * iw10 +
-                                            (db1 >> 16) * iw11,
-                                        LK_W_BITS);
+                for (int m = 0; m < 4; m++) {
                     if (!live)
-                        ival = ixval = iyval = 0;
-                    Ival[j] = ival;
-                    Ixv[j] = ixval;
-                    Iyv[j] = iyval;
-                    a11 += ixval * ixval;
-                    a12 += ixval * iyval;
-                    a22 += iyval * iyval;
-                    pa = pa1;
-                    pb = pb1;
-                    da = da1;
-                    db = db1;
+                        Ip[m] = Ixp[m] = Iyp[m] = 0;
+                    a11 = sdot2(Ixp[m], Ixp[m], a11);
+                    a12 = sdot2(Ixp[m], Iyp[m], a12);
+                    a22 = sdot2(Iyp[m], Iyp[m], a22);
                 }
             }
-            const float A11 = (float)wave_sum_i64(a11) * FLT_SCALE;
-            const float A12 = (float)wave_sum_i64(a12) * FLT_SCALE;
-            const float A22 = (float)wave_sum_i64(a22) * FLT_SCALE;
+            const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE;
+            const float A12 = wave_sum_exact_f32(a12) * FLT_SCALE;
+            const float A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
 
             float D = A11 * A22 - A12 * A12;
             const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -206,6 +170,8 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             float prevDX = 0.f, prevDY = 0.f;
             int jx0 = 0, jy0 = 0;
             bool have_tile = false;
+            // tile origins that keep the 40 x 48 tile inside the bordered allocation
+            const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
             for (int j = 0; j < prm.max_count; j++) {
                 const int inx = uni((int)floorf(nextX)), iny = uni((int)floorf(nextY));
@@ -219,8 +185,15 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                     iny + LK_WIN + 1 > jy0 + LK_JT_H) {
                     jx0 = (inx - 12) & ~3;
                     jy0 = iny - 9;
-                    __syncthreads();
-                    load_tile<LK_JT_W, LK_JT_H, LK_JT_STRIDE>(s_jt, Jimg, jstride, jw, jh, jx0, jy0, lane);
+                    jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
+                    jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
+                    __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
+                    const uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
+                    for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
+                        const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
+                        const LkU4 v = *reinterpret_cast<const LkU4 *>(tb + (ptrdiff_t)row * jstride + 16 * col);
+                        *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
+                    }
                     __syncthreads();
                     have_tile = true;
                 }
@@ -230,25 +203,37 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
                 iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
                 iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+                wt = pack_w(iw00, iw01);
+                wb = pack_w(iw10, iw11);
 
                 int b1 = 0, b2 = 0;
                 {
-                    const uint8_t *row0 = &s_jt[(iny - jy0 + r) * LK_JT_STRIDE + (inx - jx0) + c0];
-                    const uint8_t *row1 = row0 + LK_JT_STRIDE;
-                    int pa = row0[0], pb = row1[0];
+                    const int off = (iny - jy0 + r) * LK_JT_W + (inx - jx0) + c0;
+                    LkU2 t, u;
+                    if (ALIGNED_LDS) {
+                        const uint32_t *q0 = reinterpret_cast<const uint32_t *>(&s_jt[off & ~3]);
+                        const uint32_t *q1 = q0 + LK_JT_W / 4;
+                        const uint32_t sh = (uint32_t)off & 3u;
+                        const uint32_t t0 = q0[0], t1 = q0[1], t2 = q0[2], u0 = q1[0], u1 = q1[1], u2 = q1[2];
+                        t.lo = VO_ALIGNBYTE(t1, t0, sh);
+                        t.hi = VO_ALIGNBYTE(t2, t1, sh);
+                        u.lo = VO_ALIGNBYTE(u1, u0, sh);
+                        u.hi = VO_ALIGNBYTE(u2, u1, sh);
+                    } else {
+                        t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                        u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
+                    }
+                    uint32_t Jp[4];
+                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Jp);
 #pragma unroll
-                    for (int k = 0; k < 7; k++) {
-                        int pa1 = row0[k + 1], pb1 = row1[k + 1];
-                        int diff = descale(pa * iw00 + pa1 * iw01 + pb * iw10 + pb1 * iw11, LK_W_BITS - 5) -
-                                   Ival[k];
-                        b1 += diff * Ixv[k];
-                        b2 += diff * Iyv[k];
-                        pa = pa1;
-                        pb = pb1;
+                    for (int m = 0; m < 4; m++) {
+                        const uint32_t diff = pk_sub_i16(Jp[m], Ip[m]);
+                        b1 = sdot2(diff, Ixp[m], b1);
+                        b2 = sdot2(diff, Iyp[m], b2);
                     }
                 }
-                const float fb1 = (float)wave_sum_i64(b1) * FLT_SCALE;
-                const float fb2 = (float)wave_sum_i64(b2) * FLT_SCALE;
+                const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
+                const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D;
                 const float dy = (A12 * fb1 - A11 * fb2) * D;
                 nextX += dx;
@@ -283,15 +268,30 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
     }
 }
 
+#ifndef VO_HOST_EMUL
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream)
 {
     if (max_pts <= 0 || n_frames <= 0)
         return;
-    dim3 grid(max_pts, n_frames);
-    hipLaunchKernelGGL(lk_circular_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap,
-                       d_trk, d_status, prm);
+    // frames per group of 8 XCDs: largest power of two <= min(8, n_frames)
+    const int fpg = n_frames >= 8 ? 8 : n_frames >= 4 ? 4 : n_frames >= 2 ? 2 : 1;
+    const int parts = 8 / fpg, ppp = (max_pts + parts - 1) / parts;
+    const int groups = (n_frames + fpg - 1) / fpg;
+    dim3 grid((unsigned)(8 * groups * ppp));
+    static const bool aligned_lds = [] {
+        const char *e = getenv("VO_LK_ALIGNED_LDS");
+        return e && e[0] == '1';
+    }();
+    if (aligned_lds)
+        hipLaunchKernelGGL(lk_circular_kernel<true>, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts,
+                           cap, n_frames, fpg, ppp, d_trk, d_status, prm);
+    else
+        hipLaunchKernelGGL(lk_circular_kernel<false>, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts,
+                           cap, n_frames, fpg, ppp, d_trk, d_status, prm);
 }
+
+#endif // VO_HOST_EMUL
 
 } // namespace vo

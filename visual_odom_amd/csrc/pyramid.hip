@@ -1,21 +1,48 @@
-// pyramid.hip -- Gaussian image pyramid (one level per launch, batched over the image table).
+// pyramid.hip -- bordered Gaussian image pyramid + Scharr images, batched over the image table.
 //
-// Replaces the buildOpticalFlowPyramid -> cv::pyrDown chain that every cv::calcOpticalFlowPyrLK
-// call of the reference runs internally (feature.cpp:136-139; 8 pyramid builds per frame there,
-// 4 here -- each image once).  Integer arithmetic, bit-exact by construction:
-//   horizontal [1 4 6 4 1] in int, vertical [1 4 6 4 1], (v + 128) >> 8, REFLECT_101 borders.
+// Replaces what every cv::calcOpticalFlowPyrLK call of the reference rebuilds internally
+// (feature.cpp:136-139): buildOpticalFlowPyramid (cv::pyrDown chain + winSize REFLECT_101 border
+// around every level) for both images and calcSharrDeriv of the previous image's levels (zero
+// border).  The reference does 8 pyramid builds and 16 Scharr passes per frame; here every image is
+// processed once per batch run.  Integer arithmetic, bit-exact by construction:
+//   pyrDown: horizontal [1 4 6 4 1] in int, vertical [1 4 6 4 1], (v + 128) >> 8, REFLECT_101 on the
+//   level itself; Scharr: 3x3 unnormalised, REFLECT_101 (= reading the level's own border).
 //
-// Mapping: one 256-thread workgroup produces a 64 x 16 output tile.  The 136 x 35 source tile is
-// staged in LDS with aligned dword loads (byte loads + index reflection only for tiles touching
-// the image border), the horizontal pass writes u16 partial rows back to LDS, the vertical pass
-// emits 4 adjacent pixels per thread as one 32-bit store.  HBM-bound: reads S_l, writes S_l/4.
+// Kernels (all HBM-streaming; see DESIGN.md for the byte counts):
+//   border_fill_kernel  writes the REFLECT_101 border of one level from its interior
+//   pyr_down_kernel     one 256-thread workgroup -> 64 x 16 output tile; the 136 x 35 source tile is
+//                       staged in LDS with aligned dword loads (the source border makes every tile an
+//                       in-bounds read), u16 horizontal partials in LDS, 4 pixels per 32-bit store
+//   scharr_kernel       4 pixels per thread: three unaligned 8-byte row loads, one 16-byte store of
+//                       (4*Ix | 4*Iy << 16) x 4
 #include "vo_kernels.h"
+#include "vo_lkmath.h"
 
 namespace vo {
 
-constexpr int PD_TW = 64, PD_TH = 16;           // output tile
+struct __attribute__((packed, aligned(1))) U8x8 {
+    uint32_t lo, hi;
+};
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
+{
+    const PyrImage &im = imgs[blockIdx.z];
+    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
+    uint8_t *__restrict__ p = im.lvl[level];
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x) - VO_BX; // -VO_BX .. stride - VO_BX - 1
+    const int y = (int)blockIdx.y - VO_BY;                        // -VO_BY .. h + VO_BY - 1
+    if (x >= stride - VO_BX)
+        return;
+    if (x >= 0 && x < w && y >= 0 && y < h)
+        return;
+    p[(ptrdiff_t)y * stride + x] = p[(ptrdiff_t)reflect101(y, h) * stride + reflect101(x, w)];
+}
+
+// ---------------------------------------------------------------------------------------------------
+constexpr int PD_TW = 64, PD_TH = 16;             // output tile
 constexpr int PD_SW = 136, PD_SH = 2 * PD_TH + 3; // source tile (bytes x rows), x origin = 2*ox-4
-constexpr int PD_SSTRIDE = 140;                 // LDS row stride of the source tile (bytes)
+constexpr int PD_SSTRIDE = 140;                   // LDS row stride of the source tile (bytes)
 
 __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restrict__ imgs, int level)
 {
@@ -23,7 +50,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     __shared__ uint16_t s_h[PD_SH * PD_TW];
 
     const PyrImage &im = imgs[blockIdx.z];
-    const int sw = im.w[level], sh = im.h[level], sstride = im.stride[level];
+    const int sh = im.h[level], sstride = im.stride[level];
     const int dw = im.w[level + 1], dh = im.h[level + 1], dstride = im.stride[level + 1];
     const uint8_t *__restrict__ src = im.lvl[level];
     uint8_t *__restrict__ dst = im.lvl[level + 1];
@@ -31,36 +58,33 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     if (ox >= dw || oy >= dh)
         return;
     const int tid = threadIdx.x;
-    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;
+    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;   // >= -4 / -2: inside the source border
+    const int xmax = sstride - VO_BX, ymax = sh + VO_BY; // first column / row outside the allocation
 
-    const bool interior = sx0 >= 0 && sx0 + PD_SW <= sw && sy0 >= 0 && sy0 + PD_SH <= sh;
-    if (interior) {
-        // 35 rows x 34 dwords, coalesced along rows
-        for (int i = tid; i < PD_SH * (PD_SW / 4); i += 256) {
-            int r = i / (PD_SW / 4), c = i - r * (PD_SW / 4);
-            uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)(sy0 + r) * sstride + sx0 + 4 * c);
-            *reinterpret_cast<uint32_t *>(&s_src[r * PD_SSTRIDE + 4 * c]) = v;
-        }
-    } else {
-        for (int i = tid; i < PD_SH * PD_SW; i += 256) {
-            int r = i / PD_SW, c = i - r * PD_SW;
-            int y = reflect101(sy0 + r, sh), x = reflect101(sx0 + c, sw);
-            s_src[r * PD_SSTRIDE + c] = src[(size_t)y * sstride + x];
-        }
+    // 35 rows x 34 dwords, coalesced along rows; columns / rows past the allocation are never used
+    // by a valid output pixel (those need source x <= 2 dw <= w + 1, y <= h + 1) and read as 0
+    for (int i = tid; i < PD_SH * (PD_SW / 4); i += 256) {
+        const int r = i / (PD_SW / 4), c = i - r * (PD_SW / 4);
+        const int x = sx0 + 4 * c, y = sy0 + r;
+        uint32_t v = 0;
+        if (x + 4 <= xmax && y < ymax)
+            v = *reinterpret_cast<const uint32_t *>(src + (ptrdiff_t)y * sstride + x);
+        *reinterpret_cast<uint32_t *>(&s_src[r * PD_SSTRIDE + 4 * c]) = v;
     }
     __syncthreads();
 
     // horizontal 5-tap; output column x reads source columns 2x-2 .. 2x+2 = tile columns 2x+2 .. 2x+6
     for (int i = tid; i < PD_SH * PD_TW; i += 256) {
-        int r = i / PD_TW, x = i - r * PD_TW;
+        const int r = i / PD_TW, x = i - r * PD_TW;
         const uint8_t *p = &s_src[r * PD_SSTRIDE + 2 * x + 2];
         s_h[i] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
     }
     __syncthreads();
 
-    // vertical 5-tap; thread -> (row y, 4 adjacent columns)
+    // vertical 5-tap; thread -> (row y, 4 adjacent columns); columns >= dw land in the right border
+    // (stride - VO_BX - dw >= VO_BY there) and are overwritten by border_fill_kernel afterwards
     const int y = tid >> 4, x4 = (tid & 15) * 4;
-    if (oy + y < dh && ox + x4 < dstride) {
+    if (oy + y < dh && ox + x4 < dw) {
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -68,8 +92,48 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
             int v = q[2 * PD_TW] * 6 + (q[PD_TW] + q[3 * PD_TW]) * 4 + q[0] + q[4 * PD_TW];
             packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(dst + (size_t)(oy + y) * dstride + ox + x4) = packed;
+        *reinterpret_cast<uint32_t *>(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = packed;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// all levels of all images in one launch: blockIdx.z = image * n_levels + level
+__global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict__ imgs, int n_levels)
+{
+    const int img = blockIdx.z / n_levels, level = blockIdx.z - img * n_levels;
+    const PyrImage &im = imgs[img];
+    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
+    const int x4 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (x4 >= w || y >= h)
+        return;
+    const uint8_t *__restrict__ p = im.lvl[level] + (ptrdiff_t)y * stride + x4 - 1; // pixel (x4-1, y)
+    const U8x8 a = *reinterpret_cast<const U8x8 *>(p - stride);
+    const U8x8 b = *reinterpret_cast<const U8x8 *>(p);
+    const U8x8 c = *reinterpret_cast<const U8x8 *>(p + stride);
+    const uint64_t ra = ((uint64_t)a.hi << 32) | a.lo, rb = ((uint64_t)b.hi << 32) | b.lo,
+                   rc = ((uint64_t)c.hi << 32) | c.lo;
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = 8 * k;
+        out[k] = scharr4_packed((int)((ra >> s) & 0xff), (int)((ra >> (s + 8)) & 0xff), (int)((ra >> (s + 16)) & 0xff),
+                                (int)((rb >> s) & 0xff), (int)((rb >> (s + 16)) & 0xff), (int)((rc >> s) & 0xff),
+                                (int)((rc >> (s + 8)) & 0xff), (int)((rc >> (s + 16)) & 0xff));
+    }
+    // pixels >= w of the last quad fall into the (zero) right border: keep them zero
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (x4 + k >= w)
+            out[k] = 0;
+    *reinterpret_cast<uint4 *>(im.der[level] + (ptrdiff_t)y * stride + x4) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+#ifndef VO_HOST_EMUL
+void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream)
+{
+    dim3 grid((stride + 255) / 256, h + 2 * VO_BY, n_images);
+    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)
@@ -77,5 +141,13 @@ void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, in
     dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, n_images);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
+
+void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, int w0, int h0, hipStream_t stream)
+{
+    dim3 grid((w0 + 255) / 256, (h0 + 3) / 4, n_images * n_levels);
+    hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels);
+}
+
+#endif // VO_HOST_EMUL
 
 } // namespace vo

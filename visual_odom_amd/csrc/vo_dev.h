@@ -1,23 +1,47 @@
 // vo_dev.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
 //
 // HBM layout (see DESIGN.md "Data layout"):
-//   * image table: every 8-bit image owns one allocation holding its whole pyramid, level l at a
-//     16-byte aligned offset with a row stride padded to a multiple of 16 bytes (so tile loads are
-//     aligned dword/dwordx4 loads); described by a PyrImage record.
+//   * image table: every 8-bit image owns its whole pyramid.  Level l is stored WITH a border, the
+//     way OpenCV's buildOpticalFlowPyramid keeps winSize extra pixels around each level: VO_BX
+//     columns left, >= VO_BY columns right, VO_BY rows above and below, filled by REFLECT_101, so
+//     that every 21 x 21 LK window the reference admits (top-left corner in [-21, w) x [-21, h))
+//     reads real memory and no kernel needs a border path.  The row pitch `stride` (pixels) is a
+//     multiple of 16 and pixel (0, 0) of every row is 16-byte aligned.  `lvl[l]` points at pixel (0, 0).
+//   * Scharr image of every level (calcSharrDeriv of the reference's LK calls): one dword per pixel,
+//     (4*Ix as int16) | (4*Iy as int16) << 16, same geometry as the level, border = 0 exactly like
+//     OpenCV's BORDER_CONSTANT derivative buffer.  `der[l]` points at pixel (0, 0).
 //   * a "frame" (one stereo pair at t0 and t1 = the unit of work of circularMatching(),
 //     reference feature.h:61-65) is a Quad of four image-table indices (l0, r0, l1, r1).
 //   * per frame SoA feature arrays with a fixed capacity `cap`: float2 points, u8 status.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Cross-lane primitives.  The CPU test-suite compiles the kernel sources against a coroutine SIMT
+// emulator (tests/host_check/hip_emu.h defines VO_HOST_EMUL and the emu_* functions); the product
+// build always takes the CDNA4 builtins.
+#ifdef VO_HOST_EMUL
+#define VO_READFIRSTLANE(v) emu_readfirstlane(v)
+#define VO_READLANE(v, l) emu_readlane((v), (l))
+#define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define VO_ALIGNBYTE(hi, lo, sh) emu_alignbyte((hi), (lo), (sh))
+#else
+#include <hip/hip_runtime.h>
+#define VO_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
+#define VO_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
+#define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define VO_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
+#endif
+
 #define VO_MAX_LEVELS 5
+#define VO_BX 32 /* left border columns (>= 21 + tile slack, keeps x = 0 16-byte aligned) */
+#define VO_BY 24 /* top / bottom border rows and minimum right border columns (>= 21) */
 
 namespace vo {
 
 struct PyrImage {
     uint8_t *lvl[VO_MAX_LEVELS];
+    uint32_t *der[VO_MAX_LEVELS];
     int w[VO_MAX_LEVELS], h[VO_MAX_LEVELS], stride[VO_MAX_LEVELS];
 };
 
@@ -35,20 +59,46 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int uni(int v) { return VO_READFIRSTLANE(v); }
 __device__ __forceinline__ float unif(float v)
 {
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    return __int_as_float(VO_READFIRSTLANE(__float_as_int(v)));
 }
 
-// exact wave-wide sum of per-lane int32 partials, returned to every lane as int64
-__device__ __forceinline__ long long wave_sum_i64(int v)
+// DPP controls (CDNA3/4 ISA "DPP_CTRL"): quad_perm, row_half_mirror, row_mirror, row_bcast
+#define VO_DPP_QUAD_XOR1 0xB1   /* quad_perm:[1,0,3,2] */
+#define VO_DPP_QUAD_XOR2 0x4E   /* quad_perm:[2,3,0,1] */
+#define VO_DPP_ROW_HALF_MIRROR 0x141
+#define VO_DPP_ROW_MIRROR 0x140
+#define VO_DPP_ROW_BCAST15 0x142
+#define VO_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v)
 {
-    long long s = v;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        s += __shfl_xor(s, m, 64);
-    return s;
+    return v + VO_UPDATE_DPP(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+
+// Exact wave-wide sum of per-lane int32 partials, returned as a wave-uniform f32 rounded once from
+// the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| <= 2^28 so
+// that the first three butterfly steps (8-lane sums) cannot overflow int32; the 8-lane sums are then
+// split into a signed high and an unsigned low 16-bit half which are reduced separately (row_mirror,
+// row_bcast15, row_bcast31: the total lands in lane 63) and recombined exactly in f64.
+// Ten v_add_u32_dpp + two v_readlane instead of 12 ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float wave_sum_exact_f32(int v)
+{
+    v = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(v);
+    v = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(v);
+    v = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(v);
+    int lo = v & 0xffff, hi = v >> 16;
+    lo = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(lo);
+    hi = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(hi);
+    lo = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(lo);
+    hi = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(hi);
+    const int slo = VO_READLANE(lo, 63), shi = VO_READLANE(hi, 63);
+    return (float)((double)shi * 65536.0 + (double)slo);
 }
 
 } // namespace vo

@@ -31,7 +31,10 @@ struct PnpResult {
     int lm_iters;
 };
 
+#ifndef VO_HOST_EMUL
+void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream);
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
+void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, int w0, int h0, hipStream_t stream);
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
@@ -44,5 +47,7 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, int32_t *inliers,
                 PnpResult *results, hipStream_t stream);
+
+#endif // VO_HOST_EMUL
 
 } // namespace vo
