@@ -212,7 +212,11 @@ def cpu_baseline(lefts, rights, pts, world, n_frames, stages):
         dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best_t, best_dt = t, dt
-    reps = max(1, min(200, int(10.0 / max(best_dt * n_frames, 1e-6))))
+    t0 = time.perf_counter()
+    for k in range(n_frames):
+        one_frame(k, best_t)
+    pass_dt = time.perf_counter() - t0
+    reps = max(1, min(50, int(12.0 / max(pass_dt, 1e-6))))  # bounded sample: ~12 s of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         for k in range(n_frames):

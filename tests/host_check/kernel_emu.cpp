@@ -59,7 +59,7 @@ extern "C" {
 // Then tracks pts [n][2] through the quad (0,1,2,3) with the emulated LK kernel.
 int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want_level, uint8_t *lvl_out,
            uint32_t *der_out, int *lvl_w, int *lvl_h, const float *pts, int n, int max_count, double eps,
-           float min_eig, int aligned_lds, float *trk /* [4][n][2] */, uint8_t *status /* [4][n] */)
+           float min_eig, float *trk /* [4][n][2] */, uint8_t *status /* [4][n] */)
 {
     using namespace vo;
     Plan p = plan(w, h, max_level);
@@ -81,7 +81,7 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     }
     const PyrImage *d_imgs = tab.data();
     auto fill = [&](int l) {
-        launch((p.ls[l] + 255) / 256, p.lh[l] + 2 * VO_BY, n_img, 256, [&] { border_fill_kernel(d_imgs, l); });
+        launch(p.lh[l] + 2 * VO_BY, n_img, 1, 64, [&] { border_fill_kernel(d_imgs, l); });
     };
     fill(0);
     for (int l = 0; l + 1 < p.levels; l++) {
@@ -113,16 +113,9 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     std::vector<float2> out((size_t)4 * n);
     const int cap = n, n_frames = 1, fpg = 1, parts = 8, ppp = (n + parts - 1) / parts;
     for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
-        if (aligned_lds)
-            emu::run_block(64, b, 0, 0, [&] {
-                lk_circular_kernel<true>(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(),
-                                         status, prm);
-            });
-        else
-            emu::run_block(64, b, 0, 0, [&] {
-                lk_circular_kernel<false>(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(),
-                                          status, prm);
-            });
+        emu::run_block(64, b, 0, 0, [&] {
+            lk_circular_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(), status, prm);
+        });
     }
     memcpy(trk, out.data(), sizeof(float2) * 4 * (size_t)n);
     return p.levels;

@@ -32,7 +32,7 @@ def kemu():
     return lib
 
 
-def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.01, min_eig=1e-3, aligned=0):
+def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.01, min_eig=1e-3):
     imgs = np.ascontiguousarray(np.stack(imgs), np.uint8)
     n_img, h, w = imgs.shape
     pts = np.zeros((0, 2), np.float32) if pts is None else np.ascontiguousarray(pts, np.float32)
@@ -43,7 +43,7 @@ def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.
     trk = np.zeros((4, max(n, 1), 2), np.float32)
     st = np.zeros((4, max(n, 1)), np.uint8)
     levels = lib.ke_run(vp(imgs), n_img, w, h, max_level, want_level, vp(lvl), vp(der), C.byref(lw), C.byref(lh),
-                        vp(pts), n, max_count, C.c_double(eps), C.c_float(min_eig), aligned, vp(trk), vp(st))
+                        vp(pts), n, max_count, C.c_double(eps), C.c_float(min_eig), vp(trk), vp(st))
     lw, lh = lw.value, lh.value
     return dict(levels=levels, lvl=lvl.ravel()[:lw * lh].reshape(lh, lw), der=der.ravel()[:lw * lh].reshape(lh, lw),
                 trk=trk[:, :n], status=st[:, :n])
@@ -79,14 +79,13 @@ def _oracle_hops(orc, L0, R0, L1, R1, pts, **kw):
     return np.stack([p1, p2, p3, p4]), np.stack([s1, s2, s3, s4])
 
 
-@pytest.mark.parametrize("aligned", [0, 1])
-def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq, aligned):
+def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq):
     s = small_seq
     imgs = [s["L"][0], s["R"][0], s["L"][1], s["R"][1]]
     border = np.array([[0, 0], [479, 159], [2.5, 80.25], [476.2, 10.7], [240, 1.1], [250.4, 158.9],
                        [-5, 50], [100, -3], [520, 100], [12.5, 12.5], [-25, 80], [240, 185]], np.float32)
     pts = np.vstack([s["pts"][0][::6], border]).astype(np.float32)
-    r = ke_run(kemu, imgs, pts, aligned=aligned)
+    r = ke_run(kemu, imgs, pts)
     ref, st = _oracle_hops(orc, *imgs, pts)
     assert np.array_equal(r["status"], st)
     assert np.array_equal(bits(r["trk"]), bits(ref))
@@ -107,4 +106,18 @@ def test_emulated_lk_large_motion_and_params(kemu, orc):
     assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
     r = ke_run(kemu, imgs, pts[:16], max_level=2, max_count=7, eps=0.03, min_eig=0.01)
     ref, st = _oracle_hops(orc, *imgs, pts[:16], max_level=2, max_count=7, eps=0.03, min_eig=0.01)
+    assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
+
+
+def test_emulated_lk_negative_bilinear_weight(kemu, orc):
+    """regression found on the MI355X: the three rounded bilinear weights can add up to 2^14 + 1, which
+    makes iw11 = -1; feature 133 of the large-motion GPU test walks through such an iteration"""
+    from test_oracle_images import smooth_image
+    w, h = 512, 256
+    imgs = [smooth_image(w, h, seed=9), smooth_image(w, h, 13.7, -9.2, seed=9), smooth_image(w, h, 20.1, 4.4, seed=9),
+            smooth_image(w, h, -6.3, 11.8, seed=9)]
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-10, w + 10, 700), rng.uniform(-10, h + 10, 700)], 1).astype(np.float32)[[133, 7, 400]]
+    r = ke_run(kemu, imgs, pts)
+    ref, st = _oracle_hops(orc, *imgs, pts)
     assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))

@@ -18,8 +18,8 @@ struct vo_ctx {
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
     vo_params prm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[VO_NUM_STAGES + 1] = {};
-    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 1) for vo_batch_run_slot
+    hipEvent_t ev[VO_NUM_STAGES + 2] = {}; // [VO_NUM_STAGES + 1] = start of the pose solve on its stream
+    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 2) for vo_batch_run_slot
     std::string err;
 
     // batch configuration
@@ -34,14 +34,25 @@ struct vo_ctx {
     size_t pix_capacity = 0;   // in pixels (bytes of d_pix, dwords of d_der)
     PyrImage *d_imgs = nullptr;
     Quad *d_quads = nullptr;
-    float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr, *d_outB = nullptr;
+    float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr;
     uint8_t *d_status = nullptr;
-    int *d_npts = nullptr, *d_nA = nullptr, *d_nB = nullptr, *d_idxA = nullptr, *d_idxB = nullptr;
-    float *d_xyz = nullptr, *d_P = nullptr; // d_P: P_l (12) then P_r (12)
-    int32_t *d_subsets = nullptr, *d_inliers = nullptr;
-    double *d_models = nullptr;
-    int *d_counts = nullptr;
-    PnpResult *d_results = nullptr;
+    int *d_npts = nullptr, *d_nA = nullptr, *d_idxA = nullptr;
+    float *d_P = nullptr; // d_P: P_l (12) then P_r (12)
+    // Everything the pose solve reads or writes exists twice: the PnP/RANSAC chain of batch k runs on
+    // its own stream while the tracking stages of batch k + 1 already fill the other set.
+    struct PoseBufs {
+        float2 *outB = nullptr;  // [B][4][cap] l0, r0, l1, r1 after the consistency filter
+        int *idxB = nullptr, *nB = nullptr;
+        float *xyz = nullptr;
+        int32_t *subsets = nullptr, *inliers = nullptr;
+        double *models = nullptr;
+        int *counts = nullptr;
+        PnpResult *results = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr; // triangulation finished / pose solve finished
+        bool pending = false;                        // `done` has been recorded and not waited for
+    } pb[2];
+    int cur = 0, last = 0; // set the next run writes / set the last run wrote
+    hipStream_t stream_pnp = nullptr;
     int ransac_cap = 0;
     float h_P[24] = {};
     bool have_P = false;
@@ -122,13 +133,23 @@ void vo_destroy(vo_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_der, c->d_pix,    c->d_imgs,  c->d_quads,   c->d_pts,      c->d_trk,    c->d_outA,
-                    c->d_outB,   c->d_status, c->d_npts,   c->d_nA,       c->d_nB,     c->d_idxA,
-                    c->d_idxB,   c->d_xyz,   c->d_P,       c->d_subsets,  c->d_inliers, c->d_models,
-                    c->d_counts, c->d_results};
+    void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk, c->d_outA,
+                    c->d_status, c->d_npts, c->d_nA, c->d_idxA, c->d_P};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
+    for (auto &b : c->pb) {
+        void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.results};
+        for (void *p : q)
+            if (p)
+                (void)hipFree(p);
+        if (b.ready)
+            (void)hipEventDestroy(b.ready);
+        if (b.done)
+            (void)hipEventDestroy(b.done);
+    }
+    if (c->stream_pnp)
+        (void)hipStreamDestroy(c->stream_pnp);
     for (auto &e : c->ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -160,9 +181,10 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->ransac_cap = 1000;
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream_pnp, hipStreamNonBlocking) == hipSuccess;
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
-    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 1), nullptr);
+    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 2), nullptr);
     for (auto &e : c->ring)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     // worst case pyramid bytes per image (5 levels, padded strides)
@@ -183,23 +205,27 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_pts, B * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_trk, B * 4 * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_outA, B * 5 * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_outB, B * 4 * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_status, B * 4 * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_npts, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_nA, B) == hipSuccess;
-    ok = ok && dmalloc(&c->d_nB, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_idxA, B * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_idxB, B * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_xyz, B * cap * 3) == hipSuccess;
     ok = ok && dmalloc(&c->d_P, (size_t)24) == hipSuccess;
-    ok = ok && dmalloc(&c->d_subsets, B * c->ransac_cap * 5) == hipSuccess;
-    ok = ok && dmalloc(&c->d_inliers, B * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_models, B * c->ransac_cap * 6) == hipSuccess;
-    ok = ok && dmalloc(&c->d_counts, B * c->ransac_cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_results, B) == hipSuccess;
+    for (auto &b : c->pb) {
+        ok = ok && dmalloc(&b.outB, B * 4 * cap) == hipSuccess;
+        ok = ok && dmalloc(&b.nB, B) == hipSuccess;
+        ok = ok && dmalloc(&b.idxB, B * cap) == hipSuccess;
+        ok = ok && dmalloc(&b.xyz, B * cap * 3) == hipSuccess;
+        ok = ok && dmalloc(&b.subsets, B * c->ransac_cap * 5) == hipSuccess;
+        ok = ok && dmalloc(&b.inliers, B * cap) == hipSuccess;
+        ok = ok && dmalloc(&b.models, B * c->ransac_cap * 6) == hipSuccess;
+        ok = ok && dmalloc(&b.counts, B * c->ransac_cap) == hipSuccess;
+        ok = ok && dmalloc(&b.results, B) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
+    }
     if (ok) {
         ok = hipMemset(c->d_npts, 0, B * sizeof(int)) == hipSuccess &&
-             hipMemset(c->d_nB, 0, B * sizeof(int)) == hipSuccess &&
              hipMemset(c->d_nA, 0, B * sizeof(int)) == hipSuccess;
     }
     if (!ok) {
@@ -357,6 +383,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         return fail(c, VO_ERR_STATE, "vo_batch_run: projection matrices not set");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     const int B = c->n_frames, cap = c->cap;
+    const bool touches_pose = (stages & (VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) != 0;
+    vo_ctx::PoseBufs &pb = c->pb[c->cur];
     int e = 0;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
@@ -387,19 +415,30 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
+    if (touches_pose && pb.pending) {
+        // the pose solve that last used this buffer set (two runs ago) must have drained
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0));
+        pb.pending = false;
+    }
     if (stages & VO_STAGE_FILTER)
         launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
-                       c->d_idxA, c->d_nA, c->d_outB, c->d_idxB, c->d_nB, B, c->stream);
+                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, c->stream);
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_TRIANGULATE) // stage-B rows: 0 = l0, 1 = r0, 2 = l1, 3 = r1
-        launch_triangulate(c->d_P, c->d_P + 12, c->d_outB, c->d_outB + cap, (size_t)4 * cap, c->d_nB, cap,
-                           c->max_pts_set, B, c->d_xyz, c->stream);
+        launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + cap, (size_t)4 * cap, pb.nB, cap,
+                           c->max_pts_set, B, pb.xyz, c->stream);
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_PNP) {
+        // the pose solve is a chain of low-occupancy, latency-bound kernels: it runs on its own
+        // stream so that the next run's pyramid / LK launches (ctx stream) overlap it
+        VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream_pnp, pb.ready, 0));
+        if (timed)
+            VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], c->stream_pnp));
         PnpParams pp;
         pp.iters = c->prm.ransac_iterations;
         pp.reproj = c->prm.ransac_reproj_error;
@@ -408,12 +447,30 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         for (int r = 0; r < 3; r++)
             for (int k = 0; k < 3; k++)
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
-        launch_pnp(c->d_xyz, c->d_outB + 2 * cap, (size_t)4 * cap, c->d_nB, cap, B, pp, c->d_subsets,
-                   c->d_models, c->d_counts, c->d_inliers, c->d_results, c->stream);
-    }
-    if (timed)
+        launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
+                   pb.inliers, pb.results, c->stream_pnp);
+        if (timed)
+            VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream_pnp));
+        VO_HIP_TRY(c, hipEventRecord(pb.done, c->stream_pnp));
+        pb.pending = true;
+    } else if (timed) {
+        VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], c->stream));
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+    }
     VO_HIP_TRY(c, hipGetLastError());
+    if (touches_pose) {
+        c->last = c->cur;
+        c->cur ^= 1;
+    }
+    return VO_OK;
+}
+
+// both streams idle (every getter and every synchronous entry point ends with this)
+static int sync_all(vo_ctx *c)
+{
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
     return VO_OK;
 }
 
@@ -431,9 +488,11 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
     int rc = run_stages(c, stages, true);
     if (rc != VO_OK)
         return rc;
-    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
     for (int s = 0; s < VO_NUM_STAGES; s++)
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s], c->ev[s + 1]));
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s == VO_NUM_STAGES - 1 ? VO_NUM_STAGES + 1 : s], c->ev[s + 1]));
     return VO_OK;
 }
 
@@ -441,7 +500,7 @@ int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
 {
     if (!c || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
-    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 1)]);
+    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)]);
 }
 
 int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
@@ -449,9 +508,9 @@ int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
     if (!c || !ms || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 1)];
-    for (int s = 0; s < VO_NUM_STAGES; s++)
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s], evs[s + 1]));
+    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)];
+    for (int s = 0; s < VO_NUM_STAGES; s++) // the pose solve is timed on its own stream
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s == VO_NUM_STAGES - 1 ? VO_NUM_STAGES + 1 : s], evs[s + 1]));
     return VO_OK;
 }
 
@@ -459,9 +518,7 @@ int vo_batch_sync(vo_ctx *c)
 {
     if (!c)
         return VO_ERR_ARG;
-    VO_HIP_TRY(c, hipSetDevice(c->device));
-    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return VO_OK;
+    return sync_all(c);
 }
 
 #define D2H(dst, src, bytes)                                                                           \
@@ -498,20 +555,23 @@ int vo_batch_get_filtered(vo_ctx *c, int frame, float *l0, float *r0, float *l1,
         return VO_ERR_ARG;
     if (frame < 0 || frame >= c->n_frames)
         return fail(c, VO_ERR_ARG, "vo_batch_get_filtered: bad frame");
-    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    const vo_ctx::PoseBufs &pb = c->pb[c->last];
     int nAB[2] = {0, 0};
     VO_HIP_TRY(c, hipMemcpyAsync(&nAB[0], c->d_nA + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(&nAB[1], c->d_nB + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(&nAB[1], pb.nB + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t cap = c->cap;
     const int K = nAB[1], M = nAB[0];
-    const float2 *b = c->d_outB + (size_t)frame * 4 * cap;
+    const float2 *b = pb.outB + (size_t)frame * 4 * cap;
     D2H(l0, b, sizeof(float2) * K);
     D2H(r0, b + cap, sizeof(float2) * K);
     D2H(l1, b + 2 * cap, sizeof(float2) * K);
     D2H(r1, b + 3 * cap, sizeof(float2) * K);
-    D2H(xyz, c->d_xyz + (size_t)frame * cap * 3, sizeof(float) * 3 * K);
-    D2H(keep_idx, c->d_idxB + (size_t)frame * cap, sizeof(int32_t) * K);
+    D2H(xyz, pb.xyz + (size_t)frame * cap * 3, sizeof(float) * 3 * K);
+    D2H(keep_idx, pb.idxB + (size_t)frame * cap, sizeof(int32_t) * K);
     D2H(keep_idx_circ, c->d_idxA + (size_t)frame * cap, sizeof(int32_t) * M);
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_out)
@@ -548,9 +608,12 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
         return VO_ERR_ARG;
     if (frame < 0 || frame >= c->n_frames)
         return fail(c, VO_ERR_ARG, "vo_batch_get_pose: bad frame");
-    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    const vo_ctx::PoseBufs &pb = c->pb[c->last];
     PnpResult r;
-    VO_HIP_TRY(c, hipMemcpyAsync(&r, c->d_results + frame, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(&r, pb.results + frame, sizeof(r), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (r.status >= 0) {
         if (rvec)
@@ -561,7 +624,7 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
             memcpy(R, r.R, sizeof(r.R));
     }
     if (inliers && r.n_inliers > 0) {
-        D2H(inliers, c->d_inliers + (size_t)frame * c->cap, sizeof(int32_t) * r.n_inliers);
+        D2H(inliers, pb.inliers + (size_t)frame * c->cap, sizeof(int32_t) * r.n_inliers);
         VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (n_inliers)
@@ -681,7 +744,7 @@ int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uin
     if (out_l0_ret && K > 0) {
         std::vector<int32_t> idx((size_t)K);
         std::vector<float> ret((size_t)2 * (n > 0 ? n : 1));
-        VO_HIP_TRY(c, hipMemcpy(idx.data(), c->d_idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+        VO_HIP_TRY(c, hipMemcpy(idx.data(), c->pb[c->last].idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
         VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk + (size_t)3 * c->cap, sizeof(float2) * n,
                                 hipMemcpyDeviceToHost));
         for (int i = 0; i < K; i++) {
@@ -705,14 +768,18 @@ int vo_triangulate(vo_ctx *c, const float *P_l, const float *P_r, const float *p
     int rc = vo_batch_set_projection(c, P_l, P_r);
     if (rc != VO_OK)
         return rc;
+    rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
     // frame 0, stage-B rows 0 (left) and 1 (right)
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB, pl, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB + c->cap, pr, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    launch_triangulate(c->d_P, c->d_P + 12, c->d_outB, c->d_outB + c->cap, (size_t)4 * c->cap, c->d_nB, c->cap,
-                       n, 1, c->d_xyz, c->stream);
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB, pl, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + c->cap, pr, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + c->cap, (size_t)4 * c->cap, pb.nB, c->cap, n, 1,
+                       pb.xyz, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
-    VO_HIP_TRY(c, hipMemcpyAsync(xyz_out, c->d_xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(xyz_out, pb.xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VO_OK;
 }
@@ -738,22 +805,25 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
         return VO_ERR_ARG;
     if (n > c->cap)
         return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
-    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
     PnpParams pp;
     pp.iters = c->prm.ransac_iterations;
     pp.reproj = c->prm.ransac_reproj_error;
     pp.confidence = c->prm.ransac_confidence;
     memcpy(pp.K, K, sizeof(pp.K));
     if (n > 0) {
-        VO_HIP_TRY(c, hipMemcpyAsync(c->d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-        VO_HIP_TRY(c, hipMemcpyAsync(c->d_outB + 2 * (size_t)c->cap, uv, sizeof(float2) * n,
-                                     hipMemcpyHostToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + 2 * (size_t)c->cap, uv, sizeof(float2) * n, hipMemcpyHostToDevice,
+                                     c->stream));
     }
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (c->n_frames < 1)
         c->n_frames = 1;
-    launch_pnp(c->d_xyz, c->d_outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, c->d_nB, c->cap, 1, pp,
-               c->d_subsets, c->d_models, c->d_counts, c->d_inliers, c->d_results, c->stream);
+    launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
+               pb.models, pb.counts, pb.inliers, pb.results, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
 }

@@ -28,7 +28,6 @@
 #include "vo_lkmath.h"
 
 #include <float.h>
-#include <stdlib.h>
 
 namespace vo {
 
@@ -43,10 +42,6 @@ struct __attribute__((packed, aligned(4))) LkU4 {
     uint32_t a, b, c, d;
 };
 
-// ALIGNED_LDS = false: the two J rows are read as unaligned 8-byte LDS accesses (gfx950 supports
-// them; a misaligned access may take extra LDS cycles).  true: three aligned dwords per row +
-// v_alignbyte_b32.  Both are kept so the choice is a measured one (VO_LK_ALIGNED_LDS=1 selects true).
-template <bool ALIGNED_LDS>
 __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
                                                           const float2 *__restrict__ pts_in,
@@ -57,7 +52,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                                                           uint8_t *__restrict__ status,  // [B][4][cap]
                                                           LkParams prm)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_jt[LK_JT_H * LK_JT_W + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_jt[LK_JT_H * LK_JT_W];
 
     // XCD-aware block numbering: block id b runs on XCD b % 8 (observed dispatcher behaviour, used
     // for L2 affinity only): XCD x works on frames x, x + 8, x + 16, ... one frame after another
@@ -123,7 +118,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             int iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
             int iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
             int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
-            uint32_t wt = pack_w(iw00, iw01), wb = pack_w(iw10, iw11);
+            const uint32_t wt = pack_w(iw00, iw01), wb = pack_w(iw10, iw11); // signed lanes: iw11 may be -1
 
             // ---- 21 x 21 template straight from the bordered pyramid (registers) + structure tensor --
             // lane: pixels (ipx + c0 .. + 7, ipy + r) and the row below; the bordered layout makes
@@ -140,7 +135,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + o + istride + 4);
                 const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
                 const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
-                bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Ip);
+                bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Ip);
                 bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
@@ -203,28 +198,16 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
                 iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
                 iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
-                wt = pack_w(iw00, iw01);
-                wb = pack_w(iw10, iw11);
 
                 int b1 = 0, b2 = 0;
                 {
                     const int off = (iny - jy0 + r) * LK_JT_W + (inx - jx0) + c0;
-                    LkU2 t, u;
-                    if (ALIGNED_LDS) {
-                        const uint32_t *q0 = reinterpret_cast<const uint32_t *>(&s_jt[off & ~3]);
-                        const uint32_t *q1 = q0 + LK_JT_W / 4;
-                        const uint32_t sh = (uint32_t)off & 3u;
-                        const uint32_t t0 = q0[0], t1 = q0[1], t2 = q0[2], u0 = q1[0], u1 = q1[1], u2 = q1[2];
-                        t.lo = VO_ALIGNBYTE(t1, t0, sh);
-                        t.hi = VO_ALIGNBYTE(t2, t1, sh);
-                        u.lo = VO_ALIGNBYTE(u1, u0, sh);
-                        u.hi = VO_ALIGNBYTE(u2, u1, sh);
-                    } else {
-                        t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
-                        u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
-                    }
+                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
+                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
+                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
                     uint32_t Jp[4];
-                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Jp);
+                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Jp);
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         const uint32_t diff = pk_sub_i16(Jp[m], Ip[m]);
@@ -280,16 +263,8 @@ void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float
     const int parts = 8 / fpg, ppp = (max_pts + parts - 1) / parts;
     const int groups = (n_frames + fpg - 1) / fpg;
     dim3 grid((unsigned)(8 * groups * ppp));
-    static const bool aligned_lds = [] {
-        const char *e = getenv("VO_LK_ALIGNED_LDS");
-        return e && e[0] == '1';
-    }();
-    if (aligned_lds)
-        hipLaunchKernelGGL(lk_circular_kernel<true>, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts,
-                           cap, n_frames, fpg, ppp, d_trk, d_status, prm);
-    else
-        hipLaunchKernelGGL(lk_circular_kernel<false>, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts,
-                           cap, n_frames, fpg, ppp, d_trk, d_status, prm);
+    hipLaunchKernelGGL(lk_circular_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames,
+                       fpg, ppp, d_trk, d_status, prm);
 }
 
 #endif // VO_HOST_EMUL

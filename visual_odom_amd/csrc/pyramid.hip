@@ -9,7 +9,7 @@
 //   level itself; Scharr: 3x3 unnormalised, REFLECT_101 (= reading the level's own border).
 //
 // Kernels (all HBM-streaming; see DESIGN.md for the byte counts):
-//   border_fill_kernel  writes the REFLECT_101 border of one level from its interior
+//   border_fill_kernel  writes the REFLECT_101 border of one level from its interior (workgroup per row)
 //   pyr_down_kernel     one 256-thread workgroup -> 64 x 16 output tile; the 136 x 35 source tile is
 //                       staged in LDS with aligned dword loads (the source border makes every tile an
 //                       in-bounds read), u16 horizontal partials in LDS, 4 pixels per 32-bit store
@@ -25,18 +25,26 @@ struct __attribute__((packed, aligned(1))) U8x8 {
 };
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
+// one 64-thread workgroup per bordered row: rows above / below the image copy a whole reflected row,
+// image rows only write their VO_BX left and (stride - VO_BX - w) right border pixels
+__global__ __launch_bounds__(64) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
 {
-    const PyrImage &im = imgs[blockIdx.z];
+    const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
     uint8_t *__restrict__ p = im.lvl[level];
-    const int x = (int)(blockIdx.x * 256 + threadIdx.x) - VO_BX; // -VO_BX .. stride - VO_BX - 1
-    const int y = (int)blockIdx.y - VO_BY;                        // -VO_BY .. h + VO_BY - 1
-    if (x >= stride - VO_BX)
-        return;
-    if (x >= 0 && x < w && y >= 0 && y < h)
-        return;
-    p[(ptrdiff_t)y * stride + x] = p[(ptrdiff_t)reflect101(y, h) * stride + reflect101(x, w)];
+    const int y = (int)blockIdx.x - VO_BY; // -VO_BY .. h + VO_BY - 1
+    const uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
+    uint8_t *__restrict__ dst = p + (ptrdiff_t)y * stride;
+    const int right = stride - VO_BX - w; // >= VO_BY
+    if (y >= 0 && y < h) {
+        for (int i = threadIdx.x; i < VO_BX + right; i += 64) {
+            const int x = i < VO_BX ? i - VO_BX : w + (i - VO_BX);
+            dst[x] = src[reflect101(x, w)];
+        }
+    } else {
+        for (int x = (int)threadIdx.x - VO_BX; x < stride - VO_BX; x += 64)
+            dst[x] = src[reflect101(x, w)];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -132,8 +140,9 @@ __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict_
 #ifndef VO_HOST_EMUL
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream)
 {
-    dim3 grid((stride + 255) / 256, h + 2 * VO_BY, n_images);
-    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(256), 0, stream, d_imgs, level);
+    (void)stride;
+    dim3 grid(h + 2 * VO_BY, n_images);
+    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(64), 0, stream, d_imgs, level);
 }
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)

@@ -24,13 +24,11 @@
 #define VO_READFIRSTLANE(v) emu_readfirstlane(v)
 #define VO_READLANE(v, l) emu_readlane((v), (l))
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
-#define VO_ALIGNBYTE(hi, lo, sh) emu_alignbyte((hi), (lo), (sh))
 #else
 #include <hip/hip_runtime.h>
 #define VO_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
 #define VO_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
-#define VO_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #endif
 
 #define VO_MAX_LEVELS 5
