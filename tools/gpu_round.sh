@@ -33,9 +33,14 @@ stamp "bench (reference-default load, 374 points per frame)"
 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 > "$OUT/bench_kitti374.json" 2> "$OUT/bench_kitti374.err"
 cat "$OUT/bench_kitti374.json"
 
+stamp "bench (pose solve serialised on the tracking stream)"
+VO_SERIAL_POSE=1 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_serial.json" 2> "$OUT/bench_serial.err"
+cat "$OUT/bench_serial.json"
 cd /tmp
-stamp "rocprofv3 kernel trace"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/prof.log" 2>&1
+stamp "rocprofv3 kernel trace (serialised pose solve: stand-alone kernel durations)"
+VO_SERIAL_POSE=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/prof.log" 2>&1
+stamp "rocprofv3 kernel trace (overlapped, as benched)"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_overlap" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/prof_overlap.log" 2>&1
 stamp "rocprofv3 pmc FETCH_SIZE"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 stamp "rocprofv3 pmc WRITE_SIZE"

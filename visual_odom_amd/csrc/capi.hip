@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -53,6 +54,7 @@ struct vo_ctx {
     } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
     hipStream_t stream_pnp = nullptr;
+    bool serial_pose = false;
     int ransac_cap = 0;
     float h_P[24] = {};
     bool have_P = false;
@@ -182,6 +184,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream_pnp, hipStreamNonBlocking) == hipSuccess;
+    // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
+    // that a kernel trace shows every kernel's stand-alone duration
+    {
+        const char *e = getenv("VO_SERIAL_POSE");
+        c->serial_pose = e && e[0] == '1';
+    }
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 2), nullptr);
@@ -435,10 +443,11 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (stages & VO_STAGE_PNP) {
         // the pose solve is a chain of low-occupancy, latency-bound kernels: it runs on its own
         // stream so that the next run's pyramid / LK launches (ctx stream) overlap it
+        hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
-        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream_pnp, pb.ready, 0));
+        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.ready, 0));
         if (timed)
-            VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], c->stream_pnp));
+            VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], ps));
         PnpParams pp;
         pp.iters = c->prm.ransac_iterations;
         pp.reproj = c->prm.ransac_reproj_error;
@@ -448,10 +457,10 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             for (int k = 0; k < 3; k++)
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.inliers, pb.results, c->stream_pnp);
+                   pb.inliers, pb.results, ps);
         if (timed)
-            VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream_pnp));
-        VO_HIP_TRY(c, hipEventRecord(pb.done, c->stream_pnp));
+            VO_HIP_TRY(c, hipEventRecord(evs[e], ps));
+        VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
         pb.pending = true;
     } else if (timed) {
         VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], c->stream));

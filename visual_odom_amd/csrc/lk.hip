@@ -225,7 +225,9 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 outY = nextY + halfWin;
                 if ((double)dx * dx + (double)dy * dy <= prm.epsilon)
                     break;
-                if (j > 0 && fabs((double)(dx + prevDX)) < 0.01 && fabs((double)(dy + prevDY)) < 0.01) {
+                // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
+                // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f
+                if (j > 0 && fabsf(dx + prevDX) <= 0.01f && fabsf(dy + prevDY) <= 0.01f) {
                     outX -= dx * 0.5f;
                     outY -= dy * 0.5f;
                     break;

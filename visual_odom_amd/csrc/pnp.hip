@@ -67,6 +67,9 @@ __global__ __launch_bounds__(64) void epnp_kernel(const float *__restrict__ xyz,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
                                                   double *__restrict__ models /* [B][iters][6] */)
 {
+    // M^T M (12 x 12) + its column norms of every lane, lane-interleaved: element idx of lane l at
+    // s_ut[idx * 64 + l] -> consecutive lanes hit consecutive 8-byte words (conflict-free ds_*_b64)
+    __shared__ double s_ut[(144 + 12) * 64];
     const int frame = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
     if (count < 5)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64) void epnp_kernel(const float *__restrict__ xyz,
         u5[2 * i + 1] = q.y;
     }
     double rv[3], tv[3];
-    epnp5_solve(x5, u5, prm.K, rv, tv);
+    epnp5_solve_t<64>(x5, u5, prm.K, rv, tv, s_ut + threadIdx.x);
     double *m = models + ((size_t)frame * prm.iters + h) * 6;
     m[0] = rv[0];
     m[1] = rv[1];

@@ -79,24 +79,28 @@ __device__ __forceinline__ int dpp_add(int v)
 
 // Exact wave-wide sum of per-lane int32 partials, returned as a wave-uniform f32 rounded once from
 // the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| <= 2^28 so
-// that the first three butterfly steps (8-lane sums) cannot overflow int32; the 8-lane sums are then
-// split into a signed high and an unsigned low 16-bit half which are reduced separately (row_mirror,
-// row_bcast15, row_bcast31: the total lands in lane 63) and recombined exactly in f64.
-// Ten v_add_u32_dpp + two v_readlane instead of 12 ds_bpermute round trips through the LDS pipe.
+// that three butterfly steps (v_add_u32_dpp: quad_perm xor 1, xor 2, row_half_mirror = 8-lane sums)
+// cannot overflow int32.  The eight group sums are then read with v_readlane and added as int64 on
+// the SCALAR unit, which is otherwise idle in this VALU-bound kernel; the total almost always fits
+// int32, where one v_cvt_f32_i32 is the correctly rounded conversion (else via f64, exact < 2^53).
+// 3 DPP + 8 v_readlane + 1 cvt VALU instructions per sum instead of 12 ds_bpermute round trips.
 __device__ __forceinline__ float wave_sum_exact_f32(int v)
 {
     v = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(v);
     v = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(v);
     v = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(v);
-    int lo = v & 0xffff, hi = v >> 16;
-    lo = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(lo);
-    hi = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(hi);
-    lo = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(lo);
-    hi = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(hi);
-    lo = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(lo);
-    hi = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(hi);
-    const int slo = VO_READLANE(lo, 63), shi = VO_READLANE(hi, 63);
-    return (float)((double)shi * 65536.0 + (double)slo);
+    long long s = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++)
+        s += (long long)VO_READLANE(v, 8 * g);
+    const int s32 = (int)s;
+    if (__builtin_expect((long long)s32 != s, 0)) {
+#ifndef VO_HOST_EMUL
+        asm volatile("" ::: "memory"); // keep this rare path a real branch (no if-conversion into the hot path)
+#endif
+        return (float)(double)s;
+    }
+    return (float)s32;
 }
 
 } // namespace vo

@@ -30,8 +30,10 @@ VO_HD void qr_solve_6x4(double *pA, double *pb, double *pX)
 {
     const int nr = 6, nc = 4;
     double A1[4], A2[4];
+#pragma unroll
     for (int k = 0; k < nc; k++) {
         double eta = fabs(pA[k * nc + k]);
+#pragma unroll
         for (int i = k + 1; i < nr; i++) { // scans rows k .. nr-2
             double elt = fabs(pA[(i - 1) * nc + k]);
             if (eta < elt)
@@ -41,6 +43,7 @@ VO_HD void qr_solve_6x4(double *pA, double *pb, double *pX)
             return;
         }
         double sum2 = 0.0, inv_eta = 1. / eta;
+#pragma unroll
         for (int i = k; i < nr; i++) {
             pA[i * nc + k] *= inv_eta;
             sum2 += pA[i * nc + k] * pA[i * nc + k];
@@ -51,26 +54,34 @@ VO_HD void qr_solve_6x4(double *pA, double *pb, double *pX)
         pA[k * nc + k] += sigma;
         A1[k] = sigma * pA[k * nc + k];
         A2[k] = -eta * sigma;
+#pragma unroll
         for (int j = k + 1; j < nc; j++) {
             double sum = 0;
+#pragma unroll
             for (int i = k; i < nr; i++)
                 sum += pA[i * nc + k] * pA[i * nc + j];
             double tau = sum / A1[k];
+#pragma unroll
             for (int i = k; i < nr; i++)
                 pA[i * nc + j] -= tau * pA[i * nc + k];
         }
     }
+#pragma unroll
     for (int j = 0; j < nc; j++) { // b <- Qt b
         double tau = 0;
+#pragma unroll
         for (int i = j; i < nr; i++)
             tau += pA[i * nc + j] * pb[i];
         tau /= A1[j];
+#pragma unroll
         for (int i = j; i < nr; i++)
             pb[i] -= tau * pA[i * nc + j];
     }
     pX[nc - 1] = pb[nc - 1] / A2[nc - 1]; // X = R^-1 b
+#pragma unroll
     for (int i = nc - 2; i >= 0; i--) {
         double sum = 0;
+#pragma unroll
         for (int j = i + 1; j < nc; j++)
             sum += pA[i * nc + j] * pX[j];
         pX[i] = (pb[i] - sum) / A2[i];
@@ -81,6 +92,7 @@ VO_HD void epnp_gauss_newton(const double *L, const double *rho, double *betas)
 {
     double a[24], b[6], x[4] = {0, 0, 0, 0};
     for (int it = 0; it < 5; it++) {
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             const double *rowL = L + i * 10;
             double *rowA = a + i * 4;
@@ -95,51 +107,67 @@ VO_HD void epnp_gauss_newton(const double *L, const double *rho, double *betas)
                              rowL[8] * betas[2] * betas[3] + rowL[9] * betas[3] * betas[3]);
         }
         qr_solve_6x4(a, b, x);
+#pragma unroll
         for (int i = 0; i < 4; i++)
             betas[i] += x[i];
     }
 }
 
 // camera-frame control points from betas, point cloud, sign, Horn alignment, reprojection error
+template <int S>
 VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *betas, double *R /*9*/,
                                   double *t)
 {
     const int n = 5;
+#pragma unroll
     for (int i = 0; i < 4; i++)
         e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-        const double *v = ut + 12 * (11 - i);
+        const double *v = ut + 12 * (11 - i) * S;
+#pragma unroll
         for (int j = 0; j < 4; j++)
+#pragma unroll
             for (int k = 0; k < 3; k++)
-                e.ccs[j][k] += betas[i] * v[3 * j + k];
+                e.ccs[j][k] += betas[i] * v[(3 * j + k) * S];
     }
+#pragma unroll
     for (int i = 0; i < n; i++) {
         const double *a = e.alphas + 4 * i;
         double *pc = e.pcs + 3 * i;
+#pragma unroll
         for (int j = 0; j < 3; j++)
             pc[j] = a[0] * e.ccs[0][j] + a[1] * e.ccs[1][j] + a[2] * e.ccs[2][j] + a[3] * e.ccs[3][j];
     }
     if (e.pcs[2] < 0.0) { // solve_for_sign
+#pragma unroll
         for (int i = 0; i < 4; i++)
+#pragma unroll
             for (int j = 0; j < 3; j++)
                 e.ccs[i][j] = -e.ccs[i][j];
+#pragma unroll
         for (int i = 0; i < 3 * n; i++)
             e.pcs[i] = -e.pcs[i];
     }
     // estimate_R_and_t
     double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+#pragma unroll
     for (int i = 0; i < n; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             pc0[j] += e.pcs[3 * i + j];
             pw0[j] += e.pws[3 * i + j];
         }
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         pc0[j] /= n;
         pw0[j] /= n;
     }
     double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
     for (int i = 0; i < n; i++) {
         const double *pc = e.pcs + 3 * i, *pw = e.pws + 3 * i;
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
             abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
@@ -147,11 +175,15 @@ VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *beta
         }
     }
     double At[9], wd[3], vt[9];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int k = 0; k < 3; k++)
             At[i * 3 + k] = abt[k * 3 + i];
     jacobi_svd<3, 3, true>(At, wd, vt);
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) // (U V^T)[i][j], U[i][k] = At[k][i], V[j][k] = vt[k][j]
             R[i * 3 + j] = At[0 * 3 + i] * vt[0 * 3 + j] + At[1 * 3 + i] * vt[1 * 3 + j] +
                            At[2 * 3 + i] * vt[2 * 3 + j];
@@ -167,6 +199,7 @@ VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *beta
     t[2] = pc0[2] - dot3(R + 6, pw0);
     // reprojection_error
     double sum2 = 0.0;
+#pragma unroll
     for (int i = 0; i < n; i++) {
         const double *pw = e.pws + 3 * i;
         double Xc = dot3(R + 0, pw) + t[0];
@@ -182,9 +215,15 @@ VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *beta
 
 // xyz5[15], uv5[10]: the subset (f32, as RANSAC's getSubset copies them); Kf: 3x3 f32 row-major.
 // Outputs rvec[3], tvec[3] (f64).
-VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
-                                double *tvec)
+// S / ut_mem: the 12 x 12 matrix M^T M (and its 12 column norms) is the one object of this solver
+// that does not fit in registers next to everything else; the caller provides (144 + 12) * S doubles
+// for it, element idx at ut_mem[idx * S] (device: lane-interleaved LDS, S = workgroup size; host: a
+// private array, S = 1).
+template <int S>
+VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
+                                  double *tvec, double *ut)
 {
+#define VO_UT(idx) ut[(idx) * S]
     const int n = 5;
     Epnp5 e;
     e.fu = (double)Kf[0];
@@ -192,6 +231,7 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
     e.uc = (double)Kf[2];
     e.vc = (double)Kf[5];
     const double ifx = 1. / e.fu, ify = 1. / e.fv;
+#pragma unroll
     for (int i = 0; i < n; i++) {
         // undistortPoints (zero distortion) -> f32 normalised coords -> back to pixels in f64
         double x = ((double)uv5[2 * i] - e.uc) * ifx, y = ((double)uv5[2 * i + 1] - e.vc) * ify;
@@ -204,19 +244,27 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
     }
     // ---- choose_control_points
     e.cws[0][0] = e.cws[0][1] = e.cws[0][2] = 0;
+#pragma unroll
     for (int i = 0; i < n; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++)
             e.cws[0][j] += e.pws[3 * i + j];
+#pragma unroll
     for (int j = 0; j < 3; j++)
         e.cws[0][j] /= n;
     {
         double PW0[15], ptp[9], dc[3], vt[9];
+#pragma unroll
         for (int i = 0; i < n; i++)
+#pragma unroll
             for (int j = 0; j < 3; j++)
                 PW0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
+#pragma unroll
         for (int i = 0; i < 3; i++)
+#pragma unroll
             for (int j = i; j < 3; j++) {
                 double s = 0;
+#pragma unroll
                 for (int k = 0; k < n; k++)
                     s += PW0[k * 3 + i] * PW0[k * 3 + j];
                 ptp[i * 3 + j] = s;
@@ -226,8 +274,10 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
         ptp[7] = ptp[5];
         // symmetric: At == A^T == A; rows of At after the SVD = U^T
         jacobi_svd<3, 3, true>(ptp, dc, vt);
+#pragma unroll
         for (int i = 1; i < 4; i++) {
             double k = sqrt(dc[i - 1] / n);
+#pragma unroll
             for (int j = 0; j < 3; j++)
                 e.cws[i][j] = e.cws[0][j] + k * ptp[3 * (i - 1) + j];
         }
@@ -235,13 +285,17 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
     // ---- compute_barycentric_coordinates
     {
         double cc[9], ci[9];
+#pragma unroll
         for (int i = 0; i < 3; i++)
+#pragma unroll
             for (int j = 1; j < 4; j++)
                 cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
         invert_svd<3>(cc, ci);
+#pragma unroll
         for (int i = 0; i < n; i++) {
             const double *pi = e.pws + 3 * i;
             double *a = e.alphas + 4 * i;
+#pragma unroll
             for (int j = 0; j < 3; j++)
                 a[1 + j] = ci[3 * j] * (pi[0] - e.cws[0][0]) + ci[3 * j + 1] * (pi[1] - e.cws[0][1]) +
                            ci[3 * j + 2] * (pi[2] - e.cws[0][2]);
@@ -249,13 +303,22 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
         }
     }
     // ---- M (10 x 12), M^T M, its eigen-basis through the SVD
-    double ut[144], d12[12];
+    // M^T M is accumulated point by point (rows 2p and 2p+1 of M at a time): for every (i, j) the
+    // partial sums are formed in the same order k = 0 .. 9 as the plain triple loop, so the result
+    // is bit-identical, but M itself (120 doubles) never has to exist.
+    double d12[12];
     {
-        double M[120];
-        for (int i = 0; i < n; i++) {
-            const double *as = e.alphas + 4 * i;
-            double u = e.us[2 * i], v = e.us[2 * i + 1];
-            double *M1 = M + (2 * i) * 12, *M2 = M1 + 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+#pragma unroll
+            for (int j = i; j < 12; j++)
+                VO_UT(i * 12 + j) = 0;
+#pragma unroll 1
+        for (int p = 0; p < n; p++) {
+            const double *as = e.alphas + 4 * p;
+            const double u = e.us[2 * p], v = e.us[2 * p + 1];
+            double M1[12], M2[12];
+#pragma unroll
             for (int q = 0; q < 4; q++) {
                 M1[3 * q] = as[q] * e.fu;
                 M1[3 * q + 1] = 0.0;
@@ -264,31 +327,37 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
                 M2[3 * q + 1] = as[q] * e.fv;
                 M2[3 * q + 2] = as[q] * (e.vc - v);
             }
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+#pragma unroll
+                for (int j = i; j < 12; j++) {
+                    double acc = VO_UT(i * 12 + j);
+                    acc += M1[i] * M1[j];
+                    acc += M2[i] * M2[j];
+                    VO_UT(i * 12 + j) = acc;
+                }
         }
+#pragma unroll
         for (int i = 0; i < 12; i++)
-            for (int j = i; j < 12; j++) {
-                double s = 0;
-                for (int k = 0; k < 2 * n; k++)
-                    s += M[k * 12 + i] * M[k * 12 + j];
-                ut[i * 12 + j] = s;
-            }
-        for (int i = 0; i < 12; i++)
+#pragma unroll
             for (int j = 0; j < i; j++)
-                ut[i * 12 + j] = ut[j * 12 + i];
+                VO_UT(i * 12 + j) = VO_UT(j * 12 + i);
     }
-    jacobi_svd<12, 12, false>(ut, d12, nullptr);
+    jacobi_svd<12, 12, false, S>(ut, d12, nullptr);
 
     // ---- L_6x10, rho
     double L[60], rho[6];
     {
-        const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
         double dv[4][6][3];
+#pragma unroll
         for (int i = 0; i < 4; i++) {
             int a = 0, b = 1;
+#pragma unroll
             for (int j = 0; j < 6; j++) {
-                dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
-                dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
-                dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+                const int va = 12 * (11 - i) + 3 * a, vb = 12 * (11 - i) + 3 * b; // null vector i = row 11 - i
+                dv[i][j][0] = VO_UT(va) - VO_UT(vb);
+                dv[i][j][1] = VO_UT(va + 1) - VO_UT(vb + 1);
+                dv[i][j][2] = VO_UT(va + 2) - VO_UT(vb + 2);
                 b++;
                 if (b > 3) {
                     a++;
@@ -296,6 +365,7 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
                 }
             }
         }
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             double *row = L + 10 * i;
             row[0] = dot3(dv[0][i], dv[0][i]);
@@ -321,6 +391,7 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
     // ---- approximation 1: betas10 columns [B11 B12 B13 B14]
     {
         double l[24], b4[4], betas[4];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 4 + 0] = L[i * 10 + 0];
             l[i * 4 + 1] = L[i * 10 + 1];
@@ -340,11 +411,12 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
             betas[3] = b4[3] / betas[0];
         }
         epnp_gauss_newton(L, rho, betas);
-        rep[0] = epnp_compute_R_and_t(e, ut, betas, Rs[0], ts[0]);
+        rep[0] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[0], ts[0]);
     }
     // ---- approximation 2: [B11 B12 B22]
     {
         double l[18], b3[3], betas[4];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 3 + 0] = L[i * 10 + 0];
             l[i * 3 + 1] = L[i * 10 + 1];
@@ -363,11 +435,12 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
         betas[2] = 0.0;
         betas[3] = 0.0;
         epnp_gauss_newton(L, rho, betas);
-        rep[1] = epnp_compute_R_and_t(e, ut, betas, Rs[1], ts[1]);
+        rep[1] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[1], ts[1]);
     }
     // ---- approximation 3: [B11 B12 B22 B13 B23]
     {
         double l[30], b5[5], betas[4];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 5 + 0] = L[i * 10 + 0];
             l[i * 5 + 1] = L[i * 10 + 1];
@@ -388,17 +461,33 @@ VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float
         betas[2] = b5[3] / betas[0];
         betas[3] = 0.0;
         epnp_gauss_newton(L, rho, betas);
-        rep[2] = epnp_compute_R_and_t(e, ut, betas, Rs[2], ts[2]);
+        rep[2] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[2], ts[2]);
     }
-    int N = 0;
-    if (rep[1] < rep[0])
-        N = 1;
-    if (rep[2] < rep[N])
-        N = 2;
-    rodrigues_m2v(Rs[N], rvec);
-    tvec[0] = ts[N][0];
-    tvec[1] = ts[N][1];
-    tvec[2] = ts[N][2];
+    // best of the three by reprojection error (first strictly smaller wins); selected with
+    // compile-time indices so Rs / ts stay in registers
+    const bool use1 = rep[1] < rep[0];
+    const double rep01 = use1 ? rep[1] : rep[0];
+    const bool use2 = rep[2] < rep01;
+    double Rb[9], tb[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        Rb[k] = use2 ? Rs[2][k] : use1 ? Rs[1][k] : Rs[0][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        tb[k] = use2 ? ts[2][k] : use1 ? ts[1][k] : ts[0][k];
+    rodrigues_m2v(Rb, rvec);
+    tvec[0] = tb[0];
+    tvec[1] = tb[1];
+    tvec[2] = tb[2];
+#undef VO_UT
+}
+
+// private-array form (host unit tests, and any caller without a staging area)
+VO_HD_NOINLINE void epnp5_solve(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
+                                double *tvec)
+{
+    double ut[144 + 12];
+    epnp5_solve_t<1>(xyz5, uv5, Kf, rvec, tvec, ut);
 }
 
 } // namespace vo

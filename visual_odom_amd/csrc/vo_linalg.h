@@ -35,21 +35,32 @@ VO_HD double vo_hypot(double a, double b) { return sqrt(fma(a, a, b * b)); }
 // (At is N rows of length M, row stride M).  On return: W[N] descending singular values,
 // rows of At = left singular vectors (normalised), rows of Vt = right singular vectors.
 // WANT_V = false skips accumulating V (At rows are still sorted), used for EPnP's 12x12.
-template <int M, int N, bool WANT_V>
+// STRIDE: element (i, k) of At lives at At[(i * M + k) * STRIDE] -- 1 for a private array, the
+// workgroup size for a lane-interleaved LDS array (EPnP's 12 x 12: 288 registers' worth of matrix
+// that would otherwise push the kernel into scratch memory).  Small problems (N <= 6) are fully
+// unrolled so that every access has a compile-time index and the matrices live in registers.
+template <int M, int N, bool WANT_V, int STRIDE = 1>
 VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
 {
+    constexpr int UNR = N <= 6 ? N : 1; // unroll factor of the pair loops (1 = keep rolled)
+#define VO_AT(i, k) At[((i) * M + (k)) * STRIDE]
+    // squared column norms: private registers when unrolled, behind the matrix (N more strided
+    // elements: the caller provides (M * N + N) * STRIDE doubles) when the pair loops stay rolled
+#define VO_W(i) (*(STRIDE > 1 ? &At[(M * N + (i)) * STRIDE] : &W[i]))
     const double eps = DBL_EPSILON * 10;
     const double minval = DBL_MIN;
     double W[N];
     const int max_iter = M > 30 ? M : 30;
 
-    for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) { // W[] is small: always compile-time indexed
         double sd = 0;
+#pragma unroll
         for (int k = 0; k < M; k++) {
-            double t = At[i * M + k];
+            double t = VO_AT(i, k);
             sd += t * t;
         }
-        W[i] = sd;
+        VO_W(i) = sd;
         if (WANT_V) {
             for (int k = 0; k < N; k++)
                 Vt[i * N + k] = 0;
@@ -57,14 +68,19 @@ VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
         }
     }
 
+    // The pair loops are fully unrolled so that every At / W / Vt access has a compile-time index:
+    // the matrices then live in registers (VGPRs + AGPRs) instead of scratch memory, which is what
+    // the pose kernels' run time used to be made of (1.7 GB of scratch writes per EPnP launch).
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
+#pragma unroll UNR
         for (int i = 0; i < N - 1; i++)
+#pragma unroll UNR
             for (int j = i + 1; j < N; j++) {
-                double *Ai = At + i * M, *Aj = At + j * M;
-                double a = W[i], p = 0, b = W[j];
+                double a = VO_W(i), p = 0, b = VO_W(j);
+#pragma unroll
                 for (int k = 0; k < M; k++)
-                    p += Ai[k] * Aj[k];
+                    p += VO_AT(i, k) * VO_AT(j, k);
                 if (fabs(p) <= eps * sqrt(a * b))
                     continue;
                 p *= 2;
@@ -79,19 +95,22 @@ VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
                     s = p / (gamma * c * 2);
                 }
                 a = b = 0;
+#pragma unroll
                 for (int k = 0; k < M; k++) {
-                    double t0 = c * Ai[k] + s * Aj[k];
-                    double t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0;
-                    Aj[k] = t1;
+                    const double ai = VO_AT(i, k), aj = VO_AT(j, k);
+                    double t0 = c * ai + s * aj;
+                    double t1 = -s * ai + c * aj;
+                    VO_AT(i, k) = t0;
+                    VO_AT(j, k) = t1;
                     a += t0 * t0;
                     b += t1 * t1;
                 }
-                W[i] = a;
-                W[j] = b;
+                VO_W(i) = a;
+                VO_W(j) = b;
                 changed = true;
                 if (WANT_V) {
                     double *Vi = Vt + i * N, *Vj = Vt + j * N;
+#pragma unroll
                     for (int k = 0; k < N; k++) {
                         double t0 = c * Vi[k] + s * Vj[k];
                         double t1 = -s * Vi[k] + c * Vj[k];
@@ -104,79 +123,98 @@ VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
             break;
     }
 
+#pragma unroll
     for (int i = 0; i < N; i++) {
         double sd = 0;
+#pragma unroll
         for (int k = 0; k < M; k++) {
-            double t = At[i * M + k];
+            double t = VO_AT(i, k);
             sd += t * t;
         }
-        W[i] = sqrt(sd);
+        VO_W(i) = sqrt(sd);
     }
 
-    // selection sort, descending; rows of At / Vt follow
+    // selection sort, descending; rows of At / Vt follow.  OpenCV swaps row i with the FIRST index
+    // of the running maximum; the same swap is expressed with compile-time row indices (predicated
+    // on c == j) so that the rows stay in registers.
+#pragma unroll UNR
     for (int i = 0; i < N - 1; i++) {
         int j = i;
+        double wj = VO_W(i);
+#pragma unroll
         for (int k = i + 1; k < N; k++)
-            if (W[j] < W[k])
+            if (wj < VO_W(k)) {
                 j = k;
-        if (i != j) {
-            double t = W[i];
-            W[i] = W[j];
-            W[j] = t;
-            for (int k = 0; k < M; k++) {
-                t = At[i * M + k];
-                At[i * M + k] = At[j * M + k];
-                At[j * M + k] = t;
+                wj = VO_W(k);
             }
-            if (WANT_V)
-                for (int k = 0; k < N; k++) {
-                    t = Vt[i * N + k];
-                    Vt[i * N + k] = Vt[j * N + k];
-                    Vt[j * N + k] = t;
+#pragma unroll UNR
+        for (int c = i + 1; c < N; c++) {
+            if (c == j) {
+                double t = VO_W(i);
+                VO_W(i) = VO_W(c);
+                VO_W(c) = t;
+#pragma unroll
+                for (int k = 0; k < M; k++) {
+                    t = VO_AT(i, k);
+                    VO_AT(i, k) = VO_AT(c, k);
+                    VO_AT(c, k) = t;
                 }
+                if (WANT_V) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        t = Vt[i * N + k];
+                        Vt[i * N + k] = Vt[c * N + k];
+                        Vt[c * N + k] = t;
+                    }
+                }
+            }
         }
     }
+#pragma unroll
     for (int i = 0; i < N; i++)
-        Wout[i] = W[i];
+        Wout[i] = VO_W(i);
 
     // left singular vectors: normalise; exactly-zero singular values get a deterministic
     // pseudo-random vector orthogonalised against the previous ones (cv::RNG(0x12345678) stream)
     uint64_t rng = 0x12345678;
+#pragma unroll UNR
     for (int i = 0; i < N; i++) {
-        double sd = W[i];
+        double sd = VO_W(i);
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
             const double val0 = 1. / M;
             for (int k = 0; k < M; k++) {
                 rng = (uint64_t)(uint32_t)rng * 4164903690U + (uint32_t)(rng >> 32);
-                At[i * M + k] = ((uint32_t)rng & 256) != 0 ? val0 : -val0;
+                VO_AT(i, k) = ((uint32_t)rng & 256) != 0 ? val0 : -val0;
             }
             for (int iter = 0; iter < 2; iter++)
                 for (int j = 0; j < i; j++) {
                     sd = 0;
                     for (int k = 0; k < M; k++)
-                        sd += At[i * M + k] * At[j * M + k];
+                        sd += VO_AT(i, k) * VO_AT(j, k);
                     double asum = 0;
                     for (int k = 0; k < M; k++) {
-                        double t = At[i * M + k] - sd * At[j * M + k];
-                        At[i * M + k] = t;
+                        double t = VO_AT(i, k) - sd * VO_AT(j, k);
+                        VO_AT(i, k) = t;
                         asum += fabs(t);
                     }
                     asum = asum > eps * 100 ? 1 / asum : 0;
                     for (int k = 0; k < M; k++)
-                        At[i * M + k] *= asum;
+                        VO_AT(i, k) *= asum;
                 }
             sd = 0;
             for (int k = 0; k < M; k++) {
-                double t = At[i * M + k];
+                double t = VO_AT(i, k);
                 sd += t * t;
             }
             sd = sqrt(sd);
         }
         double s = sd > minval ? 1 / sd : 0.;
         for (int k = 0; k < M; k++)
-            At[i * M + k] *= s;
+            VO_AT(i, k) *= s;
     }
 }
+#undef VO_W
+#undef VO_AT
 
 // least squares / linear solve through the SVD (cv::solve(..., DECOMP_SVD), one rhs).
 // A is M x N row-major (M >= N), consumed.
