@@ -62,8 +62,10 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="frame quadruples per step per GPU")
     ap.add_argument("--quads", type=int, default=8, help="distinct rendered quadruples cycled over the batch")
     ap.add_argument("--workload", default="kitti2000", choices=sorted(WORKLOADS))
-    ap.add_argument("--stages", default="full", choices=["full", "lk"],
-                    help="full = BASELINE config 3 (LK+tri+PnP on device); lk = config 2 (circularMatching only)")
+    ap.add_argument("--stages", default="full", choices=["full", "lk", "detect+full"],
+                    help="full = BASELINE config 3 (LK+tri+PnP on device); lk = config 2 (circularMatching only); "
+                         "detect+full = additionally FAST + bucketing on the device produce the LK input points "
+                         "(SURVEY.md 8 row f1) instead of points resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     args = ap.parse_args()
@@ -108,7 +110,17 @@ def main():
         ctx.batch_set_points(b, frame_pts[b])
     P_l, P_r = world.proj_matrices()
     ctx.batch_set_projection(P_l, P_r)
-    stages = _lib.STAGE_ALL if args.stages == "full" else (_lib.STAGE_PYRAMID | _lib.STAGE_LK | _lib.STAGE_FILTER)
+    stages = (_lib.STAGE_PYRAMID | _lib.STAGE_LK | _lib.STAGE_FILTER) if args.stages == "lk" else _lib.STAGE_ALL
+    if args.stages == "detect+full":
+        # every frame starts from an empty carried set: FAST runs on its left t0 image, bucketing keeps
+        # per_bucket corners per cell -> the same ~2000-point load, produced on the device
+        for b in range(B):
+            ctx.batch_set_features(b, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+        ctx.batch_set_detect_params(features_per_bucket=WORKLOADS[args.workload][2])
+        stages |= _lib.STAGE_DETECT
+        ctx.batch_run(stages)
+        ctx.batch_sync()
+        frame_pts = [ctx.batch_get_features(b)[0] for b in range(B)]
 
     def barrier():
         ctx.batch_sync()
@@ -137,7 +149,7 @@ def main():
     pts_per_launch = sum(len(p) for p in frame_pts)
     lk_bytes = sum(ctx.model_bytes(w, h, len(p))[1] for p in frame_pts)
     frame_bytes = sum(ctx.model_bytes(w, h, len(p)).sum() for p in frame_pts) / B
-    lk_ms = float(stage_ms[1])
+    lk_ms = float(stage_ms[_lib.STAGE_NAMES.index("lk")])
     achieved = lk_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
 
     out = None

@@ -47,6 +47,20 @@ typedef struct vo_params {
 
 void vo_default_params(vo_params *p);
 
+/* Detection / bucketing parameters; vo_default_detect_params() fills the reference's literals
+ * (feature.cpp:43-45: FAST threshold 20, nonmaxSuppression true; visualOdometry.cpp:95: re-detect when
+ *  fewer than 2000 features are carried over; :106-107: bucket_size = rows / 10 (0 here = that rule),
+ *  features_per_bucket = 1). */
+typedef struct vo_detect_params {
+    int fast_threshold;
+    int fast_nonmax;
+    int redetect_below;
+    int bucket_size;
+    int features_per_bucket;
+} vo_detect_params;
+
+void vo_default_detect_params(vo_detect_params *p);
+
 /* device: HIP device ordinal.  max_w/max_h: largest image.  max_pts: per-frame point capacity.
  * max_frames: largest batch for the vo_batch_* API (1 is enough for the drop-in calls).
  * Returns NULL on failure (no HIP device, out of memory). */
@@ -86,6 +100,20 @@ int vo_triangulate(vo_ctx *ctx, const float *P_l, const float *P_r, const float 
 int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers);
 
+/* Replaces cv::FAST as called by featureDetectionFast() -- feature.cpp:39-47: TYPE_9_16 corners of an
+ * 8-bit image in row-major order.  pts_out [2 * cap]; *n_out = corners found (may exceed cap, in which
+ * case only the first cap are written). */
+int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
+                   float *pts_out, int cap, int *n_out);
+
+/* Replaces the head of matchingFeatures() -- visualOdometry.cpp:95-108: appendNewFeatures(image, set)
+ * when the set has fewer than redetect_below points (feature.cpp:255-262), then bucketingFeatures()
+ * (feature.cpp:206-253, bucket.cpp:14-51, quirks of SURVEY.md App. B1-B3 reproduced).
+ * pts_io [2 * cap] / ages_io [cap]: in: *n_pts points and *n_ages ages (n_ages >= n_pts allowed, as in
+ * the reference after a consistency filter); out: the bucketed set (*n_pts == *n_ages). */
+int vo_detect_bucket(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
+                     float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap);
+
 /* The whole per-frame hot path in one call: circularMatching + consistency filter + triangulation
  * + PnP/RANSAC (matchingFeatures' tail visualOdometry.cpp:116-127, main.cpp:169-181), one upload,
  * one download.  out_l0/out_r0/out_l1/out_r1 [2n] and xyz_out [3n] are compacted to *n_out (= K).
@@ -108,8 +136,9 @@ int vo_track_frame(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, co
 #define VO_STAGE_FILTER 4
 #define VO_STAGE_TRIANGULATE 8
 #define VO_STAGE_PNP 16
-#define VO_STAGE_ALL 31
-#define VO_NUM_STAGES 5
+#define VO_STAGE_ALL 31      /* the path with the LK input points given (vo_batch_set_points) */
+#define VO_STAGE_DETECT 32   /* + FAST / bucketing of every frame's left t0 image produce those points */
+#define VO_NUM_STAGES 6      /* timing order: PYRAMID, DETECT, LK, FILTER, TRIANGULATE, PNP */
 
 int vo_batch_configure(vo_ctx *ctx, int n_images, int w, int h, int n_frames);
 /* host -> device copy of one level-0 image */
@@ -120,10 +149,18 @@ int vo_batch_upload_image_dev(vo_ctx *ctx, int image_idx, const void *dev_pixels
 int vo_batch_set_quads(vo_ctx *ctx, const int32_t *quads4, int n_frames);
 int vo_batch_set_points(vo_ctx *ctx, int frame, const float *pts_l0_xy, int n);
 int vo_batch_set_projection(vo_ctx *ctx, const float *P_l, const float *P_r);
+/* VO_STAGE_DETECT inputs: the features carried into `frame` from the previous frame (n_pts may be 0;
+ * n_ages >= n_pts), and the detection parameters (NULL = reference defaults).  The stage leaves the
+ * bucketed set as the frame's LK input points, exactly like vo_batch_set_points would. */
+int vo_batch_set_features(vo_ctx *ctx, int frame, const float *pts_xy, int n_pts, const int32_t *ages,
+                          int n_ages);
+int vo_batch_set_detect_params(vo_ctx *ctx, const vo_detect_params *dp);
+/* the bucketed set of one frame after VO_STAGE_DETECT (after vo_batch_sync); pts [2 * cap], ages [cap] */
+int vo_batch_get_features(vo_ctx *ctx, int frame, float *pts_xy, int32_t *ages, int *n);
 /* enqueue the selected stages for all frames on the ctx stream (asynchronous) */
 int vo_batch_run(vo_ctx *ctx, int stages);
 /* same, bracketed per stage by HIP events on the ctx stream; blocks; ms_per_stage[VO_NUM_STAGES]
- * in the order PYRAMID, LK, FILTER, TRIANGULATE, PNP */
+ * in the order PYRAMID, DETECT, LK, FILTER, TRIANGULATE, PNP */
 int vo_batch_run_timed(vo_ctx *ctx, int stages, float *ms_per_stage);
 /* asynchronous variant: like vo_batch_run, with the per-stage HIP events of ring slot `slot`
  * (0 <= slot < VO_EVENT_SLOTS) recorded on the ctx stream; after vo_batch_sync,

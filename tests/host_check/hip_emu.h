@@ -16,6 +16,7 @@
 #include <string.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -199,6 +200,41 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
         return bound_ctrl ? 0 : old;
     return (int)got;
 }
+// wave-wide ballot: bit l = predicate of lane l of the caller's wavefront
+static inline unsigned long long emu_ballot(bool pred)
+{
+    emu::Block *b = emu::current();
+    const int lane = emu::lane_id(), wave0 = lane & ~63;
+    b->xbuf[lane] = pred ? 1 : 0;
+    emu::yield();
+    unsigned long long m = 0;
+    for (int l = 0; l < 64 && wave0 + l < b->n; l++)
+        if (!b->done[wave0 + l] && b->xbuf[wave0 + l])
+            m |= 1ull << l;
+    emu::yield();
+    return m;
+}
+// lanes run one at a time between yields, so plain read-modify-write is atomic here
+static inline int atomicAdd(int *p, int v)
+{
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+static inline int atomicMax(int *p, int v)
+{
+    int o = *p;
+    *p = o > v ? o : v;
+    return o;
+}
+static inline int atomicMin(int *p, int v)
+{
+    int o = *p;
+    *p = o < v ? o : v;
+    return o;
+}
+using std::max;
+using std::min;
 static inline uint32_t emu_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh)
 {
     const uint64_t v = ((uint64_t)hi << 32) | lo;

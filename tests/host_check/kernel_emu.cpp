@@ -4,6 +4,7 @@
 // arithmetic, DPP reductions, tile handling) with the oracle without a GPU.  Not a product path.
 #include "hip_emu.h"
 
+#include "../../visual_odom_amd/csrc/fast.hip"
 #include "../../visual_odom_amd/csrc/lk.hip"
 #include "../../visual_odom_amd/csrc/pyramid.hip"
 
@@ -119,5 +120,50 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     }
     memcpy(trk, out.data(), sizeof(float2) * 4 * (size_t)n);
     return p.levels;
+}
+
+// FAST + NMS + bucketing kernels of fast.hip on one image.  tracked / ages_in: the carried set
+// (n_tracked points, n_ages ages, n_ages >= n_tracked).  bucket_size == 0: return the raw corners.
+int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int do_detect, const float *tracked,
+              int n_tracked, const int *ages_in, int n_ages, int bucket_size, int fpb, float *out_pts, int *out_ages,
+              int out_cap)
+{
+    using namespace vo;
+    Plan p = plan(w, h, 0);
+    std::vector<uint8_t> pix(p.total, 0xA5);
+    PyrImage im;
+    memset(&im, 0, sizeof(im));
+    im.lvl[0] = pix.data() + p.off[0] + (size_t)VO_BY * p.ls[0] + VO_BX;
+    im.w[0] = w;
+    im.h[0] = h;
+    im.stride[0] = p.ls[0];
+    for (int y = 0; y < h; y++)
+        memcpy(im.lvl[0] + (ptrdiff_t)y * p.ls[0], img + (size_t)y * w, w);
+    Quad quad{0, 0, 0, 0};
+    const int fcap = 1 << 17;
+    std::vector<uint16_t> score((size_t)w * h, 0xBEEF);
+    std::vector<int> rowcnt(h, -1), fages(fcap, 0);
+    std::vector<float2> feat(fcap);
+    memcpy(feat.data(), tracked, sizeof(float2) * n_tracked);
+    memcpy(fages.data(), ages_in, sizeof(int) * n_ages);
+    int n_new = -1, n_out = -1;
+    launch((w + 63) / 64, (h + 3) / 4, 1, 256, [&] { fast_score_kernel(&im, &quad, &do_detect, threshold, score.data()); });
+    launch(h, 1, 1, 256, [&] {
+        fast_nms_kernel<false>(score.data(), w, h, &do_detect, nonmax, rowcnt.data(), &n_tracked, fcap, feat.data());
+    });
+    launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), h, &do_detect, &n_new); });
+    launch(h, 1, 1, 256, [&] {
+        fast_nms_kernel<true>(score.data(), w, h, &do_detect, nonmax, rowcnt.data(), &n_tracked, fcap, feat.data());
+    });
+    if (bucket_size <= 0) {
+        const int k = n_new < out_cap ? n_new : out_cap;
+        memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);
+        return n_new;
+    }
+    launch(1, 1, 1, 256, [&] {
+        bucket_kernel(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
+                      out_ages, &n_out, out_cap);
+    });
+    return n_out;
 }
 }

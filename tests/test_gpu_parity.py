@@ -323,3 +323,82 @@ def test_full_size_properties_1080p_4000(gpu_ctx, volib, orc):
     ok = g4["status4"].all(0)
     assert ok.mean() > 0.6
     assert np.median(np.abs(g4["l0_ret"][ok] - pts[ok]).max(1)) < 0.1
+
+
+# ------------------------------------------------------------------ row f1: FAST + bucketing on the device
+def test_fast_detect_dropin(gpu_ctx, orc, kitti_seq, small_seq):
+    for img in (kitti_seq["L"][0], small_seq["L"][1]):
+        for thr, nonmax in ((20, True), (40, False)):
+            ref = orc.fast_detect(img, thr, nonmax)
+            got = gpu_ctx.fast_detect(img, thr, nonmax)
+            assert len(ref) > 100 and np.array_equal(got, ref), (img.shape, thr, nonmax)
+    rng = np.random.default_rng(2)
+    noise = rng.integers(0, 256, (64, 97), dtype=np.uint8)
+    assert np.array_equal(gpu_ctx.fast_detect(noise), orc.fast_detect(noise, 20, True))
+
+
+def test_detect_bucket_dropin_with_quirks(gpu_ctx, orc, kitti_seq):
+    """head of matchingFeatures (visualOdometry.cpp:95-108) incl. aliasing / duplicate emission /
+    slot-0 overwrite / age >= 10 / ages longer than points"""
+    img = kitti_seq["L"][0]
+    h, w = img.shape
+    rng = np.random.default_rng(6)
+    tracked = np.stack([rng.uniform(0, w - 1, 500), rng.uniform(0, h - 1, 500)], 1).astype(np.float32)
+    tracked[:3] = [[w - 1, 5.5], [w - 0.25, h - 1], [1240.5, 200]]
+    ages = rng.integers(0, 13, 540).astype(np.int32)
+    fast = orc.fast_detect(img, 20, True)
+    comb_p = np.vstack([tracked, fast])
+    comb_a = np.concatenate([ages, np.zeros(len(comb_p) - len(ages), np.int32)])
+    for fpb in (1, 6):
+        ref_p, ref_a = orc.bucketing_features(h, w, comb_p, comb_a, h // 10, fpb)
+        got_p, got_a = gpu_ctx.detect_bucket(img, tracked, ages, features_per_bucket=fpb)
+        assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a), fpb
+    # a set of >= redetect_below points is bucketed without re-detection
+    ref_p, ref_a = orc.bucketing_features(h, w, tracked, ages[:500], h // 10, 1)
+    got_p, got_a = gpu_ctx.detect_bucket(img, tracked, ages[:500], redetect_below=400)
+    assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a)
+    # empty carried set (first frame of a sequence, main.cpp:110-121)
+    ref_p, ref_a = orc.bucketing_features(h, w, fast, np.zeros(len(fast), np.int32), h // 10, 1)
+    got_p, got_a = gpu_ctx.detect_bucket(img, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+    assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a) and 250 < len(got_p) <= 374
+
+
+def test_batch_detect_stage_feeds_lk(gpu_ctx, volib, orc, small_world, small_seq):
+    """VO_STAGE_DETECT leaves the bucketed set as the LK input on the device: the rest of the path must
+    equal the path run on the oracle's bucketed points"""
+    s = small_seq
+    P_l, P_r = small_world.proj_matrices()
+    h, w = s["L"][0].shape
+    gpu_ctx.batch_configure(6, w, h, 2)
+    for k in range(3):
+        gpu_ctx.batch_upload_image(2 * k, s["L"][k])
+        gpu_ctx.batch_upload_image(2 * k + 1, s["R"][k])
+    gpu_ctx.batch_set_quads([[0, 1, 2, 3], [2, 3, 4, 5]])
+    carried = [(s["pts"][0][:40], np.arange(40, dtype=np.int32) % 12), (np.zeros((0, 2), np.float32), np.zeros(0, np.int32))]
+    for f, (p, a) in enumerate(carried):
+        gpu_ctx.batch_set_features(f, p, a)
+    gpu_ctx.batch_set_detect_params(features_per_bucket=2)
+    gpu_ctx.batch_set_projection(P_l, P_r)
+    try:
+        gpu_ctx.batch_run(volib.STAGE_ALL | volib.STAGE_DETECT)
+        gpu_ctx.batch_sync()
+        for f, (p, a) in enumerate(carried):
+            L0, R0, L1, R1 = s["L"][f], s["R"][f], s["L"][f + 1], s["R"][f + 1]
+            fast = orc.fast_detect(L0, 20, True)
+            comb_p = np.vstack([p, fast])
+            comb_a = np.concatenate([a, np.zeros(len(fast), np.int32)])
+            ref_p, ref_a = orc.bucketing_features(h, w, comb_p, comb_a, h // 10, 2)
+            got_p, got_a = gpu_ctx.batch_get_features(f)
+            assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a)
+            ref = orc.circular_matching(L0, R0, L1, R1, ref_p)
+            (l0, r0, l1, r1), _ = orc.check_valid_and_remove(ref["l0"], ref["r0"], ref["l1"], ref["r1"], ref["l0_ret"])
+            got = gpu_ctx.batch_get_filtered(f)
+            assert np.array_equal(got["keep_idx_circ"], ref["keep_idx"])
+            assert np.array_equal(bits(got["l1"]), bits(l1)) and np.array_equal(bits(got["r0"]), bits(r0))
+            if len(l0) >= 5:
+                xyz = orc.triangulate(P_l, P_r, l0, r0)
+                rc, rv, tv, inl, _ = orc.solve_pnp_ransac(xyz, l1, small_world.K())
+                pose = gpu_ctx.batch_get_pose(f)
+                assert pose["status"] == rc and pose_close(pose["rvec"], pose["tvec"], rv, tv)
+    finally:
+        gpu_ctx.batch_set_detect_params()

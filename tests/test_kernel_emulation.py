@@ -22,7 +22,7 @@ def kemu():
     so = os.path.join(out_dir, "libkernel_emu.so")
     csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
-    deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h")]
+    deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -121,3 +121,51 @@ def test_emulated_lk_negative_bilinear_weight(kemu, orc):
     r = ke_run(kemu, imgs, pts)
     ref, st = _oracle_hops(orc, *imgs, pts)
     assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
+
+
+def ke_detect(lib, img, tracked=None, ages=None, threshold=20, nonmax=1, detect=1, bucket_size=0, fpb=1, cap=40000):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    tracked = np.zeros((0, 2), np.float32) if tracked is None else np.ascontiguousarray(tracked, np.float32).reshape(-1, 2)
+    ages = np.zeros(len(tracked), np.int32) if ages is None else np.ascontiguousarray(ages, np.int32)
+    out_p, out_a = np.zeros((cap, 2), np.float32), np.zeros(cap, np.int32)
+    n = lib.ke_detect(vp(img), w, h, threshold, nonmax, detect, vp(tracked), len(tracked), vp(ages), len(ages), bucket_size,
+                      fpb, vp(out_p), vp(out_a), cap)
+    assert 0 <= n <= cap
+    return out_p[:n].copy(), out_a[:n].copy()
+
+
+def test_emulated_fast_matches_oracle(kemu, orc, small_seq):
+    img = small_seq["L"][0]
+    for thr, nonmax in ((20, 1), (35, 0), (0, 1)):
+        got, _ = ke_detect(kemu, img, threshold=thr, nonmax=nonmax)
+        ref = orc.fast_detect(img, thr, bool(nonmax))
+        assert len(ref) > 50 and np.array_equal(got, ref), (thr, nonmax)
+    rng = np.random.default_rng(4)
+    noise = rng.integers(0, 256, (40, 57), dtype=np.uint8)
+    got, _ = ke_detect(kemu, noise, threshold=20)
+    assert np.array_equal(got, orc.fast_detect(noise, 20, True))
+    flat = np.full((32, 32), 77, np.uint8)
+    assert len(ke_detect(kemu, flat)[0]) == 0
+
+
+def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq):
+    """bucket.cpp / feature.cpp:206-253 quirks: aliased last column, duplicate emission, slot-0 overwrite,
+    age >= 10 dropped, ages longer than points (stale ages inherited by new corners)"""
+    img = small_seq["L"][0]
+    h, w = img.shape
+    rng = np.random.default_rng(5)
+    tracked = np.stack([rng.uniform(0, w - 1, 300), rng.uniform(0, h - 1, 300)], 1).astype(np.float32)
+    tracked[:4] = [[w - 1, 3.5], [w - 0.5, h - 1], [0, 0], [w - 2.25, 50]]      # last-column aliases
+    ages = rng.integers(0, 13, 330).astype(np.int32)                             # 30 more ages than points
+    fast = orc.fast_detect(img, 20, True)
+    for bucket, fpb in ((h // 10, 1), (h // 10, 6), (23, 3)):
+        comb_p = np.vstack([tracked, fast])
+        comb_a = np.concatenate([ages, np.zeros(len(tracked) + len(fast) - len(ages), np.int32)])
+        ref_p, ref_a = orc.bucketing_features(h, w, comb_p, comb_a, bucket, fpb)
+        got_p, got_a = ke_detect(kemu, img, tracked, ages, bucket_size=bucket, fpb=fpb)
+        assert len(ref_p) > 30 and np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a), (bucket, fpb)
+    # no re-detection: only the carried set is bucketed
+    ref_p, ref_a = orc.bucketing_features(h, w, tracked, ages[:len(tracked)], h // 10, 2)
+    got_p, got_a = ke_detect(kemu, img, tracked, ages[:len(tracked)], detect=0, bucket_size=h // 10, fpb=2)
+    assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a)

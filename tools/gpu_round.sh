@@ -33,6 +33,9 @@ stamp "bench (reference-default load, 374 points per frame)"
 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 > "$OUT/bench_kitti374.json" 2> "$OUT/bench_kitti374.err"
 cat "$OUT/bench_kitti374.json"
 
+stamp "bench (FAST + bucketing on the device feed LK)"
+timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages detect+full > "$OUT/bench_detect.json" 2> "$OUT/bench_detect.err"
+cat "$OUT/bench_detect.json"
 stamp "bench (pose solve serialised on the tracking stream)"
 VO_SERIAL_POSE=1 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_serial.json" 2> "$OUT/bench_serial.err"
 cat "$OUT/bench_serial.json"

@@ -13,12 +13,15 @@ SO_PATH = os.path.join(HERE, "libvo_hip.so")
 
 VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW = 0, -1, -2, -3, -4
 STAGE_PYRAMID, STAGE_LK, STAGE_FILTER, STAGE_TRIANGULATE, STAGE_PNP, STAGE_ALL = 1, 2, 4, 8, 16, 31
+STAGE_DETECT = 32
 EVENT_SLOTS = 256
-STAGE_NAMES = ("pyramid", "lk", "filter", "triangulate", "pnp")
+STAGE_NAMES = ("pyramid", "detect", "lk", "filter", "triangulate", "pnp")
+NUM_STAGES = len(STAGE_NAMES)
 
 # every symbol include/vo_hip.h declares (checked by the CPU test-suite against the built .so)
 EXPORTS = (
-    "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
+    "vo_default_params", "vo_default_detect_params", "vo_fast_detect", "vo_detect_bucket",
+    "vo_batch_set_features", "vo_batch_set_detect_params", "vo_batch_get_features", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
     "vo_circular_match", "vo_triangulate", "vo_pnp_ransac", "vo_track_frame",
     "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
     "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
@@ -32,6 +35,11 @@ class VoParams(C.Structure):
                 ("lk_min_eig_threshold", C.c_double), ("consistency_threshold", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_reproj_error", C.c_float),
                 ("ransac_confidence", C.c_double)]
+
+
+class VoDetectParams(C.Structure):
+    _fields_ = [("fast_threshold", C.c_int), ("fast_nonmax", C.c_int), ("redetect_below", C.c_int),
+                ("bucket_size", C.c_int), ("features_per_bucket", C.c_int)]
 
 
 class VoError(RuntimeError):
@@ -60,6 +68,8 @@ def load():
     lib.vo_last_error.argtypes = [C.c_void_p]
     lib.vo_default_params.argtypes = [C.POINTER(VoParams)]
     lib.vo_default_params.restype = None
+    lib.vo_default_detect_params.argtypes = [C.POINTER(VoDetectParams)]
+    lib.vo_default_detect_params.restype = None
     _lib = lib
     return lib
 
@@ -157,6 +167,45 @@ class Context:
                                               _p(inl), C.byref(ninl)), allow=(1,))
         return rc == VO_OK, rv, tv, R, inl[:ninl.value].copy()
 
+    def detect_params(self, **kw):
+        p = VoDetectParams()
+        self.lib.vo_default_detect_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        return p
+
+    def fast_detect(self, img, threshold=20, nonmax=True, cap=65536):
+        """featureDetectionFast (feature.cpp:39-47): corners in row-major order, (n, 2) float32"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        pts = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.vo_fast_detect(self.h, _p(img), w, h, w, int(threshold), int(bool(nonmax)), _p(pts), cap,
+                                          C.byref(n)))
+        if n.value > cap:
+            raise VoError(VO_ERR_ARG, "fast_detect: %d corners exceed cap %d" % (n.value, cap))
+        return pts[:n.value].copy()
+
+    def detect_bucket(self, img, pts, ages, **detect_kw):
+        """appendNewFeatures (if fewer than redetect_below points) + bucketingFeatures
+        (visualOdometry.cpp:95-108); returns (points, ages) of the bucketed set"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        pts = _f32(pts, (-1, 2))
+        ages = np.ascontiguousarray(ages, np.int32).reshape(-1)
+        cap = max(self.max_pts, len(ages), 1)
+        p_io = np.zeros((cap, 2), np.float32)
+        a_io = np.zeros(cap, np.int32)
+        p_io[:len(pts)] = pts
+        a_io[:len(ages)] = ages
+        n_pts, n_ages = C.c_int(len(pts)), C.c_int(len(ages))
+        dp = self.detect_params(**detect_kw)
+        self._chk(self.lib.vo_detect_bucket(self.h, _p(img), w, h, w, C.byref(dp), _p(p_io), C.byref(n_pts), _p(a_io),
+                                            C.byref(n_ages), cap))
+        return p_io[:n_pts.value].copy(), a_io[:n_ages.value].copy()
+
     def track_frame(self, l0, r0, l1, r1, pts_l0, P_l, P_r, rvec=None, tvec=None):
         imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
         h, w = imgs[0].shape
@@ -200,6 +249,22 @@ class Context:
         pts = _f32(pts, (-1, 2))
         self._chk(self.lib.vo_batch_set_points(self.h, frame, _p(pts), pts.shape[0]))
 
+    def batch_set_features(self, frame, pts, ages):
+        pts = _f32(pts, (-1, 2))
+        ages = np.ascontiguousarray(ages, np.int32).reshape(-1)
+        self._chk(self.lib.vo_batch_set_features(self.h, frame, _p(pts), pts.shape[0], _p(ages), ages.shape[0]))
+
+    def batch_set_detect_params(self, **kw):
+        dp = self.detect_params(**kw)
+        self._chk(self.lib.vo_batch_set_detect_params(self.h, C.byref(dp)))
+
+    def batch_get_features(self, frame):
+        pts = np.zeros((self.max_pts, 2), np.float32)
+        ages = np.zeros(self.max_pts, np.int32)
+        n = C.c_int(0)
+        self._chk(self.lib.vo_batch_get_features(self.h, frame, _p(pts), _p(ages), C.byref(n)))
+        return pts[:n.value].copy(), ages[:n.value].copy()
+
     def batch_set_projection(self, P_l, P_r):
         self._chk(self.lib.vo_batch_set_projection(self.h, _p(_f32(P_l, (3, 4))), _p(_f32(P_r, (3, 4)))))
 
@@ -207,7 +272,7 @@ class Context:
         self._chk(self.lib.vo_batch_run(self.h, stages))
 
     def batch_run_timed(self, stages=STAGE_ALL):
-        ms = np.zeros(5, np.float32)
+        ms = np.zeros(NUM_STAGES, np.float32)
         self._chk(self.lib.vo_batch_run_timed(self.h, stages, _p(ms)))
         return ms
 
@@ -215,7 +280,7 @@ class Context:
         self._chk(self.lib.vo_batch_run_slot(self.h, stages, slot))
 
     def batch_slot_times(self, slot):
-        ms = np.zeros(5, np.float32)
+        ms = np.zeros(NUM_STAGES, np.float32)
         self._chk(self.lib.vo_batch_slot_times(self.h, slot, _p(ms)))
         return ms
 

@@ -27,7 +27,8 @@ struct vo_ctx {
     int n_images = 0, n_frames = 0, w = 0, h = 0, levels = 0; // levels = max_level + 1 actually built
     int lw[VO_MAX_LEVELS] = {}, lh[VO_MAX_LEVELS] = {}, lstride[VO_MAX_LEVELS] = {};
     size_t loff[VO_MAX_LEVELS] = {}, img_bytes = 0;
-    int max_pts_set = 0; // largest n over the frames of the batch
+    int max_pts_set = 0; // largest n over the frames of the batch (or its bound after VO_STAGE_DETECT)
+    bool pts_on_device = false, detect_uploaded = false;
 
     // device memory
     uint8_t *d_pix = nullptr;  // all bordered pyramids, image i at d_pix + i * img_bytes
@@ -53,6 +54,16 @@ struct vo_ctx {
         bool pending = false;                        // `done` has been recorded and not waited for
     } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
+    // detection / bucketing (VO_STAGE_DETECT)
+    vo_detect_params dprm;
+    int fcap = 0;                  // capacity of the carried + detected feature list of a frame
+    uint16_t *d_score = nullptr;   // [B][max_h][max_w] FAST corner flag << 8 | score
+    int *d_rowcnt = nullptr;       // [B][max_h]
+    int *d_detect = nullptr, *d_ntracked = nullptr, *d_nnew = nullptr; // [B]
+    float2 *d_feat = nullptr;      // [B][fcap] carried features, then the new corners
+    int *d_fages = nullptr;        // [B][fcap] ages of d_feat (zero beyond the uploaded ages)
+    int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
+    std::vector<int> h_ntracked, h_detect;
     hipStream_t stream_pnp = nullptr;
     bool serial_pose = false;
     int ransac_cap = 0;
@@ -128,6 +139,15 @@ void vo_default_params(vo_params *p)
     p->ransac_confidence = (double)0.999f; // `float confidence = 0.999` in the reference
 }
 
+void vo_default_detect_params(vo_detect_params *p)
+{
+    p->fast_threshold = 20;     // feature.cpp:43
+    p->fast_nonmax = 1;         // feature.cpp:44
+    p->redetect_below = 2000;   // visualOdometry.cpp:95
+    p->bucket_size = 0;         // 0 = rows / 10, visualOdometry.cpp:106
+    p->features_per_bucket = 1; // visualOdometry.cpp:107
+}
+
 const char *vo_last_error(const vo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 void vo_destroy(vo_ctx *c)
@@ -136,7 +156,8 @@ void vo_destroy(vo_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk, c->d_outA,
-                    c->d_status, c->d_npts, c->d_nA, c->d_idxA, c->d_P};
+                    c->d_status, c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_rowcnt, c->d_detect,
+                    c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -232,10 +253,27 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
     }
+    vo_default_detect_params(&c->dprm);
+    c->fcap = max_pts * 4 > 16384 ? max_pts * 4 : 16384;
+    ok = ok && dmalloc(&c->d_score, B * (size_t)max_w * max_h) == hipSuccess;
+    ok = ok && dmalloc(&c->d_rowcnt, B * (size_t)max_h) == hipSuccess;
+    ok = ok && dmalloc(&c->d_detect, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_ntracked, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_nnew, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_feat, B * (size_t)c->fcap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_fages, B * (size_t)c->fcap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_ages, B * cap) == hipSuccess;
     if (ok) {
         ok = hipMemset(c->d_npts, 0, B * sizeof(int)) == hipSuccess &&
-             hipMemset(c->d_nA, 0, B * sizeof(int)) == hipSuccess;
+             hipMemset(c->d_nA, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_ntracked, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_nnew, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_detect, 0, B * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_fages, 0, B * (size_t)c->fcap * sizeof(int)) == hipSuccess &&
+             hipMemset(c->d_ages, 0, B * cap * sizeof(int)) == hipSuccess;
     }
+    c->h_ntracked.assign(B, 0);
+    c->h_detect.assign(B, 1);
     if (!ok) {
         vo_destroy(c);
         return nullptr;
@@ -301,7 +339,10 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     c->h = h;
     c->max_pts_set = 0;
     std::fill(c->h_npts.begin(), c->h_npts.end(), 0);
+    std::fill(c->h_ntracked.begin(), c->h_ntracked.end(), 0);
     VO_HIP_TRY(c, hipMemsetAsync(c->d_npts, 0, sizeof(int) * c->max_frames, c->stream));
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_ntracked, 0, sizeof(int) * c->max_frames, c->stream));
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_fages, 0, sizeof(int) * (size_t)c->max_frames * c->fcap, c->stream));
     return VO_OK;
 }
 
@@ -359,12 +400,73 @@ int vo_batch_set_points(vo_ctx *c, int frame, const float *pts, int n)
         VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts + (size_t)frame * c->cap, pts, sizeof(float2) * n,
                                      hipMemcpyHostToDevice, c->stream));
     c->h_npts[frame] = n;
+    c->pts_on_device = false;
     VO_HIP_TRY(c, hipMemcpyAsync(c->d_npts + frame, &c->h_npts[frame], sizeof(int), hipMemcpyHostToDevice,
                                  c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->max_pts_set = 0;
     for (int f = 0; f < c->n_frames; f++)
         c->max_pts_set = c->h_npts[f] > c->max_pts_set ? c->h_npts[f] : c->max_pts_set;
+    return VO_OK;
+}
+
+int vo_batch_set_features(vo_ctx *c, int frame, const float *pts, int n_pts, const int32_t *ages, int n_ages)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (c->n_images == 0)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_features before vo_batch_configure");
+    if (frame < 0 || frame >= c->n_frames || n_pts < 0 || n_ages < n_pts || n_ages > c->fcap ||
+        (n_pts > 0 && !pts) || (n_ages > 0 && !ages))
+        return fail(c, VO_ERR_ARG, "vo_batch_set_features: bad frame / counts (need n_pts <= n_ages <= capacity)");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    // ages beyond n_ages must read as 0 (age of a freshly appended corner, feature.cpp:260)
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_fages + (size_t)frame * c->fcap, 0, sizeof(int) * (size_t)c->fcap, c->stream));
+    if (n_pts > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_feat + (size_t)frame * c->fcap, pts, sizeof(float2) * n_pts,
+                                     hipMemcpyHostToDevice, c->stream));
+    if (n_ages > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_fages + (size_t)frame * c->fcap, ages, sizeof(int) * n_ages,
+                                     hipMemcpyHostToDevice, c->stream));
+    c->h_ntracked[frame] = n_pts;
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_ntracked + frame, &c->h_ntracked[frame], sizeof(int), hipMemcpyHostToDevice,
+                                 c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_batch_set_detect_params(vo_ctx *c, const vo_detect_params *dp)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (!dp) {
+        vo_default_detect_params(&c->dprm);
+        return VO_OK;
+    }
+    if (dp->features_per_bucket < 1 || dp->features_per_bucket > 8 || dp->bucket_size < 0)
+        return fail(c, VO_ERR_ARG, "vo_batch_set_detect_params: features_per_bucket must be 1..8, bucket_size >= 0");
+    c->dprm = *dp;
+    return VO_OK;
+}
+
+int vo_batch_get_features(vo_ctx *c, int frame, float *pts, int32_t *ages, int *n)
+{
+    if (!c || !n)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_features: bad frame");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int k = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(&k, c->d_npts + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (pts && k > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(pts, c->d_pts + (size_t)frame * c->cap, sizeof(float2) * k, hipMemcpyDeviceToHost,
+                                     c->stream));
+    if (ages && k > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(ages, c->d_ages + (size_t)frame * c->cap, sizeof(int) * k, hipMemcpyDeviceToHost,
+                                     c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n = k;
     return VO_OK;
 }
 
@@ -404,6 +506,38 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             launch_border_fill(c->d_imgs, c->n_images, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
         }
         launch_scharr(c->d_imgs, c->n_images, c->levels, c->lw[0], c->lh[0], c->stream);
+    }
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+    e++;
+    if (stages & VO_STAGE_DETECT) {
+        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
+        const int fpb = c->dprm.features_per_bucket;
+        const int cells = (c->h / bs + 1) * (c->w / bs + 1);
+        if (bs < 1 || fpb < 1 || fpb > 8 || cells > 1024)
+            return fail(c, VO_ERR_ARG, "vo_batch_run: bucket grid beyond 1024 cells / 8 features per bucket");
+        // appendNewFeatures only when fewer than redetect_below features were carried in (visualOdometry.cpp:95)
+        bool changed = false;
+        for (int f = 0; f < B; f++) {
+            const int d = c->h_ntracked[f] < c->dprm.redetect_below ? 1 : 0;
+            changed |= d != c->h_detect[f];
+            c->h_detect[f] = d;
+        }
+        if (changed || !c->detect_uploaded) {
+            VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, c->h_detect.data(), sizeof(int) * B, hipMemcpyHostToDevice,
+                                         c->stream));
+            VO_HIP_TRY(c, hipStreamSynchronize(c->stream)); // h_detect is reused by the next call
+            c->detect_uploaded = true;
+        }
+        int t = c->dprm.fast_threshold;
+        t = t < 0 ? 0 : t > 255 ? 255 : t;
+        launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
+                             c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb, c->d_pts,
+                             c->d_ages, c->d_npts, cap, c->stream);
+        // the bucketed count is only known on the device; every later grid is sized by its bound
+        const int bound = cells * fpb < cap ? cells * fpb : cap;
+        c->max_pts_set = bound;
+        c->pts_on_device = true;
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
@@ -835,6 +969,82 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
                pb.models, pb.counts, pb.inliers, pb.results, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
+}
+
+// one image as a 1-frame batch whose quad points at image 0 four times
+static int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
+{
+    if (!img)
+        return fail(c, VO_ERR_ARG, "null image");
+    int rc = vo_batch_configure(c, 4, w, h, 1);
+    if (rc != VO_OK)
+        return rc;
+    rc = upload_image(c, 0, img, stride, hipMemcpyHostToDevice);
+    if (rc != VO_OK)
+        return rc;
+    const int32_t quad[4] = {0, 0, 0, 0};
+    return vo_batch_set_quads(c, quad, 1);
+}
+
+int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
+                   float *pts_out, int cap, int *n_out)
+{
+    if (!c || !n_out || cap < 0 || (cap > 0 && !pts_out))
+        return VO_ERR_ARG;
+    int rc = single_image_setup(c, img, w, h, stride);
+    if (rc != VO_OK)
+        return rc;
+    const int one = 1, zero = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_ntracked, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->h_ntracked[0] = 0;
+    c->detect_uploaded = false;
+    threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
+    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_score, c->d_rowcnt,
+                         c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
+                         nullptr, nullptr, 0, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    int n = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(&n, c->d_nnew, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int k = n < cap ? n : cap;
+    k = k < c->fcap ? k : c->fcap;
+    if (k > 0)
+        VO_HIP_TRY(c, hipMemcpy(pts_out, c->d_feat, sizeof(float2) * k, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return VO_OK;
+}
+
+int vo_detect_bucket(vo_ctx *c, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
+                     float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap)
+{
+    if (!c || !n_pts || !n_ages || !pts_io || !ages_io || cap < 1)
+        return VO_ERR_ARG;
+    int rc = single_image_setup(c, img, w, h, stride);
+    if (rc != VO_OK)
+        return rc;
+    const vo_detect_params saved = c->dprm;
+    rc = vo_batch_set_detect_params(c, dp);
+    if (rc == VO_OK)
+        rc = vo_batch_set_features(c, 0, pts_io, *n_pts, ages_io, *n_ages);
+    if (rc == VO_OK)
+        rc = run_stages(c, VO_STAGE_DETECT, false);
+    int k = 0;
+    if (rc == VO_OK) {
+        VO_HIP_TRY(c, hipMemcpyAsync(&k, c->d_npts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (k > cap) {
+            c->dprm = saved;
+            return fail(c, VO_ERR_ARG, "vo_detect_bucket: bucketed set larger than the caller's capacity");
+        }
+        rc = vo_batch_get_features(c, 0, pts_io, ages_io, &k);
+    }
+    c->dprm = saved;
+    if (rc != VO_OK)
+        return rc;
+    *n_pts = k;
+    *n_ages = k;
+    return VO_OK;
 }
 
 int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w,

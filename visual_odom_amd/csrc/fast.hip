@@ -1,0 +1,331 @@
+// fast.hip -- feature detection + bucketing on the device.
+//
+// Replaces, for every frame of a batch, what matchingFeatures() does before circularMatching()
+// (reference src/visualOdometry.cpp:95-110):
+//   appendNewFeatures(imageLeft_t0, features)      feature.cpp:255-262
+//     -> featureDetectionFast: cv::FAST(image, keypoints, 20, true)    feature.cpp:39-47
+//        (FastFeatureDetector TYPE_9_16: >= 9 contiguous circle pixels all brighter than p + t or all
+//         darker than p - t, 3-pixel image margin; score = cornerScore<16>, the largest threshold
+//         for which the pixel is still a corner; non-maximum suppression keeps a corner whose score
+//         is strictly greater than its 8 neighbours'; keypoints in row-major scan order)
+//   bucketingFeatures(image, features, rows/10, features_per_bucket)   feature.cpp:206-253,
+//     bucket.cpp:14-51 -- including its quirks: buckets are indexed
+//     hidx * (cols/bucket) + widx with widx in [0, cols/bucket] so the last column aliases the next
+//     row's first bucket, the read-back visits (rows/bucket + 1) x (cols/bucket + 1) cells and so
+//     emits aliased buckets twice, a full bucket always overwrites its slot 0 with the incoming
+//     feature, features of age >= 10 are dropped, and ages[i] pairs with points[i] even when the
+//     ages array is longer than the points array (new corners then inherit stale ages).
+//
+// Kernels:
+//   fast_score_kernel    thread per pixel of the level-0 image already resident for LK:
+//                        16 circle pixels -> 2 x 16-bit masks -> 9-contiguous test by shift-and,
+//                        cornerScore<16> for corners; u16 map (corner flag << 8 | score)
+//   fast_nms_kernel<W>   workgroup per image row: NMS predicate, wave ballot ranks; W = false counts
+//                        the row, W = true writes (x, y) at rows_before + rank (row-major order)
+//   fast_rowscan_kernel  workgroup per frame: exclusive scan of the row counts
+//   bucket_kernel        workgroup per frame.  The sequential bucket fill is restated as order
+//                        statistics: a bucket ends up holding (slot 0) its LAST eligible feature if
+//                        more than fpb are eligible, else its first; (slots 1..) its 2nd..fpb-th
+//                        eligible feature -- found with LDS atomicMin / atomicMax rounds -- then an
+//                        exclusive scan over the visited cells gives the emission offsets.
+#include "vo_kernels.h"
+
+#include <limits.h>
+
+namespace vo {
+
+__device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int stride, int threshold, bool *corner)
+{
+    // Bresenham circle of radius 3, the 16 offsets of FAST_t<16> starting at (0, 3), clockwise
+    const int v = p[0];
+    int d[25];
+    d[0] = v - p[3 * stride];
+    d[1] = v - p[3 * stride + 1];
+    d[2] = v - p[2 * stride + 2];
+    d[3] = v - p[stride + 3];
+    d[4] = v - p[3];
+    d[5] = v - p[-stride + 3];
+    d[6] = v - p[-2 * stride + 2];
+    d[7] = v - p[-3 * stride + 1];
+    d[8] = v - p[-3 * stride];
+    d[9] = v - p[-3 * stride - 1];
+    d[10] = v - p[-2 * stride - 2];
+    d[11] = v - p[-stride - 3];
+    d[12] = v - p[-3];
+    d[13] = v - p[stride - 3];
+    d[14] = v - p[2 * stride - 2];
+    d[15] = v - p[3 * stride - 1];
+    uint32_t mb = 0, md = 0; // d > t : circle pixel darker than the centre; -d > t : brighter
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mb |= (uint32_t)(d[k] > threshold) << k;
+        md |= (uint32_t)(-d[k] > threshold) << k;
+    }
+    // >= 9 contiguous set bits on the 16-bit ring
+    auto ring9 = [](uint32_t m) {
+        m |= m << 16;
+        uint32_t x = m & (m >> 1);
+        x &= x >> 2;
+        x &= x >> 4;
+        x &= m >> 8;
+        return x != 0;
+    };
+    *corner = ring9(mb) || ring9(md);
+    if (!*corner)
+        return 0;
+#pragma unroll
+    for (int k = 16; k < 25; k++)
+        d[k] = d[k - 16];
+    // cornerScore<16> (features2d/src/fast_score.cpp)
+    int a0 = threshold;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(d[k + 1], d[k + 2]);
+        a = min(a, d[k + 3]);
+        if (a <= a0)
+            continue;
+        a = min(a, min(min(d[k + 4], d[k + 5]), min(d[k + 6], min(d[k + 7], d[k + 8]))));
+        a0 = max(a0, min(a, d[k]));
+        a0 = max(a0, min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int b = max(max(d[k + 1], d[k + 2]), max(d[k + 3], max(d[k + 4], d[k + 5])));
+        if (b >= b0)
+            continue;
+        b = max(b, max(d[k + 6], max(d[k + 7], d[k + 8])));
+        b0 = min(b0, max(b, d[k]));
+        b0 = min(b0, max(b, d[k + 9]));
+    }
+    return (-b0 - 1) & 0xff;
+}
+
+// grid (ceil(w / 64), ceil(h / 4), n_frames), 256 threads
+__global__ __launch_bounds__(256) void fast_score_kernel(const PyrImage *__restrict__ imgs,
+                                                         const Quad *__restrict__ quads,
+                                                         const int *__restrict__ detect, int threshold,
+                                                         uint16_t *__restrict__ score /* [B][h][w] */)
+{
+    const int frame = blockIdx.z;
+    if (!detect[frame])
+        return;
+    const PyrImage &im = imgs[quads[frame].l0];
+    const int w = im.w[0], h = im.h[0], stride = im.stride[0];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    uint16_t out = 0;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+        bool corner;
+        const int s = fast_score(im.lvl[0] + (ptrdiff_t)y * stride + x, stride, threshold, &corner);
+        if (corner)
+            out = (uint16_t)(0x100 | s);
+    }
+    score[((size_t)frame * h + y) * w + x] = out;
+}
+
+// grid (h, n_frames), 256 threads; WRITE = false: rowcnt[frame][y]; WRITE = true: points
+template <bool WRITE>
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint16_t *__restrict__ score, int w, int h,
+                                                        const int *__restrict__ detect, int nonmax,
+                                                        int *__restrict__ rowcnt /* [B][h] (WRITE: exclusive offsets) */,
+                                                        const int *__restrict__ n_tracked, int cap,
+                                                        float2 *__restrict__ feat /* [B][cap] */)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!detect[frame])
+        return;
+    if (tid == 0)
+        s_base = 0;
+    __syncthreads();
+    const uint16_t *__restrict__ row = score + ((size_t)frame * h + y) * w;
+    const bool inner = y >= 3 && y < h - 3;
+    const int base_out = WRITE ? n_tracked[frame] + rowcnt[(size_t)frame * h + y] : 0;
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + tid;
+        bool keep = false;
+        if (inner && x >= 3 && x < w - 3) {
+            const int c = row[x];
+            if (c & 0x100) {
+                const int sc = c & 0xff;
+                keep = !nonmax || (sc > (row[x + 1] & 0xff) && sc > (row[x - 1] & 0xff) &&
+                                   sc > (row[x - w - 1] & 0xff) && sc > (row[x - w] & 0xff) &&
+                                   sc > (row[x - w + 1] & 0xff) && sc > (row[x + w - 1] & 0xff) &&
+                                   sc > (row[x + w] & 0xff) && sc > (row[x + w + 1] & 0xff));
+            }
+        }
+        const unsigned long long m = VO_BALLOT(keep);
+        if (lane == 0)
+            s_wave[wv] = VO_POPCLL(m);
+        __syncthreads();
+        if (WRITE && keep) {
+            int off = s_base;
+            for (int q = 0; q < wv; q++)
+                off += s_wave[q];
+            const int o = base_out + off + VO_POPCLL(m & ((1ull << lane) - 1ull));
+            if (o < cap)
+                feat[(size_t)frame * cap + o] = make_float2((float)x, (float)y);
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (!WRITE && tid == 0)
+        rowcnt[(size_t)frame * h + y] = s_base;
+}
+
+// one 256-thread workgroup per frame: rowcnt -> exclusive offsets, n_new = total (0 when not detecting)
+__global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ rowcnt, int h,
+                                                           const int *__restrict__ detect,
+                                                           int *__restrict__ n_new)
+{
+    __shared__ int s_part[256];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    if (!detect[frame]) {
+        if (tid == 0)
+            n_new[frame] = 0;
+        return;
+    }
+    int *__restrict__ rc = rowcnt + (size_t)frame * h;
+    const int per = (h + 255) / 256, r0 = tid * per, r1 = min(h, r0 + per);
+    int sum = 0;
+    for (int r = r0; r < r1; r++)
+        sum += rc[r];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { // 256 partials: a serial scan is a few hundred cycles
+        int acc = 0;
+        for (int k = 0; k < 256; k++) {
+            const int t = s_part[k];
+            s_part[k] = acc;
+            acc += t;
+        }
+        n_new[frame] = acc;
+    }
+    __syncthreads();
+    int acc = s_part[tid];
+    for (int r = r0; r < r1; r++) {
+        const int t = rc[r];
+        rc[r] = acc;
+        acc += t;
+    }
+}
+
+constexpr int BK_MAX_CELLS = 1024; // (rows/bucket + 1) * (cols/bucket + 1)
+constexpr int BK_MAX_FPB = 8;
+
+// one 256-thread workgroup per frame
+__global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ feat /* [B][cap] */,
+                                                     const int *__restrict__ ages /* [B][cap] */,
+                                                     const int *__restrict__ n_tracked,
+                                                     const int *__restrict__ n_new, int cap, int rows, int cols,
+                                                     int bucket_size, int fpb, float2 *__restrict__ out_pts,
+                                                     int *__restrict__ out_ages, int *__restrict__ out_n,
+                                                     int out_cap)
+{
+    __shared__ int s_cnt[BK_MAX_CELLS], s_last[BK_MAX_CELLS];
+    __shared__ int s_first[BK_MAX_FPB][BK_MAX_CELLS];
+    __shared__ int s_scan[256];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int bh = rows / bucket_size, bw = cols / bucket_size;
+    const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
+    const float2 *__restrict__ P = feat + (size_t)frame * cap;
+    const int *__restrict__ A = ages + (size_t)frame * cap;
+    int n_in = n_tracked[frame] + n_new[frame];
+    n_in = n_in < cap ? n_in : cap;
+
+    for (int b = tid; b < nb; b += 256) {
+        s_cnt[b] = 0;
+        s_last[b] = -1;
+        for (int q = 0; q < fpb; q++)
+            s_first[q][b] = INT_MAX;
+    }
+    __syncthreads();
+    // bucket of feature i, or -1 when Bucket::add_feature ignores it (age >= 10) / the reference
+    // would index outside its bucket vector (undefined behaviour there; never hit by in-image points)
+    auto cell = [&](int i) {
+        const float2 p = P[i];
+        const int hidx = (int)(p.y / (float)bucket_size), widx = (int)(p.x / (float)bucket_size);
+        const int idx = hidx * bw + widx;
+        return (idx < 0 || idx >= nb || A[i] >= 10) ? -1 : idx;
+    };
+    for (int i = tid; i < n_in; i += 256) {
+        const int b = cell(i);
+        if (b >= 0) {
+            atomicAdd(&s_cnt[b], 1);
+            atomicMax(&s_last[b], i);
+            atomicMin(&s_first[0][b], i);
+        }
+    }
+    __syncthreads();
+    for (int q = 1; q < fpb; q++) { // q-th eligible feature of every bucket, in list order
+        for (int i = tid; i < n_in; i += 256) {
+            const int b = cell(i);
+            if (b >= 0 && i > s_first[q - 1][b])
+                atomicMin(&s_first[q][b], i);
+        }
+        __syncthreads();
+    }
+    // emission: cells (hh, ww), hh <= bh, ww <= bw, in that order, each emits bucket hh * bw + ww
+    const int per = (nb + 255) / 256, v0 = tid * per, v1 = min(nb, v0 + per);
+    int sum = 0;
+    for (int v = v0; v < v1; v++) {
+        const int idx = (v / (bw + 1)) * bw + (v % (bw + 1));
+        sum += min(s_cnt[idx], fpb);
+    }
+    s_scan[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < 256; k++) {
+            const int t = s_scan[k];
+            s_scan[k] = acc;
+            acc += t;
+        }
+        out_n[frame] = acc < out_cap ? acc : out_cap;
+    }
+    __syncthreads();
+    int off = s_scan[tid];
+    float2 *__restrict__ OP = out_pts + (size_t)frame * out_cap;
+    int *__restrict__ OA = out_ages + (size_t)frame * out_cap;
+    for (int v = v0; v < v1; v++) {
+        const int idx = (v / (bw + 1)) * bw + (v % (bw + 1));
+        const int c = s_cnt[idx], m = min(c, fpb);
+        for (int q = 0; q < m; q++) {
+            const int src = q == 0 ? (c > fpb ? s_last[idx] : s_first[0][idx]) : s_first[q][idx];
+            if (off + q < out_cap) {
+                OP[off + q] = P[src];
+                OA[off + q] = A[src];
+            }
+        }
+        off += m;
+    }
+}
+
+#ifndef VO_HOST_EMUL
+void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
+                          int h, int threshold, int nonmax, uint16_t *d_score, int *d_rowcnt,
+                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
+                          int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
+                          hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return;
+    hipLaunchKernelGGL(fast_score_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(256), 0, stream, d_imgs,
+                       d_quads, d_detect, threshold, d_score);
+    hipLaunchKernelGGL(fast_nms_kernel<false>, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect,
+                       nonmax, d_rowcnt, d_ntracked, cap, d_feat);
+    hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, h, d_detect, d_nnew);
+    hipLaunchKernelGGL(fast_nms_kernel<true>, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect,
+                       nonmax, d_rowcnt, d_ntracked, cap, d_feat);
+    if (bucket_size > 0)
+        hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew,
+                           cap, h, w, bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap);
+}
+#endif
+
+} // namespace vo

@@ -24,11 +24,15 @@
 #define VO_READFIRSTLANE(v) emu_readfirstlane(v)
 #define VO_READLANE(v, l) emu_readlane((v), (l))
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define VO_BALLOT(p) emu_ballot(p)
+#define VO_POPCLL(m) __builtin_popcountll(m)
 #else
 #include <hip/hip_runtime.h>
 #define VO_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
 #define VO_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define VO_BALLOT(p) __ballot(p)
+#define VO_POPCLL(m) __popcll(m)
 #endif
 
 #define VO_MAX_LEVELS 5
@@ -79,20 +83,28 @@ __device__ __forceinline__ int dpp_add(int v)
 
 // Exact wave-wide sum of per-lane int32 partials, returned as a wave-uniform f32 rounded once from
 // the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| <= 2^28 so
-// that three butterfly steps (v_add_u32_dpp: quad_perm xor 1, xor 2, row_half_mirror = 8-lane sums)
-// cannot overflow int32.  The eight group sums are then read with v_readlane and added as int64 on
-// the SCALAR unit, which is otherwise idle in this VALU-bound kernel; the total almost always fits
-// int32, where one v_cvt_f32_i32 is the correctly rounded conversion (else via f64, exact < 2^53).
-// 3 DPP + 8 v_readlane + 1 cvt VALU instructions per sum instead of 12 ds_bpermute round trips.
+// that the first three butterfly steps (8-lane sums) cannot overflow int32; the 8-lane sums are then
+// split into a signed high and an unsigned low 16-bit half which are reduced separately (row_mirror,
+// row_bcast15, row_bcast31: the total lands in lane 63), read with v_readlane and recombined as an
+// int64 on the scalar unit.  The total almost always fits int32, where one v_cvt_f32_i32 is the
+// correctly rounded conversion (else via f64, exact below 2^53).
+// 9 v_add_u32_dpp + 2 split + 2 v_readlane + 1 cvt instead of 12 ds_bpermute round trips per sum.
+// (Measured alternative, profiles/r01_v3: reading the eight 8-lane sums with v_readlane and adding
+// them on the scalar unit saves 4 VALU instructions per sum but costs 22 SALU ones -- the CU's single
+// scalar unit then becomes the bottleneck and the kernel runs 4 % slower.)
 __device__ __forceinline__ float wave_sum_exact_f32(int v)
 {
     v = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(v);
     v = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(v);
     v = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(v);
-    long long s = 0;
-#pragma unroll
-    for (int g = 0; g < 8; g++)
-        s += (long long)VO_READLANE(v, 8 * g);
+    int lo = v & 0xffff, hi = v >> 16;
+    lo = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(lo);
+    hi = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(hi);
+    lo = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(lo);
+    hi = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(hi);
+    const long long s = ((long long)VO_READLANE(hi, 63) << 16) + (long long)VO_READLANE(lo, 63);
     const int s32 = (int)s;
     if (__builtin_expect((long long)s32 != s, 0)) {
 #ifndef VO_HOST_EMUL

@@ -38,6 +38,11 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, int w0, i
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
+void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
+                          int h, int threshold, int nonmax, uint16_t *d_score, int *d_rowcnt,
+                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
+                          int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
+                          hipStream_t stream);
 void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
                     int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
                     int n_frames, hipStream_t stream);
