@@ -114,6 +114,13 @@ int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, in
 int vo_detect_bucket(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
                      float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap);
 
+/* Replaces the tail of the frame loop -- main.cpp:196-208: rotationMatrixToEulerAngles (utils.cpp:107-131),
+ * the |euler| < 0.1 rad gate, and integrateOdometryStereo (utils.cpp:57-91: frame_pose <- frame_pose *
+ * inv([R|t; 0 0 0 1]) iff 0.05 < |t| < 10).  Pure host arithmetic (4x4 f64), no ctx, no device.
+ * pose16: 4x4 row-major f64 in/out.  euler_out (optional, float[3]).  Returns 1 when the motion was
+ * integrated, 0 when a gate rejected it (pose unchanged, as in the reference). */
+int vo_integrate_odometry(double *pose16, const double *R9, const double *t3, float *euler_out);
+
 /* The whole per-frame hot path in one call: circularMatching + consistency filter + triangulation
  * + PnP/RANSAC (matchingFeatures' tail visualOdometry.cpp:116-127, main.cpp:169-181), one upload,
  * one download.  out_l0/out_r0/out_l1/out_r1 [2n] and xyz_out [3n] are compacted to *n_out (= K).

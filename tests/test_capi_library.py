@@ -63,3 +63,43 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("never routes through the oracle", "") \
                     .replace("never a product fallback", ""), "%s mentions the oracle" % f
+
+
+def test_detect_defaults_are_the_reference_literals(built_lib):
+    from visual_odom_amd import _lib
+    import ctypes as C
+    p = _lib.VoDetectParams()
+    built_lib.vo_default_detect_params(C.byref(p))
+    # feature.cpp:43-45, visualOdometry.cpp:95,106-107
+    assert (p.fast_threshold, p.fast_nonmax, p.redetect_below, p.bucket_size, p.features_per_bucket) == (20, 1, 2000, 0, 1)
+
+
+def test_integrate_odometry_host_math(built_lib):
+    """vo_integrate_odometry is host arithmetic inside libvo_hip (no device): gates and pose chaining of
+    main.cpp:196-208 / utils.cpp:57-131 against the checker's restatement"""
+    import numpy as np
+    from visual_odom_amd import _lib
+    from oracle import oracle as orc
+    orc.build()
+    rng = np.random.default_rng(0)
+    pose_p = pose_o = np.eye(4)
+    n_applied = 0
+    for k in range(60):
+        r = rng.normal(0, 0.03, 3)
+        if k % 11 == 5:
+            r[1] = 0.2            # yaw beyond the 0.1 rad gate
+        t = rng.normal(0, 0.4, 3)
+        if k % 7 == 3:
+            t *= 0.01             # |t| below 0.05
+        if k % 13 == 6:
+            t *= 100              # |t| above 10
+        R = orc.rodrigues(r)
+        e_o = orc.rotation_matrix_to_euler(R)
+        ok_o = False
+        if abs(e_o[1]) < 0.1 and abs(e_o[0]) < 0.1 and abs(e_o[2]) < 0.1:
+            pose_o, ok_o = orc.integrate_odometry_stereo(pose_o, R, t)
+        pose_p, ok_p, e_p = _lib.integrate_odometry(pose_p, R, t)
+        assert ok_p == ok_o and np.array_equal(e_p, e_o)
+        assert np.abs(pose_p - pose_o).max() < 1e-12
+        n_applied += ok_p
+    assert 30 < n_applied < 58

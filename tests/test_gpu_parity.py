@@ -402,3 +402,52 @@ def test_batch_detect_stage_feeds_lk(gpu_ctx, volib, orc, small_world, small_seq
                 assert pose["status"] == rc and pose_close(pose["rvec"], pose["tvec"], rv, tv)
     finally:
         gpu_ctx.batch_set_detect_params()
+
+
+# ------------------------------------------------------------------ row f3: the reference's frame loop
+def test_sequence_trajectory_matches_oracle_and_ground_truth(gpu_ctx, orc, small_world):
+    """main.cpp:123-224 replayed through the product (StereoOdometry: detect/bucket -> track_frame ->
+    integrate) and through the checker's functions chained the same way; per-frame R|t <= 1e-6, identical
+    feature state, trajectory (ATE) <= 1e-6 m vs the checker and close to the planted camera path"""
+    from visual_odom_amd import odometry, synth, _lib
+    n = 7
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    K = small_world.K()
+    h, w = L[0].shape
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, features_per_bucket=3)
+    o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
+    o_pose, o_t = np.eye(4), np.zeros(3)
+    o_traj = [o_pose[:3].copy()]
+    vo.process(L[0], R[0])
+    for k in range(1, n):
+        rec = vo.process(L[k], R[k])
+        # ---- checker chain
+        l0, r0, l1, r1 = L[k - 1], R[k - 1], L[k], R[k]
+        if len(o_pts) < 2000:
+            fast = orc.fast_detect(l0, 20, True)
+            o_pts = np.vstack([o_pts, fast])
+            o_ages = np.concatenate([o_ages, np.zeros(len(fast), np.int32)])
+        bp, ba = orc.bucketing_features(h, w, o_pts, o_ages, h // 10, 3)
+        cm = orc.circular_matching(l0, r0, l1, r1, bp, ages=ba)
+        (pl0, pr0, pl1, pr1), _ = orc.check_valid_and_remove(cm["l0"], cm["r0"], cm["l1"], cm["r1"], cm["l0_ret"])
+        o_pts, o_ages = pl1, cm["ages"]
+        xyz = orc.triangulate(P_l, P_r, pl0, pr0)
+        rc, rv, tv, inl, _ = orc.solve_pnp_ransac(xyz, pl1, K, tvec=o_t)
+        o_t = tv
+        Rm = orc.rodrigues(rv)
+        e = orc.rotation_matrix_to_euler(Rm)
+        if abs(e[1]) < 0.1 and abs(e[0]) < 0.1 and abs(e[2]) < 0.1:
+            o_pose, _ = orc.integrate_odometry_stereo(o_pose, Rm, tv)
+        o_traj.append(o_pose[:3].copy())
+        # ---- per-frame parity
+        assert rec["n_bucketed"] == len(bp) and rec["n_tracked"] == len(pl1) and rec["n_inliers"] == len(inl)
+        assert np.array_equal(bits(vo.points), bits(o_pts)) and np.array_equal(vo.ages, o_ages)
+        assert np.abs(rec["rvec"] - rv).max() <= 1e-6 and np.abs(rec["tvec"] - tv).max() <= 1e-6
+        assert np.abs(vo.frame_pose - o_pose).max() <= 1e-6
+    assert odometry.ate_rmse(vo.trajectory, o_traj) <= 1e-6
+    # against the planted motion: camera-to-world poses relative to the first frame
+    T0inv = np.linalg.inv(poses[0])
+    gt = [(T0inv @ T)[:3] for T in poses]
+    assert odometry.ate_rmse(vo.trajectory, gt) < 0.05
+    assert sum(r["integrated"] for r in vo.log) == n - 1

@@ -20,7 +20,7 @@ NUM_STAGES = len(STAGE_NAMES)
 
 # every symbol include/vo_hip.h declares (checked by the CPU test-suite against the built .so)
 EXPORTS = (
-    "vo_default_params", "vo_default_detect_params", "vo_fast_detect", "vo_detect_bucket",
+    "vo_default_params", "vo_default_detect_params", "vo_integrate_odometry", "vo_fast_detect", "vo_detect_bucket",
     "vo_batch_set_features", "vo_batch_set_detect_params", "vo_batch_get_features", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
     "vo_circular_match", "vo_triangulate", "vo_pnp_ransac", "vo_track_frame",
     "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
@@ -81,6 +81,19 @@ def _p(a):
 def _f32(a, shape=None):
     a = np.ascontiguousarray(a, np.float32)
     return a if shape is None else a.reshape(shape)
+
+
+def integrate_odometry(pose, R, t):
+    """main.cpp:196-208 + utils.cpp:57-131: returns (new 4x4 pose, integrated?, euler xyz)"""
+    lib = load()
+    pose = np.array(pose, np.float64).reshape(4, 4).copy()
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    e = np.zeros(3, np.float32)
+    rc = lib.vo_integrate_odometry(_p(pose), _p(R), _p(t), _p(e))
+    if rc < 0:
+        raise VoError(rc, "vo_integrate_odometry: bad argument")
+    return pose, bool(rc), e
 
 
 class Context:

@@ -1,0 +1,83 @@
+"""Frame loop of the reference (src/main.cpp:123-224) on top of the C ABI -- the host-side mirror a
+user of ZhenghaoFei/visual_odom switches to: the same state (FeatureSet points/ages, frame_pose,
+translation), the same order of operations, every arithmetic step inside libvo_hip:
+
+    matchingFeatures        visualOdometry.cpp:81-129   -> vo_detect_bucket + vo_track_frame
+    triangulatePoints ...   main.cpp:169-171            -> (inside vo_track_frame)
+    trackingFrame2Frame     visualOdometry.cpp:132-193  -> (inside vo_track_frame)
+    euler gate + integrateOdometryStereo  main.cpp:196-208, utils.cpp:57-131 -> vo_integrate_odometry
+
+GUI calls (displayTracking, display) and image decoding are out of scope; the trajectory the
+reference only draws (utils.cpp:19-48) is written in the KITTI pose format instead (12 doubles per
+line, row-major 3x4 -- what loadPoses reads, evaluate_odometry.cpp:24-27).  There is no CPU fallback.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class StereoOdometry:
+    def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, **detect_kw):
+        self.P_l = np.ascontiguousarray(P_l, np.float32).reshape(3, 4)
+        self.P_r = np.ascontiguousarray(P_r, np.float32).reshape(3, 4)
+        self.ctx = ctx if ctx is not None else _lib.Context(device, max_w, max_h, max_pts, 1)
+        self._own = ctx is None
+        self.detect_kw = detect_kw
+        # main.cpp:81-94
+        self.points = np.zeros((0, 2), np.float32)   # currentVOFeatures.points
+        self.ages = np.zeros(0, np.int32)            # currentVOFeatures.ages (may be longer than points)
+        self.frame_pose = np.eye(4)
+        self.translation = np.zeros(3)
+        self.rotation = np.eye(3)
+        self.prev = None
+        self.trajectory = [self.frame_pose[:3].copy()]
+        self.log = []
+
+    def close(self):
+        if self._own:
+            self.ctx.close()
+
+    def process(self, left, right):
+        """feed the next stereo pair; returns the per-frame record (None for the very first pair)"""
+        cur = (np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8))
+        if self.prev is None:
+            self.prev = cur
+            return None
+        (l0, r0), (l1, r1) = self.prev, cur
+        # matchingFeatures: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
+        pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
+        # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
+        out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
+        # deleteUnmatchFeaturesCircle: ages += 1, compacted with the circular-matching survivors only
+        # (feature.cpp:83-86,111); the consistency filter does not touch ages (quirk B3)
+        self.ages = (ages + 1)[out["keep_idx_circ"]]
+        self.points = out["l1"]                       # currentVOFeatures.points = pointsLeft_t1
+        self.prev = cur                               # main.cpp:157-158
+        rec = dict(n_bucketed=len(pts), n_tracked=len(out["l1"]), n_inliers=len(out["inliers"]), rc=out["rc"],
+                   rvec=out["rvec"].copy(), tvec=out["tvec"].copy(), integrated=False)
+        if out["rc"] == _lib.VO_ERR_TOO_FEW:
+            raise _lib.VoError(out["rc"], "fewer than 5 correspondences reached solvePnPRansac (the reference asserts here)")
+        self.rotation, self.translation = out["R"], out["tvec"]
+        self.frame_pose, rec["integrated"], rec["euler"] = _lib.integrate_odometry(self.frame_pose, self.rotation,
+                                                                                   self.translation)
+        self.trajectory.append(self.frame_pose[:3].copy())
+        self.log.append(rec)
+        return rec
+
+    def save_trajectory(self, path):
+        with open(path, "w") as f:
+            for T in self.trajectory:
+                f.write(" ".join("%.9e" % v for v in T.reshape(-1)) + "\n")
+
+
+def load_poses(path):
+    """KITTI pose file -> (n, 3, 4) array (evaluate_odometry.cpp:17-33 loadPoses)"""
+    return np.loadtxt(path).reshape(-1, 3, 4)
+
+
+def ate_rmse(traj, ref):
+    """root-mean-square translation difference of two trajectories expressed in the same frame"""
+    a = np.asarray(traj)[:, :3, 3]
+    b = np.asarray(ref)[:, :3, 3]
+    n = min(len(a), len(b))
+    return float(np.sqrt(np.mean(np.sum((a[:n] - b[:n]) ** 2, axis=1))))
