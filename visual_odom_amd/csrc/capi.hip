@@ -340,6 +340,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     c->max_pts_set = 0;
     std::fill(c->h_npts.begin(), c->h_npts.end(), 0);
     std::fill(c->h_ntracked.begin(), c->h_ntracked.end(), 0);
+    c->detect_uploaded = false; // the per-frame detect flags on the device belong to the previous batch shape
     VO_HIP_TRY(c, hipMemsetAsync(c->d_npts, 0, sizeof(int) * c->max_frames, c->stream));
     VO_HIP_TRY(c, hipMemsetAsync(c->d_ntracked, 0, sizeof(int) * c->max_frames, c->stream));
     VO_HIP_TRY(c, hipMemsetAsync(c->d_fages, 0, sizeof(int) * (size_t)c->max_frames * c->fcap, c->stream));
