@@ -39,6 +39,12 @@ typedef struct vo_params {
     int lk_max_count;
     double lk_epsilon;
     double lk_min_eig_threshold;
+    /* 0 (default): a feature stops at the first hop whose result deleteUnmatchFeaturesCircle() would
+     * reject (status 0 or a negative coordinate, feature.cpp:96-104) -- its later hops are reported as
+     * status 0 and never reach any output of the reference's interface, so the compacted results are
+     * unchanged.  1: every feature runs all four hops like the reference's four independent
+     * calcOpticalFlowPyrLK calls, so the raw per-hop tracks / status4 are reproduced too. */
+    int lk_full_chain;
     int consistency_threshold;
     int ransac_iterations;
     float ransac_reproj_error;

@@ -60,7 +60,7 @@ extern "C" {
 // Then tracks pts [n][2] through the quad (0,1,2,3) with the emulated LK kernel.
 int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want_level, uint8_t *lvl_out,
            uint32_t *der_out, int *lvl_w, int *lvl_h, const float *pts, int n, int max_count, double eps,
-           float min_eig, float *trk /* [4][n][2] */, uint8_t *status /* [4][n] */)
+           float min_eig, int full_chain, float *trk /* [4][n][2] */, uint8_t *status /* [4][n] */)
 {
     using namespace vo;
     Plan p = plan(w, h, max_level);
@@ -111,6 +111,7 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     prm.max_count = max_count;
     prm.epsilon = eps * eps;
     prm.min_eig = min_eig;
+    prm.full_chain = full_chain;
     std::vector<float2> out((size_t)4 * n);
     const int cap = n, n_frames = 1, fpg = 1, parts = 8, ppp = (n + parts - 1) / parts;
     for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {

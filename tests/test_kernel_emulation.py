@@ -32,7 +32,7 @@ def kemu():
     return lib
 
 
-def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.01, min_eig=1e-3):
+def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.01, min_eig=1e-3, full_chain=1):
     imgs = np.ascontiguousarray(np.stack(imgs), np.uint8)
     n_img, h, w = imgs.shape
     pts = np.zeros((0, 2), np.float32) if pts is None else np.ascontiguousarray(pts, np.float32)
@@ -43,7 +43,7 @@ def ke_run(lib, imgs, pts=None, max_level=3, want_level=-1, max_count=30, eps=0.
     trk = np.zeros((4, max(n, 1), 2), np.float32)
     st = np.zeros((4, max(n, 1)), np.uint8)
     levels = lib.ke_run(vp(imgs), n_img, w, h, max_level, want_level, vp(lvl), vp(der), C.byref(lw), C.byref(lh),
-                        vp(pts), n, max_count, C.c_double(eps), C.c_float(min_eig), vp(trk), vp(st))
+                        vp(pts), n, max_count, C.c_double(eps), C.c_float(min_eig), full_chain, vp(trk), vp(st))
     lw, lh = lw.value, lh.value
     return dict(levels=levels, lvl=lvl.ravel()[:lw * lh].reshape(lh, lw), der=der.ravel()[:lw * lh].reshape(lh, lw),
                 trk=trk[:, :n], status=st[:, :n])
@@ -90,6 +90,17 @@ def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq):
     assert np.array_equal(r["status"], st)
     assert np.array_equal(bits(r["trk"]), bits(ref))
     assert st[:, :len(pts) - len(border)].mean() > 0.5
+    # default mode: a feature retires at the first hop the circular filter rejects; everything up to and
+    # including that hop is unchanged, later hops read status 0, so the filter's survivors are the same
+    e = ke_run(kemu, imgs, pts, full_chain=0)
+    neg = np.concatenate([(pts < 0).any(1)[None], (ref[:3] < 0).any(2)])           # pt0 .. pt3 negative
+    bad = (st == 0) | np.vstack([neg[0] | neg[1], neg[2], neg[3], np.zeros(len(pts), bool)])
+    alive = np.vstack([np.ones(len(pts), bool), ~np.logical_or.accumulate(bad, 0)[:3]])  # hop k evaluated?
+    assert np.array_equal(e["status"][alive], st[alive]) and not e["status"][~alive].any()
+    assert np.array_equal(bits(e["trk"][alive]), bits(ref[alive]))
+    keep_full = (st != 0).all(0) & ~neg.any(0)
+    keep_early = (e["status"] != 0).all(0) & ~np.concatenate([(pts < 0).any(1)[None], (e["trk"][:3] < 0).any(2)]).any(0)
+    assert np.array_equal(keep_full, keep_early) and 0 < keep_full.sum() < len(pts)
 
 
 def test_emulated_lk_large_motion_and_params(kemu, orc):

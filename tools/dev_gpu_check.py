@@ -18,6 +18,7 @@ extra = np.array([[0, 0], [1240, 375], [3.5, 200.25], [1238.2, 10.7], [600, 2.1]
 kp = np.vstack([kp, extra]).astype(np.float32)
 print("kp", kp.shape)
 ctx = _lib.Context(0, 1241, 376, 4096, 2)
+ctx.set_params(lk_full_chain=1)  # raw per-hop diffs below need all four hops of every feature
 Pl, Pr = W.proj_matrices()
 
 # ---- pyramid

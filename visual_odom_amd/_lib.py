@@ -32,7 +32,7 @@ EXPORTS = (
 
 class VoParams(C.Structure):
     _fields_ = [("lk_max_level", C.c_int), ("lk_max_count", C.c_int), ("lk_epsilon", C.c_double),
-                ("lk_min_eig_threshold", C.c_double), ("consistency_threshold", C.c_int),
+                ("lk_min_eig_threshold", C.c_double), ("lk_full_chain", C.c_int), ("consistency_threshold", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_reproj_error", C.c_float),
                 ("ransac_confidence", C.c_double)]
 

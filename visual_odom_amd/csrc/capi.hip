@@ -133,6 +133,7 @@ void vo_default_params(vo_params *p)
     p->lk_max_count = 30;
     p->lk_epsilon = 0.01;
     p->lk_min_eig_threshold = 0.001;
+    p->lk_full_chain = 0;
     p->consistency_threshold = 0;
     p->ransac_iterations = 500;
     p->ransac_reproj_error = 0.5f;
@@ -552,6 +553,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         eps = eps < 0. ? 0. : eps > 10. ? 10. : eps;
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
+        lp.full_chain = c->prm.lk_full_chain;
         launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk,
                            c->d_status, lp, c->stream);
     }

@@ -248,6 +248,18 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             trk[((size_t)frame * 4 + hop) * cap + f] = make_float2(outX, outY);
             status[((size_t)frame * 4 + hop) * cap + f] = (uint8_t)st;
         }
+        // deleteUnmatchFeaturesCircle (feature.cpp:96-104) drops the feature if any hop failed or any
+        // of pt0..pt3 has a negative coordinate: nothing computed after that point can reach an output
+        // of circularMatching(), so the wave retires (remaining hops reported as status 0)
+        const bool dead = st == 0 || outX < 0.f || outY < 0.f || (hop == 0 && (p.x < 0.f || p.y < 0.f));
+        if (dead && !prm.full_chain && hop < 3) {
+            if (lane == 0)
+                for (int k = hop + 1; k < 4; k++) {
+                    trk[((size_t)frame * 4 + k) * cap + f] = make_float2(-1.f, -1.f);
+                    status[((size_t)frame * 4 + k) * cap + f] = 0;
+                }
+            return;
+        }
         prevPtX = unif(outX);
         prevPtY = unif(outY);
     }

@@ -11,6 +11,7 @@ struct LkParams {
     int max_count;   // 30
     double epsilon;  // (0.01)^2 after OpenCV's sanitising
     float min_eig;   // 1e-3
+    int full_chain;  // 1: run all four hops even after a hop the circular filter will reject
 };
 
 struct PnpParams {
