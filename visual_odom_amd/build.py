@@ -26,6 +26,11 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    flags = list(FLAGS)
+    # developer sweep of the pose kernels' register budget (see pnp.hip): VO_PNP_WAVES=1|2|4
+    if os.environ.get("VO_PNP_WAVES"):
+        w = int(os.environ["VO_PNP_WAVES"])
+        flags += ["-DVO_EPNP_WAVES=%d" % w, "-DVO_REFINE_WAVES=%d" % w]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "vo_hip.h"))
     objs, jobs = [], []
@@ -34,7 +39,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or not _newer(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -22,6 +22,16 @@
 
 #include <float.h>
 
+// Register budget of the two f64-heavy kernels, as minimum waves per SIMD (launch_bounds' second
+// argument).  They run on the pose stream next to the next batch's LK launch: a wave that owns all 512
+// registers of a SIMD evicts every LK wave from it, a 128-register wave co-resides with them.
+#ifndef VO_EPNP_WAVES
+#define VO_EPNP_WAVES 4
+#endif
+#ifndef VO_REFINE_WAVES
+#define VO_REFINE_WAVES 4
+#endif
+
 namespace vo {
 
 // one thread per frame (the stream is strictly sequential); n_frames threads in total
@@ -61,7 +71,7 @@ __global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frame
     }
 }
 
-__global__ __launch_bounds__(64) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
+__global__ __launch_bounds__(64, VO_EPNP_WAVES) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
@@ -69,7 +79,9 @@ __global__ __launch_bounds__(64) void epnp_kernel(const float *__restrict__ xyz,
 {
     // M^T M (12 x 12) + its column norms of every lane, lane-interleaved: element idx of lane l at
     // s_ut[idx * 64 + l] -> consecutive lanes hit consecutive 8-byte words (conflict-free ds_*_b64)
-    __shared__ double s_ut[(144 + 12) * 64];
+    // (dynamic LDS, (144 + 12) * 64 doubles: with a static array the compiler derives one wave per SIMD
+    // from the LDS footprint and spends all 512 registers, ignoring the launch bound above)
+    extern __shared__ __attribute__((aligned(16))) double s_ut[];
     const int frame = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
     if (count < 5)
@@ -165,7 +177,7 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void select_refine_kernel(const float *__restrict__ xyz,
+__global__ __launch_bounds__(256, VO_REFINE_WAVES) void select_refine_kernel(const float *__restrict__ xyz,
                                                             const float2 *__restrict__ uv, size_t uv_stride,
                                                             const int *__restrict__ n_pts, int cap,
                                                             PnpParams prm, const double *__restrict__ models,
@@ -431,7 +443,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
         return;
     hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                        prm.iters, subsets);
-    hipLaunchKernelGGL(epnp_kernel, dim3((prm.iters + 63) / 64, n_frames), dim3(64), 0, stream, xyz, uv,
+    hipLaunchKernelGGL(epnp_kernel, dim3((prm.iters + 63) / 64, n_frames), dim3(64), (144 + 12) * 64 * sizeof(double), stream, xyz, uv,
                        uv_stride, n_pts, cap, subsets, prm, models);
     hipLaunchKernelGGL(vote_kernel, dim3(prm.iters, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
                        cap, prm, models, counts);
