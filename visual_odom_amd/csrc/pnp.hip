@@ -25,11 +25,15 @@
 // Register budget of the two f64-heavy kernels, as minimum waves per SIMD (launch_bounds' second
 // argument).  They run on the pose stream next to the next batch's LK launch: a wave that owns all 512
 // registers of a SIMD evicts every LK wave from it, a 128-register wave co-resides with them.
+// Measured (gpurun_out/sweep1, bench.py 64 frames): 1 wave/SIMD (512 registers, no spills to speak of)
+// 5.42 ms/step overlapped and a 1.11 ms stand-alone pose chain; 4 waves/SIMD (128 registers, heavy
+// spilling) 5.27 ms/step overlapped but a 2.20 ms stand-alone chain.  The 3 % of batch throughput is
+// not worth doubling the latency of the single-frame drop-in calls, so the default stays 1.
 #ifndef VO_EPNP_WAVES
-#define VO_EPNP_WAVES 4
+#define VO_EPNP_WAVES 1
 #endif
 #ifndef VO_REFINE_WAVES
-#define VO_REFINE_WAVES 4
+#define VO_REFINE_WAVES 1
 #endif
 
 namespace vo {
