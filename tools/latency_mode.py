@@ -1,0 +1,31 @@
+"""Latency mode of the drop-in boundary: vo_track_frame per call with HOST images (4 uploads of 466 KB
+over PCIe, one download, synchronous), one frame in flight -- the honest "switch the reference over"
+number.  Never bench.py's `value` (that one has inputs resident in HBM); quoted in DESIGN.md section 5.
+    python tools/latency_mode.py [n_frames]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from visual_odom_amd import _lib, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default (1 per bucket)", 1)):
+    world = synth.StereoWorld(seed=20260925)
+    L, R, poses, _ = world.render_sequence(5)
+    P_l, P_r = world.proj_matrices()
+    pts = [synth.select_keypoints(L[k], bucket=37, per_bucket=per_bucket) for k in range(4)]
+    ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+    for k in range(4):                       # warm-up
+        ctx.track_frame(L[k], R[k], L[k + 1], R[k + 1], pts[k], P_l, P_r)
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i % 4
+        ctx.track_frame(L[k], R[k], L[k + 1], R[k + 1], pts[k], P_l, P_r)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(n):
+        k = i % 4
+        ctx.detect_bucket(L[k], np.zeros((0, 2), np.float32), np.zeros(0, np.int32), features_per_bucket=per_bucket)
+    dt2 = time.perf_counter() - t1
+    print("%s: track_frame %.2f ms/frame = %.0f frames/s (PCIe-inclusive, %d points); detect_bucket %.2f ms/frame"
+          % (name, 1e3 * dt / n, n / dt, len(pts[0]), 1e3 * dt2 / n))
+    ctx.close()
