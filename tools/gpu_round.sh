@@ -26,6 +26,9 @@ stamp "VALU issue-rate micro-benchmark"
 (cd tools/ubench && timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w valu_rate.hip -o /tmp/valu_rate && timeout 60 /tmp/valu_rate) > "$OUT/valu_rate.log" 2>&1
 cat "$OUT/valu_rate.log"
 
+stamp "latency mode of the drop-in boundary (host images, PCIe-inclusive)"
+timeout 300 python tools/latency_mode.py 40 > "$OUT/latency.log" 2>&1
+cat "$OUT/latency.log"
 stamp "bench (default)"
 timeout 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"

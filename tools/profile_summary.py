@@ -61,10 +61,11 @@ def main(src, prefix):
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, prefix + "_" + name)
             lines += ["## %s" % name, "", "```json", open(p).read().strip(), "```", ""]
-    for name in ("valu_rate.log",):
+    for name, title in (("valu_rate.log", "VALU issue-rate micro-benchmark (tools/ubench/valu_rate.hip)"),
+                        ("latency.log", "latency mode of the drop-in calls (tools/latency_mode.py: host images, PCIe-inclusive)")):
         p = os.path.join(src, name)
         if os.path.exists(p):
-            lines += ["## VALU issue-rate micro-benchmark (tools/ubench/valu_rate.hip)", "", "```", open(p).read().strip(), "```", ""]
+            lines += ["## " + title, "", "```", open(p).read().strip(), "```", ""]
     open(prefix + ".md", "w").write("\n".join(lines))
     lk = pmc.get("vo::lk_circular_kernel")
     bench = os.path.join(src, "bench.json")

@@ -49,6 +49,7 @@ struct vo_ctx {
         int32_t *subsets = nullptr, *inliers = nullptr;
         double *models = nullptr;
         int *counts = nullptr;
+        RansacState *rstate = nullptr;
         PnpResult *results = nullptr;
         hipEvent_t ready = nullptr, done = nullptr; // triangulation finished / pose solve finished
         bool pending = false;                        // `done` has been recorded and not waited for
@@ -163,7 +164,7 @@ void vo_destroy(vo_ctx *c)
         if (p)
             (void)hipFree(p);
     for (auto &b : c->pb) {
-        void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.results};
+        void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results};
         for (void *p : q)
             if (p)
                 (void)hipFree(p);
@@ -250,6 +251,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && dmalloc(&b.models, B * c->ransac_cap * 6) == hipSuccess;
         ok = ok && dmalloc(&b.counts, B * c->ransac_cap) == hipSuccess;
         ok = ok && dmalloc(&b.results, B) == hipSuccess;
+        ok = ok && dmalloc(&b.rstate, B) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
@@ -594,7 +596,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             for (int k = 0; k < 3; k++)
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.inliers, pb.results, ps);
+                   pb.rstate, pb.inliers, pb.results, ps);
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps));
         VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
@@ -969,7 +971,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.inliers, pb.results, c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
 }

@@ -8,15 +8,17 @@
 // not depend on earlier hypotheses (cv::RNG(-1) stream, duplicates redrawn), so all hypotheses are
 // evaluated in parallel and the sequential control flow is replayed afterwards on the vote counts:
 //   1. ransac_subsets_kernel   one thread per frame replays the RNG stream -> [iters][5] indices
+//   then, in chunks of RANSAC_CHUNK hypotheses (a frame whose adaptive iteration count has already
+//   dropped below a chunk's first hypothesis skips it -- with >= 60 % inliers OpenCV stops before 128):
 //   2. epnp_kernel             one thread per hypothesis: 5-point EPnP (vo_epnp.h) -> rvec|tvec
 //   3. vote_kernel             one wavefront per hypothesis: project all K points (f64 -> f32),
-//                              squared error <= thr^2, ballot + popcount -> inlier count
-//   4. select_refine_kernel    one workgroup per frame: replays "keep first strictly better,
-//                              niters = RANSACUpdateNumIters(...)" to find the winning hypothesis
-//                              and the last one OpenCV would have evaluated (its pose is the start
-//                              of the final refinement because rvec/tvec are shared buffers),
-//                              rebuilds the inlier mask, runs the CvLevMarq state machine with
-//                              block-wide reductions of J^T J / J^T e, and converts rvec -> R.
+//                              squared error <= thr^2, wave sum -> inlier count
+//   4. ransac_replay_kernel    one thread per frame continues "keep first strictly better,
+//                              niters = RANSACUpdateNumIters(...)" over the new counts
+//   5. select_refine_kernel    one workgroup per frame: winning hypothesis and the last one OpenCV
+//                              would have evaluated (its pose is the start of the final refinement
+//                              because rvec/tvec are shared buffers), inlier mask, the CvLevMarq
+//                              state machine with block-wide reductions of J^T J / J^T e, rvec -> R.
 #include "vo_kernels.h"
 #include "vo_epnp.h"
 
@@ -38,13 +40,22 @@
 
 namespace vo {
 
+constexpr int RANSAC_CHUNK = 128;
+
 // one thread per frame (the stream is strictly sequential); n_frames threads in total
 __global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters,
-                                       int32_t *__restrict__ subsets /* [B][iters][5] */)
+                                       int32_t *__restrict__ subsets /* [B][iters][5] */,
+                                       RansacState *__restrict__ rstate)
 {
     const int frame = blockIdx.x * blockDim.x + threadIdx.x;
     if (frame >= n_frames)
         return;
+    RansacState st0;
+    st0.it = 0;
+    st0.niters = iters > 1 ? iters : 1;
+    st0.max_good = 0;
+    st0.best = -1;
+    rstate[frame] = st0;
     const int count = n_pts[frame];
     int32_t *out = subsets + (size_t)frame * iters * 5;
     if (count < 5)
@@ -79,6 +90,7 @@ __global__ __launch_bounds__(64, VO_EPNP_WAVES) void epnp_kernel(const float *__
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
+                                                  const RansacState *__restrict__ rstate, int chunk,
                                                   double *__restrict__ models /* [B][iters][6] */)
 {
     // M^T M (12 x 12) + its column norms of every lane, lane-interleaved: element idx of lane l at
@@ -86,11 +98,12 @@ __global__ __launch_bounds__(64, VO_EPNP_WAVES) void epnp_kernel(const float *__
     // (dynamic LDS, (144 + 12) * 64 doubles: with a static array the compiler derives one wave per SIMD
     // from the LDS footprint and spends all 512 registers, ignoring the launch bound above)
     extern __shared__ __attribute__((aligned(16))) double s_ut[];
-    const int frame = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
+    const int frame = blockIdx.y, h = chunk * RANSAC_CHUNK + blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
     if (count < 5)
         return;
-    const int nh = count == 5 ? 1 : prm.iters;
+    // hypotheses beyond the iteration count the replay has already settled on are never looked at
+    const int nh = count == 5 ? 1 : min(prm.iters, rstate[frame].niters);
     if (h >= nh)
         return;
     const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
@@ -132,11 +145,12 @@ __device__ __forceinline__ bool is_inlier(const double *R, const double *t, doub
 __global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   PnpParams prm, const double *__restrict__ models,
+                                                  const RansacState *__restrict__ rstate, int chunk,
                                                   int *__restrict__ counts /* [B][iters] */)
 {
-    const int frame = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+    const int frame = blockIdx.y, h = chunk * RANSAC_CHUNK + blockIdx.x, lane = threadIdx.x;
     const int count = n_pts[frame];
-    if (count <= 5)
+    if (count <= 5 || h >= prm.iters || h >= rstate[frame].niters)
         return;
     const double *m = models + ((size_t)frame * prm.iters + h) * 6;
     double R[9], t[3] = {m[3], m[4], m[5]};
@@ -171,6 +185,32 @@ __device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 
+// RANSACPointSetRegistrator::run on the vote counts, continued chunk by chunk: one thread per frame
+__global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int chunk,
+                                      const int *__restrict__ counts, RansacState *__restrict__ rstate)
+{
+    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= n_frames)
+        return;
+    const int count = n_pts[frame];
+    if (count <= 5)
+        return;
+    RansacState st = rstate[frame];
+    const int *cf = counts + (size_t)frame * prm.iters;
+    const int end = min((chunk + 1) * RANSAC_CHUNK, prm.iters);
+    int it = st.it;
+    for (; it < st.niters && it < end; it++) {
+        const int good = cf[it];
+        if (good > (st.max_good > 4 ? st.max_good : 4)) {
+            st.max_good = good;
+            st.best = it;
+            st.niters = ransac_update_num_iters(prm.confidence, (double)(count - good) / count, 5, st.niters);
+        }
+    }
+    st.it = it;
+    rstate[frame] = st;
+}
+
 constexpr int LM_NRED = 28; // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -185,7 +225,7 @@ __global__ __launch_bounds__(256, VO_REFINE_WAVES) void select_refine_kernel(con
                                                             const float2 *__restrict__ uv, size_t uv_stride,
                                                             const int *__restrict__ n_pts, int cap,
                                                             PnpParams prm, const double *__restrict__ models,
-                                                            const int *__restrict__ counts,
+                                                            const RansacState *__restrict__ rstate,
                                                             int32_t *__restrict__ inliers /* [B][cap] */,
                                                             PnpResult *__restrict__ results)
 {
@@ -231,22 +271,13 @@ __global__ __launch_bounds__(256, VO_REFINE_WAVES) void select_refine_kernel(con
         return;
     }
 
-    // ---- replay RANSACPointSetRegistrator::run on the vote counts ----
+    // ---- outcome of RANSACPointSetRegistrator::run (ransac_replay_kernel) ----
     if (tid == 0) {
-        const int *cf = counts + (size_t)frame * prm.iters;
-        int niters = prm.iters > 1 ? prm.iters : 1, maxGood = 0, best = -1, it;
-        for (it = 0; it < niters; it++) {
-            const int good = cf[it];
-            if (good > (maxGood > 4 ? maxGood : 4)) {
-                maxGood = good;
-                best = it;
-                niters = ransac_update_num_iters(prm.confidence, (double)(count - good) / count, 5, niters);
-            }
-        }
-        s_best = best;
-        s_last = it - 1;
-        s_niters = it;
-        s_maxgood = maxGood;
+        const RansacState st = rstate[frame];
+        s_best = st.best;
+        s_last = st.it - 1;
+        s_niters = st.it;
+        s_maxgood = st.max_good;
         s_ninl = 0;
     }
     __syncthreads();
@@ -440,19 +471,24 @@ __global__ __launch_bounds__(256, VO_REFINE_WAVES) void select_refine_kernel(con
 }
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
-                const PnpParams &prm, int32_t *subsets, double *models, int *counts, int32_t *inliers,
-                PnpResult *results, hipStream_t stream)
+                const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
+                int32_t *inliers, PnpResult *results, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
     hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
-                       prm.iters, subsets);
-    hipLaunchKernelGGL(epnp_kernel, dim3((prm.iters + 63) / 64, n_frames), dim3(64), (144 + 12) * 64 * sizeof(double), stream, xyz, uv,
-                       uv_stride, n_pts, cap, subsets, prm, models);
-    hipLaunchKernelGGL(vote_kernel, dim3(prm.iters, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
-                       cap, prm, models, counts);
+                       prm.iters, subsets, state);
+    const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
+    for (int k = 0; k < n_chunks; k++) {
+        hipLaunchKernelGGL(epnp_kernel, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64), (144 + 12) * 64 * sizeof(double),
+                           stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state, k, models);
+        hipLaunchKernelGGL(vote_kernel, dim3(RANSAC_CHUNK, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
+                           cap, prm, models, state, k, counts);
+        hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
+                           prm, k, counts, state);
+    }
     hipLaunchKernelGGL(select_refine_kernel, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
-                       cap, prm, models, counts, inliers, results);
+                       cap, prm, models, state, inliers, results);
 }
 
 } // namespace vo

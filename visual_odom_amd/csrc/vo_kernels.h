@@ -32,6 +32,14 @@ struct PnpResult {
     int lm_iters;
 };
 
+// progress of the replayed RANSAC loop of one frame (RANSACPointSetRegistrator::run)
+struct RansacState {
+    int it;        // hypotheses consumed so far (= iterations OpenCV would have executed at the end)
+    int niters;    // current adaptive iteration bound
+    int max_good;  // best inlier count
+    int best;      // index of the hypothesis that achieved it (-1: none)
+};
+
 #ifndef VO_HOST_EMUL
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream);
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
@@ -51,8 +59,8 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
                         size_t frame_stride, const int *n_pts, int cap, int max_pts, int n_frames, float *xyz,
                         hipStream_t stream);
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
-                const PnpParams &prm, int32_t *subsets, double *models, int *counts, int32_t *inliers,
-                PnpResult *results, hipStream_t stream);
+                const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
+                int32_t *inliers, PnpResult *results, hipStream_t stream);
 
 #endif // VO_HOST_EMUL
 
