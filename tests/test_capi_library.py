@@ -103,3 +103,24 @@ def test_integrate_odometry_host_math(built_lib):
         assert np.abs(pose_p - pose_o).max() < 1e-12
         n_applied += ok_p
     assert 30 < n_applied < 58
+
+
+def test_cpp_host_program_builds_and_fails_loudly_without_gpu(vo_run_binary, tmp_path):
+    """the C++ mirror of main.cpp links against the C ABI; with no GPU it must exit non-zero, not fall back"""
+    import subprocess
+    import torch
+    r = subprocess.run([vo_run_binary], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    d = tmp_path / "seq"
+    for cam in (0, 1):
+        (d / ("image_%d" % cam)).mkdir(parents=True)
+        for k in range(2):
+            img = np.full((64, 96), 100 + k, np.uint8)
+            with open(d / ("image_%d" % cam) / ("%06d.pgm" % k), "wb") as f:
+                f.write(b"P5\n96 64\n255\n" + img.tobytes())
+    r = subprocess.run([vo_run_binary, str(d), "300", "48", "32", "-100", "2", str(tmp_path / "p.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr

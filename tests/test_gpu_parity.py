@@ -478,3 +478,33 @@ def test_sequence_trajectory_matches_oracle_and_ground_truth(gpu_ctx, orc, small
     gt = [(T0inv @ T)[:3] for T in poses]
     assert odometry.ate_rmse(vo.trajectory, gt) < 0.05
     assert sum(r["integrated"] for r in vo.log) == n - 1
+
+
+def test_cpp_frame_loop_equals_python_mirror(gpu_ctx, vo_run_binary, small_world, tmp_path):
+    """examples/vo_run.cpp (C++ host, C ABI) and visual_odom_amd.odometry.StereoOdometry (ctypes) replay the
+    same sequence: the KITTI-format trajectories must agree to the printed precision"""
+    import subprocess
+    from visual_odom_amd import odometry
+    n = 6
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    d = tmp_path / "seq"
+    for cam, imgs in ((0, L), (1, R)):
+        (d / ("image_%d" % cam)).mkdir(parents=True)
+        for k, img in enumerate(imgs):
+            h, w = img.shape
+            with open(d / ("image_%d" % cam) / ("%06d.pgm" % k), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (w, h) + np.ascontiguousarray(img).tobytes())
+    out = tmp_path / "poses.txt"
+    fx, cx, cy, bf = P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3]
+    r = subprocess.run([vo_run_binary, str(d), repr(float(fx)), repr(float(cx)), repr(float(cy)), repr(float(bf)), str(n),
+                        str(out), "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, features_per_bucket=3)
+    for k in range(n):
+        vo.process(L[k], R[k])
+    got = odometry.load_poses(str(out))
+    assert got.shape == (n, 3, 4)
+    assert np.abs(got - np.asarray(vo.trajectory)).max() < 1e-8
+    T0inv = np.linalg.inv(poses[0])
+    assert odometry.ate_rmse(got, [(T0inv @ T)[:3] for T in poses]) < 0.05
