@@ -36,7 +36,8 @@ WORKLOADS = {
                                    "(bucket=rows/10, 6 per bucket), maxLevel 3"),
     "kitti374": (1241, 376, 1, 3, "KITTI-00-shaped 1241x376 stereo, reference-default bucketing "
                                   "(1 per bucket, <=374 pts), maxLevel 3"),
-    "hd4000": (1920, 1080, 4, 3, "synthetic 1920x1080 stereo, ~4000 keypoints/frame, maxLevel 3"),
+    "hd4000": (1920, 1080, 60, 3, "synthetic 1920x1080 stereo, 4000 keypoints/frame fed at the boundary "
+                                  "(60 per bucket, 3 px spacing, first 4000), maxLevel 3"),
 }
 
 
@@ -50,7 +51,11 @@ def build_inputs(workload, n_quads, seed):
                                   cx=w / 2.0 - 0.5, cy=h / 2.0 - 0.5, bf=synth.KITTI_BF * w / synth.KITTI_W)
     lefts, rights, poses, _ = world.render_sequence(n_quads + 1)
     bucket = h // 10
-    pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads + 1)]
+    if workload == "hd4000":
+        pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket, min_dist=3)[:4000]
+               for k in range(n_quads + 1)]
+    else:
+        pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads + 1)]
     return world, lefts, rights, pts, max_level
 
 
