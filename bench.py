@@ -81,8 +81,9 @@ def main():
     dist = replicas.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()  # one GPU per rank on a real node
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     from visual_odom_amd import _lib
     B, S = args.frames, min(args.quads, args.frames)
@@ -90,7 +91,7 @@ def main():
     world, lefts, rights, pts, max_level = build_inputs(args.workload, S, 20260925 + rank)
     w, h = world.w, world.h
     n_pts = [len(p) for p in pts]
-    ctx = _lib.Context(local_rank, w, h, 8192, B)
+    ctx = _lib.Context(local_dev, w, h, 8192, B)
     ctx.set_params(lk_max_level=max_level)
     # table pair j shows rendered pair tri(j): the S + 1 rendered pairs are walked forwards then
     # backwards, so consecutive table pairs are always consecutive rendered frames (real motion)

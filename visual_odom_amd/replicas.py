@@ -25,7 +25,9 @@ def init(backend=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # nccl (= RCCL) when every rank owns a GPU; VO_DIST_BACKEND=gloo lets two ranks share one GPU in a
+        # smoke test of this path (RCCL refuses duplicate devices)
+        backend = os.environ.get("VO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         dist.init_process_group(backend)
     return dist
@@ -36,6 +38,8 @@ def aggregate(dist, elapsed_s, frames_done, device=None):
     if dist is None:
         return float(elapsed_s), int(frames_done)
     import torch
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     f = torch.tensor([int(frames_done)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
