@@ -19,7 +19,7 @@ struct vo_ctx {
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
     vo_params prm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[VO_NUM_STAGES + 2] = {}; // [VO_NUM_STAGES + 1] = start of the pose solve on its stream
+    hipEvent_t ev[VO_NUM_STAGES + 2] = {}; // [0..3] tracking stream (3 stages), [4..7] post stream (3 stages)
     std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 2) for vo_batch_run_slot
     std::string err;
 
@@ -66,6 +66,8 @@ struct vo_ctx {
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
     hipStream_t stream_pnp = nullptr;
+    hipEvent_t ev_inputs_free = nullptr; // recorded after the filter has read d_pts / d_trk / d_status
+    bool inputs_busy = false;
     bool serial_pose = false;
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
@@ -134,6 +136,8 @@ hipError_t dmalloc(T **p, size_t n)
 
 } // namespace
 
+static int sync_all(vo_ctx *c);
+
 extern "C" {
 
 void vo_default_params(vo_params *p)
@@ -181,6 +185,8 @@ void vo_destroy(vo_ctx *c)
         if (b.done)
             (void)hipEventDestroy(b.done);
     }
+    if (c->ev_inputs_free)
+        (void)hipEventDestroy(c->ev_inputs_free);
     if (c->stream_pnp)
         (void)hipStreamDestroy(c->stream_pnp);
     if (c->h_stage)
@@ -217,6 +223,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream_pnp, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
     {
@@ -426,7 +433,9 @@ int vo_batch_set_points(vo_ctx *c, int frame, const float *pts, int n)
         return VO_ERR_ARG;
     if (frame < 0 || frame >= c->n_frames || n < 0 || n > c->cap || (n > 0 && !pts))
         return fail(c, VO_ERR_ARG, "vo_batch_set_points: bad frame / more points than max_pts");
-    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int rcs = sync_all(c); // a queued filter of the previous run still reads the points
+    if (rcs != VO_OK)
+        return rcs;
     if (n > 0)
         VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts + (size_t)frame * c->cap, pts, sizeof(float2) * n,
                                      hipMemcpyHostToDevice, c->stream));
@@ -450,7 +459,9 @@ int vo_batch_set_features(vo_ctx *c, int frame, const float *pts, int n_pts, con
     if (frame < 0 || frame >= c->n_frames || n_pts < 0 || n_ages < n_pts || n_ages > c->fcap ||
         (n_pts > 0 && !pts) || (n_ages > 0 && !ages))
         return fail(c, VO_ERR_ARG, "vo_batch_set_features: bad frame / counts (need n_pts <= n_ages <= capacity)");
-    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
     // ages beyond n_ages must read as 0 (age of a freshly appended corner, feature.cpp:260)
     VO_HIP_TRY(c, hipMemsetAsync(c->d_fages + (size_t)frame * c->fcap, 0, sizeof(int) * (size_t)c->fcap, c->stream));
     if (n_pts > 0)
@@ -541,6 +552,11 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
+    if ((stages & (VO_STAGE_DETECT | VO_STAGE_LK)) && c->inputs_busy) {
+        // the previous run's filter (post stream) must be done with d_pts / d_trk / d_status
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_inputs_free, 0));
+        c->inputs_busy = false;
+    }
     if (stages & VO_STAGE_DETECT) {
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
@@ -587,33 +603,37 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                            c->d_status, lp, c->stream);
     }
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream)); // evs[3]: end of LK on the tracking stream
     e++;
-    if (touches_pose && pb.pending) {
-        // the pose solve that last used this buffer set (two runs ago) must have drained
-        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0));
-        pb.pending = false;
+    // Everything after LK (filter, triangulation, pose solve) is the "post" chain: small, latency-bound
+    // kernels.  It runs on its own stream so that the next run's pyramid / LK launches overlap it; the
+    // tracking stream only waits (before its next DETECT / LK, i.e. after a whole pyramid stage) for the
+    // filter to have consumed the points / tracks / status it is about to overwrite.
+    hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
+    if (touches_pose) {
+        VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
+        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.ready, 0));
     }
-    if (stages & VO_STAGE_FILTER)
-        launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
-                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, c->stream);
+    hipStream_t ts = touches_pose ? ps : c->stream;
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[4]
+    e++;
+    if (stages & VO_STAGE_FILTER) {
+        launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
+                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, ps);
+        VO_HIP_TRY(c, hipEventRecord(c->ev_inputs_free, ps));
+        c->inputs_busy = true;
+    }
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[5]
     e++;
     if (stages & VO_STAGE_TRIANGULATE) // stage-B rows: 0 = l0, 1 = r0, 2 = l1, 3 = r1
         launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + cap, (size_t)4 * cap, pb.nB, cap,
-                           c->max_pts_set, B, pb.xyz, c->stream);
+                           c->max_pts_set, B, pb.xyz, ps);
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[6]
     e++;
     if (stages & VO_STAGE_PNP) {
-        // the pose solve is a chain of low-occupancy, latency-bound kernels: it runs on its own
-        // stream so that the next run's pyramid / LK launches (ctx stream) overlap it
-        hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
-        VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
-        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.ready, 0));
-        if (timed)
-            VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], ps));
         PnpParams pp;
         pp.iters = c->prm.ransac_iterations;
         pp.reproj = c->prm.ransac_reproj_error;
@@ -624,14 +644,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                    pb.rstate, pb.inliers, pb.results, ps);
-        if (timed)
-            VO_HIP_TRY(c, hipEventRecord(evs[e], ps));
-        VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
-        pb.pending = true;
-    } else if (timed) {
-        VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 1], c->stream));
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     }
+    if (timed)
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[7]
     VO_HIP_TRY(c, hipGetLastError());
     if (touches_pose) {
         c->last = c->cur;
@@ -666,8 +681,8 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
     rc = sync_all(c);
     if (rc != VO_OK)
         return rc;
-    for (int s = 0; s < VO_NUM_STAGES; s++)
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s == VO_NUM_STAGES - 1 ? VO_NUM_STAGES + 1 : s], c->ev[s + 1]));
+    for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s < 3 ? s : s + 1], c->ev[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -684,8 +699,8 @@ int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
         return VO_ERR_ARG;
     VO_HIP_TRY(c, hipSetDevice(c->device));
     hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)];
-    for (int s = 0; s < VO_NUM_STAGES; s++) // the pose solve is timed on its own stream
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s == VO_NUM_STAGES - 1 ? VO_NUM_STAGES + 1 : s], evs[s + 1]));
+    for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s < 3 ? s : s + 1], evs[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -761,6 +776,9 @@ static int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, fl
                        int32_t *keep_idx, int *n_out)
 {
     int M = 0;
+    int rcs = sync_all(c); // the filter runs on the post stream
+    if (rcs != VO_OK)
+        return rcs;
     VO_HIP_TRY(c, hipMemcpyAsync(&M, c->d_nA + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t cap = c->cap;
