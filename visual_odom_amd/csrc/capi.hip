@@ -51,7 +51,7 @@ struct vo_ctx {
         int *counts = nullptr;
         RansacState *rstate = nullptr;
         PnpResult *results = nullptr;
-        hipEvent_t ready = nullptr, done = nullptr; // triangulation finished / pose solve finished
+        hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         bool pending = false;                        // `done` has been recorded and not waited for
     } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
@@ -65,7 +65,7 @@ struct vo_ctx {
     int *d_fages = nullptr;        // [B][fcap] ages of d_feat (zero beyond the uploaded ages)
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
-    hipStream_t stream_pnp = nullptr;
+    hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
     hipEvent_t ev_inputs_free = nullptr; // recorded after the filter has read d_pts / d_trk / d_status
     bool inputs_busy = false;
     bool serial_pose = false;
@@ -184,11 +184,15 @@ void vo_destroy(vo_ctx *c)
             (void)hipEventDestroy(b.ready);
         if (b.done)
             (void)hipEventDestroy(b.done);
+        if (b.tri_done)
+            (void)hipEventDestroy(b.tri_done);
     }
     if (c->ev_inputs_free)
         (void)hipEventDestroy(c->ev_inputs_free);
     if (c->stream_pnp)
         (void)hipStreamDestroy(c->stream_pnp);
+    if (c->stream_filter)
+        (void)hipStreamDestroy(c->stream_filter);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev)
@@ -223,6 +227,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream_pnp, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream_filter, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
@@ -273,6 +278,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && dmalloc(&b.rstate, B) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.tri_done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
     }
     vo_default_detect_params(&c->dprm);
@@ -605,23 +611,32 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream)); // evs[3]: end of LK on the tracking stream
     e++;
-    // Everything after LK (filter, triangulation, pose solve) is the "post" chain: small, latency-bound
-    // kernels.  It runs on its own stream so that the next run's pyramid / LK launches overlap it; the
-    // tracking stream only waits (before its next DETECT / LK, i.e. after a whole pyramid stage) for the
-    // filter to have consumed the points / tracks / status it is about to overwrite.
+    // Everything after LK is small, latency-bound work and leaves the tracking stream so that the next
+    // run's pyramid / LK launches overlap it:
+    //   filter stream: filter + triangulation of run k start as soon as LK(k) is done (they must not
+    //                  queue behind the pose solve of run k - 1, which is still running next to LK(k));
+    //   pose stream:   the PnP / RANSAC chain of run k.
+    // Run k writes buffer set k % 2; its filter first waits for the pose solve of run k - 2 (same set).
+    // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
+    // for the filter to have consumed the points / tracks / status it is about to overwrite.
+    hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
     hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
-        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.ready, 0));
+        VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
+        if (pb.pending) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.done, 0));
+            pb.pending = false;
+        }
     }
-    hipStream_t ts = touches_pose ? ps : c->stream;
+    hipStream_t ts = touches_pose ? fs : c->stream;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[4]
     e++;
     if (stages & VO_STAGE_FILTER) {
         launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
-                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, ps);
-        VO_HIP_TRY(c, hipEventRecord(c->ev_inputs_free, ps));
+                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
+        VO_HIP_TRY(c, hipEventRecord(c->ev_inputs_free, fs));
         c->inputs_busy = true;
     }
     if (timed)
@@ -629,11 +644,13 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     e++;
     if (stages & VO_STAGE_TRIANGULATE) // stage-B rows: 0 = l0, 1 = r0, 2 = l1, 3 = r1
         launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + cap, (size_t)4 * cap, pb.nB, cap,
-                           c->max_pts_set, B, pb.xyz, ps);
+                           c->max_pts_set, B, pb.xyz, fs);
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[6]
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[6]: end of triangulation
     e++;
     if (stages & VO_STAGE_PNP) {
+        VO_HIP_TRY(c, hipEventRecord(pb.tri_done, fs));
+        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.tri_done, 0));
         PnpParams pp;
         pp.iters = c->prm.ransac_iterations;
         pp.reproj = c->prm.ransac_reproj_error;
@@ -644,9 +661,13 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                    pb.rstate, pb.inliers, pb.results, ps);
+        if (timed)
+            VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
+        VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
+        pb.pending = true;
+    } else if (timed) {
+        VO_HIP_TRY(c, hipEventRecord(evs[e], ts));
     }
-    if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[7]
     VO_HIP_TRY(c, hipGetLastError());
     if (touches_pose) {
         c->last = c->cur;
@@ -660,6 +681,7 @@ static int sync_all(vo_ctx *c)
 {
     VO_HIP_TRY(c, hipSetDevice(c->device));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
     return VO_OK;
 }
