@@ -226,8 +226,15 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->ransac_cap = 1000;
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->stream_pnp, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->stream_filter, hipStreamNonBlocking) == hipSuccess;
+    // the post-LK streams carry a few hundred waves next to LK's hundred thousand: at equal priority
+    // their kernels trickle in behind LK's workgroups (pose chain 1.1 ms alone, 5-10 ms next to LK) and
+    // the next run ends up waiting for them, so they get the highest stream priority
+    {
+        int least = 0, greatest = 0;
+        ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
+    }
     ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
