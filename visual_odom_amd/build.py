@@ -27,10 +27,6 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     flags = list(FLAGS)
-    # developer sweep of the pose kernels' register budget (see pnp.hip): VO_PNP_WAVES=1|2|4
-    if os.environ.get("VO_PNP_WAVES"):
-        w = int(os.environ["VO_PNP_WAVES"])
-        flags += ["-DVO_EPNP_WAVES=%d" % w, "-DVO_REFINE_WAVES=%d" % w]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "vo_hip.h"))
     objs, jobs = [], []

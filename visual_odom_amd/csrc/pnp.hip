@@ -25,18 +25,15 @@
 #include <float.h>
 
 // Register budget of the two f64-heavy kernels, as minimum waves per SIMD (launch_bounds' second
-// argument).  They run on the pose stream next to the next batch's LK launch: a wave that owns all 512
-// registers of a SIMD evicts every LK wave from it, a 128-register wave co-resides with them.
-// Measured (gpurun_out/sweep1, bench.py 64 frames): 1 wave/SIMD (512 registers, no spills to speak of)
-// 5.42 ms/step overlapped and a 1.11 ms stand-alone pose chain; 4 waves/SIMD (128 registers, heavy
-// spilling) 5.27 ms/step overlapped but a 2.20 ms stand-alone chain.  The 3 % of batch throughput is
-// not worth doubling the latency of the single-frame drop-in calls, so the default stays 1.
-#ifndef VO_EPNP_WAVES
-#define VO_EPNP_WAVES 1
-#endif
-#ifndef VO_REFINE_WAVES
-#define VO_REFINE_WAVES 1
-#endif
+// argument), a template parameter with two instantiations:
+//   WAVES = 1  all 512 registers, hardly any spills: 1.1 ms stand-alone pose chain.  Used for small
+//              batches (the single-frame drop-in calls), where the GPU is otherwise idle.
+//   WAVES = 4  128 registers, heavy spilling, 2.2 ms stand-alone -- but such a wave fits on a SIMD next
+//              to LK waves, whereas a 512-register wave can only start on a completely EMPTY SIMD, which
+//              the next batch's LK launch (one hundred thousand workgroups) never leaves: next to LK the
+//              WAVES = 1 chain took 5-10 ms and the following run ended up waiting for it
+//              (gpurun_out/sweep1, r11).  Used for batches of >= 8 frames.
+constexpr int PNP_BATCH_FRAMES = 8;
 
 namespace vo {
 
@@ -86,7 +83,8 @@ __global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frame
     }
 }
 
-__global__ __launch_bounds__(64, VO_EPNP_WAVES) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
@@ -221,7 +219,8 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-__global__ __launch_bounds__(256, VO_REFINE_WAVES) void select_refine_kernel(const float *__restrict__ xyz,
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *__restrict__ xyz,
                                                             const float2 *__restrict__ uv, size_t uv_stride,
                                                             const int *__restrict__ n_pts, int cap,
                                                             PnpParams prm, const double *__restrict__ models,
@@ -479,16 +478,27 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
     hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                        prm.iters, subsets, state);
     const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
+    const bool batch = n_frames >= PNP_BATCH_FRAMES;
     for (int k = 0; k < n_chunks; k++) {
-        hipLaunchKernelGGL(epnp_kernel, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64), (144 + 12) * 64 * sizeof(double),
-                           stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state, k, models);
+        if (batch)
+            hipLaunchKernelGGL(epnp_kernel<4>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
+                               (144 + 12) * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
+                               state, k, models);
+        else
+            hipLaunchKernelGGL(epnp_kernel<1>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
+                               (144 + 12) * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
+                               state, k, models);
         hipLaunchKernelGGL(vote_kernel, dim3(RANSAC_CHUNK, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, k, counts);
         hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm, k, counts, state);
     }
-    hipLaunchKernelGGL(select_refine_kernel, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
-                       cap, prm, models, state, inliers, results);
+    if (batch)
+        hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
+                           cap, prm, models, state, inliers, results);
+    else
+        hipLaunchKernelGGL(select_refine_kernel<1>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
+                           cap, prm, models, state, inliers, results);
 }
 
 } // namespace vo
