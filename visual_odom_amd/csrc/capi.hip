@@ -667,7 +667,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             for (int k = 0; k < 3; k++)
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.rstate, pb.inliers, pb.results, ps);
+                   pb.rstate, pb.inliers, pb.results, /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
         VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
@@ -1045,7 +1045,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, /*crowded*/ false, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
 }

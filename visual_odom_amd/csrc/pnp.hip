@@ -32,8 +32,10 @@
 //              to LK waves, whereas a 512-register wave can only start on a completely EMPTY SIMD, which
 //              the next batch's LK launch (one hundred thousand workgroups) never leaves: next to LK the
 //              WAVES = 1 chain took 5-10 ms and the following run ended up waiting for it
-//              (gpurun_out/sweep1, r11).  Used for batches of >= 8 frames.
-constexpr int PNP_BATCH_FRAMES = 8;
+//              (gpurun_out/sweep1, r11 - r13).  Used when the caller says the GPU is crowded: the LK
+//              launch of the same batch has enough features to keep every SIMD full for many rounds
+//              (capi.hip: frames x points >= 65536); at the reference-default 340 points per frame LK
+//              does not, and the 512-register chain is the faster one there (37 k vs 25 k frames/s).
 
 namespace vo {
 
@@ -471,14 +473,14 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, hipStream_t stream)
+                int32_t *inliers, PnpResult *results, bool crowded, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
     hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                        prm.iters, subsets, state);
     const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
-    const bool batch = n_frames >= PNP_BATCH_FRAMES;
+    const bool batch = crowded;
     for (int k = 0; k < n_chunks; k++) {
         if (batch)
             hipLaunchKernelGGL(epnp_kernel<4>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
