@@ -67,7 +67,7 @@ struct vo_ctx {
     int *d_fages = nullptr;        // [B][fcap] ages of d_feat (zero beyond the uploaded ages)
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
-    hipStream_t stream_pnp[VO_POSE_SETS] = {}, stream_filter = nullptr; // pose solve of run k on stream k % 3
+    hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
     hipEvent_t ev_inputs_free = nullptr; // recorded after the filter has read d_pts / d_trk / d_status
     bool inputs_busy = false;
     bool serial_pose = false;
@@ -191,9 +191,8 @@ void vo_destroy(vo_ctx *c)
     }
     if (c->ev_inputs_free)
         (void)hipEventDestroy(c->ev_inputs_free);
-    for (auto &st : c->stream_pnp)
-        if (st)
-            (void)hipStreamDestroy(st);
+    if (c->stream_pnp)
+        (void)hipStreamDestroy(c->stream_pnp);
     if (c->stream_filter)
         (void)hipStreamDestroy(c->stream_filter);
     if (c->h_stage)
@@ -235,8 +234,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     {
         int least = 0, greatest = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-        for (auto &st : c->stream_pnp) // the chains are latency-bound: consecutive runs' chains overlap each other
-            ok = ok && hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
@@ -631,7 +629,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp[c->cur];
+    hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
         VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
@@ -693,8 +691,7 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipSetDevice(c->device));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
-    for (auto &st : c->stream_pnp)
-        VO_HIP_TRY(c, hipStreamSynchronize(st));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
     return VO_OK;
 }
 
