@@ -14,8 +14,6 @@
 
 using namespace vo;
 
-#define VO_POSE_SETS 3 /* run k writes set k % 3: its filter only has to wait for the pose solve of run k - 3 */
-
 struct vo_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
@@ -42,8 +40,8 @@ struct vo_ctx {
     uint8_t *d_status = nullptr;
     int *d_npts = nullptr, *d_nA = nullptr, *d_idxA = nullptr;
     float *d_P = nullptr; // d_P: P_l (12) then P_r (12)
-    // Everything the pose solve reads or writes exists VO_POSE_SETS times: the PnP/RANSAC chain of
-    // batch k runs on its own stream while the tracking stages of later batches fill the other sets.
+    // Everything the pose solve reads or writes exists twice: the PnP/RANSAC chain of batch k runs on
+    // its own stream while the tracking stages of batch k + 1 already fill the other set.
     struct PoseBufs {
         float2 *outB = nullptr;  // [B][4][cap] l0, r0, l1, r1 after the consistency filter
         int *idxB = nullptr, *nB = nullptr;
@@ -55,7 +53,7 @@ struct vo_ctx {
         PnpResult *results = nullptr;
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         bool pending = false;                        // `done` has been recorded and not waited for
-    } pb[VO_POSE_SETS];
+    } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
     // detection / bucketing (VO_STAGE_DETECT)
     vo_detect_params dprm;
@@ -625,7 +623,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     //   filter stream: filter + triangulation of run k start as soon as LK(k) is done (they must not
     //                  queue behind the pose solve of run k - 1, which is still running next to LK(k));
     //   pose stream:   the PnP / RANSAC chain of run k.
-    // Run k writes buffer set k % 3; its filter first waits for the pose solve of run k - 3 (same set).
+    // Run k writes buffer set k % 2; its filter first waits for the pose solve of run k - 2 (same set).
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
@@ -680,7 +678,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     VO_HIP_TRY(c, hipGetLastError());
     if (touches_pose) {
         c->last = c->cur;
-        c->cur = (c->cur + 1) % VO_POSE_SETS;
+        c->cur ^= 1;
     }
     return VO_OK;
 }
