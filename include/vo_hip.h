@@ -160,6 +160,12 @@ int vo_batch_upload_image(vo_ctx *ctx, int image_idx, const uint8_t *host_pixels
 int vo_batch_upload_image_dev(vo_ctx *ctx, int image_idx, const void *dev_pixels, int stride);
 /* quads4 [n_frames][4] = (l0, r0, l1, r1) image indices */
 int vo_batch_set_quads(vo_ctx *ctx, const int32_t *quads4, int n_frames);
+/* Which images VO_STAGE_PYRAMID (re)builds: [first_image, first_image + n_images).  Default after
+ * vo_batch_configure: all of them.  A streaming caller keeps the image table as a ring, uploads only the
+ * new stereo pair and builds only its two pyramids: the t1 pyramids of one frame are the t0 pyramids of the
+ * next (the reference rebuilds all four pyramids twice per frame inside calcOpticalFlowPyrLK,
+ * feature.cpp:136-139; main.cpp:157-158 only swaps the cv::Mat headers). */
+int vo_batch_set_pyramid_range(vo_ctx *ctx, int first_image, int n_images);
 int vo_batch_set_points(vo_ctx *ctx, int frame, const float *pts_l0_xy, int n);
 int vo_batch_set_projection(vo_ctx *ctx, const float *P_l, const float *P_r);
 /* VO_STAGE_DETECT inputs: the features carried into `frame` from the previous frame (n_pts may be 0;

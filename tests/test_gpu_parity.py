@@ -442,7 +442,8 @@ def test_sequence_trajectory_matches_oracle_and_ground_truth(gpu_ctx, orc, small
     P_l, P_r = small_world.proj_matrices()
     K = small_world.K()
     h, w = L[0].shape
-    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, features_per_bucket=3)
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, features_per_bucket=3)                    # streaming
+    vo_dropin = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, streaming=False, features_per_bucket=3)
     o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
     o_pose, o_t = np.eye(4), np.zeros(3)
     o_traj = [o_pose[:3].copy()]
@@ -473,6 +474,12 @@ def test_sequence_trajectory_matches_oracle_and_ground_truth(gpu_ctx, orc, small
         assert np.abs(rec["rvec"] - rv).max() <= 1e-6 and np.abs(rec["tvec"] - tv).max() <= 1e-6
         assert np.abs(vo.frame_pose - o_pose).max() <= 1e-6
     assert odometry.ate_rmse(vo.trajectory, o_traj) <= 1e-6
+    # the stateless drop-in calls (four uploads + four pyramids per frame) give the same trajectory as the
+    # streaming ring (one upload, two pyramids per frame)
+    for k in range(n):
+        vo_dropin.process(L[k], R[k])
+    assert np.array_equal(np.asarray(vo_dropin.trajectory), np.asarray(vo.trajectory))
+    assert np.array_equal(bits(vo_dropin.points), bits(vo.points)) and np.array_equal(vo_dropin.ages, vo.ages)
     # against the planted motion: camera-to-world poses relative to the first frame
     T0inv = np.linalg.inv(poses[0])
     gt = [(T0inv @ T)[:3] for T in poses]

@@ -28,4 +28,18 @@ for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default
     dt2 = time.perf_counter() - t1
     print("%s: track_frame %.2f ms/frame = %.0f frames/s (PCIe-inclusive, %d points); detect_bucket %.2f ms/frame"
           % (name, 1e3 * dt / n, n / dt, len(pts[0]), 1e3 * dt2 / n))
+    # the whole frame loop (detect/bucket -> track -> pose -> integrate) as a stream: one upload and two
+    # pyramids per frame (visual_odom_amd.odometry.StereoOdometry, streaming ring)
+    from visual_odom_amd import odometry
+    order = [0, 1, 2, 3, 4, 3, 2, 1]           # ping-pong over the rendered pairs: always adjacent frames
+    for streaming in (True, False):
+        vo = odometry.StereoOdometry(P_l, P_r, ctx=ctx, streaming=streaming, features_per_bucket=per_bucket)
+        for i in range(9):
+            vo.process(L[order[i % 8]], R[order[i % 8]])
+        t2 = time.perf_counter()
+        for i in range(9, 9 + n):
+            vo.process(L[order[i % 8]], R[order[i % 8]])
+        dt3 = time.perf_counter() - t2
+        print("    frame loop incl. FAST + bucketing + pose integration, %s: %.2f ms/frame = %.0f frames/s"
+              % ("streaming ring" if streaming else "stateless drop-in calls", 1e3 * dt3 / n, n / dt3))
     ctx.close()

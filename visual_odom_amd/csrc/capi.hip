@@ -27,6 +27,7 @@ struct vo_ctx {
     int n_images = 0, n_frames = 0, w = 0, h = 0, levels = 0; // levels = max_level + 1 actually built
     int lw[VO_MAX_LEVELS] = {}, lh[VO_MAX_LEVELS] = {}, lstride[VO_MAX_LEVELS] = {};
     size_t loff[VO_MAX_LEVELS] = {}, img_bytes = 0;
+    int pyr_first = 0, pyr_count = 0; // image range VO_STAGE_PYRAMID rebuilds
     int max_pts_set = 0; // largest n over the frames of the batch (or its bound after VO_STAGE_DETECT)
     bool pts_on_device = false, detect_uploaded = false;
 
@@ -345,8 +346,11 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
         h < 32 || w > c->max_w || h > c->max_h)
         return fail(c, VO_ERR_ARG, "vo_batch_configure: size beyond the capacity given to vo_create");
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    if (c->n_images == n_images && c->w == w && c->h == h && c->n_frames == n_frames)
+    if (c->n_images == n_images && c->w == w && c->h == h && c->n_frames == n_frames) {
+        c->pyr_first = 0; // a (re)configure always restores "build every pyramid"
+        c->pyr_count = n_images;
         return VO_OK;
+    }
     plan_levels(c, w, h);
     if (c->img_bytes * (size_t)n_images > c->pix_capacity)
         return fail(c, VO_ERR_ARG, "vo_batch_configure: pyramid storage exceeds capacity");
@@ -369,6 +373,8 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     VO_HIP_TRY(c, hipMemsetAsync(c->d_der, 0, sizeof(uint32_t) * c->img_bytes * (size_t)n_images, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_images = n_images;
+    c->pyr_first = 0;
+    c->pyr_count = n_images;
     c->n_frames = n_frames;
     c->w = w;
     c->h = h;
@@ -437,6 +443,19 @@ int vo_batch_set_quads(vo_ctx *c, const int32_t *quads4, int n_frames)
     VO_HIP_TRY(c, hipSetDevice(c->device));
     VO_HIP_TRY(c, hipMemcpyAsync(c->d_quads, quads4, sizeof(Quad) * n_frames, hipMemcpyHostToDevice, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_batch_set_pyramid_range(vo_ctx *c, int first_image, int n_images)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (c->n_images == 0)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_pyramid_range before vo_batch_configure");
+    if (first_image < 0 || n_images < 0 || first_image + n_images > c->n_images)
+        return fail(c, VO_ERR_ARG, "vo_batch_set_pyramid_range: range outside the image table");
+    c->pyr_first = first_image;
+    c->pyr_count = n_images;
     return VO_OK;
 }
 
@@ -555,12 +574,16 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_PYRAMID) {
-        launch_border_fill(c->d_imgs, c->n_images, 0, c->lstride[0], c->lh[0], c->stream);
-        for (int l = 0; l + 1 < c->levels; l++) {
-            launch_pyr_down(c->d_imgs, c->n_images, l, c->lw[l + 1], c->lh[l + 1], c->stream);
-            launch_border_fill(c->d_imgs, c->n_images, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
+        const PyrImage *tab = c->d_imgs + c->pyr_first;
+        const int ni = c->pyr_count;
+        if (ni > 0) {
+            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], c->stream);
+            for (int l = 0; l + 1 < c->levels; l++) {
+                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], c->stream);
+                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
+            }
+            launch_scharr(tab, ni, c->levels, c->lw[0], c->lh[0], c->stream);
         }
-        launch_scharr(c->d_imgs, c->n_images, c->levels, c->lw[0], c->lh[0], c->stream);
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));

@@ -17,12 +17,21 @@ from . import _lib
 
 
 class StereoOdometry:
-    def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, **detect_kw):
+    """streaming=True (default) keeps the two most recent stereo pairs resident on the device: every new
+    pair is uploaded once and only its two pyramids are built (the t1 pyramids of one frame are the t0
+    pyramids of the next), detection / bucketing, tracking and the pose solve run as one batch of one
+    frame without intermediate host round trips.  streaming=False goes through the stateless drop-in calls
+    (vo_detect_bucket + vo_track_frame: four uploads and four pyramids per frame).  Same results."""
+
+    def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=True,
+                 **detect_kw):
         self.P_l = np.ascontiguousarray(P_l, np.float32).reshape(3, 4)
         self.P_r = np.ascontiguousarray(P_r, np.float32).reshape(3, 4)
         self.ctx = ctx if ctx is not None else _lib.Context(device, max_w, max_h, max_pts, 1)
         self._own = ctx is None
         self.detect_kw = detect_kw
+        self.streaming = streaming
+        self._n_pairs = 0
         # main.cpp:81-94
         self.points = np.zeros((0, 2), np.float32)   # currentVOFeatures.points
         self.ages = np.zeros(0, np.int32)            # currentVOFeatures.ages (may be longer than points)
@@ -40,19 +49,24 @@ class StereoOdometry:
     def process(self, left, right):
         """feed the next stereo pair; returns the per-frame record (None for the very first pair)"""
         cur = (np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8))
-        if self.prev is None:
-            self.prev = cur
-            return None
-        (l0, r0), (l1, r1) = self.prev, cur
-        # matchingFeatures: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
-        pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
-        # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
-        out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
+        if self.streaming:
+            pts, ages, out = self._stream_step(cur)
+            if out is None:
+                return None
+        else:
+            if self.prev is None:
+                self.prev = cur
+                return None
+            (l0, r0), (l1, r1) = self.prev, cur
+            # matchingFeatures: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
+            pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
+            # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
+            out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
         # deleteUnmatchFeaturesCircle: ages += 1, compacted with the circular-matching survivors only
         # (feature.cpp:83-86,111); the consistency filter does not touch ages (quirk B3)
         self.ages = (ages + 1)[out["keep_idx_circ"]]
         self.points = out["l1"]                       # currentVOFeatures.points = pointsLeft_t1
-        self.prev = cur                               # main.cpp:157-158
+        self.prev = None if self.streaming else cur   # main.cpp:157-158 (streaming: the pair stays on the device)
         rec = dict(n_bucketed=len(pts), n_tracked=len(out["l1"]), n_inliers=len(out["inliers"]), rc=out["rc"],
                    rvec=out["rvec"].copy(), tvec=out["tvec"].copy(), integrated=False)
         if out["rc"] == _lib.VO_ERR_TOO_FEW:
@@ -63,6 +77,37 @@ class StereoOdometry:
         self.trajectory.append(self.frame_pose[:3].copy())
         self.log.append(rec)
         return rec
+
+    def _stream_step(self, cur):
+        """device-resident ring of two stereo pairs: slots (0, 1) and (2, 3) of the image table"""
+        ctx = self.ctx
+        h, w = cur[0].shape
+        slot = 2 * (self._n_pairs % 2)
+        if self._n_pairs == 0:
+            ctx.batch_configure(4, w, h, 1)
+            ctx.batch_set_projection(self.P_l, self.P_r)
+            ctx.batch_set_detect_params(**self.detect_kw)
+        ctx.batch_upload_image(slot, cur[0])
+        ctx.batch_upload_image(slot + 1, cur[1])
+        ctx.batch_set_pyramid_range(slot, 2)           # only the new pair's pyramids are built
+        self._n_pairs += 1
+        if self._n_pairs == 1:
+            ctx.batch_run(_lib.STAGE_PYRAMID)
+            ctx.batch_sync()
+            return None, None, None
+        old = 2 - slot
+        ctx.batch_set_quads([[old, old + 1, slot, slot + 1]])
+        ctx.batch_set_features(0, self.points, self.ages)
+        ctx.batch_run(_lib.STAGE_ALL | _lib.STAGE_DETECT)
+        ctx.batch_sync()
+        pts, ages = ctx.batch_get_features(0)
+        f = ctx.batch_get_filtered(0)
+        p = ctx.batch_get_pose(0)
+        rc = _lib.VO_ERR_TOO_FEW if p["status"] < 0 else (0 if p["status"] == 1 else 1)
+        tvec = p["tvec"] if p["status"] >= 0 else self.translation
+        out = dict(rc=rc, l1=f["l1"], keep_idx_circ=f["keep_idx_circ"], inliers=p["inliers"], rvec=p["rvec"], tvec=tvec,
+                   R=p["R"])
+        return pts, ages, out
 
     def save_trajectory(self, path):
         with open(path, "w") as f:
