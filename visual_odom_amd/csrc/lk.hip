@@ -42,6 +42,19 @@ struct __attribute__((packed, aligned(4))) LkU4 {
     uint32_t a, b, c, d;
 };
 
+// 14-bit fixed-point bilinear weights of OpenCV's LKTrackerInvoker from the fractional parts of the
+// window corner: iw00 = cvRound((1-a)*(1-b)*2^14) etc.  The scale is folded into the first factor
+// ((1-a)*2^14 is exact, so the rounded product is bit-identical) to save a multiply.
+__device__ __forceinline__ void lk_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11)
+{
+    const float s = (float)(1 << LK_W_BITS);
+    const float a1 = (1.f - a) * s, a0 = a * s, b1 = 1.f - b;
+    iw00 = __float2int_rn(a1 * b1);
+    iw01 = __float2int_rn(a0 * b1);
+    iw10 = __float2int_rn(a1 * b);
+    iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+}
+
 __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
                                                           const float2 *__restrict__ pts_in,
@@ -68,6 +81,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
     const bool live = lane < 63;
     const int lr = live ? lane : 62;
     const int r = lr / 3, c0 = 7 * (lr - 3 * r);
+    const int lane_off = r * LK_JT_W + c0; // this lane's row segment inside the search tile
 
     const Quad q = quads[frame];
     const float halfWin = (LK_WIN - 1) * 0.5f;
@@ -107,17 +121,15 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
 
             prevX -= halfWin;
             prevY -= halfWin;
-            const int ipx = uni((int)floorf(prevX)), ipy = uni((int)floorf(prevY));
+            const float fpx = floorf(prevX), fpy = floorf(prevY);
+            const int ipx = uni((int)fpx), ipy = uni((int)fpy);
             if (ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih) {
                 if (level == 0)
                     st = 0;
                 continue;
             }
-            float a = prevX - ipx, b = prevY - ipy;
-            int iw00 = uni(__float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS)));
-            int iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
-            int iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
-            int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            int iw00, iw01, iw10, iw11; // (float)ipx == floorf(prevX): the fractional part needs no int round trip
+            lk_weights(prevX - fpx, prevY - fpy, iw00, iw01, iw10, iw11);
             const uint32_t wt = pack_w(iw00, iw01), wb = pack_w(iw10, iw11); // signed lanes: iw11 may be -1
 
             // ---- 21 x 21 template straight from the bordered pyramid (registers) + structure tensor --
@@ -169,7 +181,8 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
             for (int j = 0; j < prm.max_count; j++) {
-                const int inx = uni((int)floorf(nextX)), iny = uni((int)floorf(nextY));
+                const float fnx = floorf(nextX), fny = floorf(nextY);
+                const int inx = uni((int)fnx), iny = uni((int)fny);
                 if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
                     if (level == 0)
                         st = 0;
@@ -192,16 +205,11 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                     __syncthreads();
                     have_tile = true;
                 }
-                a = nextX - inx;
-                b = nextY - iny;
-                iw00 = uni(__float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS)));
-                iw01 = uni(__float2int_rn(a * (1.f - b) * (1 << LK_W_BITS)));
-                iw10 = uni(__float2int_rn((1.f - a) * b * (1 << LK_W_BITS)));
-                iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+                lk_weights(nextX - fnx, nextY - fny, iw00, iw01, iw10, iw11);
 
                 int b1 = 0, b2 = 0;
                 {
-                    const int off = (iny - jy0 + r) * LK_JT_W + (inx - jx0) + c0;
+                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
                     // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
                     // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
                     const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);

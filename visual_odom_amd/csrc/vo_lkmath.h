@@ -96,7 +96,15 @@ VO_HD uint32_t pk_lshr1_u16(uint32_t a)
 constexpr uint32_t VO_SEL_LO16 = 0x05040100u; // (lo.lo16, hi.lo16)
 constexpr uint32_t VO_SEL_HI16 = 0x07060302u; // (lo.hi16, hi.hi16)
 
-VO_HD uint32_t pack_w(int w_lo, int w_hi) { return (uint32_t)(w_lo & 0xffff) | ((uint32_t)w_hi << 16); }
+// two weights as int16 lanes (|w| <= 2^14, so v_cvt_pk_i16_i32's saturation never triggers)
+VO_HD uint32_t pack_w(int w_lo, int w_hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(w_lo, w_hi));
+#else
+    return (uint32_t)(w_lo & 0xffff) | ((uint32_t)w_hi << 16);
+#endif
+}
 
 // ---- one 7-pixel row segment ----------------------------------------------------------------------
 // t = bytes x..x+7 of the upper image row, b = the same columns one row below.
