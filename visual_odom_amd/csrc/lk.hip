@@ -86,6 +86,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
     const Quad q = quads[frame];
     const float halfWin = (LK_WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps_lo = (float)(prm.epsilon * 0.999999), eps_hi = (float)(prm.epsilon * 1.000001);
 
     const float2 p = pts_in[(size_t)frame * cap + f];
     float prevPtX = unif(p.x), prevPtY = unif(p.y);
@@ -231,7 +232,17 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 nextY += dy;
                 outX = nextX + halfWin;
                 outY = nextY + halfWin;
-                if ((double)dx * dx + (double)dy * dy <= prm.epsilon)
+                // OpenCV: delta.ddot(delta) <= epsilon in f64.  The f32 value n2 is within 2^-23 of it, so it
+                // decides on its own unless it falls inside a 1e-6 band around epsilon (then the f64 form)
+                const float n2 = fmaf(dy, dy, dx * dx);
+                bool converged = n2 < eps_lo;
+                if (__builtin_expect(!converged && !(n2 > eps_hi), 0)) {
+#ifndef VO_HOST_EMUL
+                    asm volatile("" ::: "memory"); // keep the rare f64 evaluation out of the hot path
+#endif
+                    converged = (double)dx * dx + (double)dy * dy <= prm.epsilon;
+                }
+                if (converged)
                     break;
                 // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
                 // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f

@@ -85,10 +85,9 @@ __device__ __forceinline__ int dpp_add(int v)
 // the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| <= 2^28 so
 // that the first three butterfly steps (8-lane sums) cannot overflow int32; the 8-lane sums are then
 // split into a signed high and an unsigned low 16-bit half which are reduced separately (row_mirror,
-// row_bcast15, row_bcast31: the total lands in lane 63), read with v_readlane and recombined as an
-// int64 on the scalar unit.  The total almost always fits int32, where one v_cvt_f32_i32 is the
-// correctly rounded conversion (else via f64, exact below 2^53).
-// 9 v_add_u32_dpp + 2 split + 2 v_readlane + 1 cvt instead of 12 ds_bpermute round trips per sum.
+// row_bcast15, row_bcast31: the total lands in lane 63), read with v_readlane and recombined by one
+// v_fma_f32 (exact product and sum, one rounding).
+// 9 v_add_u32_dpp + 2 split + 2 v_readlane + 2 cvt + 1 fma instead of 12 ds_bpermute round trips per sum.
 // (Measured alternative, profiles/r01_v3: reading the eight 8-lane sums with v_readlane and adding
 // them on the scalar unit saves 4 VALU instructions per sum but costs 22 SALU ones -- the CU's single
 // scalar unit then becomes the bottleneck and the kernel runs 4 % slower.)
@@ -104,15 +103,9 @@ __device__ __forceinline__ float wave_sum_exact_f32(int v)
     hi = dpp_add<VO_DPP_ROW_BCAST15, 0xa>(hi);
     lo = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(lo);
     hi = dpp_add<VO_DPP_ROW_BCAST31, 0xc>(hi);
-    const long long s = ((long long)VO_READLANE(hi, 63) << 16) + (long long)VO_READLANE(lo, 63);
-    const int s32 = (int)s;
-    if (__builtin_expect((long long)s32 != s, 0)) {
-#ifndef VO_HOST_EMUL
-        asm volatile("" ::: "memory"); // keep this rare path a real branch (no if-conversion into the hot path)
-#endif
-        return (float)(double)s;
-    }
-    return (float)s32;
+    // hi * 2^16 + lo rounded ONCE: both halves are exact in f32 (|hi| < 2^19, lo < 2^22) and a fused
+    // multiply-add rounds the exact sum a single time = (float)(int64 total), the correctly rounded value
+    return fmaf((float)VO_READLANE(hi, 63), 65536.f, (float)VO_READLANE(lo, 63));
 }
 
 } // namespace vo
