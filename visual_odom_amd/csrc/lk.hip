@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
         int st = 1;
 
         for (int level = prm.max_level; level >= 0; level--) {
-            const float scale = 1.f / (float)(1 << level);
+            const float scale = __int_as_float((127 - level) << 23); // 2^-level, exact (no divide)
             float prevX = prevPtX * scale, prevY = prevPtY * scale;
             float nextX, nextY;
             if (level == prm.max_level) {
@@ -140,20 +140,21 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             int a11 = 0, a12 = 0, a22 = 0;
             {
                 const ptrdiff_t o = (ptrdiff_t)(ipy + r) * istride + ipx + c0;
+                // lane 63 owns no pixel: it reads its Scharr samples from the (all-zero) top-left border
+                // corner, so Ix = Iy = 0 there and every sum it feeds is 0 without any select
+                const ptrdiff_t od = live ? o : -(ptrdiff_t)VO_BY * istride - VO_BX;
                 const LkU2 t = *reinterpret_cast<const LkU2 *>(Iimg + o);
                 const LkU2 u = *reinterpret_cast<const LkU2 *>(Iimg + o + istride);
-                const LkU4 dt0 = *reinterpret_cast<const LkU4 *>(Ider + o);
-                const LkU4 dt1 = *reinterpret_cast<const LkU4 *>(Ider + o + 4);
-                const LkU4 db0 = *reinterpret_cast<const LkU4 *>(Ider + o + istride);
-                const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + o + istride + 4);
+                const LkU4 dt0 = *reinterpret_cast<const LkU4 *>(Ider + od);
+                const LkU4 dt1 = *reinterpret_cast<const LkU4 *>(Ider + od + 4);
+                const LkU4 db0 = *reinterpret_cast<const LkU4 *>(Ider + od + istride);
+                const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + od + istride + 4);
                 const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
                 const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
                 bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Ip);
                 bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    if (!live)
-                        Ip[m] = Ixp[m] = Iyp[m] = 0;
                     a11 = sdot2(Ixp[m], Ixp[m], a11);
                     a12 = sdot2(Ixp[m], Iyp[m], a12);
                     a22 = sdot2(Iyp[m], Iyp[m], a22);
@@ -247,6 +248,9 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                 // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
                 // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f
                 if (j > 0 && fabsf(dx + prevDX) <= 0.01f && fabsf(dy + prevDY) <= 0.01f) {
+#ifndef VO_HOST_EMUL
+                    asm volatile("" ::: "memory"); // do not speculate the half-step into every iteration
+#endif
                     outX -= dx * 0.5f;
                     outY -= dy * 0.5f;
                     break;
