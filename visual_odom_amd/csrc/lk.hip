@@ -28,7 +28,6 @@
 #include "vo_lkmath.h"
 
 #include <float.h>
-#include <limits.h>
 
 namespace vo {
 
@@ -180,8 +179,6 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
             float prevDX = 0.f, prevDY = 0.f;
             int jx0 = 0, jy0 = 0;
             bool have_tile = false;
-            uint32_t Jt[7], Jb[7];                        // pixel pairs of the current window cell
-            int cell_x = INT_MIN, cell_y = INT_MIN;       // ... and which cell they belong to
             // tile origins that keep the 40 x 48 tile inside the bordered allocation
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
@@ -209,25 +206,18 @@ __global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restr
                     }
                     __syncthreads();
                     have_tile = true;
-                    cell_x = INT_MIN; // the cached pairs came from the old tile position: same pixels, but keep it simple
                 }
                 lk_weights(nextX - fnx, nextY - fny, iw00, iw01, iw10, iw11);
 
                 int b1 = 0, b2 = 0;
                 {
-                    if (inx != cell_x || iny != cell_y) {
-                        // the window moved to another pixel cell (or the tile was refilled): two unaligned
-                        // 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured equal to three
-                        // aligned dwords + v_alignbyte_b32 per row) and the 14 pixel pairs
-                        const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
-                        const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
-                        const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
-                        pixel_pairs7(t.lo, t.hi, u.lo, u.hi, Jt, Jb);
-                        cell_x = inx;
-                        cell_y = iny;
-                    }
+                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
+                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
+                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
+                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
                     uint32_t Jp[4];
-                    bilinear7_from_pairs(Jt, Jb, iw00, iw01, iw10, iw11, Jp);
+                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Jp);
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         const uint32_t diff = pk_sub_i16(Jp[m], Ip[m]);

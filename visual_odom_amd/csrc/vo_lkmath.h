@@ -142,40 +142,6 @@ VO_HD void bilinear7_u8(uint32_t t_lo, uint32_t t_hi, uint32_t b_lo, uint32_t b_
         out[m] = pk_lshr1_u16(perm_b32(acc[2 * m + 1], acc[2 * m], VO_SEL_HI16));
 }
 
-// The same in two steps, for the iteration loop: the pixel pairs only depend on the integer position of
-// the window, the weights on its fractional part.  Two thirds of all Gauss-Newton iterations stay in the
-// pixel cell of the previous one, so the pairs (14 VGPRs) are kept and only the dot products repeat.
-VO_HD void pixel_pairs7(uint32_t t_lo, uint32_t t_hi, uint32_t b_lo, uint32_t b_hi, uint32_t pt[7], uint32_t pb[7])
-{
-#define VO_PAIR(k)                                  \
-    pt[k] = perm_b32(t_hi, t_lo, VO_SEL_PIX(k));    \
-    pb[k] = perm_b32(b_hi, b_lo, VO_SEL_PIX(k));
-    VO_PAIR(0) VO_PAIR(1) VO_PAIR(2) VO_PAIR(3) VO_PAIR(4) VO_PAIR(5) VO_PAIR(6)
-#undef VO_PAIR
-}
-
-VO_HD void bilinear7_from_pairs(const uint32_t pt[7], const uint32_t pb[7], int iw00, int iw01, int iw10, int iw11,
-                                uint32_t out[4])
-{
-    const uint32_t wt = pack_w(iw00, iw01);
-    uint32_t acc[8];
-    if (iw11 >= 0) {
-        const uint32_t wb = pack_w(iw10, iw11);
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-            acc[k] = udot2(pb[k], wb, udot2(pt[k], wt, 1u << 16));
-    } else { // iw11 == -1, see bilinear7_u8
-        const uint32_t wb = pack_w(iw10, 0), kneg = (uint32_t)(-iw11);
-#pragma unroll
-        for (int k = 0; k < 7; k++)
-            acc[k] = udot2(pb[k], wb, udot2(pt[k], wt, 1u << 16)) - kneg * (pb[k] >> 16);
-    }
-    acc[7] = 0;
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-        out[m] = pk_lshr1_u16(perm_b32(acc[2 * m + 1], acc[2 * m], VO_SEL_HI16));
-}
-
 // Scharr samples: d[k] = (4*Ix | 4*Iy << 16) of pixel x+k, rows top / bottom, k = 0..7.
 // ix[m] = (Ixval[2m], Ixval[2m+1]), iy likewise; *val[k] = DESCALE(sum d*iw, 14) of the true derivative.
 VO_HD void bilinear7_deriv(const uint32_t dt[8], const uint32_t db[8], uint32_t wt, uint32_t wb, uint32_t ix[4],
