@@ -27,6 +27,8 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     flags = list(FLAGS)
+    if os.environ.get("VO_LK_ATTRS"):  # developer A/B of the LK kernel's register caps
+        flags.append("-DVO_LK_ATTRS=" + os.environ["VO_LK_ATTRS"])
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "vo_hip.h"))
     objs, jobs = [], []

@@ -55,7 +55,10 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &iw00, int &iw0
     iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
 }
 
-__global__ __launch_bounds__(64) void lk_circular_kernel(const PyrImage *__restrict__ imgs,
+#ifndef VO_LK_ATTRS
+#define VO_LK_ATTRS __launch_bounds__(64)
+#endif
+__global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
                                                           const float2 *__restrict__ pts_in,
                                                           const int *__restrict__ n_pts, int cap,
