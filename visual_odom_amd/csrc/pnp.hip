@@ -41,48 +41,56 @@ namespace vo {
 
 constexpr int RANSAC_CHUNK = 128;
 
-// one thread per frame (the stream is strictly sequential); n_frames threads in total
-__global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters,
+// one thread per frame (the RNG stream is strictly sequential); n_frames threads in total.  Chunk k draws
+// the subsets of hypotheses [k * RANSAC_CHUNK, (k + 1) * RANSAC_CHUNK) continuing the frame's stream where
+// chunk k - 1 left it -- and only for frames whose adaptive iteration count still reaches that far.
+__global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters, int chunk,
                                        int32_t *__restrict__ subsets /* [B][iters][5] */,
                                        RansacState *__restrict__ rstate)
 {
     const int frame = blockIdx.x * blockDim.x + threadIdx.x;
     if (frame >= n_frames)
         return;
-    RansacState st0;
-    st0.it = 0;
-    st0.niters = iters > 1 ? iters : 1;
-    st0.max_good = 0;
-    st0.best = -1;
-    rstate[frame] = st0;
+    RansacState st;
+    if (chunk == 0) {
+        st.it = 0;
+        st.niters = iters > 1 ? iters : 1;
+        st.max_good = 0;
+        st.best = -1;
+        st.rng = 0xffffffffffffffffull; // cv::RNG rng((uint64)-1)
+    } else {
+        st = rstate[frame];
+    }
     const int count = n_pts[frame];
     int32_t *out = subsets + (size_t)frame * iters * 5;
-    if (count < 5)
-        return;
-    if (count == 5) { // model_points == npoints: solvePnP on all points in order
+    if (count == 5 && chunk == 0) // model_points == npoints: solvePnP on all points in order
         for (int i = 0; i < 5; i++)
             out[i] = i;
-        return;
-    }
-    uint64_t state = 0xffffffffffffffffull; // cv::RNG rng((uint64)-1)
-    for (int it = 0; it < iters; it++) {
-        int idx[5];
-        for (int i = 0; i < 5; i++) {
-            int idx_i;
-            for (;;) {
-                state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
-                idx_i = (int)((uint32_t)state % (uint32_t)count);
-                bool dup = false;
-                for (int k = 0; k < i; k++)
-                    dup |= idx[k] == idx_i;
-                if (!dup)
-                    break;
+    if (count > 5) {
+        const int first = chunk * RANSAC_CHUNK;
+        const int last = min(min(first + RANSAC_CHUNK, iters), st.niters);
+        uint64_t state = st.rng;
+        for (int it = first; it < last; it++) {
+            int idx[5];
+            for (int i = 0; i < 5; i++) {
+                int idx_i;
+                for (;;) {
+                    state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+                    idx_i = (int)((uint32_t)state % (uint32_t)count);
+                    bool dup = false;
+                    for (int k = 0; k < i; k++)
+                        dup |= idx[k] == idx_i;
+                    if (!dup)
+                        break;
+                }
+                idx[i] = idx_i;
             }
-            idx[i] = idx_i;
+            for (int i = 0; i < 5; i++)
+                out[it * 5 + i] = idx[i];
         }
-        for (int i = 0; i < 5; i++)
-            out[it * 5 + i] = idx[i];
+        st.rng = state;
     }
+    rstate[frame] = st;
 }
 
 template <int WAVES>
@@ -477,11 +485,11 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 {
     if (n_frames <= 0)
         return;
-    hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
-                       prm.iters, subsets, state);
     const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
     const bool batch = crowded;
     for (int k = 0; k < n_chunks; k++) {
+        hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
+                           prm.iters, k, subsets, state);
         if (batch)
             hipLaunchKernelGGL(epnp_kernel<4>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
                                (144 + 12) * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,

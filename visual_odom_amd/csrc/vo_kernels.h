@@ -38,6 +38,7 @@ struct RansacState {
     int niters;    // current adaptive iteration bound
     int max_good;  // best inlier count
     int best;      // index of the hypothesis that achieved it (-1: none)
+    uint64_t rng;  // cv::RNG state after the subsets drawn so far
 };
 
 #ifndef VO_HOST_EMUL
