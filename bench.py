@@ -100,7 +100,6 @@ def main():
         return m if m <= S else 2 * S - m
 
     n_images = 2 * (B + 1)
-    ctx.batch_set_pipeline(True)  # pyramids of step k + 1 are built on their own stream while LK of step k runs
     ctx.batch_configure(n_images, w, h, B)
     # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
     dev_imgs = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev),

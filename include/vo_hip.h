@@ -166,12 +166,6 @@ int vo_batch_set_quads(vo_ctx *ctx, const int32_t *quads4, int n_frames);
  * next (the reference rebuilds all four pyramids twice per frame inside calcOpticalFlowPyrLK,
  * feature.cpp:136-139; main.cpp:157-158 only swaps the cv::Mat headers). */
 int vo_batch_set_pyramid_range(vo_ctx *ctx, int first_image, int n_images);
-/* Throughput pipelining of consecutive vo_batch_run calls that each (re)build the pyramids: with on != 0 the
- * image table exists twice, VO_STAGE_PYRAMID of run k + 1 runs on its own stream into the other copy while
- * LK of run k still reads the first, uploads write level 0 of both copies.  Costs a second pyramid
- * allocation; call before vo_batch_configure.  Leave it off for the streaming ring (vo_batch_set_pyramid_range),
- * which relies on pyramids persisting between runs. */
-int vo_batch_set_pipeline(vo_ctx *ctx, int on);
 int vo_batch_set_points(vo_ctx *ctx, int frame, const float *pts_l0_xy, int n);
 int vo_batch_set_projection(vo_ctx *ctx, const float *P_l, const float *P_r);
 /* VO_STAGE_DETECT inputs: the features carried into `frame` from the previous frame (n_pts may be 0;

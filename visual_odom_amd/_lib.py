@@ -21,7 +21,7 @@ NUM_STAGES = len(STAGE_NAMES)
 # every symbol include/vo_hip.h declares (checked by the CPU test-suite against the built .so)
 EXPORTS = (
     "vo_default_params", "vo_default_detect_params", "vo_integrate_odometry", "vo_fast_detect", "vo_detect_bucket",
-    "vo_batch_set_features", "vo_batch_set_pyramid_range", "vo_batch_set_pipeline", "vo_batch_set_detect_params", "vo_batch_get_features", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
+    "vo_batch_set_features", "vo_batch_set_pyramid_range", "vo_batch_set_detect_params", "vo_batch_get_features", "vo_create", "vo_destroy", "vo_last_error", "vo_set_params", "vo_get_params",
     "vo_circular_match", "vo_triangulate", "vo_pnp_ransac", "vo_track_frame",
     "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
     "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
@@ -257,9 +257,6 @@ class Context:
     def batch_set_quads(self, quads):
         q = np.ascontiguousarray(quads, np.int32).reshape(-1, 4)
         self._chk(self.lib.vo_batch_set_quads(self.h, _p(q), q.shape[0]))
-
-    def batch_set_pipeline(self, on=True):
-        self._chk(self.lib.vo_batch_set_pipeline(self.h, int(bool(on))))
 
     def batch_set_pyramid_range(self, first_image, n_images):
         self._chk(self.lib.vo_batch_set_pyramid_range(self.h, first_image, n_images))

@@ -19,8 +19,8 @@ struct vo_ctx {
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
     vo_params prm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[VO_NUM_STAGES + 3] = {}; // [0..3] tracking stream (3 stages), [4..7] post streams (3 stages), [8] start of DETECT
-    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 3) for vo_batch_run_slot
+    hipEvent_t ev[VO_NUM_STAGES + 2] = {}; // [0..3] tracking stream (3 stages), [4..7] post stream (3 stages)
+    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 2) for vo_batch_run_slot
     std::string err;
 
     // batch configuration
@@ -36,15 +36,6 @@ struct vo_ctx {
     uint32_t *d_der = nullptr; // all Scharr pyramids (one dword per pixel), image i at d_der + i * img_bytes
     size_t pix_capacity = 0;   // in pixels (bytes of d_pix, dwords of d_der)
     PyrImage *d_imgs = nullptr;
-    // pipelined mode (vo_batch_set_pipeline): second copy of the image table + its own pyramid stream
-    bool pipelined = false;
-    uint8_t *d_pix2 = nullptr;
-    uint32_t *d_der2 = nullptr;
-    PyrImage *d_imgs2 = nullptr;
-    int img_next = 0, img_cur = 0;  // copy the next PYRAMID stage writes / copy the other stages read
-    hipStream_t stream_pyr = nullptr;
-    hipEvent_t ev_pyr_done[2] = {}, ev_set_free[2] = {};
-    bool set_busy[2] = {false, false};
     Quad *d_quads = nullptr;
     float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr;
     uint8_t *d_status = nullptr;
@@ -185,18 +176,6 @@ void vo_destroy(vo_ctx *c)
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
-    void *p2[] = {c->d_pix2, c->d_der2, c->d_imgs2};
-    for (void *p : p2)
-        if (p)
-            (void)hipFree(p);
-    for (int k = 0; k < 2; k++) {
-        if (c->ev_pyr_done[k])
-            (void)hipEventDestroy(c->ev_pyr_done[k]);
-        if (c->ev_set_free[k])
-            (void)hipEventDestroy(c->ev_set_free[k]);
-    }
-    if (c->stream_pyr)
-        (void)hipStreamDestroy(c->stream_pyr);
     for (auto &b : c->pb) {
         void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results};
         for (void *p : q)
@@ -258,11 +237,6 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->stream_pyr, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; k < 2; k++) {
-        ok = ok && hipEventCreateWithFlags(&c->ev_pyr_done[k], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_set_free[k], hipEventDisableTiming) == hipSuccess;
-    }
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
     {
@@ -271,7 +245,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     }
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
-    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 3), nullptr);
+    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 2), nullptr);
     for (auto &e : c->ring)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     // worst case pyramid bytes per image (5 levels, padded strides)
@@ -398,19 +372,6 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     // the Scharr border is BORDER_CONSTANT 0 (and stays 0: scharr_kernel writes interiors only)
     VO_HIP_TRY(c, hipMemsetAsync(c->d_der, 0, sizeof(uint32_t) * c->img_bytes * (size_t)n_images, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->pipelined) { // the same table over the second copy
-        for (int i = 0; i < n_images; i++)
-            for (int l = 0; l < c->levels; l++) {
-                tab[i].lvl[l] = c->d_pix2 + (tab[i].lvl[l] - c->d_pix);
-                tab[i].der[l] = c->d_der2 + (tab[i].der[l] - c->d_der);
-            }
-        VO_HIP_TRY(c, hipMemcpyAsync(c->d_imgs2, tab.data(), sizeof(PyrImage) * n_images, hipMemcpyHostToDevice,
-                                     c->stream));
-        VO_HIP_TRY(c, hipMemsetAsync(c->d_der2, 0, sizeof(uint32_t) * c->img_bytes * (size_t)n_images, c->stream));
-        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    c->img_next = c->img_cur = 0;
-    c->set_busy[0] = c->set_busy[1] = false;
     c->n_images = n_images;
     c->pyr_first = 0;
     c->pyr_count = n_images;
@@ -450,16 +411,10 @@ static int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemc
             memcpy(slot + (size_t)y * pitch, (const uint8_t *)src + (size_t)y * stride, (size_t)c->w);
         VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, pitch * (size_t)(c->h - 1) + (size_t)c->w, hipMemcpyHostToDevice,
                                      c->stream));
-        if (c->pipelined)
-            VO_HIP_TRY(c, hipMemcpyAsync(c->d_pix2 + (dst - c->d_pix), slot, pitch * (size_t)(c->h - 1) + (size_t)c->w,
-                                         hipMemcpyHostToDevice, c->stream));
         return VO_OK;
     }
     VO_HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->lstride[0], src, (size_t)stride, (size_t)c->w, (size_t)c->h,
                                    kind, c->stream));
-    if (c->pipelined)
-        VO_HIP_TRY(c, hipMemcpy2DAsync(c->d_pix2 + (dst - c->d_pix), (size_t)c->lstride[0], src, (size_t)stride,
-                                       (size_t)c->w, (size_t)c->h, kind, c->stream));
     return VO_OK;
 }
 
@@ -501,25 +456,6 @@ int vo_batch_set_pyramid_range(vo_ctx *c, int first_image, int n_images)
         return fail(c, VO_ERR_ARG, "vo_batch_set_pyramid_range: range outside the image table");
     c->pyr_first = first_image;
     c->pyr_count = n_images;
-    return VO_OK;
-}
-
-int vo_batch_set_pipeline(vo_ctx *c, int on)
-{
-    if (!c)
-        return VO_ERR_ARG;
-    int rc = sync_all(c);
-    if (rc != VO_OK)
-        return rc;
-    if (on && !c->d_pix2) {
-        bool ok = dmalloc(&c->d_pix2, c->pix_capacity) == hipSuccess && dmalloc(&c->d_der2, c->pix_capacity) == hipSuccess &&
-                  dmalloc(&c->d_imgs2, (size_t)c->max_images) == hipSuccess;
-        if (!ok)
-            return fail(c, VO_ERR_HIP, "vo_batch_set_pipeline: no memory for the second copy of the image table");
-    }
-    c->pipelined = on != 0;
-    c->n_images = 0; // the image tables are rebuilt by the next vo_batch_configure
-    c->img_next = c->img_cur = 0;
     return VO_OK;
 }
 
@@ -634,46 +570,24 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     const bool touches_pose = (stages & (VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) != 0;
     vo_ctx::PoseBufs &pb = c->pb[c->cur];
     int e = 0;
-    // Pipelined mode: the pyramid stage of this run goes to its own stream and into the copy of the image
-    // table that the previous run's LK is NOT reading, so that it overlaps that LK launch; the tracking
-    // stream then waits for it.  The copy is free again once the LK / FAST of two runs ago are done.
-    const bool piped = c->pipelined && !c->serial_pose;
-    hipStream_t ys = piped ? c->stream_pyr : c->stream;
-    if (stages & VO_STAGE_PYRAMID) {
-        const int sset = c->pipelined ? c->img_next : 0;
-        if (piped && c->set_busy[sset]) {
-            VO_HIP_TRY(c, hipStreamWaitEvent(ys, c->ev_set_free[sset], 0));
-            c->set_busy[sset] = false;
-        }
-        c->img_cur = sset;
-        if (c->pipelined)
-            c->img_next = sset ^ 1;
-    }
-    const PyrImage *imgs = c->img_cur == 0 ? c->d_imgs : c->d_imgs2;
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], (stages & VO_STAGE_PYRAMID) ? ys : c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_PYRAMID) {
-        const PyrImage *tab = imgs + c->pyr_first;
+        const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
-            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], ys);
+            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], c->stream);
             for (int l = 0; l + 1 < c->levels; l++) {
-                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], ys);
-                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], ys);
+                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], c->stream);
+                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
             }
-            launch_scharr(tab, ni, c->levels, c->lw[0], c->lh[0], ys);
+            launch_scharr(tab, ni, c->levels, c->lw[0], c->lh[0], c->stream);
         }
     }
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], (stages & VO_STAGE_PYRAMID) ? ys : c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
-    if ((stages & VO_STAGE_PYRAMID) && piped) {
-        VO_HIP_TRY(c, hipEventRecord(c->ev_pyr_done[c->img_cur], ys));
-        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_pyr_done[c->img_cur], 0));
-    }
-    if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 2], c->stream)); // start of DETECT on the tracking stream
     if ((stages & (VO_STAGE_DETECT | VO_STAGE_LK)) && c->inputs_busy) {
         // the previous run's filter (post stream) must be done with d_pts / d_trk / d_status
         VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_inputs_free, 0));
@@ -700,7 +614,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
-        launch_detect_bucket(imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
+        launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
                              c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb, c->d_pts,
                              c->d_ages, c->d_npts, cap, c->stream);
         // the bucketed count is only known on the device; every later grid is sized by its bound
@@ -721,12 +635,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        launch_lk_circular(imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk,
+        launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk,
                            c->d_status, lp, c->stream);
-    }
-    if (piped && (stages & (VO_STAGE_DETECT | VO_STAGE_LK))) { // last readers of this copy of the image table
-        VO_HIP_TRY(c, hipEventRecord(c->ev_set_free[c->img_cur], c->stream));
-        c->set_busy[c->img_cur] = true;
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream)); // evs[3]: end of LK on the tracking stream
@@ -800,7 +710,6 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
 static int sync_all(vo_ctx *c)
 {
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pyr));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
@@ -825,7 +734,7 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
     if (rc != VO_OK)
         return rc;
     for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s == 1 ? VO_NUM_STAGES + 2 : s < 3 ? s : s + 1], c->ev[s < 3 ? s + 1 : s + 2]));
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s < 3 ? s : s + 1], c->ev[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -833,7 +742,7 @@ int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
 {
     if (!c || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
-    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 3)]);
+    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)]);
 }
 
 int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
@@ -841,9 +750,9 @@ int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
     if (!c || !ms || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 3)];
+    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)];
     for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s == 1 ? VO_NUM_STAGES + 2 : s < 3 ? s : s + 1], evs[s < 3 ? s + 1 : s + 2]));
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s < 3 ? s : s + 1], evs[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -989,7 +898,7 @@ int vo_batch_get_pyramid_level(vo_ctx *c, int idx, int level, uint8_t *out, int 
         *h_l = c->lh[level];
     if (out) {
         VO_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)c->lw[level],
-                                       (c->img_cur == 0 ? c->d_pix : c->d_pix2) + (size_t)idx * c->img_bytes + c->loff[level] +
+                                       c->d_pix + (size_t)idx * c->img_bytes + c->loff[level] +
                                            (size_t)VO_BY * c->lstride[level] + VO_BX,
                                        (size_t)c->lstride[level], (size_t)c->lw[level], (size_t)c->lh[level],
                                        hipMemcpyDeviceToHost, c->stream));
