@@ -37,8 +37,14 @@ struct vo_ctx {
     size_t pix_capacity = 0;   // in pixels (bytes of d_pix, dwords of d_der)
     PyrImage *d_imgs = nullptr;
     Quad *d_quads = nullptr;
-    float2 *d_pts = nullptr, *d_trk = nullptr, *d_outA = nullptr;
-    uint8_t *d_status = nullptr;
+    float2 *d_pts = nullptr, *d_outA = nullptr;
+    // LK outputs (4 hops of positions + status per frame) are double-buffered: LK of run k + 1 writes one set
+    // while the filter of run k still reads the other, so the tracking stream never idles behind the filter
+    float2 *d_trk2[2] = {};
+    uint8_t *d_status2[2] = {};
+    hipEvent_t ev_trk_free[2] = {}; // recorded after the filter has read that set (and d_pts)
+    bool trk_busy[2] = {};
+    int trk_next = 0, trk_last = 0; // set the next LK writes / set the latest LK wrote
     int *d_npts = nullptr, *d_nA = nullptr, *d_idxA = nullptr;
     float *d_P = nullptr; // d_P: P_l (12) then P_r (12)
     // Everything the pose solve reads or writes exists twice: the PnP/RANSAC chain of batch k runs on
@@ -67,8 +73,6 @@ struct vo_ctx {
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
     hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
-    hipEvent_t ev_inputs_free = nullptr; // recorded after the filter has read d_pts / d_trk / d_status
-    bool inputs_busy = false;
     bool serial_pose = false;
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
@@ -170,8 +174,8 @@ void vo_destroy(vo_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk, c->d_outA,
-                    c->d_status, c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_rowcnt, c->d_detect,
+    void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
+                    c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_rowcnt, c->d_detect,
                     c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages};
     for (void *p : ptrs)
         if (p)
@@ -188,8 +192,9 @@ void vo_destroy(vo_ctx *c)
         if (b.tri_done)
             (void)hipEventDestroy(b.tri_done);
     }
-    if (c->ev_inputs_free)
-        (void)hipEventDestroy(c->ev_inputs_free);
+    for (auto &ev : c->ev_trk_free)
+        if (ev)
+            (void)hipEventDestroy(ev);
     if (c->stream_pnp)
         (void)hipStreamDestroy(c->stream_pnp);
     if (c->stream_filter)
@@ -236,7 +241,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
     }
-    ok = ok && hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) == hipSuccess;
+    for (auto &ev : c->ev_trk_free)
+        ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
     {
@@ -266,9 +272,11 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
     ok = ok && dmalloc(&c->d_quads, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_pts, B * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_trk, B * 4 * cap) == hipSuccess;
+    for (int k = 0; k < 2; k++) {
+        ok = ok && dmalloc(&c->d_trk2[k], B * 4 * cap) == hipSuccess;
+        ok = ok && dmalloc(&c->d_status2[k], B * 4 * cap) == hipSuccess;
+    }
     ok = ok && dmalloc(&c->d_outA, B * 5 * cap) == hipSuccess;
-    ok = ok && dmalloc(&c->d_status, B * 4 * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_npts, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_nA, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_idxA, B * cap) == hipSuccess;
@@ -588,11 +596,14 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
-    if ((stages & (VO_STAGE_DETECT | VO_STAGE_LK)) && c->inputs_busy) {
-        // the previous run's filter (post stream) must be done with d_pts / d_trk / d_status
-        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_inputs_free, 0));
-        c->inputs_busy = false;
-    }
+    // DETECT rewrites d_pts, which every filter still in flight reads; LK only rewrites its own track set,
+    // which the filter of two runs ago read
+    const int wset = (stages & VO_STAGE_LK) ? c->trk_next : c->trk_last;
+    for (int k = 0; k < 2; k++)
+        if (c->trk_busy[k] && ((stages & VO_STAGE_DETECT) || ((stages & VO_STAGE_LK) && k == wset))) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_trk_free[k], 0));
+            c->trk_busy[k] = false;
+        }
     if (stages & VO_STAGE_DETECT) {
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
@@ -635,8 +646,10 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk,
-                           c->d_status, lp, c->stream);
+        launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk2[wset],
+                           c->d_status2[wset], lp, c->stream);
+        c->trk_last = wset;
+        c->trk_next = wset ^ 1;
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream)); // evs[3]: end of LK on the tracking stream
@@ -664,10 +677,10 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[4]
     e++;
     if (stages & VO_STAGE_FILTER) {
-        launch_compact(c->d_pts, c->d_trk, c->d_status, c->d_npts, cap, c->prm.consistency_threshold, c->d_outA,
-                       c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
-        VO_HIP_TRY(c, hipEventRecord(c->ev_inputs_free, fs));
-        c->inputs_busy = true;
+        launch_compact(c->d_pts, c->d_trk2[c->trk_last], c->d_status2[c->trk_last], c->d_npts, cap,
+                       c->prm.consistency_threshold, c->d_outA, c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
+        VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->trk_last], fs));
+        c->trk_busy[c->trk_last] = true;
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[5]
@@ -778,14 +791,14 @@ int vo_batch_get_tracks(vo_ctx *c, int frame, float *r0, float *r1, float *l1, f
         return fail(c, VO_ERR_ARG, "vo_batch_get_tracks: bad frame / n");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     const size_t cap = c->cap;
-    const float2 *t = c->d_trk + (size_t)frame * 4 * cap;
+    const float2 *t = c->d_trk2[c->trk_last] + (size_t)frame * 4 * cap;
     D2H(r0, t, sizeof(float2) * n);
     D2H(r1, t + cap, sizeof(float2) * n);
     D2H(l1, t + 2 * cap, sizeof(float2) * n);
     D2H(l0_ret, t + 3 * cap, sizeof(float2) * n);
     if (status4)
         for (int hop = 0; hop < 4; hop++)
-            D2H(status4 + (size_t)hop * n, c->d_status + ((size_t)frame * 4 + hop) * cap, (size_t)n);
+            D2H(status4 + (size_t)hop * n, c->d_status2[c->trk_last] + ((size_t)frame * 4 + hop) * cap, (size_t)n);
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VO_OK;
 }
@@ -990,7 +1003,7 @@ int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uin
         std::vector<int32_t> idx((size_t)K);
         std::vector<float> ret((size_t)2 * (n > 0 ? n : 1));
         VO_HIP_TRY(c, hipMemcpy(idx.data(), c->pb[c->last].idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
-        VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk + (size_t)3 * c->cap, sizeof(float2) * n,
+        VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk2[c->trk_last] + (size_t)3 * c->cap, sizeof(float2) * n,
                                 hipMemcpyDeviceToHost));
         for (int i = 0; i < K; i++) {
             out_l0_ret[2 * i] = ret[2 * idx[i]];
