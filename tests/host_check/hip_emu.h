@@ -200,6 +200,19 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
         return bound_ctrl ? 0 : old;
     return (int)got;
 }
+// v_permlane32_swap (width 32): lanes 32-63 of a <-> lanes 0-31 of b;
+// v_permlane16_swap (width 16): odd 16-lane rows of a <-> even rows of b
+static inline void emu_permlane_swap(int &a, int &b, int width)
+{
+    const int lane = emu::lane_id(), partner = lane ^ width;
+    const bool upper = (lane & width) != 0;
+    const int ga = (int)emu::exchange((uint32_t)a, partner, 0);
+    const int gb = (int)emu::exchange((uint32_t)b, partner, 0);
+    if (upper)
+        a = gb; // this lane's a came from the partner's b
+    else
+        b = ga;
+}
 // wave-wide ballot: bit l = predicate of lane l of the caller's wavefront
 static inline unsigned long long emu_ballot(bool pred)
 {

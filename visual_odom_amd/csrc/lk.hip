@@ -20,7 +20,8 @@
 //   Search image J: a 40 x 48 byte tile in LDS (1920 B per wave), filled with 16-byte loads and
 //   re-fetched only when the window leaves it; one iteration reads two unaligned 8-byte rows.
 //   Pixel arithmetic: v_perm_b32 / v_dot2_u32_u16 / v_dot2_i32_i16 / v_pk_sub_i16 (vo_lkmath.h).
-//   Reductions: v_add_u32_dpp butterflies (vo_dev.h wave_sum_exact_f32), no LDS round trips.
+//   Reductions: v_permlane32/16_swap + v_add_u32_dpp butterflies, two sums per tree (vo_dev.h
+//   wave_sum2_exact_f32), no LDS round trips.
 // Grid: blocks are numbered so that (dispatcher: block b -> XCD b % 8) all features of one frame
 // run on ONE XCD, i.e. the frame's four pyramids are pulled into one L2 only, eight frames at a time.
 // Batches of fewer than 8 frames split each frame's feature list into contiguous parts over 8/fpg XCDs.
@@ -163,9 +164,12 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     a22 = sdot2(Iyp[m], Iyp[m], a22);
                 }
             }
-            const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE;
-            const float A12 = wave_sum_exact_f32(a12) * FLT_SCALE;
-            const float A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
+            float A11, A12, A22, zero_;
+            wave_sum2_exact_f32(a11, a12, A11, A12);
+            wave_sum2_exact_f32(a22, 0, A22, zero_);
+            A11 *= FLT_SCALE;
+            A12 *= FLT_SCALE;
+            A22 *= FLT_SCALE;
 
             float D = A11 * A22 - A12 * A12;
             const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -228,8 +232,10 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                         b2 = sdot2(diff, Iyp[m], b2);
                     }
                 }
-                const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
-                const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
+                float fb1, fb2;
+                wave_sum2_exact_f32(b1, b2, fb1, fb2);
+                fb1 *= FLT_SCALE;
+                fb2 *= FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D;
                 const float dy = (A12 * fb1 - A11 * fb2) * D;
                 nextX += dx;

@@ -26,6 +26,8 @@
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define VO_BALLOT(p) emu_ballot(p)
 #define VO_POPCLL(m) __builtin_popcountll(m)
+#define VO_PERMLANE32_SWAP(a, b) emu_permlane_swap((a), (b), 32)
+#define VO_PERMLANE16_SWAP(a, b) emu_permlane_swap((a), (b), 16)
 #else
 #include <hip/hip_runtime.h>
 #define VO_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
@@ -33,6 +35,20 @@
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define VO_BALLOT(p) __ballot(p)
 #define VO_POPCLL(m) __popcll(m)
+// gfx950 v_permlane32_swap_b32 a, b: lanes 32-63 of a <-> lanes 0-31 of b;
+//        v_permlane16_swap_b32 a, b: odd 16-lane rows of a <-> even rows of b  (both operands are rewritten)
+#define VO_PERMLANE32_SWAP(a, b)                                                                      \
+    do {                                                                                              \
+        auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)(a), (unsigned)(b), false, false);       \
+        (a) = (int)r_[0];                                                                             \
+        (b) = (int)r_[1];                                                                             \
+    } while (0)
+#define VO_PERMLANE16_SWAP(a, b)                                                                      \
+    do {                                                                                              \
+        auto r_ = __builtin_amdgcn_permlane16_swap((unsigned)(a), (unsigned)(b), false, false);       \
+        (a) = (int)r_[0];                                                                             \
+        (b) = (int)r_[1];                                                                             \
+    } while (0)
 #endif
 
 #define VO_MAX_LEVELS 5
@@ -106,6 +122,35 @@ __device__ __forceinline__ float wave_sum_exact_f32(int v)
     // hi * 2^16 + lo rounded ONCE: both halves are exact in f32 (|hi| < 2^19, lo < 2^22) and a fused
     // multiply-add rounds the exact sum a single time = (float)(int64 total), the correctly rounded value
     return fmaf((float)VO_READLANE(hi, 63), 65536.f, (float)VO_READLANE(lo, 63));
+}
+
+// Two exact wave-wide sums for the price of (less than) one: the half-swap instructions of gfx950 fold two
+// reduction trees into one register.
+//   v_permlane32_swap(a, b); t = a + b      lanes 0-31: a[l] + a[l+32], lanes 32-63: the same of b
+//   quad butterflies (2 DPP adds)           8-value sums, |t| < 2^31 for |v| <= 2^28
+//   split t into signed high / unsigned low 16 bits, v_permlane16_swap(hi, lo); u = hi + lo
+//                                           rows 0 / 1 / 2 / 3: a's high, a's low, b's high, b's low partials
+//   row_half_mirror, row_mirror (2 DPP adds) every lane of a row holds that row's total
+//   convert to f32 (exact: |high| < 2^19, low < 2^22); rows 1 and 3 fetch the high total of the row before
+//   them (row_bcast15) and fuse high * 2^16 + low with ONE rounding = (float)(int64 sum), what the CPU
+//   path computes; two v_readlane return the results.
+// 15 VALU instructions for two sums instead of 2 x 16 with wave_sum_exact_f32.
+__device__ __forceinline__ void wave_sum2_exact_f32(int a, int b, float &fa, float &fb)
+{
+    VO_PERMLANE32_SWAP(a, b);
+    int t = a + b;
+    t = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(t);
+    t = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(t);
+    int hi = t >> 16, lo = t & 0xffff;
+    VO_PERMLANE16_SWAP(hi, lo);
+    int u = hi + lo;
+    u = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(u);
+    u = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(u);
+    const float uf = (float)u;
+    const float up = __int_as_float(VO_UPDATE_DPP(0, __float_as_int(uf), VO_DPP_ROW_BCAST15, 0xa, 0xf, true));
+    const float res = fmaf(up, 65536.f, uf);
+    fa = __int_as_float(VO_READLANE(__float_as_int(res), 31));
+    fb = __int_as_float(VO_READLANE(__float_as_int(res), 63));
 }
 
 } // namespace vo
