@@ -31,7 +31,7 @@ void hc_bilinear7_u8(const uint8_t *top8, const uint8_t *bot8, const int *w4, in
         memcpy(t, top8 + 8 * i, 8);
         memcpy(b, bot8 + 8 * i, 8);
         const int *w = w4 + 4 * i;
-        vo::bilinear7_u8(t[0], t[1], b[0], b[1], w[0], w[1], w[2], w[3], out);
+        vo::bilinear7_u8(t[0], t[1], b[0], b[1], vo::pack_w(w[0], w[1]), vo::pack_w(w[2], w[3]), out);
         for (int k = 0; k < 7; k++)
             val7[7 * i + k] = (int16_t)((out[k / 2] >> (16 * (k & 1))) & 0xffff);
         val7[7 * i + 6] = (int16_t)(out[3] & 0xffff);

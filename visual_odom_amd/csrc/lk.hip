@@ -44,16 +44,23 @@ struct __attribute__((packed, aligned(4))) LkU4 {
 };
 
 // 14-bit fixed-point bilinear weights of OpenCV's LKTrackerInvoker from the fractional parts of the
-// window corner: iw00 = cvRound((1-a)*(1-b)*2^14) etc.  The scale is folded into the first factor
-// ((1-a)*2^14 is exact, so the rounded product is bit-identical) to save a multiply.
-__device__ __forceinline__ void lk_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11)
+// window corner: iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14),
+// iw11 = 2^14 - iw00 - iw01 - iw10, returned as the packed int16 pairs wt = (iw00, iw01), wb = (iw10, iw11).
+//   * the scale is folded into the first factor ((1-a)*2^14 is exact, so the rounded product is identical);
+//   * cvRound (round half to even) = adding 1.5 * 2^23: the f32 sum has ulp 1, so the add rounds the
+//     product to the nearest-even integer and leaves it in the low mantissa bits.  The raw bit patterns
+//     are packed / summed directly (0x4B400000 has no low 16 bits), no v_rndne / v_cvt per weight.
+__device__ __forceinline__ void lk_weights(float a, float b, uint32_t &wt, uint32_t &wb)
 {
-    const float s = (float)(1 << LK_W_BITS);
+    const float s = (float)(1 << LK_W_BITS), magic = 12582912.f; // 1.5 * 2^23 = 0x4B400000
     const float a1 = (1.f - a) * s, a0 = a * s, b1 = 1.f - b;
-    iw00 = __float2int_rn(a1 * b1);
-    iw01 = __float2int_rn(a0 * b1);
-    iw10 = __float2int_rn(a1 * b);
-    iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+    const uint32_t r00 = (uint32_t)__float_as_int(a1 * b1 + magic);
+    const uint32_t r01 = (uint32_t)__float_as_int(a0 * b1 + magic);
+    const uint32_t r10 = (uint32_t)__float_as_int(a1 * b + magic);
+    // iw11 = 2^14 - (r00 + r01 + r10 - 3 * 0x4B400000)   (mod 2^32)
+    const uint32_t iw11 = ((1u << LK_W_BITS) + 3u * 0x4B400000u) - (r00 + r01 + r10);
+    wt = perm_b32(r01, r00, VO_SEL_LO16);
+    wb = perm_b32(iw11, r10, VO_SEL_LO16); // signed lanes: iw11 may be -1
 }
 
 #ifndef VO_LK_ATTRS
@@ -133,15 +140,17 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     st = 0;
                 continue;
             }
-            int iw00, iw01, iw10, iw11; // (float)ipx == floorf(prevX): the fractional part needs no int round trip
-            lk_weights(prevX - fpx, prevY - fpy, iw00, iw01, iw10, iw11);
-            const uint32_t wt = pack_w(iw00, iw01), wb = pack_w(iw10, iw11); // signed lanes: iw11 may be -1
+            uint32_t wt, wb; // (float)ipx == floorf(prevX): the fractional part needs no int round trip
+            lk_weights(prevX - fpx, prevY - fpy, wt, wb);
 
             // ---- 21 x 21 template straight from the bordered pyramid (registers) + structure tensor --
             // lane: pixels (ipx + c0 .. + 7, ipy + r) and the row below; the bordered layout makes
             // every admissible window an in-bounds read (reflected pixels, zero derivatives)
-            uint32_t Ip[4], Ixp[4], Iyp[4];
-            int a11 = 0, a12 = 0, a22 = 0;
+            // b1 = sum (J - I) * Ix is accumulated as sum J * Ix - sum I * Ix: the lane's own (exact, integer)
+            // sum I * Ix is formed once per level and seeds the iteration's accumulator, so the inner loop
+            // neither keeps I nor subtracts it
+            uint32_t Ixp[4], Iyp[4];
+            int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
             {
                 const ptrdiff_t o = (ptrdiff_t)(ipy + r) * istride + ipx + c0;
                 // lane 63 owns no pixel: it reads its Scharr samples from the (all-zero) top-left border
@@ -155,13 +164,16 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + od + istride + 4);
                 const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
                 const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
-                bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Ip);
+                uint32_t Ip[4];
+                bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Ip);
                 bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     a11 = sdot2(Ixp[m], Ixp[m], a11);
                     a12 = sdot2(Ixp[m], Iyp[m], a12);
                     a22 = sdot2(Iyp[m], Iyp[m], a22);
+                    c1 = sdot2(Ip[m], Ixp[m], c1);
+                    c2 = sdot2(Ip[m], Iyp[m], c2);
                 }
             }
             float A11, A12, A22, zero_;
@@ -214,9 +226,9 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     __syncthreads();
                     have_tile = true;
                 }
-                lk_weights(nextX - fnx, nextY - fny, iw00, iw01, iw10, iw11);
+                lk_weights(nextX - fnx, nextY - fny, wt, wb);
 
-                int b1 = 0, b2 = 0;
+                int b1 = -c1, b2 = -c2;
                 {
                     const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
                     // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
@@ -224,12 +236,11 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
                     const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
                     uint32_t Jp[4];
-                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, iw00, iw01, iw10, iw11, Jp);
+                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Jp);
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
-                        const uint32_t diff = pk_sub_i16(Jp[m], Ip[m]);
-                        b1 = sdot2(diff, Ixp[m], b1);
-                        b2 = sdot2(diff, Iyp[m], b2);
+                        b1 = sdot2(Jp[m], Ixp[m], b1);
+                        b2 = sdot2(Jp[m], Iyp[m], b2);
                     }
                 }
                 float fb1, fb2;

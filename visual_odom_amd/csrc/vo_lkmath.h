@@ -108,29 +108,28 @@ VO_HD uint32_t pack_w(int w_lo, int w_hi)
 
 // ---- one 7-pixel row segment ----------------------------------------------------------------------
 // t = bytes x..x+7 of the upper image row, b = the same columns one row below.
+// wt = (iw00, iw01), wb = (iw10, iw11) as packed int16 lanes.
 // out[m] = (val[2m], val[2m+1]) as packed int16, out[3].hi = 0;
 // val[k] = DESCALE(t[k]*iw00 + t[k+1]*iw01 + b[k]*iw10 + b[k+1]*iw11, 9).
 // iw00, iw01, iw10 are rounded non-negative products, but iw11 = 2^14 - (their sum) is -1 when the
 // three roundings add up to 2^14 + 1; an unsigned dot product cannot carry a negative weight, so
 // that (rare, wave-uniform) case zeroes the weight and subtracts |iw11| * 256*p11 explicitly.
-VO_HD void bilinear7_u8(uint32_t t_lo, uint32_t t_hi, uint32_t b_lo, uint32_t b_hi, int iw00, int iw01, int iw10,
-                        int iw11, uint32_t out[4])
+VO_HD void bilinear7_u8(uint32_t t_lo, uint32_t t_hi, uint32_t b_lo, uint32_t b_hi, uint32_t wt, uint32_t wb,
+                        uint32_t out[4])
 {
-    const uint32_t wt = pack_w(iw00, iw01);
     uint32_t acc[8];
-    if (iw11 >= 0) {
-        const uint32_t wb = pack_w(iw10, iw11);
+    if (!(wb & 0x80000000u)) {
 #define VO_PIX_STEP(k)                                                                               \
     acc[k] = udot2(perm_b32(b_hi, b_lo, VO_SEL_PIX(k)), wb,                                          \
                    udot2(perm_b32(t_hi, t_lo, VO_SEL_PIX(k)), wt, 1u << 16));
         VO_PIX_STEP(0) VO_PIX_STEP(1) VO_PIX_STEP(2) VO_PIX_STEP(3) VO_PIX_STEP(4) VO_PIX_STEP(5) VO_PIX_STEP(6)
 #undef VO_PIX_STEP
     } else {
-        const uint32_t wb = pack_w(iw10, 0), kneg = (uint32_t)(-iw11);
+        const uint32_t wb0 = wb & 0xffffu, kneg = (uint32_t)(-(int32_t)((int16_t)(wb >> 16)));
 #define VO_PIX_STEP(k)                                                                               \
     {                                                                                                \
         const uint32_t pb = perm_b32(b_hi, b_lo, VO_SEL_PIX(k));                                     \
-        acc[k] = udot2(pb, wb, udot2(perm_b32(t_hi, t_lo, VO_SEL_PIX(k)), wt, 1u << 16)) -           \
+        acc[k] = udot2(pb, wb0, udot2(perm_b32(t_hi, t_lo, VO_SEL_PIX(k)), wt, 1u << 16)) -          \
                  kneg * (pb >> 16);                                                                  \
     }
         VO_PIX_STEP(0) VO_PIX_STEP(1) VO_PIX_STEP(2) VO_PIX_STEP(3) VO_PIX_STEP(4) VO_PIX_STEP(5) VO_PIX_STEP(6)
