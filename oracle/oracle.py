@@ -258,3 +258,45 @@ def integrate_odometry_stereo(pose, R, t):
     t = np.ascontiguousarray(t, np.float64).reshape(3)
     ok = lib().orc_integrate_odometry_stereo(_vp(pose), _vp(R), _vp(t))
     return pose, bool(ok)
+
+
+def five_point(q1, q2):
+    """EMEstimatorCallback::runKernel on 5 normalised correspondences -> (k, 3, 3) essential matrices"""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    Es = np.zeros((10, 9), np.float64)
+    k = lib().orc_five_point(_vp(q1), _vp(q2), _vp(Es))
+    return Es[:k].reshape(k, 3, 3).copy()
+
+
+def find_essential_mat(pts1, pts2, focal, pp, prob=0.999, threshold=1.0):
+    """visualOdometry.cpp:152.  Returns (ok, E, mask, dbg)."""
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    E = np.zeros((3, 3), np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    dbg = np.zeros(3, np.float64)
+    rc = lib().orc_find_essential_mat(_vp(p1), _vp(p2), n, C.c_double(focal), C.c_double(pp[0]), C.c_double(pp[1]),
+                                      C.c_double(prob), C.c_double(threshold), _vp(E), _vp(mask), _vp(dbg))
+    return rc, E, mask[:n].copy(), dbg
+
+
+def decompose_essential_mat(E):
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    R1, R2, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+    lib().orc_decompose_essential_mat(_vp(E), _vp(R1), _vp(R2), _vp(t))
+    return R1, R2, t
+
+
+def recover_pose(E, pts1, pts2, focal, pp, mask=None):
+    """visualOdometry.cpp:153.  Returns (n_good, R, t, mask)."""
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+    good = lib().orc_recover_pose(_vp(E), _vp(p1), _vp(p2), n, C.c_double(focal), C.c_double(pp[0]),
+                                  C.c_double(pp[1]), _vp(R), _vp(t), _vp(m))
+    return good, R, t, m

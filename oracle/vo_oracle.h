@@ -90,6 +90,21 @@ void orc_project_points(const float *xyz, int n, const double *rvec, const doubl
 /* the cv::RNG(0xffffffffffffffff) 5-subset stream RANSAC consumes: idx[iters*5] */
 void orc_ransac_subsets(int count, int iters, int32_t *idx);
 
+/* ---------- visualOdometry.cpp:146-157 : findEssentialMat(RANSAC) + recoverPose ("next" row f4) ---- */
+/* EMEstimatorCallback::runKernel: 5 normalised correspondences q1/q2 [5*2] f64 -> up to 10 row-major
+ * essential matrices in Es [10*9]; returns their number */
+int orc_five_point(const double *q1, const double *q2, double *Es);
+float orc_sampson_error(const double *E, double x1x, double x1y, double x2x, double x2y);
+/* cv::findEssentialMat(points1, points2, focal, pp, RANSAC, prob, threshold, mask): pixel points f32
+ * [n*2]; E [9] row-major; mask (optional, n) 0/1.  Returns 1 when a model was found.
+ * dbg (optional, 3): iterations executed, 10 * iteration + model index of the winner, best inlier count */
+int orc_find_essential_mat(const float *pts1, const float *pts2, int n, double focal, double ppx, double ppy,
+                           double prob, double threshold, double *E, uint8_t *mask, double *dbg);
+void orc_decompose_essential_mat(const double *E, double *R1, double *R2, double *t);
+/* cv::recoverPose(E, points1, points2, R, t, focal, pp, mask); mask in/out (NULL: none). Returns #good */
+int orc_recover_pose(const double *E, const float *pts1, const float *pts2, int n, double focal, double ppx,
+                     double ppy, double *R, double *t, uint8_t *mask);
+
 /* generic one-sided Jacobi SVD (core/lapack.cpp JacobiSVDImpl_<double>), exposed for tests.
  * A is m x n row-major (m >= n).  w[n], u[m*n] (columns = left vectors), vt[n*n]. */
 void orc_svd(const double *A, int m, int n, double *w, double *u, double *vt);

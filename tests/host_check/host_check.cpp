@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../visual_odom_amd/csrc/vo_epnp.h"
+#include "../../visual_odom_amd/csrc/vo_fivept.h"
 #include "../../visual_odom_amd/csrc/vo_linalg.h"
 #include "../../visual_odom_amd/csrc/vo_lkmath.h"
 #include "../../visual_odom_amd/csrc/vo_tri.h"
@@ -20,6 +21,14 @@ void hc_triangulate(const float *Pl, const float *Pr, const float *pl, const flo
 {
     for (int i = 0; i < n; i++)
         vo::triangulate_one(Pl, Pr, pl[2 * i], pl[2 * i + 1], pr[2 * i], pr[2 * i + 1], xyz + 3 * i);
+}
+// five-point essential matrix + pose recovery pieces (vo_fivept.h)
+int hc_five_point(const double *q1, const double *q2, double *Es) { return vo::five_point_solve(q1, q2, Es); }
+float hc_sampson(const double *E, const double *x4) { return vo::em_sampson_error(E, x4[0], x4[1], x4[2], x4[3]); }
+void hc_decompose(const double *E, double *R1, double *R2, double *t) { vo::em_decompose(E, R1, R2, t); }
+int hc_cheirality(const double *P, const double *x4, double dist)
+{
+    return vo::em_cheirality(P, x4[0], x4[1], x4[2], x4[3], dist) ? 1 : 0;
 }
 void hc_solve6(const double *A, const double *b, double *x) { vo::solve_svd<6, 6>(A, b, x); }
 

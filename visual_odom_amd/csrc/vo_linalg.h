@@ -39,7 +39,9 @@ VO_HD double vo_hypot(double a, double b) { return sqrt(fma(a, a, b * b)); }
 // workgroup size for a lane-interleaved LDS array (EPnP's 12 x 12: 288 registers' worth of matrix
 // that would otherwise push the kernel into scratch memory).  Small problems (N <= 6) are fully
 // unrolled so that every access has a compile-time index and the matrices live in registers.
-template <int M, int N, bool WANT_V, int STRIDE = 1>
+// N1 > N (cv::SVD::FULL_UV of a wide matrix): At has N1 rows, and rows N .. N1-1 are completed to an
+// orthonormal basis by the same pseudo-random fill OpenCV uses for zero singular values.
+template <int M, int N, bool WANT_V, int STRIDE = 1, int N1 = N>
 VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
 {
     constexpr int UNR = N <= 6 ? N : 1; // unroll factor of the pair loops (1 = keep rolled)
@@ -178,8 +180,8 @@ VO_HD void jacobi_svd(double *At, double *Wout, double *Vt)
     // pseudo-random vector orthogonalised against the previous ones (cv::RNG(0x12345678) stream)
     uint64_t rng = 0x12345678;
 #pragma unroll UNR
-    for (int i = 0; i < N; i++) {
-        double sd = VO_W(i);
+    for (int i = 0; i < N1; i++) {
+        double sd = i < N ? VO_W(i < N ? i : 0) : 0.;
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
             const double val0 = 1. / M;
             for (int k = 0; k < M; k++) {
