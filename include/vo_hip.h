@@ -49,6 +49,13 @@ typedef struct vo_params {
     int ransac_iterations;
     float ransac_reproj_error;
     double ransac_confidence;
+    /* trackingFrame2Frame(..., bool mono_rotation) (visualOdometry.h:42, .cpp:146-157).  0 (what main.cpp:181
+     * passes): rotation = Rodrigues(rvec) of the PnP solve.  1: rotation comes from
+     * findEssentialMat(points_t0, points_t1, focal, pp, RANSAC, em_prob, em_threshold) + recoverPose on the
+     * left-image tracks; the PnP solve still provides the translation. */
+    int mono_rotation;
+    double em_prob;      /* 0.999 */
+    double em_threshold; /* 1.0 px */
 } vo_params;
 
 void vo_default_params(vo_params *p);
@@ -109,6 +116,15 @@ int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const f
 /* Replaces cv::FAST as called by featureDetectionFast() -- feature.cpp:39-47: TYPE_9_16 corners of an
  * 8-bit image in row-major order.  pts_out [2 * cap]; *n_out = corners found (may exceed cap, in which
  * case only the first cap are written). */
+/* replaces the pair  E = cv::findEssentialMat(pts0, pts1, focal, pp, cv::RANSAC, prob, threshold, mask);
+ *                     cv::recoverPose(E, pts0, pts1, R, t, focal, pp, mask);
+ * of reference src/visualOdometry.cpp:152-153 (pixel coordinates, f32 xy pairs).  E, R: 3x3 row-major f64;
+ * t: unit translation; mask (optional, n bytes): 1 = RANSAC inlier that passes the cheirality check;
+ * *n_good = recoverPose's return value.  Returns VO_OK, 1 when RANSAC found no model (outputs untouched),
+ * VO_ERR_TOO_FEW below 5 points. */
+int vo_essential_pose(vo_ctx *ctx, const float *pts0_xy, const float *pts1_xy, int n, double focal, double ppx,
+                      double ppy, double prob, double threshold, double *E, double *R, double *t, uint8_t *mask,
+                      int *n_good);
 int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
                    float *pts_out, int cap, int *n_out);
 
@@ -196,6 +212,12 @@ int vo_batch_get_filtered(vo_ctx *ctx, int frame, float *l0, float *r0, float *l
                           int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ);
 int vo_batch_get_pose(vo_ctx *ctx, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
                       int *n_inliers, int *status, int32_t *dbg4 /* niters, best, max_good, lm_iters */);
+/* with vo_params.mono_rotation the R of vo_batch_get_pose / vo_track_frame is recoverPose's rotation (left
+ * untouched when no essential matrix was found, where OpenCV throws).  The essential-matrix side of a frame:
+ * E, R (3x3 row-major), t (unit translation), mask (n bytes, 1 = RANSAC inlier passing the cheirality check),
+ * status 1 ok / 0 no model / -1 fewer than 5 points; dbg2 = samples drawn, 10 * sample + model of the winner */
+int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double *t, uint8_t *mask, int n,
+                           int *n_inliers, int *n_good, int *status, int32_t *dbg2);
 /* one pyramid level of one image back to the host (tests): out must hold w_l*h_l bytes */
 int vo_batch_get_pyramid_level(vo_ctx *ctx, int image_idx, int level, uint8_t *out, int *w_l, int *h_l);
 

@@ -515,3 +515,76 @@ def test_cpp_frame_loop_equals_python_mirror(gpu_ctx, vo_run_binary, small_world
     assert np.abs(got - np.asarray(vo.trajectory)).max() < 1e-8
     T0inv = np.linalg.inv(poses[0])
     assert odometry.ate_rmse(got, [(T0inv @ T)[:3] for T in poses]) < 0.05
+
+
+# ------------------------------------------------------------------ f4: mono_rotation (essential matrix + recoverPose)
+def _em_scene(seed, n, outliers):
+    from test_essential_oracle import _scene, rng_rv, rng_t, F, PP
+    R, t, x1, x2, Et, rng = _scene(seed, n=n, rv=rng_rv(seed), t=rng_t(seed))
+    p1 = (x1 * F + PP).astype(np.float32)
+    p2 = (x2 * F + PP).astype(np.float32)
+    k = int(outliers * n)
+    p2[:k] += rng.uniform(-40, 40, (k, 2)).astype(np.float32)
+    p2 += rng.normal(0, 0.1, p2.shape).astype(np.float32)
+    return p1, p2, R, t, F, PP
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,outliers,seed", [(300, 0.0, 1), (2000, 0.3, 2), (60, 0.5, 3), (900, 0.7, 4), (5, 0.0, 5),
+                                             (6, 0.0, 6)])
+def test_essential_pose_dropin(gpu_ctx, orc, n, outliers, seed):
+    p1, p2, R, t, F, PP = _em_scene(seed, n, outliers)
+    found, E, Rg, tg, mask, good = gpu_ctx.essential_pose(p1, p2, F, PP)
+    ok, Eo, mo, dbg = orc.find_essential_mat(p1, p2, F, PP)
+    assert found == bool(ok)
+    if not ok:
+        return
+    assert np.abs(E - Eo).max() <= 1e-9
+    go, Ro, to, m2 = orc.recover_pose(Eo, p1, p2, F, PP, mo)
+    assert good == go and np.array_equal(mask, m2)
+    assert np.abs(Rg - Ro).max() <= 1e-9 and np.abs(tg - to).max() <= 1e-9
+    if n >= 60 and outliers <= 0.5:
+        assert np.abs(Rg - R).max() < 5e-3  # and it is the planted rotation
+
+
+@pytest.mark.gpu
+def test_essential_pose_edge_cases(gpu_ctx, volib, orc):
+    p1, p2, R, t, F, PP = _em_scene(9, 40, 0.0)
+    with pytest.raises(volib.VoError) as e:  # findEssentialMat needs 5 points (OpenCV returns an empty E, recoverPose throws)
+        gpu_ctx.essential_pose(p1[:4], p2[:4], F, PP)
+    assert e.value.code == volib.VO_ERR_TOO_FEW
+    # pure noise: whatever RANSAC does, the device does the same
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0, 1000, (80, 2)).astype(np.float32)
+    b = rng.uniform(0, 1000, (80, 2)).astype(np.float32)
+    found, E, Rg, tg, mask, good = gpu_ctx.essential_pose(a, b, F, PP)
+    ok, Eo, mo, dbg = orc.find_essential_mat(a, b, F, PP)
+    assert found == bool(ok)
+    if ok:
+        go, Ro, to, m2 = orc.recover_pose(Eo, a, b, F, PP, mo)
+        assert np.abs(E - Eo).max() <= 1e-9 and good == go and np.array_equal(mask, m2)
+
+
+@pytest.mark.gpu
+def test_track_frame_mono_rotation(gpu_ctx, orc, kitti_world, kitti_seq):
+    """trackingFrame2Frame(..., mono_rotation = true): rotation from recoverPose, translation from PnP"""
+    s = kitti_seq
+    P_l, P_r = kitti_world.proj_matrices()
+    args = (s["L"][0], s["R"][0], s["L"][1], s["R"][1])
+    base = gpu_ctx.track_frame(*args, s["pts"], P_l, P_r)
+    gpu_ctx.set_params(mono_rotation=1)
+    try:
+        got = gpu_ctx.track_frame(*args, s["pts"], P_l, P_r)
+        em = gpu_ctx.batch_get_essential(0, len(got["l0"]))
+    finally:
+        gpu_ctx.set_params(mono_rotation=0)
+    # the PnP side is unchanged
+    assert np.array_equal(got["rvec"], base["rvec"]) and np.array_equal(got["tvec"], base["tvec"])
+    focal, pp = float(P_l[0, 0]), (float(P_l[0, 2]), float(P_l[1, 2]))
+    ok, Eo, mo, dbg = orc.find_essential_mat(got["l0"], got["l1"], focal, pp)
+    assert ok == 1 and em["status"] == 1
+    go, Ro, to, m2 = orc.recover_pose(Eo, got["l0"], got["l1"], focal, pp, mo)
+    assert np.abs(em["E"] - Eo).max() <= 1e-9 and em["n_good"] == go and np.array_equal(em["mask"], m2)
+    assert np.abs(got["R"] - Ro).max() <= 1e-9 and em["niters"] == int(dbg[0])
+    # and recoverPose's rotation agrees with the PnP rotation of the same motion
+    assert np.abs(got["R"] - base["R"]).max() < 5e-3

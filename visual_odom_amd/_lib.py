@@ -26,7 +26,7 @@ EXPORTS = (
     "vo_batch_configure", "vo_batch_upload_image", "vo_batch_upload_image_dev", "vo_batch_set_quads",
     "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
-    "vo_batch_get_pyramid_level", "vo_model_bytes",
+    "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
 )
 
 
@@ -34,7 +34,8 @@ class VoParams(C.Structure):
     _fields_ = [("lk_max_level", C.c_int), ("lk_max_count", C.c_int), ("lk_epsilon", C.c_double),
                 ("lk_min_eig_threshold", C.c_double), ("lk_full_chain", C.c_int), ("consistency_threshold", C.c_int),
                 ("ransac_iterations", C.c_int), ("ransac_reproj_error", C.c_float),
-                ("ransac_confidence", C.c_double)]
+                ("ransac_confidence", C.c_double), ("mono_rotation", C.c_int), ("em_prob", C.c_double),
+                ("em_threshold", C.c_double)]
 
 
 class VoDetectParams(C.Structure):
@@ -179,6 +180,19 @@ class Context:
         rc = self._chk(self.lib.vo_pnp_ransac(self.h, _p(xyz), _p(uv), n, _p(K), _p(rv), _p(tv), _p(R),
                                               _p(inl), C.byref(ninl)), allow=(1,))
         return rc == VO_OK, rv, tv, R, inl[:ninl.value].copy()
+
+    def essential_pose(self, pts0, pts1, focal, pp, prob=0.999, threshold=1.0):
+        """findEssentialMat(RANSAC) + recoverPose (visualOdometry.cpp:152-153).
+        Returns (found, E, R, t, mask, n_good)."""
+        p0, p1 = _f32(pts0, (-1, 2)), _f32(pts1, (-1, 2))
+        n = p0.shape[0]
+        E, R, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        mask = np.zeros(max(n, 1), np.uint8)
+        good = C.c_int(0)
+        rc = self._chk(self.lib.vo_essential_pose(self.h, _p(p0), _p(p1), n, C.c_double(focal), C.c_double(pp[0]),
+                                                  C.c_double(pp[1]), C.c_double(prob), C.c_double(threshold), _p(E),
+                                                  _p(R), _p(t), _p(mask), C.byref(good)), allow=(1,))
+        return rc == VO_OK, E, R, t, mask[:n].copy(), good.value
 
     def detect_params(self, **kw):
         p = VoDetectParams()
@@ -330,6 +344,16 @@ class Context:
                                              C.byref(status), _p(dbg)))
         return dict(rvec=rv, tvec=tv, R=R, inliers=inl[:ninl.value].copy(), status=status.value,
                     niters=int(dbg[0]), best_iter=int(dbg[1]), max_good=int(dbg[2]), lm_iters=int(dbg[3]))
+
+    def batch_get_essential(self, frame, n):
+        E, R, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ninl, good, status = C.c_int(0), C.c_int(0), C.c_int(0)
+        dbg = np.zeros(2, np.int32)
+        self._chk(self.lib.vo_batch_get_essential(self.h, frame, _p(E), _p(R), _p(t), _p(mask), n, C.byref(ninl),
+                                                  C.byref(good), C.byref(status), _p(dbg)))
+        return dict(E=E, R=R, t=t, mask=mask[:n].copy(), n_inliers=ninl.value, n_good=good.value,
+                    status=status.value, niters=int(dbg[0]), best=int(dbg[1]))
 
     def batch_get_pyramid_level(self, idx, level):
         w, h = C.c_int(0), C.c_int(0)

@@ -58,10 +58,15 @@ struct vo_ctx {
         int *counts = nullptr;
         RansacState *rstate = nullptr;
         PnpResult *results = nullptr;
+        EmResult *em_results = nullptr; // mono_rotation branch (allocated with the rest of `em` on first use)
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         bool pending = false;                        // `done` has been recorded and not waited for
     } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
+    // findEssentialMat + recoverPose working set (vo_params.mono_rotation / vo_essential_pose): one copy, only
+    // ever touched on the pose stream, allocated on first use
+    EmBufs em;
+    bool em_ready = false;
     // detection / bucketing (VO_STAGE_DETECT)
     vo_detect_params dprm;
     int fcap = 0;                  // capacity of the carried + detected feature list of a frame
@@ -156,6 +161,9 @@ void vo_default_params(vo_params *p)
     p->ransac_iterations = 500;
     p->ransac_reproj_error = 0.5f;
     p->ransac_confidence = (double)0.999f; // `float confidence = 0.999` in the reference
+    p->mono_rotation = 0;                  // main.cpp:181 passes false
+    p->em_prob = 0.999;                    // visualOdometry.cpp:152
+    p->em_threshold = 1.0;                 // visualOdometry.cpp:152
 }
 
 void vo_default_detect_params(vo_detect_params *p)
@@ -181,7 +189,8 @@ void vo_destroy(vo_ctx *c)
         if (p)
             (void)hipFree(p);
     for (auto &b : c->pb) {
-        void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results};
+        void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results,
+                     b.em_results};
         for (void *p : q)
             if (p)
                 (void)hipFree(p);
@@ -191,6 +200,13 @@ void vo_destroy(vo_ctx *c)
             (void)hipEventDestroy(b.done);
         if (b.tri_done)
             (void)hipEventDestroy(b.tri_done);
+    }
+    {
+        void *q[] = {c->em.q0, c->em.q1, c->em.subsets, c->em.rstate, c->em.models, c->em.nmodels, c->em.counts,
+                     c->em.bestE, c->em.mask};
+        for (void *p : q)
+            if (p)
+                (void)hipFree(p);
     }
     for (auto &ev : c->ev_trk_free)
         if (ev)
@@ -331,7 +347,8 @@ int vo_set_params(vo_ctx *c, const vo_params *p)
     if (!c || !p)
         return VO_ERR_ARG;
     if (p->lk_max_level < 0 || p->lk_max_level >= VO_MAX_LEVELS || p->ransac_iterations < 1 ||
-        p->ransac_iterations > c->ransac_cap || !(p->ransac_confidence > 0 && p->ransac_confidence < 1))
+        p->ransac_iterations > c->ransac_cap || !(p->ransac_confidence > 0 && p->ransac_confidence < 1) ||
+        (p->mono_rotation && (!(p->em_prob > 0 && p->em_prob < 1) || !(p->em_threshold > 0))))
         return fail(c, VO_ERR_ARG, "vo_set_params: parameter out of range");
     c->prm = *p;
     c->n_images = 0; // pyramid plan depends on lk_max_level: force re-configure
@@ -565,6 +582,32 @@ int vo_batch_set_projection(vo_ctx *c, const float *P_l, const float *P_r)
     return VO_OK;
 }
 
+constexpr int EM_MAX_ITERS = 1000; // maxIters of the findEssentialMat overload the reference calls (OpenCV 4.5)
+
+// working set of the essential-matrix chain, allocated the first time it is asked for
+static int ensure_em(vo_ctx *c)
+{
+    if (c->em_ready)
+        return VO_OK;
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    const size_t B = (size_t)c->max_frames, cap = (size_t)c->cap;
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.q0, sizeof(double2) * B * cap));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.q1, sizeof(double2) * B * cap));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.subsets, sizeof(int32_t) * B * EM_MAX_ITERS * 5));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.rstate, sizeof(RansacState) * B));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.models, sizeof(double) * B * 128 * 90));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.nmodels, sizeof(int) * B * 128));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.counts, sizeof(int) * B * 128 * 10));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.bestE, sizeof(double) * B * 9));
+    VO_HIP_TRY(c, hipMalloc((void **)&c->em.mask, B * cap));
+    for (auto &b : c->pb) {
+        VO_HIP_TRY(c, hipMalloc((void **)&b.em_results, sizeof(EmResult) * B));
+        VO_HIP_TRY(c, hipMemset(b.em_results, 0, sizeof(EmResult) * B));
+    }
+    c->em_ready = true;
+    return VO_OK;
+}
+
 static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr)
 {
     if (!evs)
@@ -702,6 +745,21 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         for (int r = 0; r < 3; r++)
             for (int k = 0; k < 3; k++)
                 pp.K[r * 3 + k] = c->h_P[r * 4 + k];
+        if (c->prm.mono_rotation) {
+            // rotation from the essential matrix of (pointsLeft_t0, pointsLeft_t1) = stage-B rows 0 and 2
+            // (visualOdometry.cpp:146-157); the PnP solve below still provides the translation
+            int rce = ensure_em(c);
+            if (rce != VO_OK)
+                return rce;
+            EmParams ep;
+            ep.focal = (double)c->h_P[0];
+            ep.ppx = (double)c->h_P[2];
+            ep.ppy = (double)c->h_P[6];
+            ep.prob = c->prm.em_prob;
+            ep.threshold = c->prm.em_threshold;
+            ep.max_iters = EM_MAX_ITERS;
+            launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results, ps);
+        }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                    pb.rstate, pb.inliers, pb.results, /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
         if (timed)
@@ -878,8 +936,15 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
             memcpy(rvec, r.rvec, sizeof(r.rvec));
         if (tvec)
             memcpy(tvec, r.tvec, sizeof(r.tvec));
-        if (R)
-            memcpy(R, r.R, sizeof(r.R));
+        if (R && !c->prm.mono_rotation)
+            memcpy(R, r.R, sizeof(r.R)); // `if (!mono_rotation) Rodrigues(rvec, rotation)` (visualOdometry.cpp:186-189)
+    }
+    if (R && c->prm.mono_rotation && c->em_ready) {
+        // rotation = recoverPose's; left untouched when no essential matrix was found (OpenCV throws there)
+        EmResult e;
+        VO_HIP_TRY(c, hipMemcpy(&e, pb.em_results + frame, sizeof(e), hipMemcpyDeviceToHost));
+        if (e.status == 1)
+            memcpy(R, e.R, sizeof(e.R));
     }
     if (inliers && r.n_inliers > 0) {
         D2H(inliers, pb.inliers + (size_t)frame * c->cap, sizeof(int32_t) * r.n_inliers);
@@ -896,6 +961,85 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
         dbg4[3] = r.lm_iters;
     }
     return VO_OK;
+}
+
+int vo_batch_get_essential(vo_ctx *c, int frame, double *E, double *R, double *t, uint8_t *mask, int n,
+                           int *n_inliers, int *n_good, int *status, int32_t *dbg2)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (frame < 0 || frame >= c->n_frames || n < 0 || n > c->cap)
+        return fail(c, VO_ERR_ARG, "vo_batch_get_essential: bad frame / n");
+    if (!c->em_ready)
+        return fail(c, VO_ERR_STATE, "vo_batch_get_essential: no run with vo_params.mono_rotation yet");
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    EmResult e;
+    VO_HIP_TRY(c, hipMemcpy(&e, c->pb[c->last].em_results + frame, sizeof(e), hipMemcpyDeviceToHost));
+    if (e.status == 1) {
+        if (E)
+            memcpy(E, e.E, sizeof(e.E));
+        if (R)
+            memcpy(R, e.R, sizeof(e.R));
+        if (t)
+            memcpy(t, e.t, sizeof(e.t));
+        if (mask && n > 0)
+            VO_HIP_TRY(c, hipMemcpy(mask, c->em.mask + (size_t)frame * c->cap, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    if (n_inliers)
+        *n_inliers = e.n_inliers;
+    if (n_good)
+        *n_good = e.n_good;
+    if (status)
+        *status = e.status;
+    if (dbg2) {
+        dbg2[0] = e.niters;
+        dbg2[1] = e.best;
+    }
+    return VO_OK;
+}
+
+int vo_essential_pose(vo_ctx *c, const float *pts0, const float *pts1, int n, double focal, double ppx, double ppy,
+                      double prob, double threshold, double *E, double *R, double *t, uint8_t *mask, int *n_good)
+{
+    if (!c || n < 0 || (n > 0 && (!pts0 || !pts1)) || !(prob > 0 && prob < 1) || !(threshold > 0) || !(focal != 0))
+        return VO_ERR_ARG;
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    rcs = ensure_em(c);
+    if (rcs != VO_OK)
+        return rcs;
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    const size_t cap = (size_t)c->cap;
+    if (n > 0) {
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.outB, pts0, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + 2 * cap, pts1, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (c->n_frames < 1)
+        c->n_frames = 1;
+    EmParams ep;
+    ep.focal = focal;
+    ep.ppx = ppx;
+    ep.ppy = ppy;
+    ep.prob = prob;
+    ep.threshold = threshold;
+    ep.max_iters = EM_MAX_ITERS;
+    launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    int status = 0, good = 0;
+    int rc = vo_batch_get_essential(c, 0, E, R, t, mask, n, nullptr, &good, &status, nullptr);
+    if (rc != VO_OK)
+        return rc;
+    if (n_good)
+        *n_good = good;
+    if (status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached findEssentialMat");
+    return status == 1 ? VO_OK : 1;
 }
 
 int vo_batch_get_pyramid_level(vo_ctx *c, int idx, int level, uint8_t *out, int *w_l, int *h_l)

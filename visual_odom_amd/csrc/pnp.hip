@@ -479,6 +479,13 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
     }
 }
 
+void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
+                           RansacState *rstate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, iters,
+                       chunk, subsets, rstate);
+}
+
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, bool crowded, hipStream_t stream)

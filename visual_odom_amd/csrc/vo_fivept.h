@@ -97,7 +97,8 @@ VO_HD bool em_lu_solve(double *A, double *b)
 }
 
 // cv::solvePoly on real ascending coefficients c[0..10]; roots (re, im)[10].  The branch for iterates that
-// coincide bit for bit only skips the zero factor (see oracle/orc_essential.c header).
+// coincide bit for bit only skips the zero factor; OpenCV additionally takes a root of the correction there
+// (unreachable from the distinct starting points in practice).
 VO_HD void em_solve_poly10(const double *c0, double *re, double *im)
 {
     int n = 10;

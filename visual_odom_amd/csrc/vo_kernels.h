@@ -41,7 +41,35 @@ struct RansacState {
     uint64_t rng;  // cv::RNG state after the subsets drawn so far
 };
 
+// findEssentialMat(points0, points1, focal, pp, RANSAC, prob, threshold) + recoverPose (visualOdometry.cpp:152-153)
+struct EmParams {
+    double focal, ppx, ppy; // projMatrl(0,0), (0,2), (1,2) as doubles (visualOdometry.cpp:146-147)
+    double prob;            // 0.999
+    double threshold;       // 1.0 pixel
+    int max_iters;          // 1000 (OpenCV 4.5 default of this overload)
+};
+
+struct EmResult {
+    double E[9], R[9], t[3]; // essential matrix, recoverPose rotation / unit translation
+    int status;              // 1 ok, 0 RANSAC found no model, -1 fewer than 5 points
+    int n_inliers;           // RANSAC inliers of E
+    int n_good;              // points passing the cheirality check (recoverPose's return value)
+    int niters;              // samples OpenCV would have drawn
+    int best;                // 10 * sample + model index of the winner
+};
+
 #ifndef VO_HOST_EMUL
+struct EmBufs {
+    double2 *q0 = nullptr, *q1 = nullptr; // [B][cap] normalised points
+    int32_t *subsets = nullptr;           // [B][max_iters][5]
+    RansacState *rstate = nullptr;        // [B]
+    double *models = nullptr;             // [B][128][10][9]
+    int *nmodels = nullptr;               // [B][128]
+    int *counts = nullptr;                // [B][128][10]
+    double *bestE = nullptr;              // [B][9]
+    uint8_t *mask = nullptr;              // [B][cap]
+};
+
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream);
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
 void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, int w0, int h0, hipStream_t stream);
@@ -62,6 +90,10 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, bool crowded, hipStream_t stream);
+void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
+                           RansacState *rstate, hipStream_t stream);
+void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
+                      const EmParams &prm, const EmBufs &eb, EmResult *results, hipStream_t stream);
 
 #endif // VO_HOST_EMUL
 
