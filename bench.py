@@ -71,6 +71,9 @@ def main():
                     help="full = BASELINE config 3 (LK+tri+PnP on device); lk = config 2 (circularMatching only); "
                          "detect+full = additionally FAST + bucketing on the device produce the LK input points "
                          "(SURVEY.md 8 row f1) instead of points resident in HBM")
+    ap.add_argument("--mono-rotation", action="store_true",
+                    help="also run findEssentialMat + recoverPose per frame (trackingFrame2Frame's mono_rotation = true; "
+                         "the reference's main loop passes false)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     args = ap.parse_args()
@@ -92,7 +95,7 @@ def main():
     w, h = world.w, world.h
     n_pts = [len(p) for p in pts]
     ctx = _lib.Context(local_dev, w, h, 8192, B)
-    ctx.set_params(lk_max_level=max_level)
+    ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
     # table pair j shows rendered pair tri(j): the S + 1 rendered pairs are walked forwards then
     # backwards, so consecutive table pairs are always consecutive rendered frames (real motion)
     def tri(j):
@@ -165,7 +168,7 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world_size, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload][4], "stages": args.stages,
+            "config": {"workload": WORKLOADS[args.workload][4], "stages": args.stages + ("+mono_rotation" if args.mono_rotation else ""),
                        "frames_per_step_per_gpu": B, "pyramids_per_step_per_gpu": n_images,
                        "points_per_frame": float(np.mean([len(p) for p in frame_pts])),
                        "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,

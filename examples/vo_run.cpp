@@ -58,7 +58,7 @@ static std::string frame_path(const std::string &dir, int cam, int id)
 int main(int argc, char **argv)
 {
     if (argc < 8) {
-        fprintf(stderr, "usage: %s <sequence_dir> <fx> <cx> <cy> <bf> <n_frames> <poses_out> [features_per_bucket]\n", argv[0]);
+        fprintf(stderr, "usage: %s <sequence_dir> <fx> <cx> <cy> <bf> <n_frames> <poses_out> [features_per_bucket [mono_rotation]]\n", argv[0]);
         return 1;
     }
     const std::string dir = argv[1];
@@ -84,6 +84,12 @@ int main(int argc, char **argv)
     vo_default_detect_params(&dp);
     if (argc > 8)
         dp.features_per_bucket = atoi(argv[8]);
+    if (argc > 9 && atoi(argv[9]) != 0) { // trackingFrame2Frame(..., mono_rotation = true): rotation from recoverPose
+        vo_params prm;
+        CHECK(vo_get_params(ctx, &prm));
+        prm.mono_rotation = 1;
+        CHECK(vo_set_params(ctx, &prm));
+    }
 
     // main.cpp:81-94
     std::vector<float> points((size_t)2 * cap);  // currentVOFeatures.points

@@ -588,3 +588,49 @@ def test_track_frame_mono_rotation(gpu_ctx, orc, kitti_world, kitti_seq):
     assert np.abs(got["R"] - Ro).max() <= 1e-9 and em["niters"] == int(dbg[0])
     # and recoverPose's rotation agrees with the PnP rotation of the same motion
     assert np.abs(got["R"] - base["R"]).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_sequence_trajectory_mono_rotation(gpu_ctx, orc, small_world):
+    """the frame loop with trackingFrame2Frame(..., mono_rotation = true): per-frame rotation = recoverPose's
+    (checker chain on the same tracks), translation = PnP's, and the integrated trajectory still follows
+    the planted path"""
+    from visual_odom_amd import odometry
+    n = 5
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    K = small_world.K()
+    h, w = L[0].shape
+    focal, pp = float(P_l[0, 0]), (float(P_l[0, 2]), float(P_l[1, 2]))
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, mono_rotation=True, features_per_bucket=3)
+    try:
+        o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
+        o_pose, o_t = np.eye(4), np.zeros(3)
+        vo.process(L[0], R[0])
+        for k in range(1, n):
+            rec = vo.process(L[k], R[k])
+            l0, r0, l1, r1 = L[k - 1], R[k - 1], L[k], R[k]
+            if len(o_pts) < 2000:
+                fast = orc.fast_detect(l0, 20, True)
+                o_pts = np.vstack([o_pts, fast])
+                o_ages = np.concatenate([o_ages, np.zeros(len(fast), np.int32)])
+            bp, ba = orc.bucketing_features(h, w, o_pts, o_ages, h // 10, 3)
+            cm = orc.circular_matching(l0, r0, l1, r1, bp, ages=ba)
+            (pl0, pr0, pl1, pr1), _ = orc.check_valid_and_remove(cm["l0"], cm["r0"], cm["l1"], cm["r1"], cm["l0_ret"])
+            o_pts, o_ages = pl1, cm["ages"]
+            ok, E, mask, _ = orc.find_essential_mat(pl0, pl1, focal, pp)
+            assert ok == 1
+            _, Rm, _, _ = orc.recover_pose(E, pl0, pl1, focal, pp, mask)
+            xyz = orc.triangulate(P_l, P_r, pl0, pr0)
+            rc, rv, tv, inl, _ = orc.solve_pnp_ransac(xyz, pl1, K, tvec=o_t)
+            o_t = tv
+            e = orc.rotation_matrix_to_euler(Rm)
+            if abs(e[1]) < 0.1 and abs(e[0]) < 0.1 and abs(e[2]) < 0.1:
+                o_pose, _ = orc.integrate_odometry_stereo(o_pose, Rm, tv)
+            assert np.abs(vo.rotation - Rm).max() <= 1e-9
+            assert np.abs(rec["tvec"] - tv).max() <= 1e-6 and np.abs(vo.frame_pose - o_pose).max() <= 1e-6
+    finally:
+        gpu_ctx.set_params(mono_rotation=0)
+    T0inv = np.linalg.inv(poses[0])
+    gt = [(T0inv @ T)[:3] for T in poses]
+    assert odometry.ate_rmse(vo.trajectory, gt) < 0.05

@@ -758,7 +758,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             ep.prob = c->prm.em_prob;
             ep.threshold = c->prm.em_threshold;
             ep.max_iters = EM_MAX_ITERS;
-            launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results, ps);
+            launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
+                             /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
         }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                    pb.rstate, pb.inliers, pb.results, /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
@@ -1029,7 +1030,8 @@ int vo_essential_pose(vo_ctx *c, const float *pts0, const float *pts1, int n, do
     ep.prob = prob;
     ep.threshold = threshold;
     ep.max_iters = EM_MAX_ITERS;
-    launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results, c->stream);
+    launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results, /*crowded*/ false,
+                     c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     int status = 0, good = 0;
     int rc = vo_batch_get_essential(c, 0, E, R, t, mask, n, nullptr, &good, &status, nullptr);

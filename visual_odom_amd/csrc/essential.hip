@@ -40,7 +40,10 @@ __global__ void em_normalise_kernel(const float2 *__restrict__ p0, const float2 
     q1[(size_t)frame * cap + i] = make_double2((double)b.x * ax + bx, (double)b.y * ax + by);
 }
 
-__global__ __launch_bounds__(64) void em_solve_kernel(const double2 *__restrict__ q0, const double2 *__restrict__ q1,
+// WAVES: minimum waves per SIMD = register budget, as for the PnP kernels (pnp.hip): 1 = all 512 registers for
+// the stand-alone calls, 4 = 128 registers so that the wave fits next to the LK waves of a crowded batch
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void em_solve_kernel(const double2 *__restrict__ q0, const double2 *__restrict__ q1,
                                                       const int *__restrict__ n_pts, int cap, int iters, int chunk,
                                                       const int32_t *__restrict__ subsets,
                                                       const RansacState *__restrict__ rstate,
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void em_finish_kernel(const double2 *__restric
 }
 
 void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
-                      const EmParams &prm, const EmBufs &eb, EmResult *results, hipStream_t stream)
+                      const EmParams &prm, const EmBufs &eb, EmResult *results, bool crowded, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
@@ -268,8 +271,12 @@ void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const i
     const int n_chunks = (iters + EM_CHUNK - 1) / EM_CHUNK;
     for (int chunk = 0; chunk < n_chunks; chunk++) {
         launch_ransac_subsets(n_pts, n_frames, iters, chunk, eb.subsets, eb.rstate, stream);
-        hipLaunchKernelGGL(em_solve_kernel, dim3(EM_CHUNK / 64, n_frames), dim3(64), 0, stream, eb.q0, eb.q1, n_pts,
-                           cap, iters, chunk, eb.subsets, eb.rstate, eb.models, eb.nmodels);
+        if (crowded)
+            hipLaunchKernelGGL(em_solve_kernel<4>, dim3(EM_CHUNK / 64, n_frames), dim3(64), 0, stream, eb.q0, eb.q1,
+                               n_pts, cap, iters, chunk, eb.subsets, eb.rstate, eb.models, eb.nmodels);
+        else
+            hipLaunchKernelGGL(em_solve_kernel<1>, dim3(EM_CHUNK / 64, n_frames), dim3(64), 0, stream, eb.q0, eb.q1,
+                               n_pts, cap, iters, chunk, eb.subsets, eb.rstate, eb.models, eb.nmodels);
         hipLaunchKernelGGL(em_vote_kernel, dim3(EM_CHUNK * EM_MAX_MODELS, n_frames), dim3(64), 0, stream, eb.q0, eb.q1,
                            n_pts, cap, iters, chunk, thr2, eb.rstate, eb.models, eb.nmodels, eb.counts);
         hipLaunchKernelGGL(em_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, iters,

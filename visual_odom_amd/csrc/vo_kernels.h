@@ -93,7 +93,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
                            RansacState *rstate, hipStream_t stream);
 void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
-                      const EmParams &prm, const EmBufs &eb, EmResult *results, hipStream_t stream);
+                      const EmParams &prm, const EmBufs &eb, EmResult *results, bool crowded, hipStream_t stream);
 
 #endif // VO_HOST_EMUL
 

@@ -24,13 +24,16 @@ class StereoOdometry:
     (vo_detect_bucket + vo_track_frame: four uploads and four pyramids per frame).  Same results."""
 
     def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=True,
-                 **detect_kw):
+                 mono_rotation=False, **detect_kw):
         self.P_l = np.ascontiguousarray(P_l, np.float32).reshape(3, 4)
         self.P_r = np.ascontiguousarray(P_r, np.float32).reshape(3, 4)
         self.ctx = ctx if ctx is not None else _lib.Context(device, max_w, max_h, max_pts, 1)
         self._own = ctx is None
         self.detect_kw = detect_kw
         self.streaming = streaming
+        # trackingFrame2Frame's `mono_rotation` (visualOdometry.h:42; main.cpp:181 passes false)
+        self.mono_rotation = bool(mono_rotation)
+        self.ctx.set_params(mono_rotation=int(self.mono_rotation))
         self._n_pairs = 0
         # main.cpp:81-94
         self.points = np.zeros((0, 2), np.float32)   # currentVOFeatures.points
@@ -71,6 +74,8 @@ class StereoOdometry:
                    rvec=out["rvec"].copy(), tvec=out["tvec"].copy(), integrated=False)
         if out["rc"] == _lib.VO_ERR_TOO_FEW:
             raise _lib.VoError(out["rc"], "fewer than 5 correspondences reached solvePnPRansac (the reference asserts here)")
+        if self.mono_rotation and self.ctx.batch_get_essential(0, 0)["status"] != 1:
+            raise _lib.VoError(1, "findEssentialMat found no model (the reference's recoverPose throws on the empty E)")
         self.rotation, self.translation = out["R"], out["tvec"]
         self.frame_pose, rec["integrated"], rec["euler"] = _lib.integrate_odometry(self.frame_pose, self.rotation,
                                                                                    self.translation)
