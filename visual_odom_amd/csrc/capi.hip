@@ -60,6 +60,7 @@ struct vo_ctx {
         PnpResult *results = nullptr;
         EmResult *em_results = nullptr; // mono_rotation branch (allocated with the rest of `em` on first use)
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
+        hipEvent_t em_done = nullptr; // essential-matrix chain done (mono_rotation)
         bool pending = false;                        // `done` has been recorded and not waited for
     } pb[2];
     int cur = 0, last = 0; // set the next run writes / set the last run wrote
@@ -78,6 +79,7 @@ struct vo_ctx {
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
     hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
+    hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
@@ -200,6 +202,8 @@ void vo_destroy(vo_ctx *c)
             (void)hipEventDestroy(b.done);
         if (b.tri_done)
             (void)hipEventDestroy(b.tri_done);
+        if (b.em_done)
+            (void)hipEventDestroy(b.em_done);
     }
     {
         void *q[] = {c->em.q0, c->em.q1, c->em.subsets, c->em.rstate, c->em.models, c->em.nmodels, c->em.counts,
@@ -215,6 +219,8 @@ void vo_destroy(vo_ctx *c)
         (void)hipStreamDestroy(c->stream_pnp);
     if (c->stream_filter)
         (void)hipStreamDestroy(c->stream_filter);
+    if (c->stream_em)
+        (void)hipStreamDestroy(c->stream_em);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev)
@@ -256,6 +262,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_em, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     for (auto &ev : c->ev_trk_free)
         ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -311,6 +318,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.tri_done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.em_done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
     }
     vo_default_detect_params(&c->dprm);
@@ -758,11 +766,18 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             ep.prob = c->prm.em_prob;
             ep.threshold = c->prm.em_threshold;
             ep.max_iters = EM_MAX_ITERS;
+            // its own stream: the two chains only share their inputs, and together they would outlast the LK
+            // launch they hide behind
+            hipStream_t es = c->serial_pose ? c->stream : c->stream_em;
+            VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
             launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
-                             /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
+                             /*crowded*/ (long long)B * c->max_pts_set >= 65536, es);
+            VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                    pb.rstate, pb.inliers, pb.results, /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
+        if (c->prm.mono_rotation)
+            VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
         VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
@@ -785,6 +800,7 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
     return VO_OK;
 }
 

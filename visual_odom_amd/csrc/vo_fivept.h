@@ -96,59 +96,89 @@ VO_HD bool em_lu_solve(double *A, double *b)
     return true;
 }
 
-// cv::solvePoly on real ascending coefficients c[0..10]; roots (re, im)[10].  The branch for iterates that
-// coincide bit for bit only skips the zero factor; OpenCV additionally takes a root of the correction there
-// (unreachable from the distinct starting points in practice).
-VO_HD void em_solve_poly10(const double *c0, double *re, double *im)
+// One Durand-Kerner sweep of cv::solvePoly over the N current root estimates (updated in place, each update
+// already sees the roots updated before it).  With a compile-time N every array index is static after
+// unrolling, so the 2 N root components and the coefficients stay in registers; returns maxDiff.
+template <int N>
+VO_HD double em_dk_sweep(const double *c0, double *re, double *im)
 {
-    int n = 10;
-    for (; n > 1; n--)
-        if (fabs(c0[n]) > DBL_EPSILON)
-            break;
+    double maxDiff = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double pr = re[i], pi = im[i];
+        double nr = c0[N], ni = 0, dr = c0[N], di = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double tr = nr * pr - ni * pi, ti = nr * pi + ni * pr; // num = num * p + coeffs[n - j - 1]
+            nr = tr + c0[N - j - 1];
+            ni = ti + 0.0;
+            if (j != i) {
+                const double qr = pr - re[j], qi = pi - im[j];
+                if (qr != 0 || qi != 0) {
+                    tr = dr * qr - di * qi;
+                    ti = dr * qi + di * qr;
+                    dr = tr;
+                    di = ti;
+                }
+            }
+        }
+        const double t = 1. / (dr * dr + di * di); // num /= denom (cv::Complex operator /)
+        const double xr = (nr * dr + ni * di) * t, xi = (-nr * di + ni * dr) * t;
+        re[i] = pr - xr;
+        im[i] = pi - xi;
+        const double a = sqrt(xr * xr + xi * xi);
+        maxDiff = maxDiff > a ? maxDiff : a;
+    }
+    return maxDiff;
+}
+
+template <int N>
+VO_HD void em_dk_run(const double *c0, double *re, double *im)
+{
     double pr = 1, pi = 0;
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         re[i] = pr;
         im[i] = pi;
         const double tr = pr * 1 - pi * 1, ti = pr * 1 + pi * 1; // p *= (1, 1)
         pr = tr;
         pi = ti;
     }
-    for (int iter = 0; iter < 300; iter++) {
-        double maxDiff = 0;
-        for (int i = 0; i < n; i++) {
-            pr = re[i];
-            pi = im[i];
-            double nr = c0[n], ni = 0, dr = c0[n], di = 0;
-            for (int j = 0; j < n; j++) {
-                double tr = nr * pr - ni * pi, ti = nr * pi + ni * pr;
-                nr = tr + c0[n - j - 1];
-                ni = ti + 0.0;
-                if (j != i) {
-                    const double qr = pr - re[j], qi = pi - im[j];
-                    if (qr != 0 || qi != 0) {
-                        tr = dr * qr - di * qi;
-                        ti = dr * qi + di * qr;
-                        dr = tr;
-                        di = ti;
-                    }
-                }
-            }
-            const double t = 1. / (dr * dr + di * di);
-            const double xr = (nr * dr + ni * di) * t, xi = (-nr * di + ni * dr) * t;
-            re[i] = pr - xr;
-            im[i] = pi - xi;
-            const double a = sqrt(xr * xr + xi * xi);
-            maxDiff = maxDiff > a ? maxDiff : a;
-        }
-        if (maxDiff <= 0)
+    for (int iter = 0; iter < 300; iter++)
+        if (em_dk_sweep<N>(c0, re, im) <= 0)
             break;
-    }
-    for (int i = 0; i < n; i++)
+#pragma unroll
+    for (int i = 0; i < N; i++)
         if (fabs(im[i]) < 1e-100)
             im[i] = 0;
-    for (int i = n; i < 10; i++) {
+#pragma unroll
+    for (int i = N; i < 10; i++) { // for( ; n < n0; n++ ) roots[n+1] = roots[n]
         re[i] = re[i - 1];
         im[i] = im[i - 1];
+    }
+}
+
+// cv::solvePoly on real ascending coefficients c[0..10] (maxIters = 300): Durand-Kerner from the powers of
+// 1 + i; roots (re, im)[10].  Leading coefficients below DBL_EPSILON lower the degree first, like OpenCV.  The
+// branch for iterates that coincide bit for bit only skips the zero factor; OpenCV additionally takes a root of
+// the correction there (unreachable from the distinct starting points in practice).
+VO_HD void em_solve_poly10(const double *c0, double *re, double *im)
+{
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(c0[n]) > DBL_EPSILON)
+            break;
+    switch (n) {
+    case 10: em_dk_run<10>(c0, re, im); break;
+    case 9: em_dk_run<9>(c0, re, im); break;
+    case 8: em_dk_run<8>(c0, re, im); break;
+    case 7: em_dk_run<7>(c0, re, im); break;
+    case 6: em_dk_run<6>(c0, re, im); break;
+    case 5: em_dk_run<5>(c0, re, im); break;
+    case 4: em_dk_run<4>(c0, re, im); break;
+    case 3: em_dk_run<3>(c0, re, im); break;
+    case 2: em_dk_run<2>(c0, re, im); break;
+    default: em_dk_run<1>(c0, re, im); break;
     }
 }
 
