@@ -45,6 +45,12 @@ struct vo_ctx {
     hipEvent_t ev_trk_free[2] = {}; // recorded after the filter has read that set (and d_pts)
     bool trk_busy[2] = {};
     int trk_next = 0, trk_last = 0; // set the next LK writes / set the latest LK wrote
+    // The bucketed feature set VO_STAGE_DETECT produces belongs to the same set as the tracks made from it, so
+    // DETECT of run k + 1 never waits for the filter of run k either.  pts_sel = -1: the current features are
+    // the host-set ones (d_pts / d_npts / d_ages, vo_batch_set_points); else the DETECT output of that set.
+    float2 *d_pts_det[2] = {};
+    int *d_npts_det[2] = {}, *d_ages_det[2] = {};
+    int pts_sel = -1;
     int *d_npts = nullptr, *d_nA = nullptr, *d_idxA = nullptr;
     float *d_P = nullptr; // d_P: P_l (12) then P_r (12)
     // Everything the pose solve reads or writes exists twice: the PnP/RANSAC chain of batch k runs on
@@ -113,6 +119,10 @@ int fail(vo_ctx *ctx, int code, const char *msg)
 }
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+// the current feature set (see vo_ctx::pts_sel)
+inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
+inline int *cur_npts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_npts : c->d_npts_det[c->pts_sel]; }
+inline int *cur_ages(vo_ctx *c) { return c->pts_sel < 0 ? c->d_ages : c->d_ages_det[c->pts_sel]; }
 // row pitch (pixels) of a bordered level: VO_BX left + w + at least VO_BY right, multiple of 16
 inline int level_stride(int w) { return align_up(VO_BX + w + VO_BY, 16); }
 
@@ -186,7 +196,8 @@ void vo_destroy(vo_ctx *c)
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
                     c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_rowcnt, c->d_detect,
-                    c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages};
+                    c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages, c->d_pts_det[0], c->d_pts_det[1],
+                    c->d_npts_det[0], c->d_npts_det[1], c->d_ages_det[0], c->d_ages_det[1]};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -331,6 +342,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_feat, B * (size_t)c->fcap) == hipSuccess;
     ok = ok && dmalloc(&c->d_fages, B * (size_t)c->fcap) == hipSuccess;
     ok = ok && dmalloc(&c->d_ages, B * cap) == hipSuccess;
+    for (int k = 0; k < 2; k++) {
+        ok = ok && dmalloc(&c->d_pts_det[k], B * cap) == hipSuccess;
+        ok = ok && dmalloc(&c->d_npts_det[k], B) == hipSuccess;
+        ok = ok && dmalloc(&c->d_ages_det[k], B * cap) == hipSuccess;
+        ok = ok && hipMemset(c->d_npts_det[k], 0, B * sizeof(int)) == hipSuccess;
+    }
     if (ok) {
         ok = hipMemset(c->d_npts, 0, B * sizeof(int)) == hipSuccess &&
              hipMemset(c->d_nA, 0, B * sizeof(int)) == hipSuccess &&
@@ -416,6 +433,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     std::fill(c->h_ntracked.begin(), c->h_ntracked.end(), 0);
     c->detect_uploaded = false; // the per-frame detect flags on the device belong to the previous batch shape
     VO_HIP_TRY(c, hipMemsetAsync(c->d_npts, 0, sizeof(int) * c->max_frames, c->stream));
+    c->pts_sel = -1;
     VO_HIP_TRY(c, hipMemsetAsync(c->d_ntracked, 0, sizeof(int) * c->max_frames, c->stream));
     VO_HIP_TRY(c, hipMemsetAsync(c->d_fages, 0, sizeof(int) * (size_t)c->max_frames * c->fcap, c->stream));
     return VO_OK;
@@ -501,6 +519,16 @@ int vo_batch_set_points(vo_ctx *c, int frame, const float *pts, int n)
     int rcs = sync_all(c); // a queued filter of the previous run still reads the points
     if (rcs != VO_OK)
         return rcs;
+    if (c->pts_sel >= 0) { // the other frames keep what the last DETECT stage gave them
+        const size_t B = (size_t)c->max_frames, cap = (size_t)c->cap;
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts, cur_pts(c), sizeof(float2) * B * cap, hipMemcpyDeviceToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_ages, cur_ages(c), sizeof(int) * B * cap, hipMemcpyDeviceToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_npts, cur_npts(c), sizeof(int) * B, hipMemcpyDeviceToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(c->h_npts.data(), c->d_npts, sizeof(int) * c->n_frames, hipMemcpyDeviceToHost,
+                                     c->stream));
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->pts_sel = -1;
+    }
     if (n > 0)
         VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts + (size_t)frame * c->cap, pts, sizeof(float2) * n,
                                      hipMemcpyHostToDevice, c->stream));
@@ -564,13 +592,13 @@ int vo_batch_get_features(vo_ctx *c, int frame, float *pts, int32_t *ages, int *
         return fail(c, VO_ERR_ARG, "vo_batch_get_features: bad frame");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     int k = 0;
-    VO_HIP_TRY(c, hipMemcpyAsync(&k, c->d_npts + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(&k, cur_npts(c) + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (pts && k > 0)
-        VO_HIP_TRY(c, hipMemcpyAsync(pts, c->d_pts + (size_t)frame * c->cap, sizeof(float2) * k, hipMemcpyDeviceToHost,
+        VO_HIP_TRY(c, hipMemcpyAsync(pts, cur_pts(c) + (size_t)frame * c->cap, sizeof(float2) * k, hipMemcpyDeviceToHost,
                                      c->stream));
     if (ages && k > 0)
-        VO_HIP_TRY(c, hipMemcpyAsync(ages, c->d_ages + (size_t)frame * c->cap, sizeof(int) * k, hipMemcpyDeviceToHost,
+        VO_HIP_TRY(c, hipMemcpyAsync(ages, cur_ages(c) + (size_t)frame * c->cap, sizeof(int) * k, hipMemcpyDeviceToHost,
                                      c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n = k;
@@ -647,14 +675,13 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
-    // DETECT rewrites d_pts, which every filter still in flight reads; LK only rewrites its own track set,
-    // which the filter of two runs ago read
-    const int wset = (stages & VO_STAGE_LK) ? c->trk_next : c->trk_last;
-    for (int k = 0; k < 2; k++)
-        if (c->trk_busy[k] && ((stages & VO_STAGE_DETECT) || ((stages & VO_STAGE_LK) && k == wset))) {
-            VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_trk_free[k], 0));
-            c->trk_busy[k] = false;
-        }
+    // DETECT and LK write the set of buffers (bucketed features / tracks + status) that the filter of two runs
+    // ago read; the filter of the previous run reads the other set
+    const int wset = (stages & (VO_STAGE_DETECT | VO_STAGE_LK)) ? c->trk_next : c->trk_last;
+    if ((stages & (VO_STAGE_DETECT | VO_STAGE_LK)) && c->trk_busy[wset]) {
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_trk_free[wset], 0));
+        c->trk_busy[wset] = false;
+    }
     if (stages & VO_STAGE_DETECT) {
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
@@ -677,8 +704,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
         launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
-                             c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb, c->d_pts,
-                             c->d_ages, c->d_npts, cap, c->stream);
+                             c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
+                             c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, c->stream);
+        c->pts_sel = wset;
         // the bucketed count is only known on the device; every later grid is sized by its bound
         const int bound = cells * fpb < cap ? cells * fpb : cap;
         c->max_pts_set = bound;
@@ -697,7 +725,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        launch_lk_circular(c->d_imgs, c->d_quads, c->d_pts, c->d_npts, cap, c->max_pts_set, B, c->d_trk2[wset],
+        launch_lk_circular(c->d_imgs, c->d_quads, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
                            c->d_status2[wset], lp, c->stream);
         c->trk_last = wset;
         c->trk_next = wset ^ 1;
@@ -728,7 +756,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[4]
     e++;
     if (stages & VO_STAGE_FILTER) {
-        launch_compact(c->d_pts, c->d_trk2[c->trk_last], c->d_status2[c->trk_last], c->d_npts, cap,
+        launch_compact(cur_pts(c), c->d_trk2[c->trk_last], c->d_status2[c->trk_last], cur_npts(c), cap,
                        c->prm.consistency_threshold, c->d_outA, c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
         VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->trk_last], fs));
         c->trk_busy[c->trk_last] = true;
@@ -1308,7 +1336,7 @@ int vo_detect_bucket(vo_ctx *c, const uint8_t *img, int w, int h, int stride, co
         rc = run_stages(c, VO_STAGE_DETECT, false);
     int k = 0;
     if (rc == VO_OK) {
-        VO_HIP_TRY(c, hipMemcpyAsync(&k, c->d_npts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(&k, cur_npts(c), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (k > cap) {
             c->dprm = saved;
