@@ -39,6 +39,12 @@ cat "$OUT/bench_kitti374.json"
 stamp "bench (FAST + bucketing on the device feed LK)"
 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages detect+full > "$OUT/bench_detect.json" 2> "$OUT/bench_detect.err"
 cat "$OUT/bench_detect.json"
+stamp "bench (mono_rotation: essential matrix + recoverPose next to the PnP solve)"
+timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --mono-rotation > "$OUT/bench_mono.json" 2> "$OUT/bench_mono.err"
+cat "$OUT/bench_mono.json"
+stamp "bench (1920x1080, 4000 points per frame)"
+timeout 400 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload hd4000 --frames 16 > "$OUT/bench_hd4000.json" 2> "$OUT/bench_hd4000.err"
+cat "$OUT/bench_hd4000.json"
 stamp "bench (pose solve serialised on the tracking stream)"
 VO_SERIAL_POSE=1 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_serial.json" 2> "$OUT/bench_serial.err"
 cat "$OUT/bench_serial.json"

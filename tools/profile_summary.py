@@ -56,7 +56,7 @@ def main(src, prefix):
             lines.append("| %s | " % k + " | ".join("%.4g" % (sum(pmc[k][c]) / len(pmc[k][c])) if pmc[k].get(c) else "" for c in counters) + " |")
         lines += ["", "FETCH_SIZE / WRITE_SIZE are in KB.  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles.",
                   "GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
-    for name in ("bench.json", "bench_kitti374.json", "bench_detect.json", "bench_serial.json"):
+    for name in ("bench.json", "bench_kitti374.json", "bench_detect.json", "bench_mono.json", "bench_hd4000.json", "bench_serial.json"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, prefix + "_" + name)
