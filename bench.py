@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frame quadruples per step per GPU")
+    ap.add_argument("--frames", type=int, default=256,
+                    help="frame quadruples per step per GPU (a 256-frame sequence batch = 514 images, 1.8 GB of pyramids + Scharr images)")
     ap.add_argument("--quads", type=int, default=8, help="distinct rendered quadruples cycled over the batch")
     ap.add_argument("--workload", default="kitti2000", choices=sorted(WORKLOADS))
     ap.add_argument("--stages", default="full", choices=["full", "lk", "detect+full"],
