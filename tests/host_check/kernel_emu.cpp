@@ -89,7 +89,14 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
         launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
         fill(l + 1);
     }
-    launch((w + 255) / 256, (h + 3) / 4, n_img * p.levels, 256, [&] { scharr_kernel(d_imgs, p.levels); });
+    {
+        ScharrTiles st = {};
+        for (int l = 0; l < p.levels; l++) {
+            st.tiles_x[l] = (p.lw[l] + 255) / 256;
+            st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((p.lh[l] + 3) / 4);
+        }
+        launch(st.first[p.levels], n_img, 1, 256, [&] { scharr_kernel(d_imgs, p.levels, st); });
+    }
 
     if (want_level >= 0 && want_level < p.levels) {
         const int l = want_level;

@@ -669,7 +669,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                 launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], c->stream);
                 launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
             }
-            launch_scharr(tab, ni, c->levels, c->lw[0], c->lh[0], c->stream);
+            launch_scharr(tab, ni, c->levels, c->lw, c->lh, c->stream);
         }
     }
     if (timed)

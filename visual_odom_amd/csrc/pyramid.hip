@@ -105,14 +105,25 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------
-// all levels of all images in one launch: blockIdx.z = image * n_levels + level
-__global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict__ imgs, int n_levels)
+// all levels of all images in one launch: blockIdx.y = image, blockIdx.x = tile of 256 x 4 pixels numbered
+// level by level (every image of the table has the same geometry, so the per-level tile counts are launch
+// constants: no workgroup is launched for tiles a smaller level does not have)
+struct ScharrTiles {
+    int first[VO_MAX_LEVELS + 1]; // first[l] = tiles of the levels before l
+    int tiles_x[VO_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict__ imgs, int n_levels, ScharrTiles st)
 {
-    const int img = blockIdx.z / n_levels, level = blockIdx.z - img * n_levels;
-    const PyrImage &im = imgs[img];
+    int level = 0;
+    while (level + 1 < n_levels && (int)blockIdx.x >= st.first[level + 1])
+        level++;
+    const int tile = (int)blockIdx.x - st.first[level];
+    const int ty = tile / st.tiles_x[level], tx = tile - ty * st.tiles_x[level];
+    const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
-    const int x4 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int x4 = (int)(tx * 64 + (threadIdx.x & 63)) * 4;
+    const int y = (int)(ty * 4 + (threadIdx.x >> 6));
     if (x4 >= w || y >= h)
         return;
     const uint8_t *__restrict__ p = im.lvl[level] + (ptrdiff_t)y * stride + x4 - 1; // pixel (x4-1, y)
@@ -151,10 +162,16 @@ void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, in
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
 
-void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, int w0, int h0, hipStream_t stream)
+void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh,
+                   hipStream_t stream)
 {
-    dim3 grid((w0 + 255) / 256, (h0 + 3) / 4, n_images * n_levels);
-    hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels);
+    ScharrTiles st = {};
+    for (int l = 0; l < n_levels; l++) {
+        st.tiles_x[l] = (lw[l] + 255) / 256;
+        st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((lh[l] + 3) / 4);
+    }
+    dim3 grid(st.first[n_levels], n_images);
+    hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
 }
 
 #endif // VO_HOST_EMUL
