@@ -201,36 +201,44 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // tile origins that keep the 40 x 48 tile inside the bordered allocation
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
+            // floor of the previous iteration's window corner: while the corner stays in the same pixel cell (two
+            // iterations out of three) the admissibility test, the tile test and the LDS address are unchanged
+            float pfx = 0.f, pfy = 0.f;
+            int off = 0;
             for (int j = 0; j < prm.max_count; j++) {
                 const float fnx = floorf(nextX), fny = floorf(nextY);
-                const int inx = uni((int)fnx), iny = uni((int)fny);
-                if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
-                    if (level == 0)
-                        st = 0;
-                    break;
-                }
-                // search tile must cover cols inx..inx+21, rows iny..iny+21
-                if (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
-                    iny + LK_WIN + 1 > jy0 + LK_JT_H) {
-                    jx0 = (inx - 12) & ~3;
-                    jy0 = iny - 9;
-                    jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
-                    jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
-                    __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
-                    const uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
-                    for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
-                        const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
-                        const LkU4 v = *reinterpret_cast<const LkU4 *>(tb + (ptrdiff_t)row * jstride + 16 * col);
-                        *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
+                if (j == 0 || (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull) {
+                    pfx = fnx;
+                    pfy = fny;
+                    const int inx = uni((int)fnx), iny = uni((int)fny);
+                    if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
+                        if (level == 0)
+                            st = 0;
+                        break;
                     }
-                    __syncthreads();
-                    have_tile = true;
+                    // search tile must cover cols inx..inx+21, rows iny..iny+21
+                    if (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
+                        iny + LK_WIN + 1 > jy0 + LK_JT_H) {
+                        jx0 = (inx - 12) & ~3;
+                        jy0 = iny - 9;
+                        jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
+                        jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
+                        __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
+                        const uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
+                        for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
+                            const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
+                            const LkU4 v = *reinterpret_cast<const LkU4 *>(tb + (ptrdiff_t)row * jstride + 16 * col);
+                            *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
+                        }
+                        __syncthreads();
+                        have_tile = true;
+                    }
+                    off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
                 }
                 lk_weights(nextX - fnx, nextY - fny, wt, wb);
 
                 int b1 = -c1, b2 = -c2;
                 {
-                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
                     // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
                     // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
                     const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);

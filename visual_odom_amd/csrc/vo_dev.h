@@ -33,7 +33,7 @@
 #define VO_READFIRSTLANE(v) __builtin_amdgcn_readfirstlane(v)
 #define VO_READLANE(v, l) __builtin_amdgcn_readlane((v), (l))
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
-#define VO_BALLOT(p) __ballot(p)
+#define VO_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define VO_POPCLL(m) __popcll(m)
 // gfx950 v_permlane32_swap_b32 a, b: lanes 32-63 of a <-> lanes 0-31 of b;
 //        v_permlane16_swap_b32 a, b: odd 16-lane rows of a <-> even rows of b  (both operands are rewritten)
