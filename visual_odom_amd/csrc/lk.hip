@@ -204,7 +204,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // floor of the previous iteration's window corner: while the corner stays in the same pixel cell (two
             // iterations out of three) the admissibility test, the tile test and the LDS address are unchanged
             float pfx = 0.f, pfy = 0.f;
-            int off = 0;
+            uint32_t Jt[7], Jb[7]; // the cell's pixel pairs (two window rows per lane), lifted once per cell
             for (int j = 0; j < prm.max_count; j++) {
                 const float fnx = floorf(nextX), fny = floorf(nextY);
                 if (j == 0 || (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull) {
@@ -233,18 +233,20 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                         __syncthreads();
                         have_tile = true;
                     }
-                    off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
+                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
+                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
+                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
+                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
+                    lift7(t.lo, t.hi, Jt);
+                    lift7(u.lo, u.hi, Jb);
                 }
                 lk_weights(nextX - fnx, nextY - fny, wt, wb);
 
                 int b1 = -c1, b2 = -c2;
                 {
-                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
-                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
-                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
-                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
                     uint32_t Jp[4];
-                    bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Jp);
+                    blend7(Jt, Jb, wt, wb, Jp);
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         b1 = sdot2(Jp[m], Ixp[m], b1);

@@ -141,6 +141,35 @@ VO_HD void bilinear7_u8(uint32_t t_lo, uint32_t t_hi, uint32_t b_lo, uint32_t b_
         out[m] = pk_lshr1_u16(perm_b32(acc[2 * m + 1], acc[2 * m], VO_SEL_HI16));
 }
 
+// The same in two steps, for callers that sample one pixel cell several times with different weights:
+// lift7 does the weight-independent part (the 7 pixel pairs of one row as u16 lanes 256*p[k], 256*p[k+1]),
+// blend7 the weighted sum.  blend7(lift7(top), lift7(bottom)) == bilinear7_u8.
+VO_HD void lift7(uint32_t lo, uint32_t hi, uint32_t pair[7])
+{
+#define VO_LIFT(k) pair[k] = perm_b32(hi, lo, VO_SEL_PIX(k));
+    VO_LIFT(0) VO_LIFT(1) VO_LIFT(2) VO_LIFT(3) VO_LIFT(4) VO_LIFT(5) VO_LIFT(6)
+#undef VO_LIFT
+}
+
+VO_HD void blend7(const uint32_t pt[7], const uint32_t pb[7], uint32_t wt, uint32_t wb, uint32_t out[4])
+{
+    uint32_t acc[8];
+    if (!(wb & 0x80000000u)) {
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            acc[k] = udot2(pb[k], wb, udot2(pt[k], wt, 1u << 16));
+    } else {
+        const uint32_t wb0 = wb & 0xffffu, kneg = (uint32_t)(-(int32_t)((int16_t)(wb >> 16)));
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            acc[k] = udot2(pb[k], wb0, udot2(pt[k], wt, 1u << 16)) - kneg * (pb[k] >> 16);
+    }
+    acc[7] = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        out[m] = pk_lshr1_u16(perm_b32(acc[2 * m + 1], acc[2 * m], VO_SEL_HI16));
+}
+
 // Scharr samples: d[k] = (4*Ix | 4*Iy << 16) of pixel x+k, rows top / bottom, k = 0..7.
 // ix[m] = (Ixval[2m], Ixval[2m+1]), iy likewise; *val[k] = DESCALE(sum d*iw, 14) of the true derivative.
 VO_HD void bilinear7_deriv(const uint32_t dt[8], const uint32_t db[8], uint32_t wt, uint32_t wb, uint32_t ix[4],
