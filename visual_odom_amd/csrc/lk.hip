@@ -192,6 +192,9 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 continue;
             }
             D = 1.f / D;
+            // b1, b2 carry the same 2^-20 as the A's; a power of two moves through the rounded products unchanged
+            // (A12 * (S * 2^-20) == (A12 * 2^-20) * S bit for bit), so it is folded into the A's once per level
+            const float A11s = A11 * FLT_SCALE, A12s = A12 * FLT_SCALE, A22s = A22 * FLT_SCALE;
 
             nextX -= halfWin;
             nextY -= halfWin;
@@ -255,10 +258,8 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 }
                 float fb1, fb2;
                 wave_sum2_exact_f32(b1, b2, fb1, fb2);
-                fb1 *= FLT_SCALE;
-                fb2 *= FLT_SCALE;
-                const float dx = (A12 * fb2 - A22 * fb1) * D;
-                const float dy = (A12 * fb1 - A11 * fb2) * D;
+                const float dx = (A12s * fb2 - A22s * fb1) * D;
+                const float dy = (A12s * fb1 - A11s * fb2) * D;
                 nextX += dx;
                 nextY += dy;
                 outX = nextX + halfWin;
