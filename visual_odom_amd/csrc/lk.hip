@@ -127,9 +127,9 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
 
             const int iw = I.w[level], ih = I.h[level], istride = I.stride[level];
             const int jw = J.w[level], jh = J.h[level], jstride = J.stride[level];
-            const uint8_t *__restrict__ Iimg = I.lvl[level];
-            const uint32_t *__restrict__ Ider = I.der[level];
-            const uint8_t *__restrict__ Jimg = J.lvl[level];
+            const VO_GLOBAL uint8_t *__restrict__ Iimg = (const VO_GLOBAL uint8_t *)I.lvl[level];
+            const VO_GLOBAL uint32_t *__restrict__ Ider = (const VO_GLOBAL uint32_t *)I.der[level];
+            const VO_GLOBAL uint8_t *__restrict__ Jimg = (const VO_GLOBAL uint8_t *)J.lvl[level];
 
             prevX -= halfWin;
             prevY -= halfWin;
@@ -156,12 +156,12 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 // lane 63 owns no pixel: it reads its Scharr samples from the (all-zero) top-left border
                 // corner, so Ix = Iy = 0 there and every sum it feeds is 0 without any select
                 const ptrdiff_t od = live ? o : -(ptrdiff_t)VO_BY * istride - VO_BX;
-                const LkU2 t = *reinterpret_cast<const LkU2 *>(Iimg + o);
-                const LkU2 u = *reinterpret_cast<const LkU2 *>(Iimg + o + istride);
-                const LkU4 dt0 = *reinterpret_cast<const LkU4 *>(Ider + od);
-                const LkU4 dt1 = *reinterpret_cast<const LkU4 *>(Ider + od + 4);
-                const LkU4 db0 = *reinterpret_cast<const LkU4 *>(Ider + od + istride);
-                const LkU4 db1 = *reinterpret_cast<const LkU4 *>(Ider + od + istride + 4);
+                const LkU2 t = *(const VO_GLOBAL LkU2 *)(Iimg + o);
+                const LkU2 u = *(const VO_GLOBAL LkU2 *)(Iimg + o + istride);
+                const LkU4 dt0 = *(const VO_GLOBAL LkU4 *)(Ider + od);
+                const LkU4 dt1 = *(const VO_GLOBAL LkU4 *)(Ider + od + 4);
+                const LkU4 db0 = *(const VO_GLOBAL LkU4 *)(Ider + od + istride);
+                const LkU4 db1 = *(const VO_GLOBAL LkU4 *)(Ider + od + istride + 4);
                 const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
                 const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
                 uint32_t Ip[4];
@@ -227,10 +227,10 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                         jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
                         jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
                         __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
-                        const uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
+                        const VO_GLOBAL uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
                         for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
                             const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
-                            const LkU4 v = *reinterpret_cast<const LkU4 *>(tb + (ptrdiff_t)row * jstride + 16 * col);
+                            const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (ptrdiff_t)row * jstride + 16 * col);
                             *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
                         }
                         __syncthreads();

@@ -51,6 +51,15 @@
     } while (0)
 #endif
 
+// Image pointers come out of the PyrImage table in memory, so the compiler can only treat them as generic
+// (flat) addresses; VO_GLOBAL marks them as what they are -- global memory -- which turns flat_load into
+// global_load with a scalar base (no lgkmcnt coupling with LDS traffic, no 64-bit per-lane address math).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
+#define VO_GLOBAL __attribute__((address_space(1)))
+#else
+#define VO_GLOBAL /* host pass of hipcc, CPU emulator */
+#endif
+
 #define VO_MAX_LEVELS 5
 #define VO_BX 32 /* left border columns (>= 21 + tile slack, keeps x = 0 16-byte aligned) */
 #define VO_BY 24 /* top / bottom border rows and minimum right border columns (>= 21) */
