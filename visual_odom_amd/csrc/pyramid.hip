@@ -31,10 +31,10 @@ __global__ __launch_bounds__(64) void border_fill_kernel(const PyrImage *__restr
 {
     const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
-    uint8_t *__restrict__ p = im.lvl[level];
+    VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
     const int y = (int)blockIdx.x - VO_BY; // -VO_BY .. h + VO_BY - 1
-    const uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
-    uint8_t *__restrict__ dst = p + (ptrdiff_t)y * stride;
+    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
+    VO_GLOBAL uint8_t *__restrict__ dst = p + (ptrdiff_t)y * stride;
     const int right = stride - VO_BX - w; // >= VO_BY
     if (y >= 0 && y < h) {
         for (int i = threadIdx.x; i < VO_BX + right; i += 64) {
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     const PyrImage &im = imgs[blockIdx.z];
     const int sh = im.h[level], sstride = im.stride[level];
     const int dw = im.w[level + 1], dh = im.h[level + 1], dstride = im.stride[level + 1];
-    const uint8_t *__restrict__ src = im.lvl[level];
-    uint8_t *__restrict__ dst = im.lvl[level + 1];
+    const VO_GLOBAL uint8_t *__restrict__ src = (const VO_GLOBAL uint8_t *)im.lvl[level];
+    VO_GLOBAL uint8_t *__restrict__ dst = (VO_GLOBAL uint8_t *)im.lvl[level + 1];
     const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
     if (ox >= dw || oy >= dh)
         return;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
         const int x = sx0 + 4 * c, y = sy0 + r;
         uint32_t v = 0;
         if (x + 4 <= xmax && y < ymax)
-            v = *reinterpret_cast<const uint32_t *>(src + (ptrdiff_t)y * sstride + x);
+            v = *(const VO_GLOBAL uint32_t *)(src + (ptrdiff_t)y * sstride + x);
         *reinterpret_cast<uint32_t *>(&s_src[r * PD_SSTRIDE + 4 * c]) = v;
     }
     __syncthreads();
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
             int v = q[2 * PD_TW] * 6 + (q[PD_TW] + q[3 * PD_TW]) * 4 + q[0] + q[4 * PD_TW];
             packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = packed;
+        *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = packed;
     }
 }
 
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict_
     const int y = (int)(ty * 4 + (threadIdx.x >> 6));
     if (x4 >= w || y >= h)
         return;
-    const uint8_t *__restrict__ p = im.lvl[level] + (ptrdiff_t)y * stride + x4 - 1; // pixel (x4-1, y)
-    const U8x8 a = *reinterpret_cast<const U8x8 *>(p - stride);
-    const U8x8 b = *reinterpret_cast<const U8x8 *>(p);
-    const U8x8 c = *reinterpret_cast<const U8x8 *>(p + stride);
+    const VO_GLOBAL uint8_t *__restrict__ p = (const VO_GLOBAL uint8_t *)im.lvl[level] + (ptrdiff_t)y * stride + x4 - 1; // pixel (x4-1, y)
+    const U8x8 a = *(const VO_GLOBAL U8x8 *)(p - stride);
+    const U8x8 b = *(const VO_GLOBAL U8x8 *)(p);
+    const U8x8 c = *(const VO_GLOBAL U8x8 *)(p + stride);
     const uint64_t ra = ((uint64_t)a.hi << 32) | a.lo, rb = ((uint64_t)b.hi << 32) | b.lo,
                    rc = ((uint64_t)c.hi << 32) | c.lo;
     uint32_t out[4];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict_
     for (int k = 1; k < 4; k++)
         if (x4 + k >= w)
             out[k] = 0;
-    *reinterpret_cast<uint4 *>(im.der[level] + (ptrdiff_t)y * stride + x4) = make_uint4(out[0], out[1], out[2], out[3]);
+    *(VO_GLOBAL uint4 *)((VO_GLOBAL uint32_t *)im.der[level] + (ptrdiff_t)y * stride + x4) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 #ifndef VO_HOST_EMUL
