@@ -207,7 +207,9 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // floor of the previous iteration's window corner: while the corner stays in the same pixel cell (two
             // iterations out of three) the admissibility test, the tile test and the LDS address are unchanged
             float pfx = 0.f, pfy = 0.f;
-            uint32_t Jt[7], Jb[7]; // the cell's pixel pairs (two window rows per lane), lifted once per cell
+            // the cell's pixel pairs (two window rows per lane), lifted once per cell.  (Zero-initialised: left
+            // undefined the compiler carries them around the level loop with 56 register copies per level.)
+            uint32_t Jt[7] = {0, 0, 0, 0, 0, 0, 0}, Jb[7] = {0, 0, 0, 0, 0, 0, 0};
             for (int j = 0; j < prm.max_count; j++) {
                 const float fnx = floorf(nextX), fny = floorf(nextY);
                 if (j == 0 || (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull) {
