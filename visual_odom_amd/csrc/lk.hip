@@ -167,8 +167,13 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 uint32_t Ip[4];
                 bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Ip);
                 bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);
+                a11 = sdot2_first(Ixp[0], Ixp[0], 0);
+                a12 = sdot2_first(Ixp[0], Iyp[0], 0);
+                a22 = sdot2_first(Iyp[0], Iyp[0], 0);
+                c1 = sdot2_first(Ip[0], Ixp[0], 0);
+                c2 = sdot2_first(Ip[0], Iyp[0], 0);
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
+                for (int m = 1; m < 4; m++) {
                     a11 = sdot2(Ixp[m], Ixp[m], a11);
                     a12 = sdot2(Ixp[m], Iyp[m], a12);
                     a22 = sdot2(Iyp[m], Iyp[m], a22);
@@ -195,6 +200,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // b1, b2 carry the same 2^-20 as the A's; a power of two moves through the rounded products unchanged
             // (A12 * (S * 2^-20) == (A12 * 2^-20) * S bit for bit), so it is folded into the A's once per level
             const float A11s = A11 * FLT_SCALE, A12s = A12 * FLT_SCALE, A22s = A22 * FLT_SCALE;
+            const int nc1 = -c1, nc2 = -c2;
 
             nextX -= halfWin;
             nextY -= halfWin;
@@ -248,12 +254,14 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 }
                 lk_weights(nextX - fnx, nextY - fny, wt, wb);
 
-                int b1 = -c1, b2 = -c2;
+                int b1, b2;
                 {
                     uint32_t Jp[4];
                     blend7(Jt, Jb, wt, wb, Jp);
+                    b1 = sdot2_first(Jp[0], Ixp[0], nc1); // seeds: minus the lane's sum I * Ix, sum I * Iy
+                    b2 = sdot2_first(Jp[0], Iyp[0], nc2);
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
+                    for (int m = 1; m < 4; m++) {
                         b1 = sdot2(Jp[m], Ixp[m], b1);
                         b2 = sdot2(Jp[m], Iyp[m], b2);
                     }

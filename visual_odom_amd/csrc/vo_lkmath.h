@@ -69,6 +69,20 @@ VO_HD int32_t sdot2(uint32_t a, uint32_t b, int32_t c)
 #endif
 }
 
+// The same dot product as the first link of an accumulation chain.  v_dot2c_i32_i16 (what the compiler picks for
+// sdot2) accumulates in place, so a chain that starts from a constant or from a value that must survive costs a
+// v_mov per chain; the clamped variant only exists in the three-address VOP3P form, which takes the start value
+// from any operand.  No chain here gets anywhere near the int32 range, so the clamp never acts.
+VO_HD int32_t sdot2_first(uint32_t a, uint32_t b, int32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b), c, true);
+#else
+    return sdot2(a, b, c);
+#endif
+}
+
 // v_pk_sub_i16 (wrapping) and v_pk_lshrrev_b16 by 1
 VO_HD uint32_t pk_sub_i16(uint32_t a, uint32_t b)
 {
@@ -179,9 +193,9 @@ VO_HD void bilinear7_deriv(const uint32_t dt[8], const uint32_t db[8], uint32_t 
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         ax[k] = sdot2(perm_b32(db[k + 1], db[k], VO_SEL_LO16), wb,
-                      sdot2(perm_b32(dt[k + 1], dt[k], VO_SEL_LO16), wt, 1 << 15));
+                      sdot2_first(perm_b32(dt[k + 1], dt[k], VO_SEL_LO16), wt, 1 << 15));
         ay[k] = sdot2(perm_b32(db[k + 1], db[k], VO_SEL_HI16), wb,
-                      sdot2(perm_b32(dt[k + 1], dt[k], VO_SEL_HI16), wt, 1 << 15));
+                      sdot2_first(perm_b32(dt[k + 1], dt[k], VO_SEL_HI16), wt, 1 << 15));
     }
     ax[7] = ay[7] = 0;
 #pragma unroll
