@@ -210,47 +210,53 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // tile origins that keep the 40 x 48 tile inside the bordered allocation
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
-            // floor of the previous iteration's window corner: while the corner stays in the same pixel cell (two
-            // iterations out of three) the admissibility test, the tile test and the LDS address are unchanged
-            float pfx = 0.f, pfy = 0.f;
-            // the cell's pixel pairs (two window rows per lane), lifted once per cell.  (Zero-initialised: left
-            // undefined the compiler carries them around the level loop with 56 register copies per level.)
-            uint32_t Jt[7] = {0, 0, 0, 0, 0, 0, 0}, Jb[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (int j = 0; j < prm.max_count; j++) {
+            // The window corner stays in the same pixel cell for two iterations out of three; everything that only
+            // depends on the cell -- admissibility test, tile test / refill, LDS address, the two row reads and the 14
+            // v_perm_b32 that lift the pixel pairs -- is done when a cell is entered: once before the loop (so the
+            // pair registers are defined by real work, not by an initialisation) and then only on a change.
+            float pfx, pfy;                 // floor of the window corner = the current cell
+            uint32_t Jt[7], Jb[7];          // the cell's pixel pairs (two window rows per lane)
+            auto enter_cell = [&](float fnx, float fny) -> bool {
+                pfx = fnx;
+                pfy = fny;
+                const int inx = uni((int)fnx), iny = uni((int)fny);
+                if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh)
+                    return false;
+                // search tile must cover cols inx..inx+21, rows iny..iny+21
+                if (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
+                    iny + LK_WIN + 1 > jy0 + LK_JT_H) {
+                    jx0 = (inx - 12) & ~3;
+                    jy0 = iny - 9;
+                    jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
+                    jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
+                    __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
+                    const VO_GLOBAL uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
+                    for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
+                        const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
+                        const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (ptrdiff_t)row * jstride + 16 * col);
+                        *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
+                    }
+                    __syncthreads();
+                    have_tile = true;
+                }
+                const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
+                // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
+                // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
+                const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
+                lift7(t.lo, t.hi, Jt);
+                lift7(u.lo, u.hi, Jb);
+                return true;
+            };
+            bool admissible = prm.max_count > 0 ? enter_cell(floorf(nextX), floorf(nextY)) : true;
+            if (!admissible && level == 0)
+                st = 0;
+            for (int j = 0; admissible && j < prm.max_count; j++) {
                 const float fnx = floorf(nextX), fny = floorf(nextY);
-                if (j == 0 || (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull) {
-                    pfx = fnx;
-                    pfy = fny;
-                    const int inx = uni((int)fnx), iny = uni((int)fny);
-                    if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
-                        if (level == 0)
-                            st = 0;
-                        break;
-                    }
-                    // search tile must cover cols inx..inx+21, rows iny..iny+21
-                    if (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
-                        iny + LK_WIN + 1 > jy0 + LK_JT_H) {
-                        jx0 = (inx - 12) & ~3;
-                        jy0 = iny - 9;
-                        jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
-                        jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
-                        __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
-                        const VO_GLOBAL uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
-                        for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
-                            const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
-                            const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (ptrdiff_t)row * jstride + 16 * col);
-                            *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
-                        }
-                        __syncthreads();
-                        have_tile = true;
-                    }
-                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
-                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
-                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
-                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
-                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
-                    lift7(t.lo, t.hi, Jt);
-                    lift7(u.lo, u.hi, Jb);
+                if (j > 0 && (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull && !enter_cell(fnx, fny)) {
+                    if (level == 0)
+                        st = 0;
+                    break;
                 }
                 lk_weights(nextX - fnx, nextY - fny, wt, wb);
 
