@@ -63,8 +63,11 @@ __device__ __forceinline__ void lk_weights(float a, float b, uint32_t &wt, uint3
     wb = perm_b32(iw11, r10, VO_SEL_LO16); // signed lanes: iw11 may be -1
 }
 
+// 6 waves per SIMD = at most 80 VGPRs: the allocator lands a few registers above that on its own (5 waves);
+// held to 80 it spills a handful of per-hop values outside the loops and the sixth wave is worth ~1 %
+// (gpurun_out/r40, r47; at 7 waves = 72 VGPRs the spills reach the iteration loop and LK is 8 % slower)
 #ifndef VO_LK_ATTRS
-#define VO_LK_ATTRS __launch_bounds__(64)
+#define VO_LK_ATTRS __launch_bounds__(64, 6)
 #endif
 __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
