@@ -213,18 +213,20 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             // tile origins that keep the 40 x 48 tile inside the bordered allocation
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
-            // The window corner stays in the same pixel cell for two iterations out of three; everything that only
+            // The window corner stays in the same pixel cell for two iterations out of three, so the Gauss-Newton
+            // loop is written as two loops: the outer one is entered once per cell and does everything that only
             // depends on the cell -- admissibility test, tile test / refill, LDS address, the two row reads and the 14
-            // v_perm_b32 that lift the pixel pairs -- is done when a cell is entered: once before the loop (so the
-            // pair registers are defined by real work, not by an initialisation) and then only on a change.
-            float pfx, pfy;                 // floor of the window corner = the current cell
-            uint32_t Jt[7], Jb[7];          // the cell's pixel pairs (two window rows per lane)
-            auto enter_cell = [&](float fnx, float fny) -> bool {
-                pfx = fnx;
-                pfy = fny;
+            // v_perm_b32 that lift the pixel pairs into registers; the inner one iterates while the corner stays put.
+            int j = 0;
+            float fnx = floorf(nextX), fny = floorf(nextY);
+            bool run = prm.max_count > 0;
+            while (run) {
                 const int inx = uni((int)fnx), iny = uni((int)fny);
-                if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh)
-                    return false;
+                if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
+                    if (level == 0)
+                        st = 0;
+                    break;
+                }
                 // search tile must cover cols inx..inx+21, rows iny..iny+21
                 if (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
                     iny + LK_WIN + 1 > jy0 + LK_JT_H) {
@@ -242,71 +244,76 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     __syncthreads();
                     have_tile = true;
                 }
-                const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
-                // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
-                // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
-                const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
-                const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
-                lift7(t.lo, t.hi, Jt);
-                lift7(u.lo, u.hi, Jb);
-                return true;
-            };
-            bool admissible = prm.max_count > 0 ? enter_cell(floorf(nextX), floorf(nextY)) : true;
-            if (!admissible && level == 0)
-                st = 0;
-            for (int j = 0; admissible && j < prm.max_count; j++) {
-                const float fnx = floorf(nextX), fny = floorf(nextY);
-                if (j > 0 && (VO_BALLOT(fnx != pfx) | VO_BALLOT(fny != pfy)) != 0ull && !enter_cell(fnx, fny)) {
-                    if (level == 0)
-                        st = 0;
-                    break;
-                }
-                lk_weights(nextX - fnx, nextY - fny, wt, wb);
-
-                int b1, b2;
+                uint32_t Jt[7], Jb[7]; // the cell's pixel pairs (two window rows per lane)
                 {
-                    uint32_t Jp[4];
-                    blend7(Jt, Jb, wt, wb, Jp);
-                    b1 = sdot2_first(Jp[0], Ixp[0], nc1); // seeds: minus the lane's sum I * Ix, sum I * Iy
-                    b2 = sdot2_first(Jp[0], Iyp[0], nc2);
+                    const int off = (iny - jy0) * LK_JT_W + (inx - jx0) + lane_off; // uniform part on the scalar unit
+                    // two unaligned 8-byte LDS reads (gfx950 handles misaligned ds_read_b64; measured
+                    // equal to three aligned dwords + v_alignbyte_b32 per row, profiles/r01 notes)
+                    const LkU2 t = *reinterpret_cast<const LkU2 *>(&s_jt[off]);
+                    const LkU2 u = *reinterpret_cast<const LkU2 *>(&s_jt[off + LK_JT_W]);
+                    lift7(t.lo, t.hi, Jt);
+                    lift7(u.lo, u.hi, Jb);
+                }
+                for (;;) {
+                    lk_weights(nextX - fnx, nextY - fny, wt, wb);
+                    int b1, b2;
+                    {
+                        uint32_t Jp[4];
+                        blend7(Jt, Jb, wt, wb, Jp);
+                        b1 = sdot2_first(Jp[0], Ixp[0], nc1); // seeds: minus the lane's sum I * Ix, sum I * Iy
+                        b2 = sdot2_first(Jp[0], Iyp[0], nc2);
 #pragma unroll
-                    for (int m = 1; m < 4; m++) {
-                        b1 = sdot2(Jp[m], Ixp[m], b1);
-                        b2 = sdot2(Jp[m], Iyp[m], b2);
+                        for (int m = 1; m < 4; m++) {
+                            b1 = sdot2(Jp[m], Ixp[m], b1);
+                            b2 = sdot2(Jp[m], Iyp[m], b2);
+                        }
+                    }
+                    float fb1, fb2;
+                    wave_sum2_exact_f32(b1, b2, fb1, fb2);
+                    const float dx = (A12s * fb2 - A22s * fb1) * D;
+                    const float dy = (A12s * fb1 - A11s * fb2) * D;
+                    nextX += dx;
+                    nextY += dy;
+                    outX = nextX + halfWin;
+                    outY = nextY + halfWin;
+                    // OpenCV: delta.ddot(delta) <= epsilon in f64.  The f32 value n2 is within 2^-23 of it, so it
+                    // decides on its own unless it falls inside a 1e-6 band around epsilon (then the f64 form)
+                    const float n2 = fmaf(dy, dy, dx * dx);
+                    bool converged = n2 < eps_lo;
+                    if (__builtin_expect(!converged && !(n2 > eps_hi), 0)) {
+#ifndef VO_HOST_EMUL
+                        asm volatile("" ::: "memory"); // keep the rare f64 evaluation out of the hot path
+#endif
+                        converged = (double)dx * dx + (double)dy * dy <= prm.epsilon;
+                    }
+                    if (converged) {
+                        run = false;
+                        break;
+                    }
+                    // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
+                    // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f
+                    if (j > 0 && fabsf(dx + prevDX) <= 0.01f && fabsf(dy + prevDY) <= 0.01f) {
+#ifndef VO_HOST_EMUL
+                        asm volatile("" ::: "memory"); // do not speculate the half-step into every iteration
+#endif
+                        outX -= dx * 0.5f;
+                        outY -= dy * 0.5f;
+                        run = false;
+                        break;
+                    }
+                    prevDX = dx;
+                    prevDY = dy;
+                    if (++j >= prm.max_count) {
+                        run = false;
+                        break;
+                    }
+                    const float gx = floorf(nextX), gy = floorf(nextY);
+                    if ((VO_BALLOT(gx != fnx) | VO_BALLOT(gy != fny)) != 0ull) { // the corner left the cell
+                        fnx = gx;
+                        fny = gy;
+                        break;
                     }
                 }
-                float fb1, fb2;
-                wave_sum2_exact_f32(b1, b2, fb1, fb2);
-                const float dx = (A12s * fb2 - A22s * fb1) * D;
-                const float dy = (A12s * fb1 - A11s * fb2) * D;
-                nextX += dx;
-                nextY += dy;
-                outX = nextX + halfWin;
-                outY = nextY + halfWin;
-                // OpenCV: delta.ddot(delta) <= epsilon in f64.  The f32 value n2 is within 2^-23 of it, so it
-                // decides on its own unless it falls inside a 1e-6 band around epsilon (then the f64 form)
-                const float n2 = fmaf(dy, dy, dx * dx);
-                bool converged = n2 < eps_lo;
-                if (__builtin_expect(!converged && !(n2 > eps_hi), 0)) {
-#ifndef VO_HOST_EMUL
-                    asm volatile("" ::: "memory"); // keep the rare f64 evaluation out of the hot path
-#endif
-                    converged = (double)dx * dx + (double)dy * dy <= prm.epsilon;
-                }
-                if (converged)
-                    break;
-                // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
-                // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f
-                if (j > 0 && fabsf(dx + prevDX) <= 0.01f && fabsf(dy + prevDY) <= 0.01f) {
-#ifndef VO_HOST_EMUL
-                    asm volatile("" ::: "memory"); // do not speculate the half-step into every iteration
-#endif
-                    outX -= dx * 0.5f;
-                    outY -= dy * 0.5f;
-                    break;
-                }
-                prevDX = dx;
-                prevDY = dy;
             }
 
             // final in-bounds check OpenCV performs at level 0 when an err vector is requested
