@@ -135,3 +135,33 @@ def test_scharr_packed_matches_oracle(orc, host_check):
             v = host_check.hc_scharr4(vp(p8))
             gx, gy = np.array([v & 0xffff, v >> 16], np.uint16).view(np.int16)
             assert gx == 4 * d[y, x, 0] and gy == 4 * d[y, x, 1]
+
+
+def test_min_eig_pretest_never_contradicts_the_exact_expression():
+    """lk.hip skips the correctly rounded sqrt + divide of OpenCV's minEig when a cheap bound shows the feature
+    cannot be rejected; the bound (same f32 operations as the kernel) must imply the exact test's outcome,
+    in particular for structure tensors right at the threshold"""
+    rng = np.random.default_rng(3)
+    f = np.float32
+    thr = f(1e-3)
+    n = 4_000_000
+    # eigenvalues: lam_min around 882 * thr (log-uniform over 4 decades), lam_max above it, random orientation
+    lam_min = (f(882.0) * thr * f(10.0) ** rng.uniform(-2, 2, n)).astype(f)
+    lam_max = (lam_min * f(10.0) ** rng.uniform(0, 6, n)).astype(f)
+    th = rng.uniform(0, np.pi, n)
+    c, s = np.cos(th), np.sin(th)
+    A11 = (lam_max * c * c + lam_min * s * s).astype(f) * f(0.5)   # (A11 + A22 - sqrt(..)) = 2 * lam_min * 0.5
+    A22 = (lam_max * s * s + lam_min * c * c).astype(f) * f(0.5)
+    A12 = ((lam_max - lam_min) * c * s).astype(f) * f(0.5)
+    t = A22 + A11
+    d = A11 - A22
+    s2 = d * d + f(4.0) * A12 * A12
+    min_eig_n = thr * (f(1.001) * f(882.0))
+    u = t - (min_eig_n + t * f(3.814697265625e-6))
+    fast_ok = (u > 0) & (s2 < u * u * f(0.9999))
+    exact = (t - np.sqrt(s2)) / f(882.0)          # numpy f32 sqrt / divide are correctly rounded
+    rejected = exact < thr
+    assert not np.any(fast_ok & rejected)
+    assert fast_ok.mean() > 0.3 and rejected.mean() > 0.2   # both sides of the threshold are exercised
+    near = np.abs(exact / thr - 1) < 5e-4
+    assert near.sum() > 200 and not np.any(fast_ok & near)  # the band around the threshold always takes the exact path

@@ -101,6 +101,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
     const float halfWin = (LK_WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps_lo = (float)(prm.epsilon * 0.999999), eps_hi = (float)(prm.epsilon * 1.000001);
+    const float min_eig_n = prm.min_eig * (1.001f * (float)(2 * LK_WIN * LK_WIN)); // see the min-eigenvalue test
 
     const float2 p = pts_in[(size_t)frame * cap + f];
     float prevPtX = unif(p.x), prevPtY = unif(p.y);
@@ -192,9 +193,24 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             A22 *= FLT_SCALE;
 
             float D = A11 * A22 - A12 * A12;
-            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
-                                 (float)(2 * LK_WIN * LK_WIN);
-            if (minEig < prm.min_eig || D < FLT_EPSILON) {
+            // OpenCV: minEig = (A22 + A11 - sqrt((A11-A22)^2 + 4 A12^2)) / (2 * 21 * 21), rejected when < minEigThreshold.
+            // The correctly rounded sqrt and divide cost ~30 wave-uniform VALU instructions, and the test is almost
+            // never close: with t = A22 + A11, s2 = the radicand and u = t - (1.001 * 882 * thr + t * 2^-18),
+            // "u > 0 and s2 < 0.9999 u^2" implies sqrt(s2) < u (1 - 4e-5), hence the rounded t - sqrt(s2) exceeds
+            // 1.0009 * 882 * thr and the rounded quotient exceeds thr (every rounding involved is below 2^-23
+            // relative, the margins are 1e-3 and 2^-18 t): the exact expression cannot reject.  Otherwise evaluate it.
+            const float t = A22 + A11;
+            const float s2 = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+            const float u = t - (min_eig_n + t * 3.814697265625e-6f);
+            bool eig_ok = u > 0.f && s2 < u * u * 0.9999f;
+            if (__builtin_expect(!eig_ok, 0)) {
+#ifndef VO_HOST_EMUL
+                asm volatile("" ::: "memory"); // keep the sqrt / divide out of the common path
+#endif
+                const float minEig = (t - sqrtf(s2)) / (float)(2 * LK_WIN * LK_WIN);
+                eig_ok = !(minEig < prm.min_eig);
+            }
+            if (!eig_ok || D < FLT_EPSILON) {
                 if (level == 0)
                     st = 0;
                 continue;
