@@ -156,16 +156,22 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             uint32_t Ixp[4], Iyp[4];
             int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
             {
-                const ptrdiff_t o = (ptrdiff_t)(ipy + r) * istride + ipx + c0;
+                // Addresses as a wave-uniform base (first element of the bordered allocation, scalar registers) plus a
+                // per-lane 32-bit offset that is never negative: what global_load's scalar-base form takes, instead
+                // of 64-bit per-lane pointer arithmetic.
+                const ptrdiff_t org = (ptrdiff_t)VO_BY * istride + VO_BX;
+                const VO_GLOBAL uint8_t *Ib = Iimg - org;
+                const VO_GLOBAL uint8_t *Db = (const VO_GLOBAL uint8_t *)(Ider - org); // byte offsets: 4 * od fits 32 bits
+                const uint32_t o = (uint32_t)((ipy + r + VO_BY) * istride + ipx + c0 + VO_BX);
                 // lane 63 owns no pixel: it reads its Scharr samples from the (all-zero) top-left border
                 // corner, so Ix = Iy = 0 there and every sum it feeds is 0 without any select
-                const ptrdiff_t od = live ? o : -(ptrdiff_t)VO_BY * istride - VO_BX;
-                const LkU2 t = *(const VO_GLOBAL LkU2 *)(Iimg + o);
-                const LkU2 u = *(const VO_GLOBAL LkU2 *)(Iimg + o + istride);
-                const LkU4 dt0 = *(const VO_GLOBAL LkU4 *)(Ider + od);
-                const LkU4 dt1 = *(const VO_GLOBAL LkU4 *)(Ider + od + 4);
-                const LkU4 db0 = *(const VO_GLOBAL LkU4 *)(Ider + od + istride);
-                const LkU4 db1 = *(const VO_GLOBAL LkU4 *)(Ider + od + istride + 4);
+                const uint32_t od = live ? 4u * o : 0u, drow = 4u * (uint32_t)istride;
+                const LkU2 t = *(const VO_GLOBAL LkU2 *)(Ib + o);
+                const LkU2 u = *(const VO_GLOBAL LkU2 *)(Ib + (o + (uint32_t)istride));
+                const LkU4 dt0 = *(const VO_GLOBAL LkU4 *)(Db + od);
+                const LkU4 dt1 = *(const VO_GLOBAL LkU4 *)(Db + (od + 16u));
+                const LkU4 db0 = *(const VO_GLOBAL LkU4 *)(Db + (od + drow));
+                const LkU4 db1 = *(const VO_GLOBAL LkU4 *)(Db + (od + drow + 16u));
                 const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};
                 const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};
                 uint32_t Ip[4];
@@ -185,9 +191,8 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     c2 = sdot2(Ip[m], Iyp[m], c2);
                 }
             }
-            float A11, A12, A22, zero_;
-            wave_sum2_exact_f32(a11, a12, A11, A12);
-            wave_sum2_exact_f32(a22, 0, A22, zero_);
+            float A11, A12, A22;
+            wave_sum3_exact_f32(a11, a12, a22, A11, A12, A22);
             A11 *= FLT_SCALE;
             A12 *= FLT_SCALE;
             A22 *= FLT_SCALE;
@@ -254,7 +259,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     const VO_GLOBAL uint8_t *tb = Jimg + (ptrdiff_t)jy0 * jstride + jx0;
                     for (int c = lane; c < LK_JT_H * (LK_JT_W / 16); c += 64) {
                         const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
-                        const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (ptrdiff_t)row * jstride + 16 * col);
+                        const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (uint32_t)(row * jstride + 16 * col));
                         *reinterpret_cast<uint4 *>(&s_jt[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
                     }
                     __syncthreads();

@@ -162,4 +162,31 @@ __device__ __forceinline__ void wave_sum2_exact_f32(int a, int b, float &fa, flo
     fb = __int_as_float(VO_READLANE(__float_as_int(res), 63));
 }
 
+// Three exact sums (the structure tensor A11, A12, A22) in one tree: two half-swaps fold a|b and c|0 into two
+// registers, the 16-lane swap folds those into one (rows: a, c, b, 0; 4-value sums < 2^30), one quad step gives
+// 8-value sums < 2^31, then the signed-high / unsigned-low halves finish with three DPP steps each and one fma.
+// 22 VALU instead of two wave_sum2 calls (32).
+__device__ __forceinline__ void wave_sum3_exact_f32(int a, int b, int c, float &fa, float &fb, float &fc)
+{
+    int z = 0;
+    VO_PERMLANE32_SWAP(a, b);
+    int t1 = a + b;
+    VO_PERMLANE32_SWAP(c, z);
+    int t2 = c + z;
+    VO_PERMLANE16_SWAP(t1, t2);
+    int u = t1 + t2;
+    u = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(u);
+    int hi = u >> 16, lo = u & 0xffff;
+    hi = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(hi);
+    lo = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(lo);
+    const float r = fmaf((float)hi, 65536.f, (float)lo);
+    fa = __int_as_float(VO_READLANE(__float_as_int(r), 0));
+    fc = __int_as_float(VO_READLANE(__float_as_int(r), 16));
+    fb = __int_as_float(VO_READLANE(__float_as_int(r), 32));
+}
+
 } // namespace vo
