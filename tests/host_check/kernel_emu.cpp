@@ -132,6 +132,26 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
 
 // FAST + NMS + bucketing kernels of fast.hip on one image.  tracked / ages_in: the carried set
 // (n_tracked points, n_ages ages, n_ages >= n_tracked).  bucket_size == 0: return the raw corners.
+// the exact wave reductions of vo_dev.h on caller-chosen per-lane partials (64 each): out = {sum2 a, sum2 b,
+// sum3 a, sum3 b, sum3 c} as f32
+void ke_wave_sums(const int *a, const int *b, const int *c, float *out5)
+{
+    using namespace vo;
+    launch(1, 1, 1, 64, [&] {
+        const int l = threadIdx.x;
+        float s0, s1, t0, t1, t2;
+        wave_sum2_exact_f32(a[l], b[l], s0, s1);
+        wave_sum3_exact_f32(a[l], b[l], c[l], t0, t1, t2);
+        if (l == 0) {
+            out5[0] = s0;
+            out5[1] = s1;
+            out5[2] = t0;
+            out5[3] = t1;
+            out5[4] = t2;
+        }
+    });
+}
+
 int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int do_detect, const float *tracked,
               int n_tracked, const int *ages_in, int n_ages, int bucket_size, int fpb, float *out_pts, int *out_ages,
               int out_cap)

@@ -4,10 +4,13 @@ against the CPU oracle on the same seeded inputs.
 Stated bars: pyramids and LK (positions, status, survivor indices) BIT-EXACT; triangulation
 <= 1e-5 relative (observed bit-exact); pose rvec <= 1e-6 rad and tvec <= 1e-6 m with identical
 inlier sets and identical RANSAC control flow (observed ~1e-16)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 import contextlib
@@ -634,3 +637,15 @@ def test_sequence_trajectory_mono_rotation(gpu_ctx, orc, small_world):
     T0inv = np.linalg.inv(poses[0])
     gt = [(T0inv @ T)[:3] for T in poses]
     assert odometry.ate_rmse(vo.trajectory, gt) < 0.05
+
+
+@pytest.mark.gpu
+def test_exact_wave_sums_on_the_gpu(tmp_path):
+    """the wave reductions LK is built on (v_permlane32_swap / v_permlane16_swap + DPP, hi/lo split), on the hardware,
+    with per-lane partials at the documented bound: must equal (float)(int64 sum) bit for bit"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host_check", "wave_sums_gpu.hip")
+    exe = str(tmp_path / "wave_sums_gpu")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-w", "-o", exe, src])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr

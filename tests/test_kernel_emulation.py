@@ -180,3 +180,19 @@ def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq):
     ref_p, ref_a = orc.bucketing_features(h, w, tracked, ages[:len(tracked)], h // 10, 2)
     got_p, got_a = ke_detect(kemu, img, tracked, ages[:len(tracked)], detect=0, bucket_size=h // 10, fpb=2)
     assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a)
+
+
+def test_exact_wave_sums_at_the_extremes(kemu):
+    """wave_sum2 / wave_sum3 (v_permlane32/16_swap + DPP trees, hi/lo split) must return (float)(int64 sum) for any
+    per-lane partials below the documented bound 2^28 (8-lane sums must fit int32), including totals far beyond int32"""
+    rng = np.random.default_rng(11)
+    B = (1 << 28) - 1
+    cases = [np.full(64, B), np.full(64, -B), np.where(np.arange(64) % 2 == 0, B, -B), np.zeros(64, np.int64)]
+    cases += [rng.integers(-B, B + 1, 64) for _ in range(40)]
+    cases += [rng.integers(-3, 4, 64) * (B // 3) + rng.integers(-1, 2, 64) for _ in range(10)]  # rounding ties nearby
+    for k in range(0, len(cases) - 2):
+        a, b, c = (np.ascontiguousarray(cases[k + j], np.int32) for j in range(3))
+        out = np.zeros(5, np.float32)
+        kemu.ke_wave_sums(vp(a), vp(b), vp(c), vp(out))
+        ref = [np.float32(int(x.astype(np.int64).sum())) for x in (a, b, a, b, c)]
+        assert [bits(o) for o in out] == [bits(r) for r in ref], k

@@ -107,7 +107,7 @@ __device__ __forceinline__ int dpp_add(int v)
 }
 
 // Exact wave-wide sum of per-lane int32 partials, returned as a wave-uniform f32 rounded once from
-// the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| <= 2^28 so
+// the exact integer (= (float)(int64 sum), what the CPU path computes).  Requires |v| < 2^28 so
 // that the first three butterfly steps (8-lane sums) cannot overflow int32; the 8-lane sums are then
 // split into a signed high and an unsigned low 16-bit half which are reduced separately (row_mirror,
 // row_bcast15, row_bcast31: the total lands in lane 63), read with v_readlane and recombined by one
@@ -136,7 +136,7 @@ __device__ __forceinline__ float wave_sum_exact_f32(int v)
 // Two exact wave-wide sums for the price of (less than) one: the half-swap instructions of gfx950 fold two
 // reduction trees into one register.
 //   v_permlane32_swap(a, b); t = a + b      lanes 0-31: a[l] + a[l+32], lanes 32-63: the same of b
-//   quad butterflies (2 DPP adds)           8-value sums, |t| < 2^31 for |v| <= 2^28
+//   quad butterflies (2 DPP adds)           8-value sums, |t| < 2^31 for |v| < 2^28
 //   split t into signed high / unsigned low 16 bits, v_permlane16_swap(hi, lo); u = hi + lo
 //                                           rows 0 / 1 / 2 / 3: a's high, a's low, b's high, b's low partials
 //   row_half_mirror, row_mirror (2 DPP adds) every lane of a row holds that row's total
