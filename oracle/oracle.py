@@ -300,3 +300,77 @@ def recover_pose(E, pts1, pts2, focal, pp, mask=None):
     good = lib().orc_recover_pose(_vp(E), _vp(p1), _vp(p2), n, C.c_double(focal), C.c_double(pp[0]),
                                   C.c_double(pp[1]), _vp(R), _vp(t), _vp(m))
     return good, R, t, m
+
+
+# ---- oracle/_ref: the reference's OWN glue sources (feature.cpp, bucket.cpp) compiled where they lie ----------
+_REF_SO = os.path.join(_HERE, "_ref", "libvo_refglue.so")
+_ref = None
+
+
+def build_ref():
+    """`make -C oracle ref`: only possible where /root/reference exists (the authoring container); elsewhere the
+    prebuilt oracle/_ref/libvo_refglue.so that travelled with the snapshot is used.  Returns the path or None."""
+    if os.path.exists("/root/reference/src/feature.cpp"):
+        build()
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return _REF_SO if os.path.exists(_REF_SO) else None
+
+
+def ref_lib():
+    """the reference's own circularMatching / bucketingFeatures / appendNewFeatures (over the oracle's LK and FAST);
+    None when it cannot be built here and was not shipped"""
+    global _ref
+    if _ref is None:
+        so = build_ref()
+        if so is None:
+            return None
+        lib()  # resolves libvo_oracle.so first (rpath covers the normal layout)
+        _ref = C.CDLL(so)
+    return _ref
+
+
+def ref_circular_matching(l0, r0, l1, r1, pts_l0, ages=None):
+    imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
+    h, w = imgs[0].shape
+    p0 = np.array(pts_l0, np.float32).reshape(-1, 2).copy()
+    n = p0.shape[0]
+    p1, p2, p3, p0r = (np.zeros((max(n, 1), 2), np.float32) for _ in range(4))
+    ages_a = np.zeros(max(n, 1), np.int32) if ages is None else np.array(ages, np.int32).copy()
+    na = C.c_int(n if ages is None else len(ages_a))
+    if len(ages_a) == 0:
+        ages_a = np.zeros(1, np.int32)
+    m = ref_lib().ref_circular_matching(_vp(imgs[0]), _vp(imgs[1]), _vp(imgs[2]), _vp(imgs[3]), w, h, _vp(p0), n,
+                                        _vp(p1), _vp(p2), _vp(p3), _vp(p0r), _vp(ages_a), C.byref(na))
+    return dict(l0=p0[:m].copy(), r0=p1[:m].copy(), r1=p2[:m].copy(), l1=p3[:m].copy(), l0_ret=p0r[:m].copy(),
+                ages=ages_a[:na.value].copy(), n_out=m)
+
+
+def ref_bucketing_features(rows, cols, points, ages, bucket_size, features_per_bucket):
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    ag = np.ascontiguousarray(ages, np.int32)
+    npts = pts.shape[0]
+    cap = max(npts, len(ag), 1) + ((rows // bucket_size + 1) * (cols // bucket_size + 1)) * features_per_bucket
+    P = np.zeros((cap, 2), np.float32)
+    A = np.zeros(cap, np.int32)
+    P[:npts] = pts
+    A[:len(ag)] = ag
+    n_p, n_a = C.c_int(npts), C.c_int(len(ag))
+    rc = ref_lib().ref_bucketing_features(rows, cols, _vp(P), _vp(A), C.byref(n_p), C.byref(n_a), cap, bucket_size,
+                                          features_per_bucket)
+    assert rc == 0
+    return P[:n_p.value].copy(), A[:n_a.value].copy()
+
+
+def ref_append_new_features(img, points, ages, cap=200000):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    ag = np.ascontiguousarray(ages, np.int32)
+    P = np.zeros((cap, 2), np.float32)
+    A = np.zeros(cap, np.int32)
+    P[:len(pts)] = pts
+    A[:len(ag)] = ag
+    n_p, n_a = C.c_int(len(pts)), C.c_int(len(ag))
+    rc = ref_lib().ref_append_new_features(_vp(img), w, h, _vp(P), _vp(A), C.byref(n_p), C.byref(n_a), cap)
+    assert rc == 0
+    return P[:n_p.value].copy(), A[:n_a.value].copy()
