@@ -374,3 +374,67 @@ def ref_append_new_features(img, points, ages, cap=200000):
     rc = ref_lib().ref_append_new_features(_vp(img), w, h, _vp(P), _vp(A), C.byref(n_p), C.byref(n_a), cap)
     assert rc == 0
     return P[:n_p.value].copy(), A[:n_a.value].copy()
+
+
+class RefFrameLoop:
+    """The body of the reference's main() frame loop (main.cpp:144-208) driven through the reference's OWN functions
+    (matchingFeatures, trackingFrame2Frame, rotationMatrixToEulerAngles, integrateOdometryStereo; oracle/_ref) over the
+    oracle's OpenCV-algorithm restatement.  State as in main.cpp:81-94."""
+
+    def __init__(self, fx, cx, cy, bf, mono_rotation=False, cap=65536):
+        self.fx, self.cx, self.cy, self.bf = (float(v) for v in (fx, cx, cy, bf))
+        self.mono = int(bool(mono_rotation))
+        self.cap = cap
+        self.points = np.zeros((0, 2), np.float32)
+        self.ages = np.zeros(0, np.int32)
+        self.translation = np.zeros(3)
+        self.rotation = np.eye(3)
+        self.frame_pose = np.eye(4)
+        self.prev = None
+        self.trajectory = [self.frame_pose[:3].copy()]
+
+    def process(self, left, right):
+        cur = (np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8))
+        if self.prev is None:
+            self.prev = cur
+            return None
+        (l0, r0), (l1, r1) = self.prev, cur
+        h, w = l0.shape
+        cap = self.cap
+        P = np.zeros((cap, 2), np.float32)
+        A = np.zeros(cap, np.int32)
+        P[:len(self.points)] = self.points
+        A[:len(self.ages)] = self.ages
+        n_p, n_a = C.c_int(len(self.points)), C.c_int(len(self.ages))
+        t = self.translation.copy()
+        R = np.ascontiguousarray(self.rotation, np.float64).copy()
+        pose = np.ascontiguousarray(self.frame_pose, np.float64).copy()
+        outs = [np.zeros((cap, 2), np.float32) for _ in range(4)]
+        n_out, integrated = C.c_int(0), C.c_int(0)
+        rc = ref_lib().ref_frame_step(_vp(l0), _vp(r0), _vp(l1), _vp(r1), w, h, C.c_float(self.fx), C.c_float(self.cx),
+                                      C.c_float(self.cy), C.c_float(self.bf), _vp(P), _vp(A), C.byref(n_p), C.byref(n_a),
+                                      cap, _vp(t), _vp(R), _vp(pose), self.mono, _vp(outs[0]), _vp(outs[1]),
+                                      _vp(outs[2]), _vp(outs[3]), C.byref(n_out), C.byref(integrated))
+        assert rc == 0
+        self.points, self.ages = P[:n_p.value].copy(), A[:n_a.value].copy()
+        self.translation, self.rotation, self.frame_pose = t, R, pose
+        self.prev = cur
+        self.trajectory.append(pose[:3].copy())
+        k = n_out.value
+        return dict(l0=outs[0][:k].copy(), r0=outs[1][:k].copy(), l1=outs[2][:k].copy(), r1=outs[3][:k].copy(),
+                    integrated=bool(integrated.value), tvec=t.copy(), R=R.copy())
+
+
+def ref_rotation_matrix_to_euler(R):
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    e = np.zeros(3, np.float32)
+    ref_lib().ref_rotation_matrix_to_euler(_vp(R), _vp(e))
+    return e
+
+
+def ref_integrate_odometry_stereo(pose, R, t):
+    pose = np.array(pose, np.float64).reshape(4, 4).copy()
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    ref_lib().ref_integrate_odometry_stereo(_vp(pose), _vp(R), _vp(t))
+    return pose

@@ -13,9 +13,10 @@
  * diffed against the real library.  It is pinned instead by analytic ground
  * truth and independent numpy re-derivations (tests/test_oracle_*.py).  The
  * reference's OWN logic around those algorithms is pinned for real: `make ref`
- * compiles /root/reference/src/feature.cpp + bucket.cpp where they lie against a
- * type-only OpenCV stand-in (ref_shim/) into oracle/_ref/, and
- * tests/test_reference_glue.py holds orc_glue.c to it.
+ * compiles /root/reference/src/{feature,bucket,visualOdometry,utils}.cpp where
+ * they lie against a stand-in for the OpenCV declarations (ref_shim/) into
+ * oracle/_ref/, with the OpenCV algorithms forwarded to this oracle, and
+ * tests/test_reference_glue.py holds orc_glue.c and the oracle call chain to it.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call anything declared here.  The product (visual_odom_amd/, libvo_hip)

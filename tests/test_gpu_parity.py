@@ -649,3 +649,33 @@ def test_exact_wave_sums_on_the_gpu(tmp_path):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-w", "-o", exe, src])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mono", [False, True])
+def test_product_frame_loop_against_the_reference_sources(gpu_ctx, orc, small_world, mono):
+    """the product's frame loop (StereoOdometry over libvo_hip) against the body of the reference's main() loop run
+    through the reference's OWN sources (oracle/_ref: matchingFeatures, trackingFrame2Frame, rotationMatrixToEulerAngles,
+    integrateOdometryStereo compiled where they lie) over the oracle's OpenCV-algorithm restatement"""
+    from visual_odom_amd import odometry
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref was not shipped")
+    n = 6
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    loop = orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3], mono_rotation=mono)
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, mono_rotation=mono)   # reference defaults: 1 feature per bucket
+    try:
+        loop.process(L[0], R[0])
+        vo.process(L[0], R[0])
+        for k in range(1, n):
+            a = loop.process(L[k], R[k])
+            rec = vo.process(L[k], R[k])
+            assert np.array_equal(bits(vo.points), bits(loop.points)) and np.array_equal(vo.ages, loop.ages), k
+            assert rec["n_tracked"] == len(a["l1"])
+            assert np.abs(rec["tvec"] - a["tvec"]).max() <= 1e-6 and np.abs(vo.rotation - a["R"]).max() <= 1e-6
+            assert rec["integrated"] == a["integrated"]
+            assert np.abs(vo.frame_pose - loop.frame_pose).max() <= 1e-6
+    finally:
+        gpu_ctx.set_params(mono_rotation=0)
+    assert odometry.ate_rmse(vo.trajectory, loop.trajectory) <= 1e-6
