@@ -113,9 +113,6 @@ int vo_triangulate(vo_ctx *ctx, const float *P_l, const float *P_r, const float 
 int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers);
 
-/* Replaces cv::FAST as called by featureDetectionFast() -- feature.cpp:39-47: TYPE_9_16 corners of an
- * 8-bit image in row-major order.  pts_out [2 * cap]; *n_out = corners found (may exceed cap, in which
- * case only the first cap are written). */
 /* replaces the pair  E = cv::findEssentialMat(pts0, pts1, focal, pp, cv::RANSAC, prob, threshold, mask);
  *                     cv::recoverPose(E, pts0, pts1, R, t, focal, pp, mask);
  * of reference src/visualOdometry.cpp:152-153 (pixel coordinates, f32 xy pairs).  E, R: 3x3 row-major f64;
@@ -125,6 +122,9 @@ int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const f
 int vo_essential_pose(vo_ctx *ctx, const float *pts0_xy, const float *pts1_xy, int n, double focal, double ppx,
                       double ppy, double prob, double threshold, double *E, double *R, double *t, uint8_t *mask,
                       int *n_good);
+/* Replaces cv::FAST as called by featureDetectionFast() -- feature.cpp:39-47: TYPE_9_16 corners of an
+ * 8-bit image in row-major order.  pts_out [2 * cap]; *n_out = corners found (may exceed cap, in which
+ * case only the first cap are written). */
 int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
                    float *pts_out, int cap, int *n_out);
 

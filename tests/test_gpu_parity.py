@@ -679,3 +679,37 @@ def test_product_frame_loop_against_the_reference_sources(gpu_ctx, orc, small_wo
     finally:
         gpu_ctx.set_params(mono_rotation=0)
     assert odometry.ate_rmse(vo.trajectory, loop.trajectory) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mono", [False, True])
+def test_reference_sources_run_on_libvo_hip(orc, small_world, mono):
+    """THE DROP-IN: the reference's unmodified matchingFeatures() / trackingFrame2Frame() / integrateOdometryStereo()
+    (compiled where they lie; visualOdometry.cpp's circularMatching call reaches the INTEGRATION.md adapter, the OpenCV
+    entry points reach the C ABI: tests/ref_dropin) driving the MI355X, against the same reference code over the CPU
+    oracle (oracle/_ref), frame after frame"""
+    import ctypes
+    so = os.path.join(ROOT, "tests", "_build", "libvo_ref_dropin.so")
+    if orc.ref_lib() is None or not os.path.exists(so):
+        pytest.skip("built only where /root/reference exists (make -C tests/ref_dropin) and shipped with the snapshot")
+    hip = ctypes.CDLL(so)
+    n = 6
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    args = (P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3])
+    cpu = orc.RefFrameLoop(*args, mono_rotation=mono)
+    gpu = orc.RefFrameLoop(*args, mono_rotation=mono, lib=hip)
+    cpu.process(L[0], R[0])
+    gpu.process(L[0], R[0])
+    for k in range(1, n):
+        a, b = cpu.process(L[k], R[k]), gpu.process(L[k], R[k])
+        for name in ("l0", "r0", "l1", "r1"):
+            assert np.array_equal(bits(a[name]), bits(b[name])), (k, name)
+        assert np.array_equal(bits(cpu.points), bits(gpu.points)) and np.array_equal(cpu.ages, gpu.ages)
+        assert np.abs(a["tvec"] - b["tvec"]).max() <= 1e-6 and np.abs(a["R"] - b["R"]).max() <= 1e-6
+        assert a["integrated"] == b["integrated"] and a["integrated"]
+        assert np.abs(cpu.frame_pose - gpu.frame_pose).max() <= 1e-6
+    T0inv = np.linalg.inv(poses[0])
+    gt = [(T0inv @ T)[:3] for T in poses]
+    from visual_odom_amd import odometry
+    assert odometry.ate_rmse(gpu.trajectory, gt) < 0.05
