@@ -179,6 +179,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": measured_traffic(args.workload, B),
+                         # the contract prices the kernel against HBM; what binds it is VALU issue (profile-derived)
+                         "valu_issue": measured_issue(args.workload, B),
                          "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch},
         }
         if not args.no_cpu_baseline and world_size == 1:
@@ -189,6 +191,20 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     return out
+
+
+def measured_issue(workload, frames):
+    """VALU issue figures of the LK launch from the committed PMC pass (profiles/lk_issue.json): the bound this
+    kernel actually runs at; None when no pass matches this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "lk_issue.json")) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload and rec.get("frames_per_step") == frames:
+            return {k: rec[k] for k in ("valu_instructions_per_feature", "simd_cycles_per_valu_instruction",
+                                        "valu_issue_utilisation")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def measured_traffic(workload, frames):

@@ -84,6 +84,21 @@ def main(src, prefix):
                          "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; KB -> bytes; FETCH_SIZE doubled (gfx950 "
                          "correction, calibrated in profiles/r01_fetch_calibration.txt); WRITE_SIZE as reported"}
         json.dump(rec, open(os.path.join(os.path.dirname(prefix), "lk_traffic.json"), "w"), indent=1)
+    if lk and lk.get("SQ_INSTS_VALU") and lk.get("GRBM_GUI_ACTIVE") and lk.get("SQ_WAVES") and os.path.exists(bench):
+        b = json.loads(open(bench).read().strip().splitlines()[-1])
+        mean = lambda k: sum(lk[k]) / len(lk[k])
+        valu, waves, cyc = mean("SQ_INSTS_VALU"), mean("SQ_WAVES"), mean("GRBM_GUI_ACTIVE") / 8.0
+        rec = {"workload": "kitti2000", "frames_per_step": b["config"]["frames_per_step_per_gpu"],
+               "valu_instructions_per_launch": valu, "waves_per_launch": waves,
+               "valu_instructions_per_feature": valu / waves,
+               "salu_instructions_per_feature": mean("SQ_INSTS_SALU") / waves if lk.get("SQ_INSTS_SALU") else None,
+               "shader_cycles_per_launch": cyc,
+               # 1024 SIMDs; one VALU instruction of a wave64 occupies a SIMD's issue slot for 4 cycles
+               "simd_cycles_per_valu_instruction": cyc * 1024.0 / valu,
+               "valu_issue_utilisation": 4.0 * valu / (cyc * 1024.0),
+               "source": os.path.basename(prefix) + ": rocprofv3 --pmc SQ_INSTS_VALU ... GRBM_GUI_ACTIVE (its own run of "
+                         "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`), means over the lk_circular_kernel dispatches"}
+        json.dump(rec, open(os.path.join(os.path.dirname(prefix), "lk_issue.json"), "w"), indent=1)
     print(open(prefix + ".md").read()[:3000])
 
 
