@@ -87,6 +87,8 @@ struct vo_ctx {
     hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
+    long long crowded_min = 65536; // frames x points from which the 128-register pose kernels are used (VO_CROWDED_MIN)
+    int crowded_min_pts = 1024;    // ... and points per frame (VO_CROWDED_MIN_PTS)
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
     // 1241 x 376 image measured, tools/latency_mode.py)
@@ -280,6 +282,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
     // that a kernel trace shows every kernel's stand-alone duration
     {
+        const char *ec = getenv("VO_CROWDED_MIN");
+        if (ec)
+            c->crowded_min = atoll(ec);
+        const char *ep = getenv("VO_CROWDED_MIN_PTS");
+        if (ep)
+            c->crowded_min_pts = atoi(ep);
         const char *e = getenv("VO_SERIAL_POSE");
         c->serial_pose = e && e[0] == '1';
     }
@@ -656,6 +664,12 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     const int B = c->n_frames, cap = c->cap;
     const bool touches_pose = (stages & (VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) != 0;
     vo_ctx::PoseBufs &pb = c->pb[c->cur];
+    // "crowded": the LK launch of this batch keeps every SIMD full for long enough that a 512-register pose wave
+    // would starve next to it -> 128-register instantiations of the f64 pose kernels.  That takes many point-frames
+    // AND many points per frame: 256 frames x 340 points are 87 k point-frames, but LK is over in 2.4 ms and the
+    // pose chain is the long pole there -- the fast (512-register) kernels give 59 k instead of 53 k frames/s
+    // (gpurun_out/r59)
+    const bool crowded = (long long)B * c->max_pts_set >= c->crowded_min && c->max_pts_set >= c->crowded_min_pts;
     int e = 0;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
@@ -799,11 +813,11 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             hipStream_t es = c->serial_pose ? c->stream : c->stream_em;
             VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
             launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
-                             /*crowded*/ (long long)B * c->max_pts_set >= 65536, es);
+                             /*crowded*/ crowded, es);
             VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.rstate, pb.inliers, pb.results, /*crowded*/ (long long)B * c->max_pts_set >= 65536, ps);
+                   pb.rstate, pb.inliers, pb.results, /*crowded*/ crowded, ps);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
         if (timed)
