@@ -176,13 +176,11 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
     memcpy(fages.data(), ages_in, sizeof(int) * n_ages);
     int n_new = -1, n_out = -1;
     launch((w + 63) / 64, (h + 3) / 4, 1, 256, [&] { fast_score_kernel(&im, &quad, &do_detect, threshold, score.data()); });
-    launch(h, 1, 1, 256, [&] {
-        fast_nms_kernel<false>(score.data(), w, h, &do_detect, nonmax, rowcnt.data(), &n_tracked, fcap, feat.data());
-    });
+    const int segs = (w + 63) / 64;
+    std::vector<unsigned long long> nmsmask((size_t)h * segs, 0xDEADBEEFDEADBEEFull);
+    launch(h, 1, 1, 256, [&] { fast_nms_mask_kernel(score.data(), w, h, &do_detect, nonmax, nmsmask.data(), segs, rowcnt.data()); });
     launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), h, &do_detect, &n_new); });
-    launch(h, 1, 1, 256, [&] {
-        fast_nms_kernel<true>(score.data(), w, h, &do_detect, nonmax, rowcnt.data(), &n_tracked, fcap, feat.data());
-    });
+    launch(h, 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowcnt.data(), &n_tracked, fcap, feat.data()); });
     if (bucket_size <= 0) {
         const int k = n_new < out_cap ? n_new : out_cap;
         memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);

@@ -78,6 +78,7 @@ struct vo_ctx {
     vo_detect_params dprm;
     int fcap = 0;                  // capacity of the carried + detected feature list of a frame
     uint16_t *d_score = nullptr;   // [B][max_h][max_w] FAST corner flag << 8 | score
+    unsigned long long *d_nmsmask = nullptr; // [B][max_h][ceil(max_w / 64)] NMS keep ballots
     int *d_rowcnt = nullptr;       // [B][max_h]
     int *d_detect = nullptr, *d_ntracked = nullptr, *d_nnew = nullptr; // [B]
     float2 *d_feat = nullptr;      // [B][fcap] carried features, then the new corners
@@ -197,7 +198,7 @@ void vo_destroy(vo_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
-                    c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_rowcnt, c->d_detect,
+                    c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_nmsmask, c->d_rowcnt, c->d_detect,
                     c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages, c->d_pts_det[0], c->d_pts_det[1],
                     c->d_npts_det[0], c->d_npts_det[1], c->d_ages_det[0], c->d_ages_det[1]};
     for (void *p : ptrs)
@@ -343,6 +344,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     vo_default_detect_params(&c->dprm);
     c->fcap = max_pts * 4 > 16384 ? max_pts * 4 : 16384;
     ok = ok && dmalloc(&c->d_score, B * (size_t)max_w * max_h) == hipSuccess;
+    ok = ok && dmalloc(&c->d_nmsmask, B * (size_t)max_h * ((max_w + 63) / 64)) == hipSuccess;
     ok = ok && dmalloc(&c->d_rowcnt, B * (size_t)max_h) == hipSuccess;
     ok = ok && dmalloc(&c->d_detect, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_ntracked, B) == hipSuccess;
@@ -702,6 +704,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         const int cells = (c->h / bs + 1) * (c->w / bs + 1);
         if (bs < 1 || fpb < 1 || fpb > 8 || cells > 1024)
             return fail(c, VO_ERR_ARG, "vo_batch_run: bucket grid beyond 1024 cells / 8 features per bucket");
+        if (c->w > 4096)
+            return fail(c, VO_ERR_ARG, "vo_batch_run: VO_STAGE_DETECT handles images up to 4096 pixels wide");
         // appendNewFeatures only when fewer than redetect_below features were carried in (visualOdometry.cpp:95)
         bool changed = false;
         for (int f = 0; f < B; f++) {
@@ -718,7 +722,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
         launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
-                             c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
+                             c->d_nmsmask, c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
                              c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, c->stream);
         c->pts_sel = wset;
         // the bucketed count is only known on the device; every later grid is sized by its bound
@@ -1310,6 +1314,8 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
 {
     if (!c || !n_out || cap < 0 || (cap > 0 && !pts_out))
         return VO_ERR_ARG;
+    if (w > 4096)
+        return fail(c, VO_ERR_ARG, "vo_fast_detect: images up to 4096 pixels wide");
     int rc = single_image_setup(c, img, w, h, stride);
     if (rc != VO_OK)
         return rc;
@@ -1319,7 +1325,7 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     c->h_ntracked[0] = 0;
     c->detect_uploaded = false;
     threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
-    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_score, c->d_rowcnt,
+    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_score, c->d_nmsmask, c->d_rowcnt,
                          c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
                          nullptr, nullptr, 0, c->stream);
     VO_HIP_TRY(c, hipGetLastError());

@@ -20,9 +20,9 @@
 //   fast_score_kernel    thread per pixel of the level-0 image already resident for LK:
 //                        16 circle pixels -> 2 x 16-bit masks -> 9-contiguous test by shift-and,
 //                        cornerScore<16> for corners; u16 map (corner flag << 8 | score)
-//   fast_nms_kernel<W>   workgroup per image row: NMS predicate, wave ballot ranks; W = false counts
-//                        the row, W = true writes (x, y) at rows_before + rank (row-major order)
+//   fast_nms_mask_kernel workgroup per image row: NMS predicate once, one 64-bit ballot per 64-pixel segment, row count
 //   fast_rowscan_kernel  workgroup per frame: exclusive scan of the row counts
+//   fast_nms_write_kernel workgroup per image row: (x, y) at rows_before + rank from the stored ballots (row-major)
 //   bucket_kernel        workgroup per frame.  The sequential bucket fill is restated as order
 //                        statistics: a bucket ends up holding (slot 0) its LAST eligible feature if
 //                        more than fpb are eligible, else its first; (slots 1..) its 2nd..fpb-th
@@ -125,27 +125,32 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const PyrImage *__restr
     score[((size_t)frame * h + y) * w + x] = out;
 }
 
-// grid (h, n_frames), 256 threads; WRITE = false: rowcnt[frame][y]; WRITE = true: points
-template <bool WRITE>
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint16_t *__restrict__ score, int w, int h,
-                                                        const int *__restrict__ detect, int nonmax,
-                                                        int *__restrict__ rowcnt /* [B][h] (WRITE: exclusive offsets) */,
-                                                        const int *__restrict__ n_tracked, int cap,
-                                                        float2 *__restrict__ feat /* [B][cap] */)
+// Non-maximum suppression + row-major compaction in two passes without re-reading the score map:
+//   fast_nms_mask_kernel   grid (h, n_frames), 256 threads: every wavefront takes 64-pixel segments of the row
+//                          (s = wave, wave + 4, ...), evaluates the keep predicate (corner, score strictly above its 8
+//                          neighbours') and stores the 64-bit ballot of the segment; the row count is the popcount sum
+//   fast_rowscan_kernel    row counts -> exclusive offsets (row-major order = cv::FAST's keypoint order)
+//   fast_nms_write_kernel  grid (h, n_frames): segment prefix from the stored ballots, each kept pixel writes
+//                          (x, y) at rows_before + segments_before + its rank inside the ballot
+// One barrier per workgroup in each pass (the first version evaluated the predicate twice and synchronised three
+// times per 256 pixels).
+constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
+
+__global__ __launch_bounds__(256) void fast_nms_mask_kernel(const uint16_t *__restrict__ score, int w, int h,
+                                                             const int *__restrict__ detect, int nonmax,
+                                                             unsigned long long *__restrict__ mask /* [B][h][segs] */,
+                                                             int segs, int *__restrict__ rowcnt /* [B][h] */)
 {
     __shared__ int s_wave[4];
-    __shared__ int s_base;
     const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!detect[frame])
         return;
-    if (tid == 0)
-        s_base = 0;
-    __syncthreads();
     const uint16_t *__restrict__ row = score + ((size_t)frame * h + y) * w;
+    unsigned long long *__restrict__ mrow = mask + ((size_t)frame * h + y) * segs;
     const bool inner = y >= 3 && y < h - 3;
-    const int base_out = WRITE ? n_tracked[frame] + rowcnt[(size_t)frame * h + y] : 0;
-    for (int x0 = 0; x0 < w; x0 += 256) {
-        const int x = x0 + tid;
+    int cnt = 0;
+    for (int s = wv; s < segs; s += 4) {
+        const int x = s * 64 + lane;
         bool keep = false;
         if (inner && x >= 3 && x < w - 3) {
             const int c = row[x];
@@ -159,23 +164,47 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const uint16_t *__restric
         }
         const unsigned long long m = VO_BALLOT(keep);
         if (lane == 0)
-            s_wave[wv] = VO_POPCLL(m);
-        __syncthreads();
-        if (WRITE && keep) {
-            int off = s_base;
-            for (int q = 0; q < wv; q++)
-                off += s_wave[q];
-            const int o = base_out + off + VO_POPCLL(m & ((1ull << lane) - 1ull));
-            if (o < cap)
-                feat[(size_t)frame * cap + o] = make_float2((float)x, (float)y);
-        }
-        __syncthreads();
-        if (tid == 0)
-            s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
+            mrow[s] = m;
+        cnt += VO_POPCLL(m);
     }
-    if (!WRITE && tid == 0)
-        rowcnt[(size_t)frame * h + y] = s_base;
+    if (lane == 0)
+        s_wave[wv] = cnt;
+    __syncthreads();
+    if (tid == 0)
+        rowcnt[(size_t)frame * h + y] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+__global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long long *__restrict__ mask, int segs,
+                                                              int h, const int *__restrict__ detect,
+                                                              const int *__restrict__ rowoff /* [B][h] exclusive */,
+                                                              const int *__restrict__ n_tracked, int cap,
+                                                              float2 *__restrict__ feat /* [B][cap] */)
+{
+    __shared__ int s_pre[FAST_MAX_SEGS + 1];
+    const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!detect[frame])
+        return;
+    const unsigned long long *__restrict__ mrow = mask + ((size_t)frame * h + y) * segs;
+    if (tid == 0) { // segs <= 64: a serial prefix is a few dozen cycles
+        int acc = 0;
+        for (int s = 0; s < segs; s++) {
+            s_pre[s] = acc;
+            acc += VO_POPCLL(mrow[s]);
+        }
+        s_pre[segs] = acc;
+    }
+    __syncthreads();
+    if (s_pre[segs] == 0)
+        return;
+    const int base = n_tracked[frame] + rowoff[(size_t)frame * h + y];
+    for (int s = wv; s < segs; s += 4) {
+        const unsigned long long m = mrow[s];
+        if ((m >> lane) & 1ull) {
+            const int o = base + s_pre[s] + VO_POPCLL(m & ((1ull << lane) - 1ull));
+            if (o < cap)
+                feat[(size_t)frame * cap + o] = make_float2((float)(s * 64 + lane), (float)y);
+        }
+    }
 }
 
 // one 256-thread workgroup per frame: rowcnt -> exclusive offsets, n_new = total (0 when not detecting)
@@ -308,7 +337,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
 
 #ifndef VO_HOST_EMUL
 void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
-                          int h, int threshold, int nonmax, uint16_t *d_score, int *d_rowcnt,
+                          int h, int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask,
+                          int *d_rowcnt,
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
                           hipStream_t stream)
@@ -317,11 +347,12 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
         return;
     hipLaunchKernelGGL(fast_score_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(256), 0, stream, d_imgs,
                        d_quads, d_detect, threshold, d_score);
-    hipLaunchKernelGGL(fast_nms_kernel<false>, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect,
-                       nonmax, d_rowcnt, d_ntracked, cap, d_feat);
+    const int segs = (w + 63) / 64;
+    hipLaunchKernelGGL(fast_nms_mask_kernel, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect, nonmax,
+                       d_nmsmask, segs, d_rowcnt);
     hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, h, d_detect, d_nnew);
-    hipLaunchKernelGGL(fast_nms_kernel<true>, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect,
-                       nonmax, d_rowcnt, d_ntracked, cap, d_feat);
+    hipLaunchKernelGGL(fast_nms_write_kernel, dim3(h, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
+                       d_rowcnt, d_ntracked, cap, d_feat);
     if (bucket_size > 0)
         hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew,
                            cap, h, w, bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap);
