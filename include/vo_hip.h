@@ -27,6 +27,12 @@ extern "C" {
 #define VO_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define VO_ERR_STATE (-3)    /* call order violated (e.g. run before configure) */
 #define VO_ERR_TOO_FEW (-4)  /* fewer than 5 correspondences reached PnP (OpenCV would CV_Assert) */
+#define VO_ERR_OVERFLOW (-5) /* detection / bucketing produced more features than the capacity given to vo_create:
+                                the stored result is truncated and differs from the reference's -- never silent */
+/* positive return codes of the pose calls: the call worked, the reference's algorithm reported a failure */
+#define VO_NO_MODEL 1        /* solvePnPRansac returned false (no consensus); rvec / tvec hold the last hypothesis */
+#define VO_NO_ESSENTIAL 2    /* mono_rotation: findEssentialMat found no model (the reference's recoverPose throws);
+                                R_out is left untouched */
 
 typedef struct vo_ctx vo_ctx;
 
@@ -109,7 +115,8 @@ int vo_triangulate(vo_ctx *ctx, const float *P_l, const float *P_r, const float 
  * they receive the refined pose (on VO_ERR_TOO_FEW they are left untouched).  R_out (optional,
  * f64[9] row-major) = Rodrigues(rvec).  inliers (optional, int32[n]) / n_inliers as cv::Mat
  * inliers.  Iterations / threshold / confidence come from vo_params.
- * Returns VO_OK when a model was found, 1 when RANSAC found none (OpenCV returns false). */
+ * R_out is Rodrigues(rvec) whatever vo_params.mono_rotation says (that flag belongs to vo_track_frame).
+ * Returns VO_OK when a model was found, VO_NO_MODEL when RANSAC found none (OpenCV returns false). */
 int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers);
 
@@ -190,7 +197,9 @@ int vo_batch_set_projection(vo_ctx *ctx, const float *P_l, const float *P_r);
 int vo_batch_set_features(vo_ctx *ctx, int frame, const float *pts_xy, int n_pts, const int32_t *ages,
                           int n_ages);
 int vo_batch_set_detect_params(vo_ctx *ctx, const vo_detect_params *dp);
-/* the bucketed set of one frame after VO_STAGE_DETECT (after vo_batch_sync); pts [2 * cap], ages [cap] */
+/* the bucketed set of one frame after VO_STAGE_DETECT (after vo_batch_sync); pts [2 * cap], ages [cap].
+ * VO_ERR_OVERFLOW when the frame's carried + detected features or its bucketed set exceeded the capacity
+ * (*n and the arrays are still filled with the truncated set). */
 int vo_batch_get_features(vo_ctx *ctx, int frame, float *pts_xy, int32_t *ages, int *n);
 /* enqueue the selected stages for all frames on the ctx stream (asynchronous) */
 int vo_batch_run(vo_ctx *ctx, int stages);
@@ -218,6 +227,54 @@ int vo_batch_get_pose(vo_ctx *ctx, int frame, double *rvec, double *tvec, double
  * status 1 ok / 0 no model / -1 fewer than 5 points; dbg2 = samples drawn, 10 * sample + model of the winner */
 int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double *t, uint8_t *mask, int n,
                            int *n_inliers, int *n_good, int *status, int32_t *dbg2);
+/* ------------------------------------------------------------------------------------------
+ * Lock-step sequence loop: the reference's frame loop (main.cpp:123-224) for S independent sequences at
+ * once, one frame of every sequence per step, with the state that chains frame k to frame k + 1 --
+ * currentVOFeatures (points = pointsLeft_t1, visualOdometry.cpp:127; ages, feature.cpp:83-86,111, quirk B3),
+ * the previous stereo pair (main.cpp:157-158) and frame_pose (utils.cpp:84) -- resident in HBM.  Per step the
+ * host only hands over the new stereo pair of every sequence; nothing comes back until it asks.
+ * Within a sequence frames are serial, so S sequences x 1 frame is the exact-replay way to fill the GPU
+ * (BASELINE config 5: sequences 00-07, one vo_ctx per GPU, several sequences per ctx).
+ *
+ *   vo_seq_configure(ctx, S, w, h, ring, max_steps)   ring = stereo pairs resident per sequence: 2, or 3 so that
+ *                                                     the upload of pair k + 1 overlaps the step on pairs (k - 1, k)
+ *   per step:  vo_seq_push_pair(ctx, s, left, right, stride, pinned)  for every sequence that has a new pair
+ *              vo_seq_step(ctx)                                        asynchronous
+ *   A sequence processes a frame in a step iff it received a pair for this step AND for the previous one (its
+ *   first pair only builds pyramids, main.cpp:110-113); a sequence that receives nothing simply pauses.
+ *   Detection / LK / RANSAC parameters: vo_set_params (before vo_seq_configure), vo_batch_set_detect_params,
+ *   vo_batch_set_projection.
+ * ------------------------------------------------------------------------------------------ */
+#define VO_SEQ_ROW 27          /* doubles per trajectory row: frame_pose 3x4 (12), rvec (3), tvec (3), rotation (9) */
+#define VO_SEQ_INFO 8          /* ints per row: n_bucketed, n_circ, n_tracked, n_inliers, pnp_status, flags,
+                                  ransac_iters, overflow */
+#define VO_SEQ_F_ACTIVE 1      /* flags */
+#define VO_SEQ_F_INTEGRATED 2  /* the motion passed the gates of main.cpp:201 / utils.cpp:80 and was integrated */
+#define VO_SEQ_F_TOO_FEW 4     /* fewer than 5 points reached solvePnPRansac (the reference asserts) */
+#define VO_SEQ_F_NO_ESSENTIAL 8
+int vo_seq_configure(vo_ctx *ctx, int n_seq, int w, int h, int ring, int max_steps);
+/* empty feature set, identity pose, no trajectory rows, no resident pair -- for sequence `seq`, or all if seq < 0 */
+int vo_seq_reset(vo_ctx *ctx, int seq);
+/* the next stereo pair of sequence `seq` (8-bit gray, byte stride).  host_pinned = 0: pageable memory, staged
+ * through the library's pinned buffers (the call returns when the images have been copied out of the caller's
+ * memory).  host_pinned = 1: page-locked memory (hipHostMalloc / hipHostRegister / torch pin_memory) read by the
+ * copy engine directly; it must stay unchanged until the step that consumes it has finished.  Either way the
+ * transfer runs on a copy stream next to the previous step's kernels. */
+int vo_seq_push_pair(vo_ctx *ctx, int seq, const uint8_t *left, const uint8_t *right, int stride, int host_pinned);
+/* same from device memory (e.g. torch uint8 tensors) */
+int vo_seq_push_pair_dev(vo_ctx *ctx, int seq, const void *left, const void *right, int stride);
+/* enqueue one step over all sequences (asynchronous; at most VO_SEQ_INFLIGHT steps run ahead of the device) */
+int vo_seq_step(vo_ctx *ctx);
+int vo_seq_sync(vo_ctx *ctx);
+/* state of one sequence after vo_seq_sync: currentVOFeatures (points [2 * n_pts], ages [n_ages], n_ages >= n_pts)
+ * and frame_pose (4x4 row-major f64); any pointer may be NULL; caller arrays hold max_pts entries */
+int vo_seq_get_state(vo_ctx *ctx, int seq, float *pts_xy, int *n_pts, int32_t *ages, int *n_ages, double *pose16);
+/* rows [first, first + count) of the sequence's trajectory: one row per processed frame; rows27 [count][VO_SEQ_ROW],
+ * info8 [count][VO_SEQ_INFO]; *n_rows = rows available.  VO_ERR_OVERFLOW if a returned frame overflowed. */
+int vo_seq_get_trajectory(vo_ctx *ctx, int seq, int first, int count, double *rows27, int32_t *info8, int *n_rows);
+/* HIP-event duration of the last `n` steps' stages is available through vo_batch_slot_times: step k records
+ * ring slot k % VO_EVENT_SLOTS */
+
 /* one pyramid level of one image back to the host (tests): out must hold w_l*h_l bytes */
 int vo_batch_get_pyramid_level(vo_ctx *ctx, int image_idx, int level, uint8_t *out, int *w_l, int *h_l);
 

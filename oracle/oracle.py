@@ -441,3 +441,15 @@ def ref_integrate_odometry_stereo(pose, R, t):
     t = np.ascontiguousarray(t, np.float64).reshape(3)
     ref_lib().ref_integrate_odometry_stereo(_vp(pose), _vp(R), _vp(t))
     return pose
+
+
+def ref_calc_sequence_errors(poses_gt, poses_result, cap=100000):
+    """the reference's own calcSequenceErrors (src/evaluate/evaluate_odometry.cpp:71-116, compiled where it lies):
+    (k, 5) float32 rows (first_frame, r_err, t_err, len, speed)"""
+    g = np.ascontiguousarray([np.asarray(T, np.float64)[:3].reshape(12) for T in poses_gt], np.float64)
+    r = np.ascontiguousarray([np.asarray(T, np.float64)[:3].reshape(12) for T in poses_result], np.float64)
+    assert len(g) == len(r)
+    out = np.zeros((cap, 5), np.float32)
+    k = ref_lib().ref_calc_sequence_errors(_vp(g), _vp(r), len(g), _vp(out), cap)
+    assert k <= cap
+    return out[:k].copy()

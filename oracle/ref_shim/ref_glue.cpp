@@ -17,6 +17,7 @@
 #include "feature.h" /* the reference's headers, found through -I/root/reference/src */
 #include "utils.h"
 #include "visualOdometry.h"
+#include "evaluate_odometry.h" /* src/evaluate: calcSequenceErrors and friends (no OpenCV in there) */
 #include "vo_oracle.h"
 
 namespace cv {
@@ -395,6 +396,38 @@ void ref_integrate_odometry_stereo(double *frame_pose, const double *R, const do
     integrateOdometryStereo(0, rbt, pose, rot, trans);
     for (int i = 0; i < 16; i++)
         frame_pose[i] = pose.at<double>(i / 4, i % 4);
+}
+
+
+/* calcSequenceErrors(poses_gt, poses_result) (evaluate/evaluate_odometry.cpp:71-116, compiled where it lies): poses are
+ * n rows of 12 doubles (3x4 row-major, the KITTI pose-file layout loadPoses reads).  out5 [cap][5] =
+ * (first_frame, r_err, t_err, len, speed) per segment; returns the number of segments. */
+int ref_calc_sequence_errors(const double *gt12, const double *res12, int n, float *out5, int cap)
+{
+    std::vector<Matrix> G, Rr;
+    for (int i = 0; i < n; i++) {
+        Matrix a = Matrix::eye(4), b = Matrix::eye(4);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) {
+                a.val[r][c] = gt12[12 * i + 4 * r + c];
+                b.val[r][c] = res12[12 * i + 4 * r + c];
+            }
+        G.push_back(a);
+        Rr.push_back(b);
+    }
+    std::vector<errors> e = calcSequenceErrors(G, Rr);
+    int k = 0;
+    for (const errors &x : e) {
+        if (k >= cap)
+            break;
+        out5[5 * k + 0] = (float)x.first_frame;
+        out5[5 * k + 1] = x.r_err;
+        out5[5 * k + 2] = x.t_err;
+        out5[5 * k + 3] = x.len;
+        out5[5 * k + 4] = x.speed;
+        k++;
+    }
+    return (int)e.size();
 }
 
 } /* extern "C" */

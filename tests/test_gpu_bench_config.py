@@ -1,0 +1,133 @@
+"""Parity on the configuration bench.py TIMES (-m gpu).
+
+The headline number comes from a 256-frame batch: an LK grid with 32 groups of eight frames (one frame per XCD),
+the 128-register instantiations of the f64 pose kernels (`crowded`: epnp_kernel<4>, select_refine_kernel<4>,
+and the five-point / essential kernels' crowded variants), and runs k / k + 1 overlapping on three streams with a
+double-buffered hand-off.  None of that is reached by the single-frame tests, so it is held to the oracle here:
+  (a) a 64-frame KITTI-size batch (crowded, eight XCD groups), three runs enqueued back to back without a host
+      sync: every frame of the batch against the oracle (survivors + tracks bit-exact, inlier sets and RANSAC control
+      flow identical, pose <= 1e-6), and the overlapped result equal to a lone run's bit for bit;
+  (b) the crowded kernel variants forced on small inputs (VO_CROWDED_MIN = VO_CROWDED_MIN_PTS = 1): the existing
+      PnP / essential-matrix / full-path cases re-run through them;
+  (c) bench.py's own validation hook (validate_frames) is the code under (a), so the BENCH line's
+      "validated_frames" field is produced by tested code.
+Reference semantics held: feature.cpp:118-148, visualOdometry.cpp:161-189."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bench_inputs():
+    import bench
+    S = 4  # distinct rendered quadruples, walked forwards and backwards like bench.py does
+    world, lefts, rights, pts, max_level = bench.build_inputs("kitti2000", S, 20260925)
+    return bench, S, world, lefts, rights, pts
+
+
+def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs):
+    bench, S, world, lefts, rights, pts = bench_inputs
+    B = 64
+    ctx = volib.Context(0, world.w, world.h, 8192, B)
+    try:
+        frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
+        assert min(len(p) for p in frame_pts) >= 1024 and B * min(len(p) for p in frame_pts) >= 65536  # -> `crowded`
+        cache = {}
+        # a lone run, synchronised: the reference result of this test, itself checked against the oracle on all frames
+        ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        n = bench.validate_frames(ctx, range(B), lefts, rights, frame_pts, world, S, cache=cache)
+        assert n == B
+        lone = [(ctx.batch_get_filtered(b), ctx.batch_get_pose(b)) for b in (0, 7, 8, 31, 56, 63)]
+        # three runs back to back, no host sync in between (pose chain of run k under pyramid + LK of run k + 1,
+        # both PoseBufs sets and both track sets in use), then every frame again
+        for _ in range(3):
+            ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        assert bench.validate_frames(ctx, range(B), lefts, rights, frame_pts, world, S, cache=cache) == B
+        for (f0, p0), b in zip(lone, (0, 7, 8, 31, 56, 63)):
+            f1, p1 = ctx.batch_get_filtered(b), ctx.batch_get_pose(b)
+            for k in ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ"):
+                assert np.array_equal(f0[k], f1[k]), (b, k)
+            assert np.array_equal(p0["rvec"], p1["rvec"]) and np.array_equal(p0["tvec"], p1["tvec"])  # deterministic
+            assert np.array_equal(p0["inliers"], p1["inliers"])
+        # the slot-timed entry point bench.py's loop uses
+        for k in range(4):
+            ctx.batch_run_slot(volib.STAGE_ALL, k)
+        ctx.batch_sync()
+        assert bench.validate_frames(ctx, (0, 21, 42, 63), lefts, rights, frame_pts, world, S, cache=cache) == 4
+        assert all(t >= 0 for t in ctx.batch_slot_times(3))
+    finally:
+        ctx.close()
+
+
+def test_bench_configuration_detect_and_lk_only(volib, orc, bench_inputs):
+    """the other two stage sets bench.py offers (config 2 `--stages lk`, and `--stages detect+full`) on a 16-frame batch:
+    two XCD groups, DETECT output feeding LK on the device"""
+    bench, S, world, lefts, rights, pts = bench_inputs
+    B = 16
+    ctx = volib.Context(0, world.w, world.h, 8192, B)
+    try:
+        frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
+        lk = volib.STAGE_PYRAMID | volib.STAGE_LK | volib.STAGE_FILTER
+        ctx.batch_run(lk)
+        ctx.batch_run(lk)
+        ctx.batch_sync()
+        assert bench.validate_frames(ctx, range(B), lefts, rights, frame_pts, world, S, full=False) == B
+        for b in range(B):
+            ctx.batch_set_features(b, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+        ctx.batch_set_detect_params(features_per_bucket=6)
+        for _ in range(2):
+            ctx.batch_run(volib.STAGE_ALL | volib.STAGE_DETECT)
+        ctx.batch_sync()
+        h, w = lefts[0].shape
+        det_pts = []
+        for b in range(B):
+            got_p, got_a = ctx.batch_get_features(b)
+            if b < 2 * S:  # the distinct t0 images of the batch
+                fast = orc.fast_detect(lefts[bench.tri(b, S)], 20, True)
+                ref_p, ref_a = orc.bucketing_features(h, w, fast, np.zeros(len(fast), np.int32), h // 10, 6)
+                assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a), b
+            det_pts.append(got_p)
+        assert bench.validate_frames(ctx, range(B), lefts, rights, det_pts, world, S) == B
+    finally:
+        ctx.batch_set_detect_params()
+        ctx.close()
+
+
+@pytest.fixture()
+def crowded_ctx(volib, monkeypatch):
+    """a context whose `crowded` predicate is always true: every pose launch takes the 128-register instantiations"""
+    monkeypatch.setenv("VO_CROWDED_MIN", "1")
+    monkeypatch.setenv("VO_CROWDED_MIN_PTS", "1")
+    ctx = volib.Context(0, 1241, 376, 8192, 4)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,outliers,noise,seed", [(400, 0.0, 0.0, 1), (1500, 0.3, 0.15, 2), (60, 0.5, 0.2, 3),
+                                                   (3000, 0.1, 0.05, 4), (6, 0.0, 0.05, 5)])
+def test_crowded_pnp_kernels(crowded_ctx, orc, n, outliers, noise, seed):
+    import test_gpu_parity as t
+    t.test_pnp_ransac_dropin(crowded_ctx, orc, n, outliers, noise, seed)
+
+
+def test_crowded_pnp_edge_cases(crowded_ctx, volib, orc):
+    import test_gpu_parity as t
+    t.test_pnp_ransac_edge_cases(crowded_ctx, volib, orc)
+
+
+@pytest.mark.parametrize("n,outliers,seed", [(300, 0.0, 1), (2000, 0.3, 2), (60, 0.5, 3), (5, 0.0, 5), (6, 0.0, 6)])
+def test_crowded_essential_kernels(crowded_ctx, orc, n, outliers, seed):
+    import test_gpu_parity as t
+    t.test_essential_pose_dropin(crowded_ctx, orc, n, outliers, seed)
+
+
+def test_crowded_full_path_and_batch(crowded_ctx, volib, orc, kitti_world, kitti_seq, small_world, small_seq):
+    import test_gpu_parity as t
+    t.test_track_frame_full_path_kitti(crowded_ctx, orc, kitti_world, kitti_seq)
+    t.test_track_frame_mono_rotation(crowded_ctx, orc, kitti_world, kitti_seq)
+    t.test_batch_ragged_equals_single(crowded_ctx, volib, orc, small_world, small_seq)

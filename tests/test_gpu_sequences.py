@@ -1,0 +1,234 @@
+"""Lock-step sequence loop (vo_seq_*, -m gpu): S independent sequences advance one frame per step with the feature
+state, the previous stereo pair and frame_pose carried on the device.  The checker is the body of the reference's
+main() loop run through the reference's OWN sources (oracle/_ref: matchingFeatures, trackingFrame2Frame,
+rotationMatrixToEulerAngles, integrateOdometryStereo over the oracle's OpenCV restatement), one independent loop
+per sequence.  Bars: feature state (points, ages incl. the longer-ages quirk B3) BIT-EXACT after every frame,
+rvec / tvec / frame_pose <= 1e-6, identical gating; long sequence: ATE <= 1e-3 m."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _worlds(n, **kw):
+    from visual_odom_amd import synth
+    return [synth.StereoWorld(seed=100 + 7 * s, **kw) for s in range(n)]
+
+
+SMALL = dict(width=480, height=160, fx=300.0, cx=239.5, cy=79.5, bf=-160.0, tex_size=1024)
+
+
+def _check_state(vo, s, loop, where):
+    pts, ages, pose = vo.state(s)
+    assert np.array_equal(bits(pts), bits(loop.points)), (where, s, "points")
+    assert np.array_equal(ages, loop.ages), (where, s, "ages")
+    assert np.abs(pose - loop.frame_pose).max() <= 1e-6, (where, s, "frame_pose")
+
+
+def test_lockstep_sequences_equal_independent_reference_loops(volib, orc):
+    """8 sequences x 20 frames, ring of 3 pairs; sequence 6 starts three steps late, sequence 7 ends five steps
+    early and sequence 5 pauses for two steps; the first half is checked after every step, the second half runs
+    without any host synchronisation (steps in flight, uploads on the copy stream under the kernels)"""
+    from visual_odom_amd import odometry
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref was not shipped")
+    S, N = 8, 20
+    worlds = _worlds(S, **SMALL)
+    seqs = [w.render_sequence(N) for w in worlds]
+    P_l, P_r = worlds[0].proj_matrices()
+    ctx = volib.Context(0, 480, 160, 4096, S)
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, S, 480, 160, ctx=ctx, ring=3, max_steps=64)
+        loops = [orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3]) for _ in range(S)]
+        fed = [0] * S  # pairs fed per sequence
+
+        def wants(s, step):
+            if s == 6:
+                return step >= 3
+            if s == 7:
+                return step < N - 5
+            if s == 5:
+                return step not in (8, 9)
+            return True
+
+        for step in range(N):
+            for s in range(S):
+                if wants(s, step) and fed[s] < N:
+                    L, R = seqs[s][0][fed[s]], seqs[s][1][fed[s]]
+                    vo.push(s, L, R)
+                    if s == 5 and step == 10:
+                        loops[s].prev = None  # the pair before the pause is gone: the reference loop restarts its images
+                    loops[s].process(L, R)
+                    fed[s] += 1
+            vo.step()
+            if step < N // 2:
+                for s in range(S):
+                    _check_state(vo, s, loops[s], step)
+        for s in range(S):
+            _check_state(vo, s, loops[s], "end")
+            traj = vo.trajectory(s)
+            assert len(traj) == len(loops[s].trajectory), s
+            assert odometry.ate_rmse(traj, loops[s].trajectory) <= 1e-6
+            log = vo.log(s)
+            assert all(r["flags"] & volib.SEQ_F_ACTIVE for r in log) and all(r["overflow"] == 0 for r in log)
+            assert sum(r["integrated"] for r in log) >= len(log) - 1
+            # and it is the planted motion
+            T0inv = np.linalg.inv(seqs[s][2][0])
+            if s not in (5, 6, 7):
+                gt = [(T0inv @ T)[:3] for T in seqs[s][2]]
+                assert odometry.ate_rmse(traj, gt) < 0.5
+    finally:
+        ctx.close()
+
+
+def test_lockstep_ring_of_two_six_per_bucket_against_the_oracle_chain(volib, orc, small_world):
+    """ring = 2 (the upload of the next pair has to wait for the LK that still reads the slot), detection parameters
+    other than the reference's (3 per bucket), checked against the oracle's functions chained like matchingFeatures /
+    trackingFrame2Frame / integrateOdometryStereo; the same sequence runs in two slots, one fed from pageable memory,
+    one from device memory"""
+    import torch
+    from visual_odom_amd import odometry
+    n = 9
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    K = small_world.K()
+    h, w = L[0].shape
+    ctx = volib.Context(0, w, h, 4096, 2)
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, 2, w, h, ctx=ctx, ring=2, max_steps=16, features_per_bucket=3)
+        dev = [(torch.from_numpy(np.ascontiguousarray(L[k])).cuda(), torch.from_numpy(np.ascontiguousarray(R[k])).cuda())
+               for k in range(n)]
+        torch.cuda.synchronize()
+        o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
+        o_pose, o_t = np.eye(4), np.zeros(3)
+        for k in range(n):
+            vo.push(0, L[k], R[k])
+            ctx.seq_push_pair_dev(1, dev[k][0].data_ptr(), dev[k][1].data_ptr(), w)
+            vo.step()
+            if k == 0:
+                continue
+            l0, r0, l1, r1 = L[k - 1], R[k - 1], L[k], R[k]
+            if len(o_pts) < 2000:
+                fast = orc.fast_detect(l0, 20, True)
+                o_pts = np.vstack([o_pts, fast])
+                o_ages = np.concatenate([o_ages, np.zeros(len(fast), np.int32)])
+            bp, ba = orc.bucketing_features(h, w, o_pts, o_ages, h // 10, 3)
+            cm = orc.circular_matching(l0, r0, l1, r1, bp, ages=ba)
+            (pl0, pr0, pl1, pr1), _ = orc.check_valid_and_remove(cm["l0"], cm["r0"], cm["l1"], cm["r1"], cm["l0_ret"])
+            o_pts, o_ages = pl1, cm["ages"]
+            xyz = orc.triangulate(P_l, P_r, pl0, pr0)
+            rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(xyz, pl1, K, tvec=o_t)
+            o_t = tv
+            Rm = orc.rodrigues(rv)
+            e = orc.rotation_matrix_to_euler(Rm)
+            if abs(e[1]) < 0.1 and abs(e[0]) < 0.1 and abs(e[2]) < 0.1:
+                o_pose, _ = orc.integrate_odometry_stereo(o_pose, Rm, tv)
+            for s in (0, 1):
+                pts, ages, pose = vo.state(s)
+                assert np.array_equal(bits(pts), bits(o_pts)) and np.array_equal(ages, o_ages), (k, s)
+                assert np.abs(pose - o_pose).max() <= 1e-6
+                rec = vo.log(s)[-1]
+                assert (rec["n_bucketed"], rec["n_circ"], rec["n_tracked"], rec["n_inliers"]) == \
+                    (len(bp), len(cm["l0"]), len(pl1), len(inl)), (k, s)
+                assert np.abs(rec["rvec"] - rv).max() <= 1e-6 and np.abs(rec["tvec"] - tv).max() <= 1e-6
+                assert rec["ransac_iters"] == int(dbg[0]) and rec["pnp_status"] == rc
+        assert len(vo.trajectory(0)) == n
+    finally:
+        ctx.close()
+
+
+def test_long_sequence_kitti_size_against_the_reference_loop(volib, orc, kitti_world):
+    """a long KITTI-00-shaped sequence (1241 x 376, reference-default bucketing = 1 feature per bucket,
+    <= 374 points) through the product -- 200 frames forwards in slot 0, the first 100 of them played backwards in
+    slot 1 -- against the reference's own frame loop (oracle/_ref): feature state bit-exact after EVERY frame,
+    per-frame pose <= 1e-6, ATE <= 1e-3 m (observed ~1e-12), plus the KITTI segment errors of the run
+    (evaluate_odometry.cpp:71-116) against the planted trajectory"""
+    from visual_odom_amd import odometry
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref was not shipped")
+    n = int(os.environ.get("VO_LONG_TEST_FRAMES", "200")) + 1
+    L, R, poses, _ = kitti_world.render_sequence(n)
+    m = n // 2 + 1
+    feeds = [list(range(n)), list(range(m - 1, -1, -1))]
+    P_l, P_r = kitti_world.proj_matrices()
+    ctx = volib.Context(0, 1241, 376, 4096, 2)
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, 2, 1241, 376, ctx=ctx, ring=3, max_steps=n + 8)
+        loops = [orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3]) for _ in range(2)]
+        for step in range(n):
+            for s in (0, 1):
+                if step < len(feeds[s]):
+                    k = feeds[s][step]
+                    vo.push(s, L[k], R[k])
+                    loops[s].process(L[k], R[k])
+            vo.step()
+            for s in (0, 1):
+                if step < len(feeds[s]):
+                    _check_state(vo, s, loops[s], step)
+        for s in (0, 1):
+            traj = vo.trajectory(s)
+            assert len(traj) == len(feeds[s]) == len(loops[s].trajectory)
+            assert odometry.ate_rmse(traj, loops[s].trajectory) <= 1e-3          # the stated bar
+            assert np.abs(np.asarray(traj) - np.asarray(loops[s].trajectory)).max() <= 1e-6
+            log = vo.log(s)
+            assert all(200 <= r["n_bucketed"] <= 374 for r in log) and all(r["overflow"] == 0 for r in log)
+        # against the planted camera path: ATE and the KITTI segment errors of the forward run
+        T0inv = np.linalg.inv(poses[0])
+        gt = [(T0inv @ T) for T in poses]
+        traj = vo.trajectory(0)
+        ate = odometry.ate_rmse(traj, [T[:3] for T in gt])
+        summ = odometry.sequence_error_summary(gt, traj, lengths=(25, 50, 100, 150))
+        print("long sequence: %d frames, ATE %.3f m over %.0f m, segment errors %s" % (
+            n - 1, ate, float(odometry.trajectory_distances(gt)[-1]), summ))
+        assert ate < 0.02 * float(odometry.trajectory_distances(gt)[-1])
+        assert summ is not None and summ["t_err_percent"] < 3.0
+    finally:
+        ctx.close()
+
+
+def test_sequence_loop_guards(volib, small_world):
+    L, R, poses, _ = small_world.render_sequence(2)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    ctx = volib.Context(0, w, h, 1024, 2)
+    try:
+        with pytest.raises(volib.VoError) as e:
+            ctx.seq_step()
+        assert e.value.code == volib.VO_ERR_STATE
+        with pytest.raises(volib.VoError):
+            ctx.seq_configure(3, w, h, 3, 8)            # more sequences than max_frames
+        ctx.seq_configure(2, w, h, 2, 8)
+        ctx.batch_set_projection(P_l, P_r)
+        ctx.seq_push_pair(0, L[0], R[0])
+        with pytest.raises(volib.VoError) as e:         # one pair per sequence per step
+            ctx.seq_push_pair(0, L[1], R[1])
+        assert e.value.code == volib.VO_ERR_STATE
+        with pytest.raises(volib.VoError) as e:         # the batch entry points are closed while the loop owns the batch
+            ctx.batch_run(volib.STAGE_ALL)
+        assert e.value.code == volib.VO_ERR_STATE
+        ctx.seq_step()
+        ctx.seq_push_pair(0, L[1], R[1])
+        ctx.seq_step()
+        pts, ages, pose = ctx.seq_get_state(0)
+        assert len(pts) > 20 and len(ages) >= len(pts)
+        pts1, ages1, pose1 = ctx.seq_get_state(1)        # never fed: untouched
+        assert len(pts1) == 0 and len(ages1) == 0 and np.array_equal(pose1, np.eye(4))
+        rows, info = ctx.seq_get_trajectory(0)
+        assert rows.shape == (1, volib.SEQ_ROW) and info[0][5] & volib.SEQ_F_ACTIVE
+        assert ctx.seq_get_trajectory(1)[0].shape[0] == 0
+        ctx.seq_reset(0)
+        assert len(ctx.seq_get_state(0)[0]) == 0 and ctx.seq_get_trajectory(0)[0].shape[0] == 0
+        # the drop-in calls leave the loop cleanly
+        got = ctx.circular_match(L[0], R[0], L[1], R[1], pts[:10])
+        assert got["n_out"] <= 10
+        with pytest.raises(volib.VoError):
+            ctx.seq_step()
+    finally:
+        ctx.close()

@@ -1,0 +1,90 @@
+#!/bin/bash
+# Round-2 GPU session driver.  Usage (from the authoring container):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r2.sh <tag> <part> [<part> ...]'
+# parts: tests ubench bench seq seqhost prof pmc latency
+TAG=${1:-r2}
+shift
+PARTS="$*"
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT" || exit 1
+export TMPDIR=/tmp
+t0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a "$OUT/timeline.log"; }
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+
+if has tests; then
+    stamp "pytest -m gpu"
+    timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > "$OUT/pytest.log" 2>&1
+    stamp "pytest rc=$?"
+    tail -25 "$OUT/pytest.log"
+fi
+if has newtests; then
+    stamp "pytest (new files only)"
+    timeout 1200 python -m pytest tests/test_gpu_bench_config.py tests/test_gpu_sequences.py -m gpu -x -q --durations=10 > "$OUT/pytest_new.log" 2>&1
+    stamp "pytest rc=$?"
+    tail -40 "$OUT/pytest_new.log"
+fi
+if has ubench; then
+    stamp "VALU issue-cost micro-benchmark"
+    (cd tools/ubench && timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w valu_rate.hip -o /tmp/valu_rate && timeout 120 /tmp/valu_rate) > "$OUT/valu_rate.log" 2>&1
+    cat "$OUT/valu_rate.log"
+    (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/ubench_pmc" -- /tmp/valu_rate --quick > "$OUT/ubench_pmc.log" 2>&1)
+    python tools/ubench_table.py "$OUT/ubench_pmc" > "$OUT/valu_issue_cost_pmc.txt" 2>&1
+    cat "$OUT/valu_issue_cost_pmc.txt"
+fi
+if has bench; then
+    stamp "bench (default)"
+    timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    cat "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+fi
+if has bench374; then
+    stamp "bench (reference-default load)"
+    timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 > "$OUT/bench_kitti374.json" 2> "$OUT/bench_kitti374.err"
+    cat "$OUT/bench_kitti374.json"; tail -3 "$OUT/bench_kitti374.err"
+fi
+if has seq; then
+    for S in 256 64 8 1; do
+        stamp "bench --mode sequences --seqs $S (reference-default bucketing, pairs resident in HBM)"
+        timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate $([ $S = 256 ] && echo 3 || echo 0) > "$OUT/bench_seq_${S}.json" 2> "$OUT/bench_seq_${S}.err"
+        cat "$OUT/bench_seq_${S}.json"; tail -3 "$OUT/bench_seq_${S}.err"
+    done
+    stamp "bench --mode sequences, ~2000 points per frame"
+    timeout 600 python bench.py --mode sequences --workload kitti2000 --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 2 > "$OUT/bench_seq2000_256.json" 2> "$OUT/bench_seq2000_256.err"
+    cat "$OUT/bench_seq2000_256.json"; tail -3 "$OUT/bench_seq2000_256.err"
+fi
+if has seqhost; then
+    for ING in pinned host; do
+        for S in 256 8; do
+            stamp "bench --mode sequences --seqs $S --ingest $ING (PCIe-inclusive)"
+            timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 --ingest $ING > "$OUT/bench_seq_${S}_${ING}.json" 2> "$OUT/bench_seq_${S}_${ING}.err"
+            cat "$OUT/bench_seq_${S}_${ING}.json"; tail -3 "$OUT/bench_seq_${S}_${ING}.err"
+        done
+    done
+fi
+if has latency; then
+    stamp "latency mode of the drop-in boundary"
+    timeout 300 python tools/latency_mode.py 40 > "$OUT/latency.log" 2>&1
+    cat "$OUT/latency.log"
+fi
+if has prof; then
+    cd /tmp
+    stamp "rocprofv3 kernel trace (overlapped, as benched)"
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_overlap" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/prof_overlap.log" 2>&1
+    stamp "rocprofv3 kernel trace (sequence mode)"
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_seq" -- python "$ROOT/bench.py" --mode sequences --workload kitti374 --seqs 256 --steps 10 --warmup 2 --no-cpu-baseline --validate 0 > "$OUT/prof_seq.log" 2>&1
+    cd "$ROOT"
+fi
+if has pmc; then
+    cd /tmp
+    stamp "rocprofv3 pmc SQ pass (LK instruction counts)"
+    timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_sq.log" 2>&1
+    stamp "rocprofv3 pmc FETCH_SIZE"
+    timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_fetch.log" 2>&1
+    stamp "rocprofv3 pmc WRITE_SIZE"
+    timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_write.log" 2>&1
+    cd "$ROOT"
+fi
+stamp "done"
+du -sh "$OUT"

@@ -11,7 +11,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libvo_hip.so")
 
-VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW = 0, -1, -2, -3, -4
+VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW, VO_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
+VO_NO_MODEL, VO_NO_ESSENTIAL = 1, 2
+SEQ_ROW, SEQ_INFO = 27, 8
+SEQ_F_ACTIVE, SEQ_F_INTEGRATED, SEQ_F_TOO_FEW, SEQ_F_NO_ESSENTIAL = 1, 2, 4, 8
+SEQ_INFO_NAMES = ("n_bucketed", "n_circ", "n_tracked", "n_inliers", "pnp_status", "flags", "ransac_iters", "overflow")
 STAGE_PYRAMID, STAGE_LK, STAGE_FILTER, STAGE_TRIANGULATE, STAGE_PNP, STAGE_ALL = 1, 2, 4, 8, 16, 31
 STAGE_DETECT = 32
 EVENT_SLOTS = 256
@@ -27,6 +31,8 @@ EXPORTS = (
     "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
+    "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_step", "vo_seq_sync",
+    "vo_seq_get_state", "vo_seq_get_trajectory",
 )
 
 
@@ -250,7 +256,7 @@ class Context:
                                                w, h, w, _p(pts), n, _p(P_l), _p(P_r), _p(o[0]), _p(o[1]),
                                                _p(o[2]), _p(o[3]), _p(xyz), _p(keep), C.byref(n_out),
                                                _p(keepc), C.byref(n_circ), _p(rv), _p(tv), _p(R), _p(inl),
-                                               C.byref(ninl)), allow=(1, VO_ERR_TOO_FEW))
+                                               C.byref(ninl)), allow=(VO_NO_MODEL, VO_NO_ESSENTIAL, VO_ERR_TOO_FEW))
         k = n_out.value
         return dict(rc=rc, l0=o[0][:k].copy(), r0=o[1][:k].copy(), l1=o[2][:k].copy(), r1=o[3][:k].copy(),
                     xyz=xyz[:k].copy(), keep_idx=keep[:k].copy(), keep_idx_circ=keepc[:n_circ.value].copy(),
@@ -354,6 +360,49 @@ class Context:
                                                   C.byref(good), C.byref(status), _p(dbg)))
         return dict(E=E, R=R, t=t, mask=mask[:n].copy(), n_inliers=ninl.value, n_good=good.value,
                     status=status.value, niters=int(dbg[0]), best=int(dbg[1]))
+
+    # ---- lock-step sequence loop ------------------------------------------------------------
+    def seq_configure(self, n_seq, w, h, ring=3, max_steps=1024):
+        self._chk(self.lib.vo_seq_configure(self.h, n_seq, w, h, ring, max_steps))
+        self.n_frames = n_seq
+
+    def seq_reset(self, seq=-1):
+        self._chk(self.lib.vo_seq_reset(self.h, seq))
+
+    def seq_push_pair(self, seq, left, right, pinned=False):
+        """left / right: uint8 (h, w) numpy arrays (pinned=True: views of page-locked memory that stay untouched
+        until the step has run)"""
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        self._chk(self.lib.vo_seq_push_pair(self.h, seq, _p(left), _p(right), left.shape[1], int(bool(pinned))))
+
+    def seq_push_pair_dev(self, seq, left_ptr, right_ptr, stride):
+        self._chk(self.lib.vo_seq_push_pair_dev(self.h, seq, C.c_void_p(left_ptr), C.c_void_p(right_ptr), stride))
+
+    def seq_step(self):
+        self._chk(self.lib.vo_seq_step(self.h))
+
+    def seq_sync(self):
+        self._chk(self.lib.vo_seq_sync(self.h))
+
+    def seq_get_state(self, seq):
+        """(points (n, 2) f32, ages (m,) i32 with m >= n, frame_pose 4x4 f64) of one sequence"""
+        pts = np.zeros((self.max_pts, 2), np.float32)
+        ages = np.zeros(self.max_pts, np.int32)
+        pose = np.zeros((4, 4))
+        n, m = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.vo_seq_get_state(self.h, seq, _p(pts), C.byref(n), _p(ages), C.byref(m), _p(pose)))
+        return pts[:n.value].copy(), ages[:m.value].copy(), pose
+
+    def seq_get_trajectory(self, seq, first=0, count=None):
+        """rows (k, 27) f64 = frame_pose 3x4 | rvec | tvec | rotation 3x3, info (k, 8) i32 (SEQ_INFO_NAMES)"""
+        n = C.c_int(0)
+        self._chk(self.lib.vo_seq_get_trajectory(self.h, seq, 0, 0, None, None, C.byref(n)))
+        k = max(0, n.value - first) if count is None else max(0, min(count, n.value - first))
+        rows = np.zeros((max(k, 1), SEQ_ROW))
+        info = np.zeros((max(k, 1), SEQ_INFO), np.int32)
+        self._chk(self.lib.vo_seq_get_trajectory(self.h, seq, first, k, _p(rows), _p(info), C.byref(n)))
+        return rows[:k].copy(), info[:k].copy()
 
     def batch_get_pyramid_level(self, idx, level):
         w, h = C.c_int(0), C.c_int(0)

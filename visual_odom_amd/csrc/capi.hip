@@ -3,6 +3,7 @@
 // message retrievable through vo_last_error().
 #include "../../include/vo_hip.h"
 #include "vo_kernels.h"
+#include "vo_integrate.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -13,6 +14,9 @@
 #include <vector>
 
 using namespace vo;
+
+#define VO_SEQ_INFLIGHT 8 // steps the host may run ahead of the device
+#define VO_SEQ_MAX_RING 3
 
 struct vo_ctx {
     int device = 0;
@@ -100,6 +104,37 @@ struct vo_ctx {
     float h_P[24] = {};
     bool have_P = false;
     std::vector<int> h_npts;
+    int *d_overflow = nullptr;     // [B] VO_STAGE_DETECT capacity flags (bit 0: feature list, bit 1: bucketed set)
+    Quad *quads_cur = nullptr;     // the quad table the launches read: d_quads, or one phase of seq.d_quads
+    std::vector<Quad> h_quads;     // host copy of d_quads (stale-pyramid check)
+    std::vector<uint8_t> img_stale; // image re-uploaded since its pyramid was last built
+    // ---- lock-step sequence loop (vo_seq_*): S sequences x 1 frame per step, state carried on the device ----
+    struct Seq {
+        bool on = false;
+        int S = 0, ring = 0, max_steps = 0;
+        long long step = 0;           // steps enqueued so far
+        Quad *d_quads = nullptr;      // [ring][S]: phase r = (t0 in ring slot r, t1 in slot (r + 1) % ring)
+        int *d_active = nullptr;      // [VO_SEQ_INFLIGHT][S]
+        int *h_active = nullptr;      // pinned, same shape
+        double *d_pose = nullptr;     // [S][16]
+        double *d_traj = nullptr;     // [S][max_steps][VO_SEQ_ROW]
+        SeqFrameInfo *d_info = nullptr; // [S][max_steps]
+        int *d_rows = nullptr, *d_rows_carry = nullptr, *d_nages = nullptr; // [S]
+        std::vector<uint8_t> pushed, had_prev; // pair pushed for the pending step / for the previous step
+        hipStream_t copy = nullptr;
+        hipEvent_t ev_upload = nullptr, ev_carry = nullptr;
+        hipEvent_t ev_slot_free[VO_SEQ_MAX_RING] = {}; // the LK that read ring slot r as its t0 pair has finished
+        bool slot_busy[VO_SEQ_MAX_RING] = {};
+        bool carry_pending = false;
+        hipEvent_t ev_step[VO_SEQ_INFLIGHT] = {};
+        bool step_pending[VO_SEQ_INFLIGHT] = {};
+        // pinned staging for pageable host images: two generations of [S][2] pitched level-0 images
+        uint8_t *h_stage = nullptr;
+        size_t stage_img = 0;
+        hipEvent_t ev_stage[2] = {};
+        bool stage_busy[2] = {};
+        bool slot_waited = false; // the copy stream already waits for the pending slot to be free
+    } seq;
 };
 
 #define VO_STAGE_SLOTS 4
@@ -122,6 +157,12 @@ int fail(vo_ctx *ctx, int code, const char *msg)
 }
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+// "crowded": the LK launch of a batch keeps every SIMD full for long enough that a 512-register pose wave would
+// starve next to it -> the 128-register instantiations of the f64 pose kernels (see run_stages)
+inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
+{
+    return frames * pts >= c->crowded_min && pts >= c->crowded_min_pts;
+}
 // the current feature set (see vo_ctx::pts_sel)
 inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
 inline int *cur_npts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_npts : c->d_npts_det[c->pts_sel]; }
@@ -163,6 +204,32 @@ hipError_t dmalloc(T **p, size_t n)
 
 static int sync_all(vo_ctx *c);
 
+static void seq_free(vo_ctx *c)
+{
+    vo_ctx::Seq &q = c->seq;
+    void *ptrs[] = {q.d_quads, q.d_active, q.d_pose, q.d_traj, q.d_info, q.d_rows, q.d_rows_carry, q.d_nages};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (q.h_active)
+        (void)hipHostFree(q.h_active);
+    if (q.h_stage)
+        (void)hipHostFree(q.h_stage);
+    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_stage[0], q.ev_stage[1]};
+    for (hipEvent_t e : evs)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto &e : q.ev_slot_free)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto &e : q.ev_step)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (q.copy)
+        (void)hipStreamDestroy(q.copy);
+    q = vo_ctx::Seq();
+}
+
 extern "C" {
 
 void vo_default_params(vo_params *p)
@@ -200,10 +267,11 @@ void vo_destroy(vo_ctx *c)
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
                     c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_nmsmask, c->d_rowcnt, c->d_detect,
                     c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages, c->d_pts_det[0], c->d_pts_det[1],
-                    c->d_npts_det[0], c->d_npts_det[1], c->d_ages_det[0], c->d_ages_det[1]};
+                    c->d_npts_det[0], c->d_npts_det[1], c->d_ages_det[0], c->d_ages_det[1], c->d_overflow};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
+    seq_free(c);
     for (auto &b : c->pb) {
         void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results,
                      b.em_results};
@@ -263,7 +331,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->max_h = max_h;
     c->cap = max_pts;
     c->max_frames = max_frames;
-    c->max_images = 4 * max_frames;
+    c->max_images = 6 * max_frames; // 4 per frame for independent quads; 2 x ring (<= 3) per sequence of the lock-step loop
     vo_default_params(&c->prm);
     c->ransac_cap = 1000;
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
@@ -342,7 +410,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && hipMemset(b.nB, 0, B * sizeof(int)) == hipSuccess;
     }
     vo_default_detect_params(&c->dprm);
+    // carried + detected features of one frame before bucketing: cv::FAST on a textured image returns one corner
+    // per ~20-40 pixels at most (non-maximum suppression leaves no two adjacent corners); beyond this capacity the
+    // DETECT stage reports VO_ERR_OVERFLOW instead of silently bucketing a truncated list
     c->fcap = max_pts * 4 > 16384 ? max_pts * 4 : 16384;
+    if ((long long)max_w * max_h / 16 > c->fcap)
+        c->fcap = (int)((long long)max_w * max_h / 16);
     ok = ok && dmalloc(&c->d_score, B * (size_t)max_w * max_h) == hipSuccess;
     ok = ok && dmalloc(&c->d_nmsmask, B * (size_t)max_h * ((max_w + 63) / 64)) == hipSuccess;
     ok = ok && dmalloc(&c->d_rowcnt, B * (size_t)max_h) == hipSuccess;
@@ -352,6 +425,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_feat, B * (size_t)c->fcap) == hipSuccess;
     ok = ok && dmalloc(&c->d_fages, B * (size_t)c->fcap) == hipSuccess;
     ok = ok && dmalloc(&c->d_ages, B * cap) == hipSuccess;
+    ok = ok && dmalloc(&c->d_overflow, B) == hipSuccess;
+    ok = ok && hipMemset(c->d_overflow, 0, B * sizeof(int)) == hipSuccess;
     for (int k = 0; k < 2; k++) {
         ok = ok && dmalloc(&c->d_pts_det[k], B * cap) == hipSuccess;
         ok = ok && dmalloc(&c->d_npts_det[k], B) == hipSuccess;
@@ -374,6 +449,9 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         return nullptr;
     }
     c->h_npts.assign(B, 0);
+    c->h_quads.assign(B, Quad{0, 0, 0, 0});
+    c->img_stale.assign((size_t)c->max_images, 0);
+    c->quads_cur = c->d_quads;
     return c;
 }
 
@@ -406,6 +484,14 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
         h < 32 || w > c->max_w || h > c->max_h)
         return fail(c, VO_ERR_ARG, "vo_batch_configure: size beyond the capacity given to vo_create");
     VO_HIP_TRY(c, hipSetDevice(c->device));
+    if (c->seq.on) { // leaving the lock-step sequence loop: its steps may still be in flight
+        int rcs = sync_all(c);
+        if (rcs != VO_OK)
+            return rcs;
+        c->seq.on = false;
+        c->quads_cur = c->d_quads;
+        c->n_images = 0; // force the full re-plan below
+    }
     if (c->n_images == n_images && c->w == w && c->h == h && c->n_frames == n_frames) {
         c->pyr_first = 0; // a (re)configure always restores "build every pyramid"
         c->pyr_count = n_images;
@@ -441,6 +527,10 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     c->max_pts_set = 0;
     std::fill(c->h_npts.begin(), c->h_npts.end(), 0);
     std::fill(c->h_ntracked.begin(), c->h_ntracked.end(), 0);
+    std::fill(c->img_stale.begin(), c->img_stale.end(), 0);
+    std::fill(c->h_quads.begin(), c->h_quads.end(), Quad{0, 0, 0, 0});
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_quads, 0, sizeof(Quad) * c->max_frames, c->stream));
+    VO_HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(int) * c->max_frames, c->stream));
     c->detect_uploaded = false; // the per-frame detect flags on the device belong to the previous batch shape
     VO_HIP_TRY(c, hipMemsetAsync(c->d_npts, 0, sizeof(int) * c->max_frames, c->stream));
     c->pts_sel = -1;
@@ -457,8 +547,14 @@ static int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemc
         return fail(c, VO_ERR_STATE, "upload before vo_batch_configure");
     if (idx < 0 || idx >= c->n_images || !src || stride < c->w)
         return fail(c, VO_ERR_ARG, "vo_batch_upload_image: bad index / stride");
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_upload_image inside the sequence loop: use vo_seq_push_pair");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX;
+    // the pyramid levels, borders and Scharr images of this image now belong to the previous pixels: LK / DETECT
+    // refuse to read it until VO_STAGE_PYRAMID has covered it again (the contiguous host copy below also
+    // overwrites the level-0 border columns with staging bytes)
+    c->img_stale[idx] = 1;
     if (kind == hipMemcpyHostToDevice) {
         // repack to the device pitch in pinned memory, then one contiguous copy from pixel (0, 0) to the
         // last interior pixel.  The bytes between two rows land in border columns, which the pyramid
@@ -501,9 +597,12 @@ int vo_batch_set_quads(vo_ctx *c, const int32_t *quads4, int n_frames)
     for (int i = 0; i < 4 * n_frames; i++)
         if (quads4[i] < 0 || quads4[i] >= c->n_images)
             return fail(c, VO_ERR_ARG, "vo_batch_set_quads: image index out of range");
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_quads inside the sequence loop");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     VO_HIP_TRY(c, hipMemcpyAsync(c->d_quads, quads4, sizeof(Quad) * n_frames, hipMemcpyHostToDevice, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_quads.data(), quads4, sizeof(Quad) * n_frames);
     return VO_OK;
 }
 
@@ -524,6 +623,8 @@ int vo_batch_set_points(vo_ctx *c, int frame, const float *pts, int n)
 {
     if (!c)
         return VO_ERR_ARG;
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_points inside the sequence loop (vo_seq_* owns the feature state)");
     if (frame < 0 || frame >= c->n_frames || n < 0 || n > c->cap || (n > 0 && !pts))
         return fail(c, VO_ERR_ARG, "vo_batch_set_points: bad frame / more points than max_pts");
     int rcs = sync_all(c); // a queued filter of the previous run still reads the points
@@ -559,6 +660,8 @@ int vo_batch_set_features(vo_ctx *c, int frame, const float *pts, int n_pts, con
         return VO_ERR_ARG;
     if (c->n_images == 0)
         return fail(c, VO_ERR_STATE, "vo_batch_set_features before vo_batch_configure");
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_set_features inside the sequence loop (vo_seq_* owns the feature state)");
     if (frame < 0 || frame >= c->n_frames || n_pts < 0 || n_ages < n_pts || n_ages > c->fcap ||
         (n_pts > 0 && !pts) || (n_ages > 0 && !ages))
         return fail(c, VO_ERR_ARG, "vo_batch_set_features: bad frame / counts (need n_pts <= n_ages <= capacity)");
@@ -610,8 +713,14 @@ int vo_batch_get_features(vo_ctx *c, int frame, float *pts, int32_t *ages, int *
     if (ages && k > 0)
         VO_HIP_TRY(c, hipMemcpyAsync(ages, cur_ages(c) + (size_t)frame * c->cap, sizeof(int) * k, hipMemcpyDeviceToHost,
                                      c->stream));
+    int ovf = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(&ovf, c->d_overflow + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n = k;
+    if (ovf)
+        return fail(c, VO_ERR_OVERFLOW, ovf & 1 ? "VO_STAGE_DETECT: carried + detected features exceed the feature-list "
+                                                  "capacity (4 x max_pts, >= 16384, >= w * h / 16): bucketed set truncated"
+                                                : "VO_STAGE_DETECT: the bucketed set exceeds max_pts");
     return VO_OK;
 }
 
@@ -671,7 +780,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // AND many points per frame: 256 frames x 340 points are 87 k point-frames, but LK is over in 2.4 ms and the
     // pose chain is the long pole there -- the fast (512-register) kernels give 59 k instead of 53 k frames/s
     // (gpurun_out/r59)
-    const bool crowded = (long long)B * c->max_pts_set >= c->crowded_min && c->max_pts_set >= c->crowded_min_pts;
+    const bool crowded = is_crowded(c, B, c->max_pts_set);
     int e = 0;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
@@ -686,6 +795,17 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                 launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
             }
             launch_scharr(tab, ni, c->levels, c->lw, c->lh, c->stream);
+            std::fill(c->img_stale.begin() + c->pyr_first, c->img_stale.begin() + c->pyr_first + ni, (uint8_t)0);
+        }
+    }
+    vo_ctx::Seq &sq = c->seq;
+    const int *seq_active = sq.on ? sq.d_active + (size_t)(sq.step % VO_SEQ_INFLIGHT) * sq.S : nullptr;
+    if (!sq.on && (stages & VO_STAGE_LK)) {
+        for (int f = 0; f < B; f++) {
+            const Quad &q = c->h_quads[f];
+            if (c->img_stale[q.l0] | c->img_stale[q.r0] | c->img_stale[q.l1] | c->img_stale[q.r1])
+                return fail(c, VO_ERR_STATE, "vo_batch_run: VO_STAGE_LK on an image uploaded after its pyramid was last "
+                                             "built (run VO_STAGE_PYRAMID over it first)");
         }
     }
     if (timed)
@@ -707,23 +827,34 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         if (c->w > 4096)
             return fail(c, VO_ERR_ARG, "vo_batch_run: VO_STAGE_DETECT handles images up to 4096 pixels wide");
         // appendNewFeatures only when fewer than redetect_below features were carried in (visualOdometry.cpp:95)
-        bool changed = false;
-        for (int f = 0; f < B; f++) {
-            const int d = c->h_ntracked[f] < c->dprm.redetect_below ? 1 : 0;
-            changed |= d != c->h_detect[f];
-            c->h_detect[f] = d;
-        }
-        if (changed || !c->detect_uploaded) {
-            VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, c->h_detect.data(), sizeof(int) * B, hipMemcpyHostToDevice,
-                                         c->stream));
-            VO_HIP_TRY(c, hipStreamSynchronize(c->stream)); // h_detect is reused by the next call
-            c->detect_uploaded = true;
+        if (sq.on) {
+            // the carried set lives on the device (seq_carry_kernel of the previous step wrote it on the filter stream)
+            if (sq.carry_pending) {
+                VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_carry, 0));
+                sq.carry_pending = false;
+            }
+            launch_seq_prepare(seq_active, c->d_ntracked, c->dprm.redetect_below, c->d_detect, B, c->stream);
+            c->detect_uploaded = false;
+        } else {
+            bool changed = false;
+            for (int f = 0; f < B; f++) {
+                const int d = c->h_ntracked[f] < c->dprm.redetect_below ? 1 : 0;
+                changed |= d != c->h_detect[f];
+                c->h_detect[f] = d;
+            }
+            if (changed || !c->detect_uploaded) {
+                VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, c->h_detect.data(), sizeof(int) * B, hipMemcpyHostToDevice,
+                                             c->stream));
+                VO_HIP_TRY(c, hipStreamSynchronize(c->stream)); // h_detect is reused by the next call
+                c->detect_uploaded = true;
+            }
         }
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
-        launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
+        launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
                              c->d_nmsmask, c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
-                             c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, c->stream);
+                             c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
+                             c->d_overflow, c->stream);
         c->pts_sel = wset;
         // the bucketed count is only known on the device; every later grid is sized by its bound
         const int bound = cells * fpb < cap ? cells * fpb : cap;
@@ -743,10 +874,16 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        launch_lk_circular(c->d_imgs, c->d_quads, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
+        launch_lk_circular(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
                            c->d_status2[wset], lp, c->stream);
         c->trk_last = wset;
         c->trk_next = wset ^ 1;
+        if (sq.on) { // the ring slots holding this step's pairs may be overwritten once this LK has finished
+            const int r0 = (int)((sq.step - 1) % sq.ring), r1 = (int)(sq.step % sq.ring);
+            VO_HIP_TRY(c, hipEventRecord(sq.ev_slot_free[r0], c->stream));
+            VO_HIP_TRY(c, hipEventRecord(sq.ev_slot_free[r1], c->stream));
+            sq.slot_busy[r0] = sq.slot_busy[r1] = true;
+        }
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream)); // evs[3]: end of LK on the tracking stream
@@ -776,8 +913,21 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (stages & VO_STAGE_FILTER) {
         launch_compact(cur_pts(c), c->d_trk2[c->trk_last], c->d_status2[c->trk_last], cur_npts(c), cap,
                        c->prm.consistency_threshold, c->d_outA, c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
+        if (sq.on) { // currentVOFeatures of every sequence after this frame (seq.hip)
+            launch_seq_carry(seq_active, pb.outB, pb.nB, c->d_idxA, c->d_nA, cur_ages(c), cur_npts(c), cap, c->fcap,
+                             c->d_feat, c->d_fages, c->d_ntracked, c->d_overflow, sq.d_rows_carry, sq.d_nages, sq.d_info,
+                             sq.max_steps, B, fs);
+            VO_HIP_TRY(c, hipEventRecord(sq.ev_carry, fs));
+            sq.carry_pending = true;
+        }
         VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->trk_last], fs));
         c->trk_busy[c->trk_last] = true;
+        if (c->pts_sel >= 0 && c->pts_sel != c->trk_last) {
+            // the points / ages this filter read belong to the OTHER set (a run without DETECT after a run with it):
+            // the next DETECT into that set must wait for this filter too
+            VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->pts_sel], fs));
+            c->trk_busy[c->pts_sel] = true;
+        }
     }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[5]
@@ -824,6 +974,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                    pb.rstate, pb.inliers, pb.results, /*crowded*/ crowded, ps);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
+        if (sq.on) // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
+            launch_seq_integrate(seq_active, pb.results, c->prm.mono_rotation ? pb.em_results : nullptr, sq.d_pose,
+                                 sq.d_traj, sq.d_info, sq.d_rows, sq.max_steps, B, ps);
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
         VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
@@ -847,6 +1000,8 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
+    if (c->seq.copy)
+        VO_HIP_TRY(c, hipStreamSynchronize(c->seq.copy));
     return VO_OK;
 }
 
@@ -854,6 +1009,8 @@ int vo_batch_run(vo_ctx *c, int stages)
 {
     if (!c)
         return VO_ERR_ARG;
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_run inside the sequence loop: use vo_seq_step");
     return run_stages(c, stages, false);
 }
 
@@ -861,6 +1018,8 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
 {
     if (!c || !ms)
         return VO_ERR_ARG;
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_run_timed inside the sequence loop: use vo_seq_step");
     int rc = run_stages(c, stages, true);
     if (rc != VO_OK)
         return rc;
@@ -876,6 +1035,8 @@ int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
 {
     if (!c || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
+    if (c->seq.on)
+        return fail(c, VO_ERR_STATE, "vo_batch_run_slot inside the sequence loop: use vo_seq_step");
     return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)]);
 }
 
@@ -980,8 +1141,10 @@ static int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, fl
     return VO_OK;
 }
 
-int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
-                      int *n_inliers, int *status, int32_t *dbg4)
+// pnp_rotation: R = Rodrigues(rvec) even under mono_rotation (vo_pnp_ransac).  em_status (optional): status of the
+// essential-matrix side of the frame under mono_rotation (1 ok, 0 no model, -1 too few points), 1 otherwise.
+static int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
+                         int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -999,15 +1162,19 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
             memcpy(rvec, r.rvec, sizeof(r.rvec));
         if (tvec)
             memcpy(tvec, r.tvec, sizeof(r.tvec));
-        if (R && !c->prm.mono_rotation)
+        if (R && (pnp_rotation || !c->prm.mono_rotation))
             memcpy(R, r.R, sizeof(r.R)); // `if (!mono_rotation) Rodrigues(rvec, rotation)` (visualOdometry.cpp:186-189)
     }
-    if (R && c->prm.mono_rotation && c->em_ready) {
+    if (em_status)
+        *em_status = 1;
+    if (!pnp_rotation && c->prm.mono_rotation && c->em_ready) {
         // rotation = recoverPose's; left untouched when no essential matrix was found (OpenCV throws there)
         EmResult e;
         VO_HIP_TRY(c, hipMemcpy(&e, pb.em_results + frame, sizeof(e), hipMemcpyDeviceToHost));
-        if (e.status == 1)
+        if (e.status == 1 && R)
             memcpy(R, e.R, sizeof(e.R));
+        if (em_status)
+            *em_status = e.status;
     }
     if (inliers && r.n_inliers > 0) {
         D2H(inliers, pb.inliers + (size_t)frame * c->cap, sizeof(int32_t) * r.n_inliers);
@@ -1024,6 +1191,12 @@ int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *
         dbg4[3] = r.lm_iters;
     }
     return VO_OK;
+}
+
+int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
+                      int *n_inliers, int *status, int32_t *dbg4)
+{
+    return get_pose_impl(c, frame, rvec, tvec, R, inliers, n_inliers, status, dbg4, false, nullptr);
 }
 
 int vo_batch_get_essential(vo_ctx *c, int frame, double *E, double *R, double *t, uint8_t *mask, int n,
@@ -1092,8 +1265,8 @@ int vo_essential_pose(vo_ctx *c, const float *pts0, const float *pts1, int n, do
     ep.prob = prob;
     ep.threshold = threshold;
     ep.max_iters = EM_MAX_ITERS;
-    launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results, /*crowded*/ false,
-                     c->stream);
+    launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results,
+                     /*crowded*/ is_crowded(c, 1, n), c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     int status = 0, good = 0;
     int rc = vo_batch_get_essential(c, 0, E, R, t, mask, n, nullptr, &good, &status, nullptr);
@@ -1154,6 +1327,302 @@ int vo_model_bytes(const vo_ctx *c, int w, int h, int n_points, double *b)
     // B_lk = 4 hops x N x [(L+1) x ((win+3)^2 + (win+1)^2) + 8 + 8 + 1]
     b[1] = 4.0 * n_points * ((L + 1) * (576.0 + 484.0) + 17.0);
     b[2] = 48.0 * n_points + 48.0;
+    return VO_OK;
+}
+
+
+/* ---------------------------------- lock-step sequence loop -------------------------------- */
+
+int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    if (n_seq < 1 || n_seq > c->max_frames || ring < 2 || ring > VO_SEQ_MAX_RING || max_steps < 1 ||
+        2 * ring * n_seq > c->max_images)
+        return fail(c, VO_ERR_ARG, "vo_seq_configure: need 1 <= n_seq <= max_frames, ring 2 or 3, "
+                                   "2 * ring * n_seq <= 6 * max_frames images");
+    // image table: ring slot r holds the pairs [r][s] = images (r * S + s) * 2 + {0 left, 1 right}, so that the
+    // pairs a step receives are one contiguous range for the pyramid stage
+    int rc = vo_batch_configure(c, 2 * ring * n_seq, w, h, n_seq);
+    if (rc != VO_OK)
+        return rc;
+    rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    seq_free(c);
+    vo_ctx::Seq &q = c->seq;
+    const size_t S = (size_t)n_seq;
+    q.S = n_seq;
+    q.ring = ring;
+    q.max_steps = max_steps;
+    bool ok = hipStreamCreateWithFlags(&q.copy, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && dmalloc(&q.d_quads, (size_t)ring * S) == hipSuccess;
+    ok = ok && dmalloc(&q.d_active, (size_t)VO_SEQ_INFLIGHT * S) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&q.h_active, sizeof(int) * VO_SEQ_INFLIGHT * S, hipHostMallocDefault) == hipSuccess;
+    ok = ok && dmalloc(&q.d_pose, S * 16) == hipSuccess;
+    ok = ok && dmalloc(&q.d_traj, S * (size_t)max_steps * VO_SEQ_ROW) == hipSuccess;
+    ok = ok && dmalloc(&q.d_info, S * (size_t)max_steps) == hipSuccess;
+    ok = ok && dmalloc(&q.d_rows, S) == hipSuccess;
+    ok = ok && dmalloc(&q.d_rows_carry, S) == hipSuccess;
+    ok = ok && dmalloc(&q.d_nages, S) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q.ev_upload, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q.ev_carry, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : q.ev_slot_free)
+        ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : q.ev_step)
+        ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : q.ev_stage)
+        ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        seq_free(c);
+        return fail(c, VO_ERR_HIP, "vo_seq_configure: allocation failed");
+    }
+    std::vector<Quad> tab((size_t)ring * S);
+    for (int r = 0; r < ring; r++)
+        for (int s = 0; s < n_seq; s++) {
+            const int a = (r * n_seq + s) * 2, b = (((r + 1) % ring) * n_seq + s) * 2;
+            tab[(size_t)r * S + s] = Quad{a, a + 1, b, b + 1};
+        }
+    VO_HIP_TRY(c, hipMemcpy(q.d_quads, tab.data(), sizeof(Quad) * tab.size(), hipMemcpyHostToDevice));
+    VO_HIP_TRY(c, hipMemset(q.d_info, 0, sizeof(SeqFrameInfo) * S * (size_t)max_steps));
+    q.pushed.assign(S, 0);
+    q.had_prev.assign(S, 0);
+    q.step = 0;
+    q.on = true;
+    return vo_seq_reset(c, -1);
+}
+
+int vo_seq_reset(vo_ctx *c, int seq)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_ctx::Seq &q = c->seq;
+    if (!q.on)
+        return fail(c, VO_ERR_STATE, "vo_seq_reset before vo_seq_configure");
+    if (seq >= q.S)
+        return fail(c, VO_ERR_ARG, "vo_seq_reset: bad sequence");
+    int rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    const int s0 = seq < 0 ? 0 : seq, s1 = seq < 0 ? q.S : seq + 1;
+    double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int s = s0; s < s1; s++) {
+        VO_HIP_TRY(c, hipMemcpy(q.d_pose + (size_t)s * 16, eye, sizeof(eye), hipMemcpyHostToDevice));
+        q.pushed[s] = q.had_prev[s] = 0;
+    }
+    const size_t n = (size_t)(s1 - s0);
+    VO_HIP_TRY(c, hipMemset(q.d_rows + s0, 0, sizeof(int) * n));
+    VO_HIP_TRY(c, hipMemset(q.d_rows_carry + s0, 0, sizeof(int) * n));
+    VO_HIP_TRY(c, hipMemset(q.d_nages + s0, 0, sizeof(int) * n));
+    VO_HIP_TRY(c, hipMemset(c->d_ntracked + s0, 0, sizeof(int) * n));
+    VO_HIP_TRY(c, hipMemset(c->d_fages + (size_t)s0 * c->fcap, 0, sizeof(int) * n * c->fcap));
+    return VO_OK;
+}
+
+// ring slot the pending step's new pairs go to, and the copy stream made to wait until the LK that still reads
+// that slot's previous occupant has finished
+static int seq_pending_slot(vo_ctx *c, int *slot)
+{
+    vo_ctx::Seq &q = c->seq;
+    const int r = (int)(q.step % q.ring);
+    if (!q.slot_waited) {
+        if (q.slot_busy[r]) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_slot_free[r], 0));
+            q.slot_busy[r] = false;
+        }
+        q.slot_waited = true;
+    }
+    *slot = r;
+    return VO_OK;
+}
+
+static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode /*0 pageable, 1 pinned, 2 device*/)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_ctx::Seq &q = c->seq;
+    if (!q.on)
+        return fail(c, VO_ERR_STATE, "vo_seq_push_pair before vo_seq_configure");
+    if (seq < 0 || seq >= q.S || !left || !right || stride < c->w)
+        return fail(c, VO_ERR_ARG, "vo_seq_push_pair: bad sequence / image / stride");
+    if (q.pushed[seq])
+        return fail(c, VO_ERR_STATE, "vo_seq_push_pair: this sequence already has a pair for the pending step");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    int r = 0;
+    int rc = seq_pending_slot(c, &r);
+    if (rc != VO_OK)
+        return rc;
+    const void *src[2] = {left, right};
+    const size_t pitch = (size_t)c->lstride[0];
+    for (int side = 0; side < 2; side++) {
+        const int idx = (r * q.S + seq) * 2 + side;
+        uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0] + (size_t)VO_BY * pitch + VO_BX;
+        if (mode == 0) {
+            // pageable: repack to the device pitch in pinned memory, one contiguous copy (bytes between rows land
+            // in border columns, which this step's pyramid stage rewrites)
+            const int g = (int)(q.step & 1);
+            if (!q.h_stage) {
+                q.stage_img = pitch * (size_t)c->h;
+                VO_HIP_TRY(c, hipHostMalloc((void **)&q.h_stage, q.stage_img * 2 * 2 * (size_t)q.S, hipHostMallocDefault));
+            }
+            if (q.stage_busy[g]) { // the transfers of step - 2 out of this half of the staging area
+                VO_HIP_TRY(c, hipEventSynchronize(q.ev_stage[g]));
+                q.stage_busy[g] = false;
+            }
+            uint8_t *slot = q.h_stage + (((size_t)g * q.S + seq) * 2 + side) * q.stage_img;
+            for (int y = 0; y < c->h; y++)
+                memcpy(slot + (size_t)y * pitch, (const uint8_t *)src[side] + (size_t)y * stride, (size_t)c->w);
+            VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, pitch * (size_t)(c->h - 1) + (size_t)c->w, hipMemcpyHostToDevice,
+                                         q.copy));
+        } else {
+            VO_HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src[side], (size_t)stride, (size_t)c->w, (size_t)c->h,
+                                           mode == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, q.copy));
+        }
+    }
+    q.pushed[seq] = 1;
+    return VO_OK;
+}
+
+int vo_seq_push_pair(vo_ctx *c, int seq, const uint8_t *left, const uint8_t *right, int stride, int host_pinned)
+{
+    return seq_push(c, seq, left, right, stride, host_pinned ? 1 : 0);
+}
+
+int vo_seq_push_pair_dev(vo_ctx *c, int seq, const void *left, const void *right, int stride)
+{
+    return seq_push(c, seq, left, right, stride, 2);
+}
+
+int vo_seq_step(vo_ctx *c)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_ctx::Seq &q = c->seq;
+    if (!q.on)
+        return fail(c, VO_ERR_STATE, "vo_seq_step before vo_seq_configure");
+    if (!c->have_P)
+        return fail(c, VO_ERR_STATE, "vo_seq_step: projection matrices not set");
+    VO_HIP_TRY(c, hipSetDevice(c->device));
+    const int slot = (int)(q.step % VO_SEQ_INFLIGHT);
+    if (q.step_pending[slot]) { // bounds the host's run-ahead; frees this slot of the pinned flag ring
+        VO_HIP_TRY(c, hipEventSynchronize(q.ev_step[slot]));
+        q.step_pending[slot] = false;
+    }
+    int r = 0;
+    int rc = seq_pending_slot(c, &r); // (a step without any push still claims its ring slot)
+    if (rc != VO_OK)
+        return rc;
+    // a sequence processes a frame iff it has a pair for this step and had one for the previous step
+    int *act = q.h_active + (size_t)slot * q.S;
+    int n_active = 0;
+    for (int s = 0; s < q.S; s++) {
+        act[s] = (q.pushed[s] && q.had_prev[s]) ? 1 : 0;
+        n_active += act[s];
+        q.had_prev[s] = q.pushed[s];
+        q.pushed[s] = 0;
+    }
+    // uploads of this step's pairs (copy stream) -> pyramids (tracking stream)
+    VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
+    if (q.h_stage) {
+        const int g = (int)(q.step & 1);
+        VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));
+        q.stage_busy[g] = true;
+    }
+    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
+    q.slot_waited = false;
+    c->pyr_first = r * q.S * 2;
+    c->pyr_count = q.S * 2;
+    int stages = VO_STAGE_PYRAMID;
+    if (n_active > 0) {
+        VO_HIP_TRY(c, hipMemcpyAsync(q.d_active + (size_t)slot * q.S, act, sizeof(int) * q.S, hipMemcpyHostToDevice,
+                                     c->stream));
+        c->quads_cur = q.d_quads + (size_t)((q.step - 1) % q.ring) * q.S;
+        stages |= VO_STAGE_DETECT | VO_STAGE_LK | VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP;
+    }
+    rc = run_stages(c, stages, true, &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_NUM_STAGES + 2)]);
+    if (rc != VO_OK)
+        return rc;
+    // end of the step = end of its last stream: the pose stream when a frame was processed
+    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && !c->serial_pose ? c->stream_pnp : c->stream));
+    q.step_pending[slot] = true;
+    q.step++;
+    return VO_OK;
+}
+
+int vo_seq_sync(vo_ctx *c)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    int rc = sync_all(c);
+    if (rc == VO_OK)
+        for (auto &p : c->seq.step_pending)
+            p = false;
+    return rc;
+}
+
+int vo_seq_get_state(vo_ctx *c, int seq, float *pts, int *n_pts, int32_t *ages, int *n_ages, double *pose16)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_ctx::Seq &q = c->seq;
+    if (!q.on)
+        return fail(c, VO_ERR_STATE, "vo_seq_get_state before vo_seq_configure");
+    if (seq < 0 || seq >= q.S)
+        return fail(c, VO_ERR_ARG, "vo_seq_get_state: bad sequence");
+    int rc = vo_seq_sync(c);
+    if (rc != VO_OK)
+        return rc;
+    int np = 0, na = 0;
+    VO_HIP_TRY(c, hipMemcpy(&np, c->d_ntracked + seq, sizeof(int), hipMemcpyDeviceToHost));
+    VO_HIP_TRY(c, hipMemcpy(&na, q.d_nages + seq, sizeof(int), hipMemcpyDeviceToHost));
+    if (pts && np > 0)
+        VO_HIP_TRY(c, hipMemcpy(pts, c->d_feat + (size_t)seq * c->fcap, sizeof(float2) * np, hipMemcpyDeviceToHost));
+    if (ages && na > 0)
+        VO_HIP_TRY(c, hipMemcpy(ages, c->d_fages + (size_t)seq * c->fcap, sizeof(int) * na, hipMemcpyDeviceToHost));
+    if (pose16)
+        VO_HIP_TRY(c, hipMemcpy(pose16, q.d_pose + (size_t)seq * 16, sizeof(double) * 16, hipMemcpyDeviceToHost));
+    if (n_pts)
+        *n_pts = np;
+    if (n_ages)
+        *n_ages = na;
+    return VO_OK;
+}
+
+int vo_seq_get_trajectory(vo_ctx *c, int seq, int first, int count, double *rows, int32_t *info, int *n_rows)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_ctx::Seq &q = c->seq;
+    if (!q.on)
+        return fail(c, VO_ERR_STATE, "vo_seq_get_trajectory before vo_seq_configure");
+    if (seq < 0 || seq >= q.S || first < 0 || count < 0)
+        return fail(c, VO_ERR_ARG, "vo_seq_get_trajectory: bad sequence / range");
+    int rc = vo_seq_sync(c);
+    if (rc != VO_OK)
+        return rc;
+    int n = 0;
+    VO_HIP_TRY(c, hipMemcpy(&n, q.d_rows + seq, sizeof(int), hipMemcpyDeviceToHost));
+    n = n < q.max_steps ? n : q.max_steps;
+    if (n_rows)
+        *n_rows = n;
+    const int k = first + count <= n ? count : (first < n ? n - first : 0);
+    static_assert(sizeof(SeqFrameInfo) == VO_SEQ_INFO * sizeof(int32_t), "SeqFrameInfo layout is the public info8 row");
+    if (k > 0 && rows)
+        VO_HIP_TRY(c, hipMemcpy(rows, q.d_traj + ((size_t)seq * q.max_steps + first) * VO_SEQ_ROW,
+                                sizeof(double) * VO_SEQ_ROW * k, hipMemcpyDeviceToHost));
+    bool ovf = false;
+    if (k > 0) {
+        std::vector<SeqFrameInfo> tmp((size_t)k);
+        VO_HIP_TRY(c, hipMemcpy(tmp.data(), q.d_info + (size_t)seq * q.max_steps + first, sizeof(SeqFrameInfo) * k,
+                                hipMemcpyDeviceToHost));
+        for (const SeqFrameInfo &f : tmp)
+            ovf |= f.overflow != 0;
+        if (info)
+            memcpy(info, tmp.data(), sizeof(SeqFrameInfo) * k);
+    }
+    if (ovf)
+        return fail(c, VO_ERR_OVERFLOW, "vo_seq_get_trajectory: a frame's detection / bucketing exceeded the capacity "
+                                        "given to vo_create (its result is truncated)");
     return VO_OK;
 }
 
@@ -1251,17 +1720,19 @@ int vo_triangulate(vo_ctx *c, const float *P_l, const float *P_r, const float *p
 }
 
 static int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
-                      int *n_inliers)
+                      int *n_inliers, bool pnp_rotation)
 {
-    int status = 0, ninl = 0;
-    int rc = vo_batch_get_pose(c, 0, rvec_io, tvec_io, R_out, inliers, &ninl, &status, nullptr);
+    int status = 0, ninl = 0, em_status = 1;
+    int rc = get_pose_impl(c, 0, rvec_io, tvec_io, R_out, inliers, &ninl, &status, nullptr, pnp_rotation, &em_status);
     if (rc != VO_OK)
         return rc;
     if (n_inliers)
         *n_inliers = ninl;
     if (status < 0)
         return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached solvePnPRansac");
-    return status == 1 ? VO_OK : 1;
+    if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
+        return VO_NO_ESSENTIAL;
+    return status == 1 ? VO_OK : VO_NO_MODEL;
 }
 
 int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
@@ -1289,9 +1760,9 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, /*crowded*/ false, c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, /*crowded*/ is_crowded(c, 1, n), c->stream);
     VO_HIP_TRY(c, hipGetLastError());
-    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
+    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }
 
 // one image as a 1-frame batch whose quad points at image 0 four times
@@ -1327,7 +1798,7 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
     launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_score, c->d_nmsmask, c->d_rowcnt,
                          c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
-                         nullptr, nullptr, 0, c->stream);
+                         nullptr, nullptr, 0, nullptr, nullptr, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     int n = 0;
     VO_HIP_TRY(c, hipMemcpyAsync(&n, c->d_nnew, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1376,67 +1847,7 @@ int vo_integrate_odometry(double *pose, const double *R, const double *t, float 
 {
     if (!pose || !R || !t)
         return VO_ERR_ARG;
-    // rotationMatrixToEulerAngles: f64 arithmetic stored to float, x and z swapped w.r.t. MATLAB
-    const float sy = (float)sqrt(R[0] * R[0] + R[3] * R[3]);
-    float ex, ey, ez;
-    if (!(sy < 1e-6)) {
-        ex = (float)atan2(R[7], R[8]);
-        ey = (float)atan2(-R[6], (double)sy);
-        ez = (float)atan2(R[3], R[0]);
-    } else {
-        ex = (float)atan2(-R[5], R[4]);
-        ey = (float)atan2(-R[6], (double)sy);
-        ez = 0.f;
-    }
-    if (euler_out) {
-        euler_out[0] = ex;
-        euler_out[1] = ey;
-        euler_out[2] = ez;
-    }
-    if (!(fabsf(ey) < 0.1f && fabsf(ex) < 0.1f && fabsf(ez) < 0.1f))
-        return 0; // "Too large rotation" (main.cpp:201-207)
-    const double scale = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
-    if (!(scale > 0.05 && scale < 10))
-        return 0; // utils.cpp:80-90
-    // inverse of the 4x4 [R|t; 0 0 0 1] by Gauss-Jordan elimination with partial pivoting (what
-    // cv::Mat::inv() DECOMP_LU amounts to for a well-conditioned 4x4)
-    double a[4][8];
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 8; j++)
-            a[i][j] = j < 4 ? (i < 3 ? (j < 3 ? R[3 * i + j] : t[i]) : (j == 3 ? 1.0 : 0.0)) : (j - 4 == i ? 1.0 : 0.0);
-    for (int col = 0; col < 4; col++) {
-        int piv = col;
-        for (int r = col + 1; r < 4; r++)
-            if (fabs(a[r][col]) > fabs(a[piv][col]))
-                piv = r;
-        if (fabs(a[piv][col]) < 1e-300)
-            return 0;
-        if (piv != col)
-            for (int j = 0; j < 8; j++) {
-                const double tmp = a[col][j];
-                a[col][j] = a[piv][j];
-                a[piv][j] = tmp;
-            }
-        const double d = 1.0 / a[col][col];
-        for (int j = 0; j < 8; j++)
-            a[col][j] *= d;
-        for (int r = 0; r < 4; r++)
-            if (r != col) {
-                const double f = a[r][col];
-                for (int j = 0; j < 8; j++)
-                    a[r][j] -= f * a[col][j];
-            }
-    }
-    double out[16];
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double sum = 0;
-            for (int k = 0; k < 4; k++)
-                sum += pose[4 * i + k] * a[k][4 + j];
-            out[4 * i + j] = sum;
-        }
-    memcpy(pose, out, sizeof(out));
-    return 1;
+    return integrate_odometry(pose, R, t, euler_out); // vo_integrate.h: the code the sequence loop runs on the device
 }
 
 int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w,
@@ -1460,7 +1871,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
                                n_circ);
     if (rc != VO_OK)
         return rc;
-    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers);
+    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ false);
 }
 
 } // extern "C"

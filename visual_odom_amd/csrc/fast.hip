@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
                                                      const int *__restrict__ n_new, int cap, int rows, int cols,
                                                      int bucket_size, int fpb, float2 *__restrict__ out_pts,
                                                      int *__restrict__ out_ages, int *__restrict__ out_n,
-                                                     int out_cap)
+                                                     int out_cap, const int *__restrict__ active /* or null */,
+                                                     int *__restrict__ overflow /* or null */)
 {
     __shared__ int s_cnt[BK_MAX_CELLS], s_last[BK_MAX_CELLS];
     __shared__ int s_first[BK_MAX_FPB][BK_MAX_CELLS];
@@ -264,7 +265,18 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
     const float2 *__restrict__ P = feat + (size_t)frame * cap;
     const int *__restrict__ A = ages + (size_t)frame * cap;
+    if (active && !active[frame]) { // lock-step sequence loop: this sequence has no frame in this step
+        if (tid == 0) {
+            out_n[frame] = 0;
+            if (overflow)
+                overflow[frame] = 0;
+        }
+        return;
+    }
     int n_in = n_tracked[frame] + n_new[frame];
+    // Capacity: carried + detected features beyond `cap` were not stored (fast_nms_write_kernel), and bucketing keeps
+    // the LAST eligible feature of a cell, so a truncated list changes the result -- reported, never silent
+    const bool list_overflow = n_in > cap;
     n_in = n_in < cap ? n_in : cap;
 
     for (int b = tid; b < nb; b += 256) {
@@ -316,6 +328,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
             acc += t;
         }
         out_n[frame] = acc < out_cap ? acc : out_cap;
+        if (overflow)
+            overflow[frame] = (list_overflow ? 1 : 0) | (acc > out_cap ? 2 : 0);
     }
     __syncthreads();
     int off = s_scan[tid];
@@ -341,7 +355,7 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                           int *d_rowcnt,
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
-                          hipStream_t stream)
+                          const int *d_active, int *d_overflow, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
@@ -355,7 +369,7 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                        d_rowcnt, d_ntracked, cap, d_feat);
     if (bucket_size > 0)
         hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew,
-                           cap, h, w, bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap);
+                           cap, h, w, bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow);
 }
 #endif
 

@@ -1,0 +1,163 @@
+// seq.hip -- device-side state hand-off of the reference's frame loop, for S sequences in lock step.
+//
+// The reference processes ONE sequence, one frame after another (main.cpp:123-224): frame k + 1 starts from the
+// feature set frame k left behind (currentVOFeatures.points = pointsLeft_t1, visualOdometry.cpp:127; ages compacted by
+// deleteUnmatchFeaturesCircle only, feature.cpp:83-86,111 -- quirk B3 of SURVEY.md), from the images of frame k
+// (main.cpp:157-158) and from frame_pose (utils.cpp:84).  Within a sequence that chain is serial, so the exact way
+// to fill the chip is S independent sequences x 1 frame per step (vo_seq_* in include/vo_hip.h).  These kernels
+// keep the chain on the device; per step the host only hands over the new stereo pairs:
+//   seq_prepare_kernel    `if (currentVOFeatures.size() < 2000) appendNewFeatures(...)`  visualOdometry.cpp:95-101
+//   seq_carry_kernel      currentVOFeatures after the frame: points = pointsLeft_t1 (the K consistency-filter
+//                         survivors), ages = (bucketed ages + 1) compacted with the M >= K circular-matching survivors
+//                         -- the ages array keeps the longer length, so the next frame's first M - K new corners
+//                         inherit stale ages exactly like the reference
+//   seq_integrate_kernel  rotationMatrixToEulerAngles + gates + integrateOdometryStereo  main.cpp:196-208,
+//                         utils.cpp:57-131 (vo_integrate.h, the same code vo_integrate_odometry() runs on the host),
+//                         one trajectory row per processed frame
+#include "vo_kernels.h"
+#include "vo_integrate.h"
+
+namespace vo {
+
+__global__ void seq_prepare_kernel(const int *__restrict__ active, const int *__restrict__ n_tracked,
+                                   int redetect_below, int *__restrict__ detect, int n_seq)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_seq)
+        detect[f] = (active[f] && n_tracked[f] < redetect_below) ? 1 : 0;
+}
+
+// one 256-thread workgroup per sequence
+__global__ __launch_bounds__(256) void seq_carry_kernel(const int *__restrict__ active,
+                                                        const float2 *__restrict__ outB /* [S][4][cap] */,
+                                                        const int *__restrict__ nB, const int *__restrict__ idxA,
+                                                        const int *__restrict__ nA,
+                                                        const int *__restrict__ ages /* [S][cap] bucketed */,
+                                                        const int *__restrict__ n_bucketed, int cap, int fcap,
+                                                        float2 *__restrict__ feat /* [S][fcap] */,
+                                                        int *__restrict__ fages /* [S][fcap] */,
+                                                        int *__restrict__ n_tracked,
+                                                        const int *__restrict__ overflow,
+                                                        int *__restrict__ n_rows_carry,
+                                                        int *__restrict__ n_ages /* [S] length of `ages` */,
+                                                        SeqFrameInfo *__restrict__ info /* [S][max_steps] */,
+                                                        int max_steps)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (!active[f])
+        return;
+    const int nb = nB[f], na = nA[f];
+    const float2 *__restrict__ l1 = outB + ((size_t)f * 4 + 2) * cap; // stage-B row 2 = pointsLeft_t1
+    float2 *__restrict__ F = feat + (size_t)f * fcap;
+    int *__restrict__ A = fages + (size_t)f * fcap;
+    const int *__restrict__ ia = idxA + (size_t)f * cap;
+    const int *__restrict__ ag = ages + (size_t)f * cap;
+    for (int i = tid; i < nb; i += 256)
+        F[i] = l1[i];
+    // ages[i] += 1 for all, then erase-compacted with the circular-matching survivors (feature.cpp:83-86,111);
+    // entries beyond it read as 0 = the age appendNewFeatures gives a fresh corner (feature.cpp:260)
+    for (int i = tid; i < fcap; i += 256)
+        A[i] = i < na ? ag[ia[i]] + 1 : 0;
+    if (tid == 0) {
+        n_tracked[f] = nb;
+        n_ages[f] = na;
+        // rows are counted twice -- here and in seq_integrate_kernel, which runs on the pose stream and may lag a
+        // step behind: both count the frames this sequence has processed
+        const int row = n_rows_carry[f];
+        if (row < max_steps) {
+            SeqFrameInfo &o = info[(size_t)f * max_steps + row];
+            o.n_bucketed = n_bucketed[f];
+            o.n_circ = na;
+            o.n_tracked = nb;
+            o.overflow = overflow[f];
+        }
+        n_rows_carry[f] = row + 1;
+    }
+}
+
+// one thread per sequence
+__global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpResult *__restrict__ results,
+                                     const EmResult *__restrict__ em /* nullptr unless mono_rotation */,
+                                     double *__restrict__ pose /* [S][16] */,
+                                     double *__restrict__ traj /* [S][max_steps][VO_SEQ_ROW] */,
+                                     SeqFrameInfo *__restrict__ info, int *__restrict__ n_rows, int max_steps,
+                                     int n_seq)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_seq || !active[f])
+        return;
+    const PnpResult r = results[f];
+    double *P = pose + (size_t)f * 16;
+    int flags = VO_SEQ_F_ACTIVE;
+    float euler[3] = {0.f, 0.f, 0.f};
+    double R[9], t[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
+    for (int k = 0; k < 9; k++)
+        R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (r.status < 0) {
+        flags |= VO_SEQ_F_TOO_FEW; // the reference's solvePnPRansac asserts here; the pose stays
+    } else {
+        for (int k = 0; k < 3; k++) {
+            t[k] = r.tvec[k];
+            rv[k] = r.rvec[k];
+        }
+        bool have_R = true;
+        if (em) { // mono_rotation: rotation = recoverPose's (visualOdometry.cpp:146-157)
+            const EmResult e = em[f];
+            if (e.status == 1) {
+                for (int k = 0; k < 9; k++)
+                    R[k] = e.R[k];
+            } else {
+                have_R = false;
+                flags |= VO_SEQ_F_NO_ESSENTIAL; // recoverPose throws on the empty E in the reference
+            }
+        } else {
+            for (int k = 0; k < 9; k++)
+                R[k] = r.R[k];
+        }
+        if (have_R && integrate_odometry(P, R, t, euler))
+            flags |= VO_SEQ_F_INTEGRATED;
+    }
+    const int row = n_rows[f];
+    if (row < max_steps) {
+        double *o = traj + ((size_t)f * max_steps + row) * VO_SEQ_ROW;
+        for (int k = 0; k < 12; k++)
+            o[k] = P[k];
+        for (int k = 0; k < 3; k++) {
+            o[12 + k] = rv[k];
+            o[15 + k] = t[k];
+        }
+        for (int k = 0; k < 9; k++)
+            o[18 + k] = R[k];
+        SeqFrameInfo &q = info[(size_t)f * max_steps + row];
+        q.n_inliers = r.status >= 0 ? r.n_inliers : 0;
+        q.pnp_status = r.status;
+        q.flags = flags;
+        q.ransac_iters = r.niters;
+    }
+    n_rows[f] = row + 1;
+}
+
+void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
+                        hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_prepare_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, active, n_tracked,
+                       redetect_below, detect, n_seq);
+}
+
+void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,
+                      const int *ages, const int *n_bucketed, int cap, int fcap, float2 *feat, int *fages,
+                      int *n_tracked, const int *overflow, int *n_rows_carry, int *n_ages, SeqFrameInfo *info,
+                      int max_steps, int n_seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_carry_kernel, dim3(n_seq), dim3(256), 0, stream, active, outB, nB, idxA, nA, ages,
+                       n_bucketed, cap, fcap, feat, fages, n_tracked, overflow, n_rows_carry, n_ages, info, max_steps);
+}
+
+void launch_seq_integrate(const int *active, const PnpResult *results, const EmResult *em, double *pose, double *traj, SeqFrameInfo *info, int *n_rows, int max_steps, int n_seq,
+                          hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_integrate_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, active, results, em,
+                       pose, traj, info, n_rows, max_steps, n_seq);
+}
+
+} // namespace vo

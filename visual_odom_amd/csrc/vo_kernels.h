@@ -58,6 +58,25 @@ struct EmResult {
     int best;                // 10 * sample + model index of the winner
 };
 
+// one processed frame of one sequence of the lock-step loop (vo_seq_*, seq.hip)
+struct SeqFrameInfo {
+    int n_bucketed;   // points that entered circularMatching
+    int n_circ;       // survivors of deleteUnmatchFeaturesCircle (length of `ages` afterwards)
+    int n_tracked;    // survivors of the consistency filter (= currentVOFeatures.points.size() afterwards)
+    int n_inliers;    // solvePnPRansac inliers
+    int pnp_status;   // 1 ok, 0 no model, < 0 fewer than 5 points
+    int flags;        // VO_SEQ_F_* (include/vo_hip.h)
+    int ransac_iters; // RANSAC iterations OpenCV would have executed
+    int overflow;     // detection / bucketing capacity exceeded in this frame (results truncated)
+};
+#ifndef VO_SEQ_ROW // also in include/vo_hip.h (public)
+#define VO_SEQ_ROW 27 // doubles per trajectory row: frame_pose 3x4, rvec, tvec, rotation 3x3
+#define VO_SEQ_F_ACTIVE 1
+#define VO_SEQ_F_INTEGRATED 2
+#define VO_SEQ_F_TOO_FEW 4
+#define VO_SEQ_F_NO_ESSENTIAL 8
+#endif
+
 #ifndef VO_HOST_EMUL
 struct EmBufs {
     double2 *q0 = nullptr, *q1 = nullptr; // [B][cap] normalised points
@@ -82,6 +101,15 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                           int *d_rowcnt,
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
+                          const int *d_active, int *d_overflow, hipStream_t stream);
+void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
+                        hipStream_t stream);
+void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,
+                      const int *ages, const int *n_bucketed, int cap, int fcap, float2 *feat, int *fages,
+                      int *n_tracked, const int *overflow, int *n_rows_carry, int *n_ages, SeqFrameInfo *info,
+                      int max_steps, int n_seq, hipStream_t stream);
+void launch_seq_integrate(const int *active, const PnpResult *results, const EmResult *em, double *pose,
+                          double *traj, SeqFrameInfo *info, int *n_rows, int max_steps, int n_seq,
                           hipStream_t stream);
 void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
                     int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,

@@ -120,9 +120,127 @@ class StereoOdometry:
                 f.write(" ".join("%.9e" % v for v in T.reshape(-1)) + "\n")
 
 
+class MultiSequenceOdometry:
+    """The same frame loop for S independent sequences in lock step (vo_seq_* of the C ABI): every step consumes one
+    new stereo pair per sequence, and everything that chains frame k to frame k + 1 -- currentVOFeatures (points and
+    the longer ages array, quirk B3), the previous pair, frame_pose -- stays on the device.  Within a sequence frames
+    are serial (visualOdometry.cpp:127, main.cpp:157-158), so S sequences x 1 frame per step is the exact-replay way
+    to fill the GPU; nothing crosses PCIe but the new images (on a copy stream, under the previous step's kernels)
+    and, when asked for, the trajectories."""
+
+    def __init__(self, P_l, P_r, n_seq, width, height, device=0, max_pts=4096, ring=3, max_steps=1024, ctx=None,
+                 mono_rotation=False, **detect_kw):
+        self.ctx = ctx if ctx is not None else _lib.Context(device, width, height, max_pts, n_seq)
+        self._own = ctx is None
+        self.n_seq = n_seq
+        self.ctx.set_params(mono_rotation=int(bool(mono_rotation)))
+        self.ctx.seq_configure(n_seq, width, height, ring, max_steps)
+        self.ctx.batch_set_projection(P_l, P_r)
+        self.ctx.batch_set_detect_params(**detect_kw)
+
+    def close(self):
+        if self._own:
+            self.ctx.close()
+
+    def push(self, seq, left, right, pinned=False):
+        """next stereo pair of sequence `seq` (a sequence that gets no pair in a step pauses)"""
+        self.ctx.seq_push_pair(seq, left, right, pinned)
+
+    def step(self):
+        """enqueue one step over all sequences (asynchronous)"""
+        self.ctx.seq_step()
+
+    def sync(self):
+        self.ctx.seq_sync()
+
+    def state(self, seq):
+        """currentVOFeatures.points, .ages and frame_pose of one sequence (blocks)"""
+        return self.ctx.seq_get_state(seq)
+
+    def trajectory(self, seq):
+        """list of 3x4 poses like StereoOdometry.trajectory: identity, then one per processed frame"""
+        rows, _ = self.ctx.seq_get_trajectory(seq)
+        return [np.eye(4)[:3]] + [r[:12].reshape(3, 4) for r in rows]
+
+    def log(self, seq):
+        rows, info = self.ctx.seq_get_trajectory(seq)
+        out = []
+        for r, i in zip(rows, info):
+            rec = dict(zip(_lib.SEQ_INFO_NAMES, (int(v) for v in i)))
+            rec.update(rvec=r[12:15].copy(), tvec=r[15:18].copy(), R=r[18:27].reshape(3, 3).copy(),
+                       integrated=bool(rec["flags"] & _lib.SEQ_F_INTEGRATED))
+            out.append(rec)
+        return out
+
+    def save_trajectory(self, seq, path):
+        with open(path, "w") as f:
+            for T in self.trajectory(seq):
+                f.write(" ".join("%.9e" % v for v in np.asarray(T).reshape(-1)) + "\n")
+
+
 def load_poses(path):
     """KITTI pose file -> (n, 3, 4) array (evaluate_odometry.cpp:17-33 loadPoses)"""
     return np.loadtxt(path).reshape(-1, 3, 4)
+
+
+KITTI_LENGTHS = (100, 200, 300, 400, 500, 600, 700, 800)  # evaluate_odometry.cpp:14
+
+
+def _as4x4(T):
+    T = np.asarray(T, np.float64)
+    if T.shape == (4, 4):
+        return T
+    M = np.eye(4)
+    M[:3] = T.reshape(3, 4)
+    return M
+
+
+def trajectory_distances(poses):
+    """evaluate_odometry.cpp:35-47 trajectoryDistances: cumulative path length, float32 like the reference"""
+    dist = [np.float32(0)]
+    for i in range(1, len(poses)):
+        d = (np.asarray(poses[i - 1])[:3, 3] - np.asarray(poses[i])[:3, 3]).astype(np.float32)
+        dist.append(np.float32(dist[i - 1] + np.float32(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])))))
+    return dist
+
+
+def calc_sequence_errors(poses_gt, poses_result, lengths=KITTI_LENGTHS, step_size=10):
+    """evaluate_odometry.cpp:71-116 calcSequenceErrors: for every 10th start frame and every segment length, the
+    rotation error [rad/m] and translation error [fraction] of the result's relative motion against ground truth.
+    Returns a list of (first_frame, r_err, t_err, len, speed) like the reference's `errors` records."""
+    gt = [_as4x4(T) for T in poses_gt]
+    res = [_as4x4(T) for T in poses_result]
+    dist = trajectory_distances(gt)
+    err = []
+    for first in range(0, len(gt), step_size):
+        for length in lengths:
+            last = -1
+            for i in range(first, len(dist)):                       # lastFrameFromSegmentLength (:49-54)
+                if dist[i] > dist[first] + np.float32(length):
+                    last = i
+                    break
+            if last == -1 or last >= len(res):
+                continue
+            delta_gt = np.linalg.inv(gt[first]) @ gt[last]
+            delta_res = np.linalg.inv(res[first]) @ res[last]
+            E = np.linalg.inv(delta_res) @ delta_gt
+            d = np.float32(0.5) * (np.float32(E[0, 0]) + np.float32(E[1, 1]) + np.float32(E[2, 2]) - np.float32(1.0))
+            r_err = float(np.arccos(max(min(d, np.float32(1.0)), np.float32(-1.0))))        # rotationError (:56-62)
+            t_err = float(np.sqrt(np.sum(E[:3, 3].astype(np.float32) ** 2, dtype=np.float32)))  # translationError
+            num_frames = float(last - first + 1)
+            err.append((first, r_err / length, t_err / length, float(length), length / (0.1 * num_frames)))
+    return err
+
+
+def sequence_error_summary(poses_gt, poses_result, lengths=KITTI_LENGTHS):
+    """mean t_err [%] and r_err [deg/m] over all segments -- the two numbers the KITTI benchmark quotes; None when
+    the sequence is shorter than the shortest segment length"""
+    err = calc_sequence_errors(poses_gt, poses_result, lengths)
+    if not err:
+        return None
+    e = np.asarray(err)
+    return dict(t_err_percent=float(100.0 * e[:, 2].mean()), r_err_deg_per_m=float(np.degrees(e[:, 1].mean())),
+                segments=len(err))
 
 
 def ate_rmse(traj, ref):
