@@ -29,6 +29,10 @@ import argparse
 import json
 import os
 import sys
+
+# bounded default width of the CPU checker's OpenMP loops (tests/conftest.py has the measurement); before torch's runtime
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 8, 32))))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 import time
 
 import numpy as np
@@ -346,30 +350,27 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     def feed(s, k):  # rendered pair sequence s shows at its k-th pair: same street, every sequence phase-shifted
         return tri(k + s, Q)
 
+    # the S new pairs of a step are handed over in ONE call (pointer tables built once per phase of the cycle)
     if args.ingest == "device":
         src = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev),
                 torch.from_numpy(np.ascontiguousarray(rights[k])).to(dev)) for k in range(Q + 1)]
         torch.cuda.synchronize()
-
-        def push(s, k):
-            a, b = src[feed(s, k)]
-            ctx.seq_push_pair_dev(s, a.data_ptr(), b.data_ptr(), w)
+        ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in src]
+        kind = 2
     elif args.ingest == "pinned":
         src = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).pin_memory(),
                 torch.from_numpy(np.ascontiguousarray(rights[k])).pin_memory()) for k in range(Q + 1)]
-        views = [(a.numpy(), b.numpy()) for a, b in src]
-
-        def push(s, k):
-            a, b = views[feed(s, k)]
-            ctx.seq_push_pair(s, a, b, pinned=True)
+        ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in src]
+        kind = 1
     else:
-        def push(s, k):
-            f = feed(s, k)
-            ctx.seq_push_pair(s, lefts[f], rights[f], pinned=False)
+        src = [(np.ascontiguousarray(lefts[k]), np.ascontiguousarray(rights[k])) for k in range(Q + 1)]
+        ptrs = [(a.ctypes.data, b.ctypes.data) for a, b in src]
+        kind = 0
+    tables = [ctx.seq_pair_table(range(S), [ptrs[feed(s, k)][0] for s in range(S)], [ptrs[feed(s, k)][1] for s in range(S)])
+              for k in range(2 * Q)]  # feed() has period 2 Q in k
 
     def one_step(k):
-        for s in range(S):
-            push(s, k)
+        ctx.seq_push_pairs(tables[k % (2 * Q)], w, kind)
         ctx.seq_step()
 
     for k in range(W + 1):  # the first step of a sequence only builds pyramids (main.cpp:110-113)

@@ -263,6 +263,11 @@ int vo_seq_reset(vo_ctx *ctx, int seq);
 int vo_seq_push_pair(vo_ctx *ctx, int seq, const uint8_t *left, const uint8_t *right, int stride, int host_pinned);
 /* same from device memory (e.g. torch uint8 tensors) */
 int vo_seq_push_pair_dev(vo_ctx *ctx, int seq, const void *left, const void *right, int stride);
+/* n pairs in one call: sequence seq_ids[i] gets (left[i], right[i]); kind 0 = pageable host, 1 = page-locked host,
+ * 2 = device memory.  (A push only records where a pair is -- pageable images are copied to pinned staging -- and
+ * vo_seq_step moves all pairs of the step with one kernel on the copy stream.) */
+int vo_seq_push_pairs(vo_ctx *ctx, int n, const int32_t *seq_ids, const void *const *left, const void *const *right,
+                      int stride, int kind);
 /* enqueue one step over all sequences (asynchronous; at most VO_SEQ_INFLIGHT steps run ahead of the device) */
 int vo_seq_step(vo_ctx *ctx);
 int vo_seq_sync(vo_ctx *ctx);

@@ -36,6 +36,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        # bounded default OpenMP width (see tests/conftest.py: 256 threads on the GPU box's host are 30x slower than 128)
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 8, 32))))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         _lib = C.CDLL(_SO)
         _lib.orc_lk_last_iteration_count.restype = C.c_longlong
     return _lib

@@ -2,6 +2,13 @@ import os
 import subprocess
 import sys
 
+# The CPU oracle is OpenMP code.  On a many-core host (the GPU box lists 256 CPUs) its default width makes the small
+# per-level loops crawl (measured there: 3.1 s per frame at 256 threads against 0.1 s at 128 and 0.4 s at 8; a
+# 20-minute test session was lost to it), so the checker runs at a bounded width unless the caller chose one.
+# Must be set before the first OpenMP runtime of the process initialises (torch brings one too).
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 8, 32))))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import numpy as np
 import pytest
 

@@ -22,7 +22,7 @@ if has tests; then
 fi
 if has newtests; then
     stamp "pytest (new files only)"
-    timeout 1200 python -m pytest tests/test_gpu_bench_config.py tests/test_gpu_sequences.py -m gpu -x -q --durations=10 > "$OUT/pytest_new.log" 2>&1
+    timeout ${NEWTESTS_TIMEOUT:-600} python -m pytest ${NEWTESTS:-tests/test_gpu_sequences.py} -m gpu -x -q --durations=10 > "$OUT/pytest_new.log" 2>&1
     stamp "pytest rc=$?"
     tail -40 "$OUT/pytest_new.log"
 fi

@@ -31,7 +31,7 @@ EXPORTS = (
     "vo_batch_set_points", "vo_batch_set_projection", "vo_batch_run", "vo_batch_run_timed", "vo_batch_run_slot", "vo_batch_slot_times",
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
-    "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_step", "vo_seq_sync",
+    "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_push_pairs", "vo_seq_step", "vo_seq_sync",
     "vo_seq_get_state", "vo_seq_get_trajectory",
 )
 
@@ -378,6 +378,19 @@ class Context:
 
     def seq_push_pair_dev(self, seq, left_ptr, right_ptr, stride):
         self._chk(self.lib.vo_seq_push_pair_dev(self.h, seq, C.c_void_p(left_ptr), C.c_void_p(right_ptr), stride))
+
+    def seq_pair_table(self, seq_ids, left_ptrs, right_ptrs):
+        """ctypes arrays for seq_push_pairs (build once, reuse every step: the per-step host cost is one C call)"""
+        n = len(seq_ids)
+        ids = (C.c_int32 * n)(*[int(i) for i in seq_ids])
+        lp = (C.c_void_p * n)(*[int(p) for p in left_ptrs])
+        rp = (C.c_void_p * n)(*[int(p) for p in right_ptrs])
+        return n, ids, lp, rp
+
+    def seq_push_pairs(self, table, stride, kind):
+        """kind: 0 pageable host, 1 page-locked host, 2 device; table from seq_pair_table"""
+        n, ids, lp, rp = table
+        self._chk(self.lib.vo_seq_push_pairs(self.h, n, ids, lp, rp, stride, kind))
 
     def seq_step(self):
         self._chk(self.lib.vo_seq_step(self.h))

@@ -133,7 +133,9 @@ struct vo_ctx {
         size_t stage_img = 0;
         hipEvent_t ev_stage[2] = {};
         bool stage_busy[2] = {};
-        bool slot_waited = false; // the copy stream already waits for the pending slot to be free
+        SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
+        int n_ing = 0;
+        bool begun = false, staged = false;
     } seq;
 };
 
@@ -207,12 +209,14 @@ static int sync_all(vo_ctx *c);
 static void seq_free(vo_ctx *c)
 {
     vo_ctx::Seq &q = c->seq;
-    void *ptrs[] = {q.d_quads, q.d_active, q.d_pose, q.d_traj, q.d_info, q.d_rows, q.d_rows_carry, q.d_nages};
+    void *ptrs[] = {q.d_quads, q.d_active, q.d_pose, q.d_traj, q.d_info, q.d_rows, q.d_rows_carry, q.d_nages, q.d_ing};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     if (q.h_active)
         (void)hipHostFree(q.h_active);
+    if (q.h_ing)
+        (void)hipHostFree(q.h_ing);
     if (q.h_stage)
         (void)hipHostFree(q.h_stage);
     hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_stage[0], q.ev_stage[1]};
@@ -1359,6 +1363,8 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     ok = ok && dmalloc(&q.d_quads, (size_t)ring * S) == hipSuccess;
     ok = ok && dmalloc(&q.d_active, (size_t)VO_SEQ_INFLIGHT * S) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&q.h_active, sizeof(int) * VO_SEQ_INFLIGHT * S, hipHostMallocDefault) == hipSuccess;
+    ok = ok && dmalloc(&q.d_ing, (size_t)VO_SEQ_INFLIGHT * S) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&q.h_ing, sizeof(SeqIngest) * VO_SEQ_INFLIGHT * S, hipHostMallocDefault) == hipSuccess;
     ok = ok && dmalloc(&q.d_pose, S * 16) == hipSuccess;
     ok = ok && dmalloc(&q.d_traj, S * (size_t)max_steps * VO_SEQ_ROW) == hipSuccess;
     ok = ok && dmalloc(&q.d_info, S * (size_t)max_steps) == hipSuccess;
@@ -1401,6 +1407,8 @@ int vo_seq_reset(vo_ctx *c, int seq)
         return fail(c, VO_ERR_STATE, "vo_seq_reset before vo_seq_configure");
     if (seq >= q.S)
         return fail(c, VO_ERR_ARG, "vo_seq_reset: bad sequence");
+    if (q.begun && q.n_ing > 0)
+        return fail(c, VO_ERR_STATE, "vo_seq_reset between vo_seq_push_pair and vo_seq_step");
     int rc = sync_all(c);
     if (rc != VO_OK)
         return rc;
@@ -1419,24 +1427,27 @@ int vo_seq_reset(vo_ctx *c, int seq)
     return VO_OK;
 }
 
-// ring slot the pending step's new pairs go to, and the copy stream made to wait until the LK that still reads
-// that slot's previous occupant has finished
-static int seq_pending_slot(vo_ctx *c, int *slot)
+// First touch of the pending step (a push or the step call itself): its slot of the pinned per-step tables must
+// have been consumed (step - VO_SEQ_INFLIGHT has finished), which also bounds the host's run-ahead.
+static int seq_begin_step(vo_ctx *c)
 {
     vo_ctx::Seq &q = c->seq;
-    const int r = (int)(q.step % q.ring);
-    if (!q.slot_waited) {
-        if (q.slot_busy[r]) {
-            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_slot_free[r], 0));
-            q.slot_busy[r] = false;
-        }
-        q.slot_waited = true;
+    if (q.begun)
+        return VO_OK;
+    const int slot = (int)(q.step % VO_SEQ_INFLIGHT);
+    if (q.step_pending[slot]) {
+        VO_HIP_TRY(c, hipEventSynchronize(q.ev_step[slot]));
+        q.step_pending[slot] = false;
     }
-    *slot = r;
+    q.n_ing = 0;
+    q.begun = true;
     return VO_OK;
 }
 
-static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode /*0 pageable, 1 pinned, 2 device*/)
+// A push only records where the pair is; vo_seq_step moves all pairs of the step with ONE kernel on the copy stream
+// (seq_ingest_kernel).  mode 0: pageable host memory, copied into the pinned staging area now so the caller's buffer
+// is free on return; 1: page-locked host memory, read by the GPU over PCIe when the step runs; 2: device memory.
+static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -1448,37 +1459,58 @@ static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int
     if (q.pushed[seq])
         return fail(c, VO_ERR_STATE, "vo_seq_push_pair: this sequence already has a pair for the pending step");
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    int r = 0;
-    int rc = seq_pending_slot(c, &r);
+    int rc = seq_begin_step(c);
     if (rc != VO_OK)
         return rc;
-    const void *src[2] = {left, right};
-    const size_t pitch = (size_t)c->lstride[0];
-    for (int side = 0; side < 2; side++) {
-        const int idx = (r * q.S + seq) * 2 + side;
-        uint8_t *dst = c->d_pix + (size_t)idx * c->img_bytes + c->loff[0] + (size_t)VO_BY * pitch + VO_BX;
-        if (mode == 0) {
-            // pageable: repack to the device pitch in pinned memory, one contiguous copy (bytes between rows land
-            // in border columns, which this step's pyramid stage rewrites)
-            const int g = (int)(q.step & 1);
-            if (!q.h_stage) {
-                q.stage_img = pitch * (size_t)c->h;
-                VO_HIP_TRY(c, hipHostMalloc((void **)&q.h_stage, q.stage_img * 2 * 2 * (size_t)q.S, hipHostMallocDefault));
+    const int r = (int)(q.step % q.ring);
+    SeqIngest e;
+    e.stride = stride;
+    e.image0 = (r * q.S + seq) * 2;
+    if (mode == 0) {
+        const int g = (int)(q.step & 1);
+        const size_t img = (size_t)c->w * c->h;
+        if (!q.h_stage || q.stage_img != img) {
+            if (q.h_stage) {
+                VO_HIP_TRY(c, hipStreamSynchronize(q.copy));
+                VO_HIP_TRY(c, hipHostFree(q.h_stage));
+                q.h_stage = nullptr;
             }
-            if (q.stage_busy[g]) { // the transfers of step - 2 out of this half of the staging area
-                VO_HIP_TRY(c, hipEventSynchronize(q.ev_stage[g]));
-                q.stage_busy[g] = false;
-            }
-            uint8_t *slot = q.h_stage + (((size_t)g * q.S + seq) * 2 + side) * q.stage_img;
-            for (int y = 0; y < c->h; y++)
-                memcpy(slot + (size_t)y * pitch, (const uint8_t *)src[side] + (size_t)y * stride, (size_t)c->w);
-            VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, pitch * (size_t)(c->h - 1) + (size_t)c->w, hipMemcpyHostToDevice,
-                                         q.copy));
-        } else {
-            VO_HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src[side], (size_t)stride, (size_t)c->w, (size_t)c->h,
-                                           mode == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, q.copy));
+            q.stage_img = img;
+            VO_HIP_TRY(c, hipHostMalloc((void **)&q.h_stage, img * 2 * 2 * (size_t)q.S, hipHostMallocDefault));
         }
+        if (q.stage_busy[g]) { // the ingest kernel of step - 2 still reads this half of the staging area
+            VO_HIP_TRY(c, hipEventSynchronize(q.ev_stage[g]));
+            q.stage_busy[g] = false;
+        }
+        uint8_t *sl = q.h_stage + (((size_t)g * q.S + seq) * 2) * img, *sr = sl + img;
+        const uint8_t *srcs[2] = {(const uint8_t *)left, (const uint8_t *)right};
+        uint8_t *dsts[2] = {sl, sr};
+        for (int side = 0; side < 2; side++) {
+            if (stride == c->w)
+                memcpy(dsts[side], srcs[side], img);
+            else
+                for (int y = 0; y < c->h; y++)
+                    memcpy(dsts[side] + (size_t)y * c->w, srcs[side] + (size_t)y * stride, (size_t)c->w);
+        }
+        e.left = sl;
+        e.right = sr;
+        e.stride = c->w;
+        q.staged = true;
+    } else if (mode == 1) {
+        void *dl = nullptr, *dr = nullptr;
+        if (hipHostGetDevicePointer(&dl, const_cast<void *>(left), 0) != hipSuccess ||
+            hipHostGetDevicePointer(&dr, const_cast<void *>(right), 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, VO_ERR_ARG, "vo_seq_push_pair: host_pinned = 1 but the memory is not page-locked / mapped "
+                                       "(hipHostMalloc, hipHostRegister, torch pin_memory)");
+        }
+        e.left = (const uint8_t *)dl;
+        e.right = (const uint8_t *)dr;
+    } else {
+        e.left = (const uint8_t *)left;
+        e.right = (const uint8_t *)right;
     }
+    q.h_ing[(size_t)(q.step % VO_SEQ_INFLIGHT) * q.S + q.n_ing++] = e;
     q.pushed[seq] = 1;
     return VO_OK;
 }
@@ -1493,6 +1525,19 @@ int vo_seq_push_pair_dev(vo_ctx *c, int seq, const void *left, const void *right
     return seq_push(c, seq, left, right, stride, 2);
 }
 
+int vo_seq_push_pairs(vo_ctx *c, int n, const int32_t *seq_ids, const void *const *left, const void *const *right,
+                      int stride, int kind)
+{
+    if (!c || n < 0 || (n > 0 && (!seq_ids || !left || !right)) || kind < 0 || kind > 2)
+        return VO_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        int rc = seq_push(c, seq_ids[i], left[i], right[i], stride, kind);
+        if (rc != VO_OK)
+            return rc;
+    }
+    return VO_OK;
+}
+
 int vo_seq_step(vo_ctx *c)
 {
     if (!c)
@@ -1503,15 +1548,11 @@ int vo_seq_step(vo_ctx *c)
     if (!c->have_P)
         return fail(c, VO_ERR_STATE, "vo_seq_step: projection matrices not set");
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    const int slot = (int)(q.step % VO_SEQ_INFLIGHT);
-    if (q.step_pending[slot]) { // bounds the host's run-ahead; frees this slot of the pinned flag ring
-        VO_HIP_TRY(c, hipEventSynchronize(q.ev_step[slot]));
-        q.step_pending[slot] = false;
-    }
-    int r = 0;
-    int rc = seq_pending_slot(c, &r); // (a step without any push still claims its ring slot)
+    int rc = seq_begin_step(c);
     if (rc != VO_OK)
         return rc;
+    const int slot = (int)(q.step % VO_SEQ_INFLIGHT);
+    const int r = (int)(q.step % q.ring);
     // a sequence processes a frame iff it has a pair for this step and had one for the previous step
     int *act = q.h_active + (size_t)slot * q.S;
     int n_active = 0;
@@ -1521,15 +1562,28 @@ int vo_seq_step(vo_ctx *c)
         q.had_prev[s] = q.pushed[s];
         q.pushed[s] = 0;
     }
-    // uploads of this step's pairs (copy stream) -> pyramids (tracking stream)
-    VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
-    if (q.h_stage) {
-        const int g = (int)(q.step & 1);
-        VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));
-        q.stage_busy[g] = true;
+    // this step's pairs -> ring slot r, on the copy stream: after the LK that still reads the slot's previous
+    // occupant (ring 2: the previous step's; ring 3: the one before, long finished), next to the previous step's kernels
+    if (q.n_ing > 0) {
+        if (q.slot_busy[r]) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_slot_free[r], 0));
+            q.slot_busy[r] = false;
+        }
+        SeqIngest *d_tab = q.d_ing + (size_t)slot * q.S;
+        VO_HIP_TRY(c, hipMemcpyAsync(d_tab, q.h_ing + (size_t)slot * q.S, sizeof(SeqIngest) * q.n_ing,
+                                     hipMemcpyHostToDevice, q.copy));
+        launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
+                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.copy);
+        if (q.staged) {
+            const int g = (int)(q.step & 1);
+            VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));
+            q.stage_busy[g] = true;
+            q.staged = false;
+        }
     }
+    VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
     VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
-    q.slot_waited = false;
+    q.begun = false;
     c->pyr_first = r * q.S * 2;
     c->pyr_count = q.S * 2;
     int stages = VO_STAGE_PYRAMID;

@@ -137,6 +137,48 @@ __global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpRe
     n_rows[f] = row + 1;
 }
 
+// One launch moves every new stereo pair of a step into its ring slot: block (x, y) copies 4 rows of image y (2 per
+// pushed pair).  Sources are row-major 8-bit images with a byte stride, in device memory or in page-locked host
+// memory the GPU reads over PCIe directly (one kernel instead of 2 S pitched copies: at S = 256 the 512
+// hipMemcpy2DAsync calls alone cost the host 8 ms per step -- more than the step's kernels).  8 bytes per lane:
+// unaligned source loads (rows of a 1241-pixel image start anywhere), aligned destination stores.
+struct __attribute__((packed, aligned(1))) IngU2 {
+    uint32_t lo, hi;
+};
+
+__global__ __launch_bounds__(256) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int w, int h, int pitch,
+                                                         uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
+                                                         size_t img_bytes)
+{
+    const SeqIngest e = tab[blockIdx.y >> 1];
+    const int side = blockIdx.y & 1;
+    const uint8_t *__restrict__ src = side ? e.right : e.left;
+    uint8_t *__restrict__ dst = pix0 + (size_t)(e.image0 + side) * img_bytes;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= h)
+        return;
+    const uint8_t *__restrict__ s = src + (size_t)row * e.stride;
+    uint8_t *__restrict__ d = dst + (size_t)row * pitch;
+    for (int x = lane * 8; x < w; x += 512) {
+        if (x + 8 <= w) {
+            const IngU2 v = *reinterpret_cast<const IngU2 *>(s + x);
+            *reinterpret_cast<uint2 *>(d + x) = make_uint2(v.lo, v.hi);
+        } else {
+            for (int k = x; k < w; k++)
+                d[k] = s[k];
+        }
+    }
+}
+
+void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
+                       hipStream_t stream)
+{
+    if (n_pairs <= 0)
+        return;
+    hipLaunchKernelGGL(seq_ingest_kernel, dim3((h + 3) / 4, 2 * n_pairs), dim3(256), 0, stream, tab, w, h, pitch, pix0,
+                       img_bytes);
+}
+
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
                         hipStream_t stream)
 {

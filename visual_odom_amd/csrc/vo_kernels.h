@@ -69,6 +69,11 @@ struct SeqFrameInfo {
     int ransac_iters; // RANSAC iterations OpenCV would have executed
     int overflow;     // detection / bucketing capacity exceeded in this frame (results truncated)
 };
+// one pushed stereo pair of a step (seq_ingest_kernel): source images + first image-table index of its ring slot
+struct SeqIngest {
+    const uint8_t *left, *right;
+    int stride, image0;
+};
 #ifndef VO_SEQ_ROW // also in include/vo_hip.h (public)
 #define VO_SEQ_ROW 27 // doubles per trajectory row: frame_pose 3x4, rvec, tvec, rotation 3x3
 #define VO_SEQ_F_ACTIVE 1
@@ -102,6 +107,8 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
                           const int *d_active, int *d_overflow, hipStream_t stream);
+void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
+                       hipStream_t stream);
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
                         hipStream_t stream);
 void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,
