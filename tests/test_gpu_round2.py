@@ -1,0 +1,171 @@
+"""Round-2 behaviour tests (-m gpu): capacity overflow is reported, stale pyramids are refused, the pose calls'
+rotation / return-code rules under mono_rotation, DETECT / non-DETECT runs mixed back to back, BASELINE config 4
+as written (1920x1080, 4000 points, maxLevel 4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_detect_capacity_overflow_is_reported(volib, orc, small_seq):
+    """VO_STAGE_DETECT / vo_detect_bucket used to truncate silently.  (a) a bucketed set larger than
+    max_pts, (b) more carried + detected features than the feature-list capacity: both now come back as
+    VO_ERR_OVERFLOW; a context that is large enough reproduces the oracle."""
+    img = small_seq["L"][0]
+    h, w = img.shape
+    small = volib.Context(0, w, h, 64, 1)       # ~340 bucket cells > 64 points
+    try:
+        with pytest.raises(volib.VoError) as e:
+            small.detect_bucket(img, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+        assert e.value.code == volib.VO_ERR_OVERFLOW
+    finally:
+        small.close()
+    rng = np.random.default_rng(4)
+    noise = rng.integers(0, 256, (512, 1024), dtype=np.uint8)  # FAST(1, no NMS) fires on a large share of the pixels
+    n_ref = len(orc.fast_detect(noise, 1, False, cap=600000))
+    ctx = volib.Context(0, 1024, 512, 4096, 1)  # feature list: max(4 * 4096, 16384, 1024 * 512 / 16) = 32768
+    try:
+        assert n_ref > 32768
+        with pytest.raises(volib.VoError) as e:
+            ctx.detect_bucket(noise, np.zeros((0, 2), np.float32), np.zeros(0, np.int32), fast_threshold=1, fast_nonmax=0)
+        assert e.value.code == volib.VO_ERR_OVERFLOW
+        # the same context on an ordinary image: no flag, oracle result
+        fast = orc.fast_detect(img, 20, True)
+        ref_p, ref_a = orc.bucketing_features(h, w, fast, np.zeros(len(fast), np.int32), h // 10, 1)
+        got_p, got_a = ctx.detect_bucket(img, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+        assert np.array_equal(got_p, ref_p) and np.array_equal(got_a, ref_a)
+    finally:
+        ctx.close()
+
+
+def test_stale_pyramid_is_refused(gpu_ctx, volib, small_seq):
+    """an image re-uploaded after its pyramid was built (its level-0 borders are overwritten by the
+    contiguous host copy, its upper levels belong to the old pixels) must not be tracked on"""
+    s = small_seq
+    h, w = s["L"][0].shape
+    gpu_ctx.batch_configure(4, w, h, 1)
+    for i, im in enumerate((s["L"][0], s["R"][0], s["L"][1], s["R"][1])):
+        gpu_ctx.batch_upload_image(i, im)
+    gpu_ctx.batch_set_quads([[0, 1, 2, 3]])
+    gpu_ctx.batch_set_points(0, s["pts"][0])
+    gpu_ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+    gpu_ctx.batch_sync()
+    ref = gpu_ctx.batch_get_tracks(0, len(s["pts"][0]))
+    gpu_ctx.batch_upload_image(2, s["L"][2])
+    with pytest.raises(volib.VoError) as e:
+        gpu_ctx.batch_run(volib.STAGE_LK)
+    assert e.value.code == volib.VO_ERR_STATE
+    gpu_ctx.batch_set_pyramid_range(0, 2)              # a range that does not cover image 2: still stale
+    with pytest.raises(volib.VoError):
+        gpu_ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+    gpu_ctx.batch_upload_image(2, s["L"][1])
+    gpu_ctx.batch_set_pyramid_range(2, 1)
+    gpu_ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+    gpu_ctx.batch_sync()
+    again = gpu_ctx.batch_get_tracks(0, len(s["pts"][0]))
+    for k in ("r0", "r1", "l1", "l0_ret", "status4"):
+        assert np.array_equal(ref[k], again[k]), k
+    gpu_ctx.batch_configure(4, w, h, 1)                # back to "build every pyramid" for the next test
+
+
+def test_pose_calls_under_mono_rotation(gpu_ctx, volib, orc):
+    """vo_pnp_ransac returns Rodrigues(rvec) whatever mono_rotation says (the flag belongs to
+    trackingFrame2Frame, i.e. vo_track_frame)"""
+    from test_oracle_geom import planted_problem, K_KITTI
+    X, uv, r, t, _ = planted_problem(orc, 300, 0.2, 0.1, 11)
+    found0, rv0, tv0, R0, inl0 = gpu_ctx.pnp_ransac(X, uv, K_KITTI)
+    gpu_ctx.set_params(mono_rotation=1)
+    try:
+        found1, rv1, tv1, R1, inl1 = gpu_ctx.pnp_ransac(X, uv, K_KITTI)
+    finally:
+        gpu_ctx.set_params(mono_rotation=0)
+    assert found0 and found1 and np.array_equal(rv0, rv1) and np.array_equal(inl0, inl1)
+    assert np.array_equal(R0, R1) and np.allclose(R1, orc.rodrigues(rv1), atol=1e-15)
+
+
+def test_detect_and_plain_runs_mixed_back_to_back(volib, orc, small_world, small_seq):
+    """a run without DETECT enqueued right after a run with it reads the other buffer set's points;
+    the next DETECT must wait for that filter.  Three runs without a host sync equal three synchronised runs."""
+    s = small_seq
+    P_l, P_r = small_world.proj_matrices()
+    h, w = s["L"][0].shape
+    B = 4
+    ctx = volib.Context(0, w, h, 4096, B)
+    try:
+        ctx.batch_configure(6, w, h, B)
+        for k in range(3):
+            ctx.batch_upload_image(2 * k, s["L"][k])
+            ctx.batch_upload_image(2 * k + 1, s["R"][k])
+        ctx.batch_set_quads([[0, 1, 2, 3], [2, 3, 4, 5], [2, 3, 0, 1], [4, 5, 2, 3]])
+        ctx.batch_set_projection(P_l, P_r)
+        for f in range(B):
+            ctx.batch_set_features(f, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+        ctx.batch_set_detect_params(features_per_bucket=2)
+        det, plain = volib.STAGE_ALL | volib.STAGE_DETECT, volib.STAGE_ALL
+
+        def snapshot():
+            return [(ctx.batch_get_filtered(f), ctx.batch_get_pose(f)) for f in range(B)]
+
+        ctx.batch_run(det)
+        ctx.batch_sync()
+        want = snapshot()
+        for seq in ((det, plain, det), (plain, plain, det), (det, det, plain)):
+            for st in seq:
+                ctx.batch_run(st)
+            ctx.batch_sync()
+            got = snapshot()
+            for (f0, p0), (f1, p1) in zip(want, got):
+                for k in ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ"):
+                    assert np.array_equal(f0[k], f1[k]), (seq, k)
+                assert np.array_equal(p0["rvec"], p1["rvec"]) and np.array_equal(p0["inliers"], p1["inliers"])
+    finally:
+        ctx.close()
+
+
+def test_config4_as_written_1080p_4000_points_max_level_4(volib, orc):
+    """BASELINE config 4: 1920 x 1080, 4000 points, '4-level pyramid' read as maxLevel 4 (5 levels: the 120 x 68 level is
+    still larger than the 21 x 21 window).  The oracle is too slow for all of it: a 120-point subset bit-exactly
+    (features are independent), the whole set for determinism, and the pyramid levels bit-exactly."""
+    from visual_odom_amd import synth
+    w, h = 1920, 1080
+    world = synth.StereoWorld(seed=5, width=w, height=h, fx=1112.0, cx=959.5, cy=539.5, bf=-597.0, tex_size=1024)
+    L, R, poses, _ = world.render_sequence(2)
+    pts = synth.select_keypoints(L[0], bucket=108, per_bucket=60, min_dist=3)[:4000]
+    assert len(pts) == 4000
+    ctx = volib.Context(0, w, h, 4096, 1)
+    try:
+        ctx.set_params(lk_max_level=4, lk_full_chain=1)
+        ctx.batch_configure(4, w, h, 1)
+        imgs = [L[0], R[0], L[1], R[1]]
+        for i, im in enumerate(imgs):
+            ctx.batch_upload_image(i, im)
+        ctx.batch_set_quads([[0, 1, 2, 3]])
+        ctx.batch_set_points(0, pts)
+        ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+        ctx.batch_sync()
+        g1 = ctx.batch_get_tracks(0, len(pts))
+        ref_pyr = orc.build_pyramid(imgs[1], 4)
+        for lvl in range(5):
+            assert np.array_equal(ctx.batch_get_pyramid_level(1, lvl), ref_pyr[lvl]), lvl
+        sub = np.arange(0, len(pts), len(pts) // 120)
+        p = pts[sub]
+        ref, sts = [], []
+        for a, b in ((L[0], R[0]), (R[0], R[1]), (R[1], L[1]), (L[1], L[0])):
+            p, st, _ = orc.calc_optical_flow_pyr_lk(a, b, p, max_level=4)
+            ref.append(p)
+            sts.append(st)
+        assert np.array_equal(g1["status4"][:, sub], np.stack(sts))
+        for name, r_ in zip(("r0", "r1", "l1", "l0_ret"), ref):
+            assert np.array_equal(bits(g1[name][sub]), bits(r_)), name
+        assert np.stack(sts).all(0).mean() > 0.5
+        ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+        ctx.batch_sync()
+        g2 = ctx.batch_get_tracks(0, len(pts))
+        for k in ("r0", "r1", "l1", "l0_ret", "status4"):
+            assert np.array_equal(g1[k], g2[k])
+    finally:
+        ctx.close()

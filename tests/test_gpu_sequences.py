@@ -88,12 +88,39 @@ def test_lockstep_sequences_equal_independent_reference_loops(volib, orc):
         ctx.close()
 
 
+class _DeviceImages:
+    """device copies of host images through the HIP runtime libvo_hip.so itself is linked against (no torch: a second
+    HIP runtime initialised after the first one does not see the GPU on this image)"""
+
+    def __init__(self):
+        import ctypes
+        self.C = ctypes
+        try:
+            self.hip = ctypes.CDLL("libamdhip64.so.7")  # already mapped by libvo_hip.so
+        except OSError:
+            self.hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+        self.ptrs = []
+
+    def upload(self, img):
+        C = self.C
+        img = np.ascontiguousarray(img, np.uint8)
+        p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), C.c_size_t(img.size)) == 0
+        assert self.hip.hipMemcpy(p, img.ctypes.data_as(C.c_void_p), C.c_size_t(img.size), 1) == 0  # hipMemcpyHostToDevice
+        self.ptrs.append(p)
+        return p.value
+
+    def free(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []
+
+
 def test_lockstep_ring_of_two_six_per_bucket_against_the_oracle_chain(volib, orc, small_world):
     """ring = 2 (the upload of the next pair has to wait for the LK that still reads the slot), detection parameters
     other than the reference's (3 per bucket), checked against the oracle's functions chained like matchingFeatures /
     trackingFrame2Frame / integrateOdometryStereo; the same sequence runs in two slots, one fed from pageable memory,
     one from device memory"""
-    import torch
     from visual_odom_amd import odometry
     n = 9
     L, R, poses, _ = small_world.render_sequence(n)
@@ -103,14 +130,13 @@ def test_lockstep_ring_of_two_six_per_bucket_against_the_oracle_chain(volib, orc
     ctx = volib.Context(0, w, h, 4096, 2)
     try:
         vo = odometry.MultiSequenceOdometry(P_l, P_r, 2, w, h, ctx=ctx, ring=2, max_steps=16, features_per_bucket=3)
-        dev = [(torch.from_numpy(np.ascontiguousarray(L[k])).cuda(), torch.from_numpy(np.ascontiguousarray(R[k])).cuda())
-               for k in range(n)]
-        torch.cuda.synchronize()
+        di = _DeviceImages()
+        dev = [(di.upload(L[k]), di.upload(R[k])) for k in range(n)]
         o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
         o_pose, o_t = np.eye(4), np.zeros(3)
         for k in range(n):
             vo.push(0, L[k], R[k])
-            ctx.seq_push_pair_dev(1, dev[k][0].data_ptr(), dev[k][1].data_ptr(), w)
+            ctx.seq_push_pair_dev(1, dev[k][0], dev[k][1], w)
             vo.step()
             if k == 0:
                 continue
@@ -140,6 +166,7 @@ def test_lockstep_ring_of_two_six_per_bucket_against_the_oracle_chain(volib, orc
                 assert np.abs(rec["rvec"] - rv).max() <= 1e-6 and np.abs(rec["tvec"] - tv).max() <= 1e-6
                 assert rec["ransac_iters"] == int(dbg[0]) and rec["pnp_status"] == rc
         assert len(vo.trajectory(0)) == n
+        di.free()
     finally:
         ctx.close()
 

@@ -44,6 +44,21 @@ if has bench374; then
     timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 > "$OUT/bench_kitti374.json" 2> "$OUT/bench_kitti374.err"
     cat "$OUT/bench_kitti374.json"; tail -3 "$OUT/bench_kitti374.err"
 fi
+if has config4; then
+    for WL in hd4000 hd4000l4; do
+        stamp "bench (config 4: 1920x1080, 4000 points, $WL)"
+        timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $WL --frames 16 --validate 0 > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err"
+        cat "$OUT/bench_$WL.json"; tail -3 "$OUT/bench_$WL.err"
+    done
+fi
+if has stageslk; then
+    stamp "bench (config 2: circularMatching only on the device)"
+    timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages lk > "$OUT/bench_stages_lk.json" 2> "$OUT/bench_stages_lk.err"
+    cat "$OUT/bench_stages_lk.json"; tail -3 "$OUT/bench_stages_lk.err"
+    stamp "bench (detect+full)"
+    timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages detect+full > "$OUT/bench_detect.json" 2> "$OUT/bench_detect.err"
+    cat "$OUT/bench_detect.json"; tail -3 "$OUT/bench_detect.err"
+fi
 if has seq; then
     for S in 256 64 8 1; do
         stamp "bench --mode sequences --seqs $S (reference-default bucketing, pairs resident in HBM)"
