@@ -69,6 +69,19 @@ if has seq; then
     timeout 600 python bench.py --mode sequences --workload kitti2000 --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 2 > "$OUT/bench_seq2000_256.json" 2> "$OUT/bench_seq2000_256.err"
     cat "$OUT/bench_seq2000_256.json"; tail -3 "$OUT/bench_seq2000_256.err"
 fi
+if has seqab; then
+    for S in 1 8 64 256; do
+        stamp "A/B seq S=$S: second pose stream off"
+        VO_POSE2_MAX=0 timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/ab_seq_${S}_onepose.json" 2>/dev/null
+        python -c "import json,sys; b=json.load(open('$OUT/ab_seq_${S}_onepose.json')); print('  one pose stream: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        stamp "A/B seq S=$S: 512-register pose kernels"
+        VO_SEQ_CROWDED_MIN=100000 timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/ab_seq_${S}_bigpose.json" 2>/dev/null
+        python -c "import json,sys; b=json.load(open('$OUT/ab_seq_${S}_bigpose.json')); print('  512-reg pose:    %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+    done
+    stamp "A/B batch kitti374: 128-register pose kernels forced"
+    VO_CROWDED_MIN=1 VO_CROWDED_MIN_PTS=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 > "$OUT/ab_kitti374_crowded.json" 2>/dev/null
+    python -c "import json,sys; b=json.load(open('$OUT/ab_kitti374_crowded.json')); print('  kitti374 crowded: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+fi
 if has seqhost; then
     for ING in pinned host; do
         for S in 256 8; do

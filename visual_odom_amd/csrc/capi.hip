@@ -90,6 +90,15 @@ struct vo_ctx {
     int *d_ages = nullptr;         // [B][cap] ages of the bucketed set (parallel to d_pts)
     std::vector<int> h_ntracked, h_detect;
     hipStream_t stream_pnp = nullptr, stream_filter = nullptr;
+    // second pose stream: in a SMALL batch the pose chain is a few latency-bound waves (1.0-1.3 ms for one frame) and
+    // longer than the tracking stages of the next run, so back-to-back runs were throttled by it (lock-step loop with
+    // one sequence: 1.35 ms per step, of which 1.3 ms waiting behind the previous step's chain).  Runs alternate between
+    // the two buffer sets anyway; giving each set its own stream lets two chains overlap.  Large batches keep one
+    // stream (two were measured slower there).
+    hipStream_t stream_pnp2 = nullptr;
+    long long pose2_max = 16384;   // frames x points up to which the second pose stream is used (VO_POSE2_MAX; 0 = never)
+    int seq_crowded_min = 32;      // sequences from which the lock-step loop takes the 128-register pose kernels
+    hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
     long long crowded_min = 65536; // frames x points from which the 128-register pose kernels are used (VO_CROWDED_MIN)
@@ -122,7 +131,8 @@ struct vo_ctx {
         int *d_rows = nullptr, *d_rows_carry = nullptr, *d_nages = nullptr; // [S]
         std::vector<uint8_t> pushed, had_prev; // pair pushed for the pending step / for the previous step
         hipStream_t copy = nullptr;
-        hipEvent_t ev_upload = nullptr, ev_carry = nullptr;
+        hipEvent_t ev_upload = nullptr, ev_carry = nullptr, ev_integ = nullptr;
+        bool integ_pending = false;
         hipEvent_t ev_slot_free[VO_SEQ_MAX_RING] = {}; // the LK that read ring slot r as its t0 pair has finished
         bool slot_busy[VO_SEQ_MAX_RING] = {};
         bool carry_pending = false;
@@ -219,7 +229,7 @@ static void seq_free(vo_ctx *c)
         (void)hipHostFree(q.h_ing);
     if (q.h_stage)
         (void)hipHostFree(q.h_stage);
-    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_stage[0], q.ev_stage[1]};
+    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_stage[0], q.ev_stage[1]};
     for (hipEvent_t e : evs)
         if (e)
             (void)hipEventDestroy(e);
@@ -303,6 +313,8 @@ void vo_destroy(vo_ctx *c)
             (void)hipEventDestroy(ev);
     if (c->stream_pnp)
         (void)hipStreamDestroy(c->stream_pnp);
+    if (c->stream_pnp2)
+        (void)hipStreamDestroy(c->stream_pnp2);
     if (c->stream_filter)
         (void)hipStreamDestroy(c->stream_filter);
     if (c->stream_em)
@@ -347,6 +359,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         int least = 0, greatest = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp2, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_em, hipStreamNonBlocking, greatest) == hipSuccess;
     }
@@ -363,6 +376,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
             c->crowded_min_pts = atoi(ep);
         const char *e = getenv("VO_SERIAL_POSE");
         c->serial_pose = e && e[0] == '1';
+        const char *e2 = getenv("VO_POSE2_MAX");
+        if (e2)
+            c->pose2_max = atoll(e2);
+        const char *e3 = getenv("VO_SEQ_CROWDED_MIN");
+        if (e3)
+            c->seq_crowded_min = atoi(e3);
     }
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -784,7 +803,10 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // AND many points per frame: 256 frames x 340 points are 87 k point-frames, but LK is over in 2.4 ms and the
     // pose chain is the long pole there -- the fast (512-register) kernels give 59 k instead of 53 k frames/s
     // (gpurun_out/r59)
-    const bool crowded = is_crowded(c, B, c->max_pts_set);
+    // (the lock-step loop has DETECT on its critical path and the pose chain off it: from a few dozen sequences on, a
+    // 512-register pose wave -- which needs a whole SIMD to itself -- keeps the pyramid / detection kernels of the next
+    // step waiting: bucket_kernel 0.54 ms instead of 0.02 behind select_refine_kernel<1>, profiles/r02)
+    const bool crowded = is_crowded(c, B, c->max_pts_set) || (c->seq.on && B >= c->seq_crowded_min);
     int e = 0;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
@@ -901,7 +923,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    hipStream_t ps = c->serial_pose ? c->stream : c->stream_pnp;
+    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded && c->pose2_max > 0 &&
+                                  (long long)B * (c->max_pts_set > 0 ? c->max_pts_set : 1) <= c->pose2_max;
+    hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
         VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
@@ -978,9 +1002,15 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                    pb.rstate, pb.inliers, pb.results, /*crowded*/ crowded, ps);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
-        if (sq.on) // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
+        if (sq.on) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
+            if (sq.integ_pending) // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it
+                VO_HIP_TRY(c, hipStreamWaitEvent(ps, sq.ev_integ, 0));
             launch_seq_integrate(seq_active, pb.results, c->prm.mono_rotation ? pb.em_results : nullptr, sq.d_pose,
                                  sq.d_traj, sq.d_info, sq.d_rows, sq.max_steps, B, ps);
+            VO_HIP_TRY(c, hipEventRecord(sq.ev_integ, ps));
+            sq.integ_pending = true;
+        }
+        c->last_pose_stream = ps;
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
         VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
@@ -1003,6 +1033,7 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp2));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
     if (c->seq.copy)
         VO_HIP_TRY(c, hipStreamSynchronize(c->seq.copy));
@@ -1373,6 +1404,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     ok = ok && dmalloc(&q.d_nages, S) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&q.ev_upload, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&q.ev_carry, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q.ev_integ, hipEventDisableTiming) == hipSuccess;
     for (auto &e : q.ev_slot_free)
         ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : q.ev_step)
@@ -1597,7 +1629,7 @@ int vo_seq_step(vo_ctx *c)
     if (rc != VO_OK)
         return rc;
     // end of the step = end of its last stream: the pose stream when a frame was processed
-    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && !c->serial_pose ? c->stream_pnp : c->stream));
+    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream : c->stream));
     q.step_pending[slot] = true;
     q.step++;
     return VO_OK;

@@ -275,8 +275,16 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     lift7(t.lo, t.hi, Jt);
                     lift7(u.lo, u.hi, Jb);
                 }
+                // fractional position of the window corner inside its pixel cell: the bilinear weights come from it, and
+                // the corner is still inside the cell exactly as long as both parts are in [0, 1).  fl(nextX - fnx) is what
+                // OpenCV itself computes (nextPt.x - inextPt.x); a true difference >= 1 or < 0 can never round into [0, 1),
+                // so "inside" is never wrong -- a spurious "left" (difference just below 1 rounding up to 1.0) only
+                // re-enters the same cell through the outer loop.  As raw bits, [0, 1) is "below 0x3f800000, unsigned"
+                // (negative values have the sign bit set), so one unsigned max + one compare replace two floors, two
+                // compares and two selects per iteration.
+                float fa = nextX - fnx, fb = nextY - fny;
                 for (;;) {
-                    lk_weights(nextX - fnx, nextY - fny, wt, wb);
+                    lk_weights(fa, fb, wt, wb);
                     int b1, b2;
                     {
                         uint32_t Jp[4];
@@ -298,18 +306,17 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                     outX = nextX + halfWin;
                     outY = nextY + halfWin;
                     // OpenCV: delta.ddot(delta) <= epsilon in f64.  The f32 value n2 is within 2^-23 of it, so it
-                    // decides on its own unless it falls inside a 1e-6 band around epsilon (then the f64 form)
+                    // decides on its own unless it falls inside a 1e-6 band around epsilon (then the f64 form).  The hot
+                    // path carries ONE compare ("clearly not converged"); everything else happens once per level.
                     const float n2 = fmaf(dy, dy, dx * dx);
-                    bool converged = n2 < eps_lo;
-                    if (__builtin_expect(!converged && !(n2 > eps_hi), 0)) {
+                    if (__builtin_expect(!(n2 > eps_hi), 0)) {
 #ifndef VO_HOST_EMUL
-                        asm volatile("" ::: "memory"); // keep the rare f64 evaluation out of the hot path
+                        asm volatile("" ::: "memory"); // keep the rare evaluation out of the hot path
 #endif
-                        converged = (double)dx * dx + (double)dy * dy <= prm.epsilon;
-                    }
-                    if (converged) {
-                        run = false;
-                        break;
+                        if (n2 < eps_lo || (double)dx * dx + (double)dy * dy <= prm.epsilon) {
+                            run = false;
+                            break;
+                        }
                     }
                     // OpenCV: std::abs(delta.x + prevDelta.x) < 0.01 (f32 sum compared as double).  0.01f is
                     // the largest f32 below the double 0.01, so for an f32 s:  |s| < 0.01  <=>  |s| <= 0.01f
@@ -328,10 +335,12 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                         run = false;
                         break;
                     }
-                    const float gx = floorf(nextX), gy = floorf(nextY);
-                    if ((VO_BALLOT(gx != fnx) | VO_BALLOT(gy != fny)) != 0ull) { // the corner left the cell
-                        fnx = gx;
-                        fny = gy;
+                    fa = nextX - fnx;
+                    fb = nextY - fny;
+                    const uint32_t ua = (uint32_t)__float_as_int(fa), ub = (uint32_t)__float_as_int(fb);
+                    if (VO_BALLOT((ua > ub ? ua : ub) >= 0x3f800000u) != 0ull) { // the corner left the cell
+                        fnx = floorf(nextX);
+                        fny = floorf(nextY);
                         break;
                     }
                 }
