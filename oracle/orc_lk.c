@@ -180,6 +180,15 @@ static inline int cv_floor_f(float v)
 
 static long long g_iter_count;
 long long orc_lk_last_iteration_count(void) { return g_iter_count; }
+/* optional log of the Gauss-Newton iteration count of every (level, point) of the next call(s): buf [levels][n]
+ * (tools/lk_pairing_study.py: what a kernel that runs two features in lock step would pay) */
+static int *g_iter_log;
+static int g_iter_log_n;
+void orc_lk_set_iteration_log(int *buf, int n)
+{
+    g_iter_log = buf;
+    g_iter_log_n = n;
+}
 /* histogram of the inner-iteration count of every (point, level) solve since the last reset:
  * hist[k] = solves that executed k iterations (k = 0..100); used to size the GPU kernel's loops */
 static long long g_iter_hist[101];
@@ -359,6 +368,8 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
 #pragma omp atomic
 #endif
         g_iter_hist[my_iters]++;
+        if (g_iter_log && ptidx < g_iter_log_n)
+            g_iter_log[(size_t)level * g_iter_log_n + ptidx] = my_iters;
 
         /* status[ptidx] && err && level == 0 && !(flags & OPTFLOW_LK_GET_MIN_EIGENVALS) */
         if (status[ptidx] && err && level == 0) {

@@ -34,6 +34,29 @@ if has ubench; then
     python tools/ubench_table.py "$OUT/ubench_pmc" > "$OUT/valu_issue_cost_pmc.txt" 2>&1
     cat "$OUT/valu_issue_cost_pmc.txt"
 fi
+if has lkprobe; then
+    stamp "LK probe: parity subset, two bench lines, VALU count"
+    timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_config.py -m gpu -x -q -k "lk or circular or bench_configuration or track_frame" 2>&1 | tail -2
+    for i in 1 2; do
+        timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/probe_bench_$i.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/probe_bench_$i.json')); print('  %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+    done
+    (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/probe_pmc" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > /dev/null 2>&1)
+    python - <<PY
+import glob, csv
+from collections import defaultdict
+acc = defaultdict(list)
+for f in glob.glob("$OUT/probe_pmc/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "lk_circular" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in acc.items()}
+if m:
+    print("LK per feature: VALU %.0f SALU %.0f LDS %.1f; cycles/VALU %.2f; launch cycles %.0f" % (
+        m["SQ_INSTS_VALU"] / m["SQ_WAVES"], m["SQ_INSTS_SALU"] / m["SQ_WAVES"], m["SQ_INSTS_LDS"] / m["SQ_WAVES"],
+        m["GRBM_GUI_ACTIVE"] / 8 * 1024 / m["SQ_INSTS_VALU"], m["GRBM_GUI_ACTIVE"] / 8))
+PY
+fi
 if has bench; then
     stamp "bench (default)"
     timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -81,6 +104,21 @@ if has seqab; then
     stamp "A/B batch kitti374: 128-register pose kernels forced"
     VO_CROWDED_MIN=1 VO_CROWDED_MIN_PTS=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 > "$OUT/ab_kitti374_crowded.json" 2>/dev/null
     python -c "import json,sys; b=json.load(open('$OUT/ab_kitti374_crowded.json')); print('  kitti374 crowded: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+fi
+if has posewaves; then
+    for WV in 1 2 4; do
+        stamp "pose kernels at $WV waves per SIMD"
+        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 > "$OUT/pw_kitti374_$WV.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/pw_kitti374_$WV.json')); print('  batch kitti374 : %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        for S in 16 64 256; do
+            VO_POSE_WAVES=$WV timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/pw_seq_${S}_$WV.json" 2>/dev/null
+            python -c "import json; b=json.load(open('$OUT/pw_seq_${S}_$WV.json')); print('  seq S=%-4d      : %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        done
+        VO_POSE_WAVES=$WV timeout 300 python bench.py --mode sequences --workload kitti2000 --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/pw_seq2000_$WV.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/pw_seq2000_$WV.json')); print('  seq2000 S=256   : %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pw_default_$WV.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/pw_default_$WV.json')); print('  batch kitti2000: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+    done
 fi
 if has seqhost; then
     for ING in pinned host; do

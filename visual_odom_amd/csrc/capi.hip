@@ -97,7 +97,13 @@ struct vo_ctx {
     // stream (two were measured slower there).
     hipStream_t stream_pnp2 = nullptr;
     long long pose2_max = 16384;   // frames x points up to which the second pose stream is used (VO_POSE2_MAX; 0 = never)
-    int seq_crowded_min = 32;      // sequences from which the lock-step loop takes the 128-register pose kernels
+    // sequences from which the lock-step loop takes the 128-register pose kernels (VO_SEQ_CROWDED_MIN).  Measured at the
+    // reference-default load (gpurun_out/r2_04): 64 sequences 41.3 k frames/s with the 512-register kernels against
+    // 22.4 k with the 128-register ones (their chain then takes 5.5 ms and throttles the loop); 256 sequences 42.1 k
+    // against 44.2 k -> only from 256 on.
+    int seq_crowded_min = 256;
+    int pose_waves_forced = 0;         // VO_POSE_WAVES = 1 / 2 / 4: developer A/B of the pose kernels' register budget
+    long long pose_medium_min = 16384; // frames x points from which the 256-register pose kernels are used
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
@@ -174,6 +180,16 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
 {
     return frames * pts >= c->crowded_min && pts >= c->crowded_min_pts;
+}
+// register budget of the f64 pose kernels as waves per SIMD: 4 (128 registers) next to a long LK launch, 2 (256) when
+// the tracking stages of the next run are short but must not wait for whole SIMDs, 1 (512) when the GPU is idle
+inline int pose_waves(const vo_ctx *c, long long frames, int pts, bool crowded)
+{
+    if (c->pose_waves_forced)
+        return c->pose_waves_forced;
+    if (crowded)
+        return 4;
+    return frames * (pts > 0 ? pts : 1) >= c->pose_medium_min ? 2 : 1;
 }
 // the current feature set (see vo_ctx::pts_sel)
 inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
@@ -382,6 +398,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         const char *e3 = getenv("VO_SEQ_CROWDED_MIN");
         if (e3)
             c->seq_crowded_min = atoi(e3);
+        const char *e4 = getenv("VO_POSE_WAVES");
+        if (e4 && (atoi(e4) == 1 || atoi(e4) == 2 || atoi(e4) == 4))
+            c->pose_waves_forced = atoi(e4);
+        const char *e5 = getenv("VO_POSE_MEDIUM_MIN");
+        if (e5)
+            c->pose_medium_min = atoll(e5);
     }
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -999,7 +1021,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.rstate, pb.inliers, pb.results, /*crowded*/ crowded, ps);
+                   pb.rstate, pb.inliers, pb.results, pose_waves(c, B, c->max_pts_set, crowded), ps);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
         if (sq.on) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
@@ -1846,7 +1868,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, /*crowded*/ is_crowded(c, 1, n), c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, pose_waves(c, 1, n, is_crowded(c, 1, n)), c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }

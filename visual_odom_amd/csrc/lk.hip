@@ -63,11 +63,12 @@ __device__ __forceinline__ void lk_weights(float a, float b, uint32_t &wt, uint3
     wb = perm_b32(iw11, r10, VO_SEL_LO16); // signed lanes: iw11 may be -1
 }
 
-// 6 waves per SIMD = at most 80 VGPRs: the allocator lands a few registers above that on its own (5 waves);
-// held to 80 it spills a handful of per-hop values outside the loops and the sixth wave is worth ~1 %
-// (gpurun_out/r40, r47; at 7 waves = 72 VGPRs the spills reach the iteration loop and LK is 8 % slower)
+// 7 waves per SIMD = at most 72 VGPRs.  Round 1 had the bound at 6 waves and the allocator happened to land on 70
+// registers (so 7 waves were resident anyway); with the round-2 loop it took 78 under that bound -- one wave fewer per
+// SIMD, LK 11.9 -> 12.2 ms (gpurun_out/r2_04) -- so the bound now says what is meant: 71 registers, no spills.
+// (8 waves = 64 VGPRs spills inside the iteration loop and is slower, gpurun_out/lksweep1.)
 #ifndef VO_LK_ATTRS
-#define VO_LK_ATTRS __launch_bounds__(64, 6)
+#define VO_LK_ATTRS __launch_bounds__(64, 7)
 #endif
 __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs,
                                                           const Quad *__restrict__ quads,
@@ -282,9 +283,8 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                 // re-enters the same cell through the outer loop.  As raw bits, [0, 1) is "below 0x3f800000, unsigned"
                 // (negative values have the sign bit set), so one unsigned max + one compare replace two floors, two
                 // compares and two selects per iteration.
-                float fa = nextX - fnx, fb = nextY - fny;
                 for (;;) {
-                    lk_weights(fa, fb, wt, wb);
+                    lk_weights(nextX - fnx, nextY - fny, wt, wb);
                     int b1, b2;
                     {
                         uint32_t Jp[4];
@@ -335,9 +335,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
                         run = false;
                         break;
                     }
-                    fa = nextX - fnx;
-                    fb = nextY - fny;
-                    const uint32_t ua = (uint32_t)__float_as_int(fa), ub = (uint32_t)__float_as_int(fb);
+                    const uint32_t ua = (uint32_t)__float_as_int(nextX - fnx), ub = (uint32_t)__float_as_int(nextY - fny);
                     if (VO_BALLOT((ua > ub ? ua : ub) >= 0x3f800000u) != 0ull) { // the corner left the cell
                         fnx = floorf(nextX);
                         fny = floorf(nextY);

@@ -36,6 +36,11 @@
 //              launch of the same batch has enough features to keep every SIMD full for many rounds
 //              (capi.hip: frames x points >= 65536); at the reference-default 340 points per frame LK
 //              does not, and the 512-register chain is the faster one there (37 k vs 25 k frames/s).
+//   WAVES = 2  256 registers: the middle ground for batches whose tracking stages are short but busy (the
+//              reference-default 340-point load, the lock-step sequence loop): a 512-register wave needs a whole SIMD
+//              to itself and keeps the NEXT step's pyramid / detection kernels waiting (bucket_kernel 0.54 ms instead
+//              of 0.02 behind select_refine_kernel<1>, pyr_down 0.77 instead of 0.13 ms; profiles/r02), a 256-register
+//              wave leaves half of it to them.
 
 namespace vo {
 
@@ -492,30 +497,36 @@ void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk,
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, bool crowded, hipStream_t stream)
+                int32_t *inliers, PnpResult *results, int waves /* 1, 2 or 4 per SIMD: 512 / 256 / 128 registers */,
+                hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
     const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
-    const bool batch = crowded;
+    const dim3 eg(RANSAC_CHUNK / 64, n_frames);
+    const size_t lds = (144 + 12) * 64 * sizeof(double);
     for (int k = 0; k < n_chunks; k++) {
         hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm.iters, k, subsets, state);
-        if (batch)
-            hipLaunchKernelGGL(epnp_kernel<4>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
-                               (144 + 12) * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
-                               state, k, models);
+        if (waves >= 4)
+            hipLaunchKernelGGL(epnp_kernel<4>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               k, models);
+        else if (waves == 2)
+            hipLaunchKernelGGL(epnp_kernel<2>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               k, models);
         else
-            hipLaunchKernelGGL(epnp_kernel<1>, dim3(RANSAC_CHUNK / 64, n_frames), dim3(64),
-                               (144 + 12) * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
-                               state, k, models);
+            hipLaunchKernelGGL(epnp_kernel<1>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               k, models);
         hipLaunchKernelGGL(vote_kernel, dim3(RANSAC_CHUNK, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, k, counts);
         hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm, k, counts, state);
     }
-    if (batch)
+    if (waves >= 4)
         hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
+                           cap, prm, models, state, inliers, results);
+    else if (waves == 2)
+        hipLaunchKernelGGL(select_refine_kernel<2>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, inliers, results);
     else
         hipLaunchKernelGGL(select_refine_kernel<1>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,

@@ -126,7 +126,7 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
                         hipStream_t stream);
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, bool crowded, hipStream_t stream);
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream);
 void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
                            RansacState *rstate, hipStream_t stream);
 void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
