@@ -205,11 +205,29 @@ def main(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the additional sustained leg (0 = off)")
     ap.add_argument("--validate", type=int, default=3, help="frames held to the oracle after the timed loop (0 = off)")
+    ap.add_argument("--selftest-replicas", action="store_true",
+                    help="CPU-only self-test of the N > 1 control flow (rank discovery, process group, barrier, max-over-ranks "
+                         "time / summed frames, rank-0 JSON): no GPU work, fabricated per-rank timings (tests/test_replicas_gloo.py)")
     args = ap.parse_args(argv)
 
     import torch
     from visual_odom_amd import replicas
     rank, local_rank, world_size = replicas.rank_info()
+    if args.selftest_replicas:
+        dist = replicas.init("gloo")
+        if dist is not None:
+            dist.barrier()
+        elapsed, frames_total = replicas.aggregate(dist, 1.0 + 0.25 * rank, args.frames * args.steps)
+        out = {"metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features", "value": frames_total / elapsed,
+               "unit": "frames/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "data": "SELFTEST of the multi-rank control flow: no GPU work, fabricated timings -- not a measurement"}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     dist = replicas.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")

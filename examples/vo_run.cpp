@@ -126,6 +126,10 @@ int main(int argc, char **argv)
             return 3;
         }
         CHECK(rc);
+        if (rc == VO_NO_ESSENTIAL) { // mono_rotation and findEssentialMat found nothing: the reference's recoverPose throws
+            fprintf(stderr, "frame %d: no essential matrix (the reference throws here)\n", id);
+            return 4;
+        }
         // deleteUnmatchFeaturesCircle: ages += 1, compacted with the circular-matching survivors only
         // (feature.cpp:83-86,111); the consistency filter leaves ages alone (quirk B3)
         for (int i = 0; i < m_circ; i++)

@@ -92,6 +92,27 @@ def vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _build_example(name):
+    from visual_odom_amd import build
+    build.build()
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, name)
+    src = os.path.join(ROOT, "examples", name + ".cpp")
+    libdir = os.path.join(ROOT, "visual_odom_amd")
+    deps = [src, os.path.join(ROOT, "include", "vo_hip.h"), os.path.join(libdir, "libvo_hip.so")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(ROOT, "include"), "-L" + libdir,
+                               "-lvo_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+@pytest.fixture(scope="session")
+def vo_seq_run_binary():
+    """examples/vo_seq_run.cpp (the lock-step sequence loop as a C++ host program over the C ABI), built with g++"""
+    return _build_example("vo_seq_run")
+
+
 @pytest.fixture(scope="session")
 def vo_run_binary():
     """examples/vo_run.cpp (the reference's frame loop as a C++ host program over the C ABI), built with g++"""

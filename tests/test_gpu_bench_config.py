@@ -1,14 +1,15 @@
 """Parity on the configuration bench.py TIMES (-m gpu).
 
 The headline number comes from a 256-frame batch: an LK grid with 32 groups of eight frames (one frame per XCD),
-the 128-register instantiations of the f64 pose kernels (`crowded`: epnp_kernel<4>, select_refine_kernel<4>,
-and the five-point / essential kernels' crowded variants), and runs k / k + 1 overlapping on three streams with a
-double-buffered hand-off.  None of that is reached by the single-frame tests, so it is held to the oracle here:
+the reduced-register instantiations of the f64 pose kernels (round 1: epnp_kernel<4> / select_refine_kernel<4>; since
+round 2 the 256-register <2> ones from 32 k point-frames on; the five-point / essential kernels' crowded variants), and
+runs k / k + 1 overlapping on three streams with a double-buffered hand-off.  None of that is reached by the
+single-frame tests, so it is held to the oracle here:
   (a) a 64-frame KITTI-size batch (crowded, eight XCD groups), three runs enqueued back to back without a host
       sync: every frame of the batch against the oracle (survivors + tracks bit-exact, inlier sets and RANSAC control
       flow identical, pose <= 1e-6), and the overlapped result equal to a lone run's bit for bit;
-  (b) the crowded kernel variants forced on small inputs (VO_CROWDED_MIN = VO_CROWDED_MIN_PTS = 1): the existing
-      PnP / essential-matrix / full-path cases re-run through them;
+  (b) every reduced-register kernel variant forced on small inputs (VO_POSE_WAVES = 2 and 4, VO_CROWDED_MIN =
+      VO_CROWDED_MIN_PTS = 1): the existing PnP / essential-matrix / full-path cases re-run through them;
   (c) bench.py's own validation hook (validate_frames) is the code under (a), so the BENCH line's
       "validated_frames" field is produced by tested code.
 Reference semantics held: feature.cpp:118-148, visualOdometry.cpp:161-189."""
@@ -34,7 +35,7 @@ def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs)
     ctx = volib.Context(0, world.w, world.h, 8192, B)
     try:
         frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
-        assert min(len(p) for p in frame_pts) >= 1024 and B * min(len(p) for p in frame_pts) >= 65536  # -> `crowded`
+        assert min(len(p) for p in frame_pts) >= 1024 and B * min(len(p) for p in frame_pts) >= 65536  # -> `crowded`, <2>
         cache = {}
         # a lone run, synchronised: the reference result of this test, itself checked against the oracle on all frames
         ctx.batch_run(volib.STAGE_ALL)
@@ -98,11 +99,13 @@ def test_bench_configuration_detect_and_lk_only(volib, orc, bench_inputs):
         ctx.close()
 
 
-@pytest.fixture()
-def crowded_ctx(volib, monkeypatch):
-    """a context whose `crowded` predicate is always true: every pose launch takes the 128-register instantiations"""
+@pytest.fixture(params=[2, 4])
+def crowded_ctx(volib, monkeypatch, request):
+    """a context whose `crowded` predicate is always true and whose PnP kernels are the 256- / 128-register
+    instantiations: every pose launch takes the reduced-register code"""
     monkeypatch.setenv("VO_CROWDED_MIN", "1")
     monkeypatch.setenv("VO_CROWDED_MIN_PTS", "1")
+    monkeypatch.setenv("VO_POSE_WAVES", str(request.param))
     ctx = volib.Context(0, 1241, 376, 8192, 4)
     yield ctx
     ctx.close()

@@ -220,6 +220,50 @@ def test_long_sequence_kitti_size_against_the_reference_loop(volib, orc, kitti_w
         ctx.close()
 
 
+def test_cpp_sequence_loop_equals_python_mirror(volib, vo_seq_run_binary, tmp_path):
+    """examples/vo_seq_run.cpp (C++ host, C ABI, images from disk through the pinned staging) and
+    MultiSequenceOdometry (ctypes) replay the same three sequences of different lengths: the KITTI-format
+    trajectories agree to the printed precision"""
+    import subprocess
+    from visual_odom_amd import odometry
+    worlds = _worlds(3, **SMALL)
+    lengths = [7, 5, 6]
+    seqs = [w.render_sequence(n) for w, n in zip(worlds, lengths)]
+    P_l, P_r = worlds[0].proj_matrices()
+    dirs = []
+    for s, (L, R, _, _) in enumerate(seqs):
+        d = tmp_path / ("seq%d" % s)
+        for cam, imgs in ((0, L), (1, R)):
+            (d / ("image_%d" % cam)).mkdir(parents=True)
+            for k, img in enumerate(imgs):
+                h, w = img.shape
+                with open(d / ("image_%d" % cam) / ("%06d.pgm" % k), "wb") as f:
+                    f.write(b"P5\n%d %d\n255\n" % (w, h) + np.ascontiguousarray(img).tobytes())
+        dirs.append(str(d))
+    fx, cx, cy, bf = P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3]
+    prefix = str(tmp_path / "poses")
+    r = subprocess.run([vo_seq_run_binary, repr(float(fx)), repr(float(cx)), repr(float(cy)), repr(float(bf)), "10", "2",
+                        prefix] + dirs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ctx = volib.Context(0, 480, 160, 4096, 3)
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, 3, 480, 160, ctx=ctx, ring=3, max_steps=16, features_per_bucket=2)
+        for k in range(max(lengths)):
+            for s in range(3):
+                if k < lengths[s]:
+                    vo.push(s, seqs[s][0][k], seqs[s][1][k])
+            vo.step()
+        for s in range(3):
+            got = odometry.load_poses(prefix + "_%d.txt" % s)
+            want = np.asarray(vo.trajectory(s))
+            assert got.shape == want.shape == (lengths[s], 3, 4)
+            assert np.abs(got - want).max() < 1e-8
+            T0inv = np.linalg.inv(seqs[s][2][0])
+            assert odometry.ate_rmse(got, [(T0inv @ T)[:3] for T in seqs[s][2]]) < 0.3
+    finally:
+        ctx.close()
+
+
 def test_sequence_loop_guards(volib, small_world):
     L, R, poses, _ = small_world.render_sequence(2)
     P_l, P_r = small_world.proj_matrices()

@@ -49,3 +49,25 @@ def test_single_rank_is_passthrough(monkeypatch):
     assert replicas.init() is None
     assert replicas.aggregate(None, 0.5, 64) == (0.5, 64)
     assert replicas.shard_sequences(8, 0, 1) == list(range(8))
+
+
+def test_bench_multi_rank_launch_line():
+    """bench.py's N > 1 branch exactly as the driver launches it (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2 ...), on CPU through --selftest-replicas: rank
+    discovery from the environment, the gloo process group, barriers, MAX-over-ranks time and summed frames, one JSON
+    line from rank 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--frames", "16", "--selftest-replicas"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 16 * 4 / 1.25) < 1e-9      # frames of both ranks / the slower rank's time
+    assert "SELFTEST" in out["data"]

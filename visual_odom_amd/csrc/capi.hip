@@ -103,7 +103,7 @@ struct vo_ctx {
     // against 44.2 k -> only from 256 on.
     int seq_crowded_min = 256;
     int pose_waves_forced = 0;         // VO_POSE_WAVES = 1 / 2 / 4: developer A/B of the pose kernels' register budget
-    long long pose_medium_min = 16384; // frames x points from which the 256-register pose kernels are used
+    long long pose_medium_min = 32768; // frames x points from which the 256-register pose kernels are used
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
@@ -181,14 +181,18 @@ inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
 {
     return frames * pts >= c->crowded_min && pts >= c->crowded_min_pts;
 }
-// register budget of the f64 pose kernels as waves per SIMD: 4 (128 registers) next to a long LK launch, 2 (256) when
-// the tracking stages of the next run are short but must not wait for whole SIMDs, 1 (512) when the GPU is idle
+// Register budget of the f64 PnP kernels as waves per SIMD (pnp.hip): 1 = 512 registers (fastest alone: small batches,
+// the drop-in calls), 2 = 256 registers from ~32 k point-frames per run on -- a 512-register wave needs a whole SIMD to
+// itself and makes the next run's pyramid / detection kernels wait, a 256-register wave leaves half of it to them.
+// Measured (gpurun_out/r2_06, frames/s at 1 / 2 / 4 waves): 256-frame batch at 340 points 59.2 k / 69.6 k / 46.6 k;
+// at 2040 points 18.8 k / 19.7 k / 18.6 k; lock-step loop with 256 sequences 42.6 k / 49.2 k / 44.3 k, with 64
+// sequences 41.3 k / 32.8 k / 22.3 k, with 16 sequences 15.7 k / 14.0 k / 10.2 k.  The 128-register instantiation
+// round 1 used for crowded batches is never the best one any more and stays reachable through VO_POSE_WAVES = 4 only.
 inline int pose_waves(const vo_ctx *c, long long frames, int pts, bool crowded)
 {
+    (void)crowded;
     if (c->pose_waves_forced)
         return c->pose_waves_forced;
-    if (crowded)
-        return 4;
     return frames * (pts > 0 ? pts : 1) >= c->pose_medium_min ? 2 : 1;
 }
 // the current feature set (see vo_ctx::pts_sel)
@@ -828,7 +832,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // (the lock-step loop has DETECT on its critical path and the pose chain off it: from a few dozen sequences on, a
     // 512-register pose wave -- which needs a whole SIMD to itself -- keeps the pyramid / detection kernels of the next
     // step waiting: bucket_kernel 0.54 ms instead of 0.02 behind select_refine_kernel<1>, profiles/r02)
-    const bool crowded = is_crowded(c, B, c->max_pts_set) || (c->seq.on && B >= c->seq_crowded_min);
+    const bool crowded = is_crowded(c, B, c->max_pts_set) || (c->seq.on && B >= c->seq_crowded_min); // essential-matrix kernels
     int e = 0;
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
