@@ -188,7 +188,7 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
     }
     launch(1, 1, 1, 256, [&] {
         bucket_kernel(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
-                      out_ages, &n_out, out_cap, nullptr, nullptr);
+                      out_ages, &n_out, out_cap, nullptr, nullptr, nullptr);
     });
     return n_out;
 }

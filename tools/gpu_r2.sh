@@ -120,6 +120,19 @@ if has posewaves; then
         python -c "import json; b=json.load(open('$OUT/pw_default_$WV.json')); print('  batch kitti2000: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
     done
 fi
+if has prepab; then
+    for PREP in 0 1; do
+        stamp "lock-step loop, VO_SEQ_PREP=$PREP"
+        for S in 1 8 64 256; do
+            VO_SEQ_PREP=$PREP timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate $([ $S = 256 ] && echo 3 || echo 0) > "$OUT/prep${PREP}_seq_$S.json" 2>"$OUT/prep${PREP}_seq_$S.err" || tail -3 "$OUT/prep${PREP}_seq_$S.err"
+            python -c "import json; b=json.load(open('$OUT/prep${PREP}_seq_$S.json')); print('  seq S=%-4d      : %.0f fps %.3f ms/step validated %d' % ($S, b['value'], b['ms_per_step'], b['validated_frames']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        done
+        VO_SEQ_PREP=$PREP timeout 300 python bench.py --mode sequences --workload kitti2000 --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 2 > "$OUT/prep${PREP}_seq2000.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/prep${PREP}_seq2000.json')); print('  seq2000 S=256   : %.0f fps %.3f ms/step validated %d' % (b['value'], b['ms_per_step'], b['validated_frames']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
+        VO_SEQ_PREP=$PREP timeout 300 python bench.py --mode sequences --workload kitti374 --seqs 256 --steps 40 --warmup 4 --no-cpu-baseline --validate 0 --ingest pinned > "$OUT/prep${PREP}_seq_256_pinned.json" 2>/dev/null
+        python -c "import json; b=json.load(open('$OUT/prep${PREP}_seq_256_pinned.json')); print('  S=256 pinned    : %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']))"
+    done
+fi
 if has seqhost; then
     for ING in pinned host; do
         for S in 256 8; do

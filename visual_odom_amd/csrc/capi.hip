@@ -16,6 +16,9 @@
 using namespace vo;
 
 #define VO_SEQ_INFLIGHT 8 // steps the host may run ahead of the device
+// timing events of one run: [0..3] tracking stream (3 stages), [4..7] post streams (3 stages), [8] start of DETECT on
+// the tracking stream (differs from [1] when the pyramid stage runs on the lock-step loop's prepare stream)
+#define VO_EV_PER_RUN (VO_NUM_STAGES + 3)
 #define VO_SEQ_MAX_RING 3
 
 struct vo_ctx {
@@ -23,8 +26,8 @@ struct vo_ctx {
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
     vo_params prm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[VO_NUM_STAGES + 2] = {}; // [0..3] tracking stream (3 stages), [4..7] post stream (3 stages)
-    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_NUM_STAGES + 2) for vo_batch_run_slot
+    hipEvent_t ev[VO_EV_PER_RUN] = {}; // [0..3] tracking stream (3 stages), [4..7] post stream (3 stages)
+    std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_EV_PER_RUN) for vo_batch_run_slot
     std::string err;
 
     // batch configuration
@@ -149,6 +152,16 @@ struct vo_ctx {
         size_t stage_img = 0;
         hipEvent_t ev_stage[2] = {};
         bool stage_busy[2] = {};
+        // "prepare" work of a step runs on the copy stream, off the tracking stream's critical path: ingest of the new pairs,
+        // their pyramids, and FAST + non-maximum suppression of their LEFT images -- the corners the NEXT step's
+        // appendNewFeatures needs (visualOdometry.cpp:95-101 detects on imageLeft_t0, i.e. on the pair that arrived one
+        // step earlier).  Per step the tracking stream is left with: bucketing -> LK -> filter -> carry.
+        bool prep = true;                 // VO_SEQ_PREP = 0: everything on the tracking stream (round-2 first version)
+        float2 *d_corners = nullptr;      // [ring][S][fcap] FAST corners of the left image in each ring slot
+        int *d_ncorn = nullptr;           // [ring][S]
+        hipEvent_t ev_pyr = nullptr;      // pyramids of the pending step built (prep stream)
+        hipEvent_t ev_fast[VO_SEQ_MAX_RING] = {}; // corners of ring slot r ready (prep stream)
+        bool fast_pending[VO_SEQ_MAX_RING] = {};
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
         int n_ing = 0;
         bool begun = false, staged = false;
@@ -239,7 +252,8 @@ static int sync_all(vo_ctx *c);
 static void seq_free(vo_ctx *c)
 {
     vo_ctx::Seq &q = c->seq;
-    void *ptrs[] = {q.d_quads, q.d_active, q.d_pose, q.d_traj, q.d_info, q.d_rows, q.d_rows_carry, q.d_nages, q.d_ing};
+    void *ptrs[] = {q.d_quads, q.d_active, q.d_pose, q.d_traj, q.d_info, q.d_rows, q.d_rows_carry, q.d_nages, q.d_ing,
+                    q.d_corners, q.d_ncorn};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -249,7 +263,10 @@ static void seq_free(vo_ctx *c)
         (void)hipHostFree(q.h_ing);
     if (q.h_stage)
         (void)hipHostFree(q.h_stage);
-    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_stage[0], q.ev_stage[1]};
+    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_pyr, q.ev_stage[0], q.ev_stage[1]};
+    for (auto &e : q.ev_fast)
+        if (e)
+            (void)hipEventDestroy(e);
     for (hipEvent_t e : evs)
         if (e)
             (void)hipEventDestroy(e);
@@ -411,7 +428,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     }
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
-    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_NUM_STAGES + 2), nullptr);
+    c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_EV_PER_RUN), nullptr);
     for (auto &e : c->ring)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     // worst case pyramid bytes per image (5 levels, padded strides)
@@ -833,24 +850,28 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // 512-register pose wave -- which needs a whole SIMD to itself -- keeps the pyramid / detection kernels of the next
     // step waiting: bucket_kernel 0.54 ms instead of 0.02 behind select_refine_kernel<1>, profiles/r02)
     const bool crowded = is_crowded(c, B, c->max_pts_set) || (c->seq.on && B >= c->seq_crowded_min); // essential-matrix kernels
+    vo_ctx::Seq &sq = c->seq;
+    const bool prep = sq.on && sq.prep; // lock-step loop: pyramids (and, from vo_seq_step, FAST) on the prepare stream
+    hipStream_t pyrs = prep ? sq.copy : c->stream;
     int e = 0;
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], pyrs));
     e++;
     if (stages & VO_STAGE_PYRAMID) {
         const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
-            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], c->stream);
+            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], pyrs);
             for (int l = 0; l + 1 < c->levels; l++) {
-                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], c->stream);
-                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], c->stream);
+                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], pyrs);
+                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], pyrs);
             }
-            launch_scharr(tab, ni, c->levels, c->lw, c->lh, c->stream);
+            launch_scharr(tab, ni, c->levels, c->lw, c->lh, pyrs);
             std::fill(c->img_stale.begin() + c->pyr_first, c->img_stale.begin() + c->pyr_first + ni, (uint8_t)0);
         }
     }
-    vo_ctx::Seq &sq = c->seq;
+    if (prep)
+        VO_HIP_TRY(c, hipEventRecord(sq.ev_pyr, pyrs));
     const int *seq_active = sq.on ? sq.d_active + (size_t)(sq.step % VO_SEQ_INFLIGHT) * sq.S : nullptr;
     if (!sq.on && (stages & VO_STAGE_LK)) {
         for (int f = 0; f < B; f++) {
@@ -861,7 +882,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
     }
     if (timed)
-        VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
+        VO_HIP_TRY(c, hipEventRecord(evs[e], pyrs));
     e++;
     // DETECT and LK write the set of buffers (bucketed features / tracks + status) that the filter of two runs
     // ago read; the filter of the previous run reads the other set
@@ -870,6 +891,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_trk_free[wset], 0));
         c->trk_busy[wset] = false;
     }
+    if (timed && !(stages & VO_STAGE_DETECT))
+        VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 2], c->stream));
     if (stages & VO_STAGE_DETECT) {
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
@@ -879,13 +902,21 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         if (c->w > 4096)
             return fail(c, VO_ERR_ARG, "vo_batch_run: VO_STAGE_DETECT handles images up to 4096 pixels wide");
         // appendNewFeatures only when fewer than redetect_below features were carried in (visualOdometry.cpp:95)
+        if (timed)
+            VO_HIP_TRY(c, hipEventRecord(evs[VO_NUM_STAGES + 2], c->stream));
         if (sq.on) {
             // the carried set lives on the device (seq_carry_kernel of the previous step wrote it on the filter stream)
             if (sq.carry_pending) {
                 VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_carry, 0));
                 sq.carry_pending = false;
             }
-            launch_seq_prepare(seq_active, c->d_ntracked, c->dprm.redetect_below, c->d_detect, B, c->stream);
+            const int rp = (int)((sq.step - 1) % sq.ring); // ring slot of this step's t0 pair
+            if (prep && sq.fast_pending[rp]) {              // its corners come from the prepare stream, one step ago
+                VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_fast[rp], 0));
+                sq.fast_pending[rp] = false;
+            }
+            launch_seq_prepare(seq_active, c->d_ntracked, c->dprm.redetect_below, c->d_detect,
+                               prep ? sq.d_ncorn + (size_t)rp * sq.S : nullptr, c->d_nnew, B, c->stream);
             c->detect_uploaded = false;
         } else {
             bool changed = false;
@@ -903,10 +934,17 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
-        launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
-                             c->d_nmsmask, c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
-                             c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
-                             c->d_overflow, c->stream);
+        if (prep) {
+            const int rp = (int)((sq.step - 1) % sq.ring);
+            launch_bucket(c->d_feat, sq.d_corners + (size_t)rp * sq.S * c->fcap, c->d_fages, c->d_ntracked, c->d_nnew, c->fcap,
+                          c->w, c->h, bs, fpb, c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
+                          c->d_overflow, B, c->stream);
+        } else {
+            launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
+                                 c->d_nmsmask, c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
+                                 c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
+                                 c->d_overflow, c->stream);
+        }
         c->pts_sel = wset;
         // the bucketed count is only known on the device; every later grid is sized by its bound
         const int bound = cells * fpb < cap ? cells * fpb : cap;
@@ -917,6 +955,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         VO_HIP_TRY(c, hipEventRecord(evs[e], c->stream));
     e++;
     if (stages & VO_STAGE_LK) {
+        if (prep) // the t1 pyramids of this step were built on the prepare stream
+            VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_pyr, 0));
         LkParams lp;
         lp.max_level = c->levels - 1;
         int mc = c->prm.lk_max_count;
@@ -1088,7 +1128,7 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
     if (rc != VO_OK)
         return rc;
     for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s < 3 ? s : s + 1], c->ev[s < 3 ? s + 1 : s + 2]));
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], c->ev[s == 1 ? VO_NUM_STAGES + 2 : s < 3 ? s : s + 1], c->ev[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -1098,7 +1138,7 @@ int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
         return VO_ERR_ARG;
     if (c->seq.on)
         return fail(c, VO_ERR_STATE, "vo_batch_run_slot inside the sequence loop: use vo_seq_step");
-    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)]);
+    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_EV_PER_RUN)]);
 }
 
 int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
@@ -1106,9 +1146,9 @@ int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
     if (!c || !ms || slot < 0 || slot >= VO_EVENT_SLOTS)
         return VO_ERR_ARG;
     VO_HIP_TRY(c, hipSetDevice(c->device));
-    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_NUM_STAGES + 2)];
+    hipEvent_t *evs = &c->ring[(size_t)slot * (VO_EV_PER_RUN)];
     for (int s = 0; s < VO_NUM_STAGES; s++) // PYRAMID, DETECT, LK on the tracking stream; the rest on the post stream
-        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s < 3 ? s : s + 1], evs[s < 3 ? s + 1 : s + 2]));
+        VO_HIP_TRY(c, hipEventElapsedTime(&ms[s], evs[s == 1 ? VO_NUM_STAGES + 2 : s < 3 ? s : s + 1], evs[s < 3 ? s + 1 : s + 2]));
     return VO_OK;
 }
 
@@ -1416,7 +1456,21 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     q.S = n_seq;
     q.ring = ring;
     q.max_steps = max_steps;
-    bool ok = hipStreamCreateWithFlags(&q.copy, hipStreamNonBlocking) == hipSuccess;
+    // the prepare stream gets the highest priority: its kernels are short and memory-bound, and they have to find SIMD
+    // slots between the LK waves of the step that is running
+    int least = 0, greatest = 0;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&q.copy, hipStreamNonBlocking, greatest) == hipSuccess;
+    {
+        const char *e = getenv("VO_SEQ_PREP");
+        q.prep = !(e && e[0] == '0');
+    }
+    ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
+    ok = ok && dmalloc(&q.d_ncorn, (size_t)ring * S) == hipSuccess;
+    ok = ok && hipMemset(q.d_ncorn, 0, sizeof(int) * ring * S) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q.ev_pyr, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : q.ev_fast)
+        ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && dmalloc(&q.d_quads, (size_t)ring * S) == hipSuccess;
     ok = ok && dmalloc(&q.d_active, (size_t)VO_SEQ_INFLIGHT * S) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&q.h_active, sizeof(int) * VO_SEQ_INFLIGHT * S, hipHostMallocDefault) == hipSuccess;
@@ -1639,8 +1693,10 @@ int vo_seq_step(vo_ctx *c)
             q.staged = false;
         }
     }
-    VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
-    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
+    if (!q.prep) {
+        VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
+    }
     q.begun = false;
     c->pyr_first = r * q.S * 2;
     c->pyr_count = q.S * 2;
@@ -1651,9 +1707,23 @@ int vo_seq_step(vo_ctx *c)
         c->quads_cur = q.d_quads + (size_t)((q.step - 1) % q.ring) * q.S;
         stages |= VO_STAGE_DETECT | VO_STAGE_LK | VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP;
     }
-    rc = run_stages(c, stages, true, &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_NUM_STAGES + 2)]);
+    rc = run_stages(c, stages, true, &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_EV_PER_RUN)]);
     if (rc != VO_OK)
         return rc;
+    if (q.prep) {
+        // FAST + non-maximum suppression of the new pairs' left images, for the NEXT step's appendNewFeatures: on the
+        // prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
+        int t = c->dprm.fast_threshold;
+        t = t < 0 ? 0 : t > 255 ? 255 : t;
+        if (c->w > 4096)
+            return fail(c, VO_ERR_ARG, "vo_seq_step: detection handles images up to 4096 pixels wide");
+        launch_fast_corners(c->d_imgs, q.d_quads + (size_t)r * q.S, nullptr, q.S, c->w, c->h, t, c->dprm.fast_nonmax,
+                            c->d_score, c->d_nmsmask, c->d_rowcnt, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
+                            q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
+        VO_HIP_TRY(c, hipEventRecord(q.ev_fast[r], q.copy));
+        q.fast_pending[r] = true;
+        VO_HIP_TRY(c, hipGetLastError());
+    }
     // end of the step = end of its last stream: the pose stream when a frame was processed
     VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream : c->stream));
     q.step_pending[slot] = true;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const PyrImage *__restr
                                                          uint16_t *__restrict__ score /* [B][h][w] */)
 {
     const int frame = blockIdx.z;
-    if (!detect[frame])
+    if (detect && !detect[frame])
         return;
     const PyrImage &im = imgs[quads[frame].l0];
     const int w = im.w[0], h = im.h[0], stride = im.stride[0];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void fast_nms_mask_kernel(const uint16_t *__re
 {
     __shared__ int s_wave[4];
     const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (!detect[frame])
+    if (detect && !detect[frame])
         return;
     const uint16_t *__restrict__ row = score + ((size_t)frame * h + y) * w;
     unsigned long long *__restrict__ mrow = mask + ((size_t)frame * h + y) * segs;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
 {
     __shared__ int s_pre[FAST_MAX_SEGS + 1];
     const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (!detect[frame])
+    if (detect && !detect[frame])
         return;
     const unsigned long long *__restrict__ mrow = mask + ((size_t)frame * h + y) * segs;
     if (tid == 0) { // segs <= 64: a serial prefix is a few dozen cycles
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
     __syncthreads();
     if (s_pre[segs] == 0)
         return;
-    const int base = n_tracked[frame] + rowoff[(size_t)frame * h + y];
+    const int base = (n_tracked ? n_tracked[frame] : 0) + rowoff[(size_t)frame * h + y];
     for (int s = wv; s < segs; s += 4) {
         const unsigned long long m = mrow[s];
         if ((m >> lane) & 1ull) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ row
 {
     __shared__ int s_part[256];
     const int frame = blockIdx.x, tid = threadIdx.x;
-    if (!detect[frame]) {
+    if (detect && !detect[frame]) {
         if (tid == 0)
             n_new[frame] = 0;
         return;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
                                                      int bucket_size, int fpb, float2 *__restrict__ out_pts,
                                                      int *__restrict__ out_ages, int *__restrict__ out_n,
                                                      int out_cap, const int *__restrict__ active /* or null */,
-                                                     int *__restrict__ overflow /* or null */)
+                                                     int *__restrict__ overflow /* or null */,
+                                                     const float2 *__restrict__ corners /* or null: [B][cap] */)
 {
     __shared__ int s_cnt[BK_MAX_CELLS], s_last[BK_MAX_CELLS];
     __shared__ int s_first[BK_MAX_FPB][BK_MAX_CELLS];
@@ -263,8 +264,16 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int bh = rows / bucket_size, bw = cols / bucket_size;
     const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
+    // The list appendNewFeatures leaves (feature.cpp:255-262) is "carried features, then the new corners".  Combined
+    // form (corners == null): both live in `feat`.  Split form: the corners were detected ahead of time into their own
+    // array (lock-step loop: FAST of a frame's left image runs one step early, off the critical path), element i of the
+    // list is feat[i] for i < n_tracked and corners[i - n_tracked] after that.
     const float2 *__restrict__ P = feat + (size_t)frame * cap;
+    const float2 *__restrict__ Cn = corners ? corners + (size_t)frame * cap : nullptr;
     const int *__restrict__ A = ages + (size_t)frame * cap;
+    const int nt = n_tracked[frame];
+    auto point = [&](int i) { return (Cn && i >= nt) ? Cn[i - nt] : P[i]; };
+    auto age = [&](int i) { return i < cap ? A[i] : 0; };
     if (active && !active[frame]) { // lock-step sequence loop: this sequence has no frame in this step
         if (tid == 0) {
             out_n[frame] = 0;
@@ -273,11 +282,19 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         }
         return;
     }
-    int n_in = n_tracked[frame] + n_new[frame];
     // Capacity: carried + detected features beyond `cap` were not stored (fast_nms_write_kernel), and bucketing keeps
     // the LAST eligible feature of a cell, so a truncated list changes the result -- reported, never silent
-    const bool list_overflow = n_in > cap;
-    n_in = n_in < cap ? n_in : cap;
+    int n_in;
+    bool list_overflow;
+    if (Cn) {
+        const int nn = n_new[frame];
+        list_overflow = nn > cap;
+        n_in = nt + (nn < cap ? nn : cap);
+    } else {
+        n_in = nt + n_new[frame];
+        list_overflow = n_in > cap;
+        n_in = n_in < cap ? n_in : cap;
+    }
 
     for (int b = tid; b < nb; b += 256) {
         s_cnt[b] = 0;
@@ -289,10 +306,10 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     // bucket of feature i, or -1 when Bucket::add_feature ignores it (age >= 10) / the reference
     // would index outside its bucket vector (undefined behaviour there; never hit by in-image points)
     auto cell = [&](int i) {
-        const float2 p = P[i];
+        const float2 p = point(i);
         const int hidx = (int)(p.y / (float)bucket_size), widx = (int)(p.x / (float)bucket_size);
         const int idx = hidx * bw + widx;
-        return (idx < 0 || idx >= nb || A[i] >= 10) ? -1 : idx;
+        return (idx < 0 || idx >= nb || age(i) >= 10) ? -1 : idx;
     };
     for (int i = tid; i < n_in; i += 256) {
         const int b = cell(i);
@@ -341,8 +358,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         for (int q = 0; q < m; q++) {
             const int src = q == 0 ? (c > fpb ? s_last[idx] : s_first[0][idx]) : s_first[q][idx];
             if (off + q < out_cap) {
-                OP[off + q] = P[src];
-                OA[off + q] = A[src];
+                OP[off + q] = point(src);
+                OA[off + q] = age(src);
             }
         }
         off += m;
@@ -350,12 +367,11 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
 }
 
 #ifndef VO_HOST_EMUL
-void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
-                          int h, int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask,
-                          int *d_rowcnt,
-                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
-                          int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
-                          const int *d_active, int *d_overflow, hipStream_t stream)
+// cv::FAST of every frame's left t0 image: corners in row-major order at out[frame][base ...], count in n_new[frame]
+// (base = n_tracked[frame] when given -- the combined list -- else 0)
+void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w, int h,
+                         int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask, int *d_rowcnt,
+                         const int *d_ntracked, int *d_nnew, int cap, float2 *d_out, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
@@ -366,10 +382,31 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                        d_nmsmask, segs, d_rowcnt);
     hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, h, d_detect, d_nnew);
     hipLaunchKernelGGL(fast_nms_write_kernel, dim3(h, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
-                       d_rowcnt, d_ntracked, cap, d_feat);
+                       d_rowcnt, d_ntracked, cap, d_out);
+}
+
+void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_ages, const int *d_ntracked,
+                   const int *d_nnew, int cap, int w, int h, int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages,
+                   int *d_out_n, int out_cap, const int *d_active, int *d_overflow, int n_frames, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return;
+    hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
+                       bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow, d_corners);
+}
+
+void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
+                          int h, int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask,
+                          int *d_rowcnt,
+                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
+                          int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
+                          const int *d_active, int *d_overflow, hipStream_t stream)
+{
+    launch_fast_corners(d_imgs, d_quads, d_detect, n_frames, w, h, threshold, nonmax, d_score, d_nmsmask, d_rowcnt,
+                        d_ntracked, d_nnew, cap, d_feat, stream);
     if (bucket_size > 0)
-        hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew,
-                           cap, h, w, bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow);
+        launch_bucket(d_feat, nullptr, d_ages, d_ntracked, d_nnew, cap, w, h, bucket_size, fpb, d_out_pts, d_out_ages,
+                      d_out_n, out_cap, d_active, d_overflow, n_frames, stream);
 }
 #endif
 

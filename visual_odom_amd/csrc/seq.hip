@@ -19,12 +19,19 @@
 
 namespace vo {
 
+// n_corners (optional): the FAST corners of every sequence's t0 image were detected one step ahead (vo_seq_step);
+// a sequence that does not re-detect in this frame simply does not append them (n_new = 0)
 __global__ void seq_prepare_kernel(const int *__restrict__ active, const int *__restrict__ n_tracked,
-                                   int redetect_below, int *__restrict__ detect, int n_seq)
+                                   int redetect_below, int *__restrict__ detect,
+                                   const int *__restrict__ n_corners, int *__restrict__ n_new, int n_seq)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n_seq)
-        detect[f] = (active[f] && n_tracked[f] < redetect_below) ? 1 : 0;
+    if (f < n_seq) {
+        const int d = (active[f] && n_tracked[f] < redetect_below) ? 1 : 0;
+        detect[f] = d;
+        if (n_corners)
+            n_new[f] = d ? n_corners[f] : 0;
+    }
 }
 
 // one 256-thread workgroup per sequence
@@ -179,11 +186,11 @@ void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitc
                        img_bytes);
 }
 
-void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
-                        hipStream_t stream)
+void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,
+                        const int *n_corners, int *n_new, int n_seq, hipStream_t stream)
 {
     hipLaunchKernelGGL(seq_prepare_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, active, n_tracked,
-                       redetect_below, detect, n_seq);
+                       redetect_below, detect, n_corners, n_new, n_seq);
 }
 
 void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,

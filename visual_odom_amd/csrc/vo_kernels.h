@@ -107,10 +107,16 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
                           const int *d_active, int *d_overflow, hipStream_t stream);
+void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w, int h,
+                         int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask, int *d_rowcnt,
+                         const int *d_ntracked, int *d_nnew, int cap, float2 *d_out, hipStream_t stream);
+void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_ages, const int *d_ntracked,
+                   const int *d_nnew, int cap, int w, int h, int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages,
+                   int *d_out_n, int out_cap, const int *d_active, int *d_overflow, int n_frames, hipStream_t stream);
 void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
                        hipStream_t stream);
-void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect, int n_seq,
-                        hipStream_t stream);
+void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,
+                        const int *n_corners, int *n_new, int n_seq, hipStream_t stream);
 void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,
                       const int *ages, const int *n_bucketed, int cap, int fcap, float2 *feat, int *fages,
                       int *n_tracked, const int *overflow, int *n_rows_carry, int *n_ages, SeqFrameInfo *info,
