@@ -1456,15 +1456,22 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     q.S = n_seq;
     q.ring = ring;
     q.max_steps = max_steps;
-    // the prepare stream gets the highest priority: its kernels are short and memory-bound, and they have to find SIMD
-    // slots between the LK waves of the step that is running
+    // Prepare stream or plain copy stream?  Moving the pyramids and FAST off the tracking stream shortens a step's
+    // critical path, which is what a SMALL number of sequences is bound by (1 sequence 1.39 k -> 1.58 k frames/s,
+    // 8 sequences 9.3 k -> 12.3 k); with many sequences the GPU is saturated, the step costs the sum of its kernels
+    // either way and the extra concurrency only disturbs them (64 sequences 41.3 k -> 35.8 k, 256: 49.2 k -> 46.7 k;
+    // gpurun_out/r2_06, r2_07).  So: prepare stream (highest priority -- its short memory-bound kernels have to find
+    // SIMD slots between the running step's LK waves) up to ~16 k point-frames per step, plain copy stream above.
+    {
+        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : h / 10;
+        const long long cells = bs > 0 ? (long long)(h / bs + 1) * (w / bs + 1) : 1;
+        const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
+        q.prep = e ? e[0] != '0' : (long long)n_seq * cells * c->dprm.features_per_bucket <= c->pose2_max;
+    }
     int least = 0, greatest = 0;
     bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-    ok = ok && hipStreamCreateWithPriority(&q.copy, hipStreamNonBlocking, greatest) == hipSuccess;
-    {
-        const char *e = getenv("VO_SEQ_PREP");
-        q.prep = !(e && e[0] == '0');
-    }
+    ok = ok && (q.prep ? hipStreamCreateWithPriority(&q.copy, hipStreamNonBlocking, greatest)
+                       : hipStreamCreateWithFlags(&q.copy, hipStreamNonBlocking)) == hipSuccess;
     ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
     ok = ok && dmalloc(&q.d_ncorn, (size_t)ring * S) == hipSuccess;
     ok = ok && hipMemset(q.d_ncorn, 0, sizeof(int) * ring * S) == hipSuccess;
