@@ -83,7 +83,7 @@ if has stageslk; then
     cat "$OUT/bench_detect.json"; tail -3 "$OUT/bench_detect.err"
 fi
 if has seq; then
-    for S in 256 64 8 1; do
+    for S in 256 64 16 8 1; do
         stamp "bench --mode sequences --seqs $S (reference-default bucketing, pairs resident in HBM)"
         timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate $([ $S = 256 ] && echo 3 || echo 0) > "$OUT/bench_seq_${S}.json" 2> "$OUT/bench_seq_${S}.err"
         cat "$OUT/bench_seq_${S}.json"; tail -3 "$OUT/bench_seq_${S}.err"

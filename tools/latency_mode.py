@@ -43,3 +43,19 @@ for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default
         print("    frame loop incl. FAST + bucketing + pose integration, %s: %.2f ms/frame = %.0f frames/s"
               % ("streaming ring" if streaming else "stateless drop-in calls", 1e3 * dt3 / n, n / dt3))
     ctx.close()
+    # the same loop PIPELINED (vo_seq_* with one sequence, host images): the pose solve of frame k runs under detection
+    # and tracking of frame k + 1, nothing comes back until the trajectory is asked for
+    vo = odometry.MultiSequenceOdometry(P_l, P_r, 1, world.w, world.h, ring=3, max_steps=n + 32, features_per_bucket=per_bucket)
+    for i in range(9):
+        vo.push(0, L[order[i % 8]], R[order[i % 8]])
+        vo.step()
+    vo.sync()
+    t4 = time.perf_counter()
+    for i in range(9, 9 + n):
+        vo.push(0, L[order[i % 8]], R[order[i % 8]])
+        vo.step()
+    vo.sync()
+    dt4 = time.perf_counter() - t4
+    print("    frame loop, lock-step sequence API with ONE sequence (pipelined, host images): %.2f ms/frame = %.0f frames/s"
+          % (1e3 * dt4 / n, n / dt4))
+    vo.close()
