@@ -6,6 +6,9 @@
 // three beta approximations each refined by 5 Gauss-Newton steps, Horn absolute orientation,
 // best-of-three by reprojection error; then R -> rvec.  VO_HD so tests/host_check can run the very
 // same code on the CPU (unit test only, never a product fallback).
+// Attribution: follows the operation order of OpenCV's modules/calib3d/src/epnp.cpp (EPnP, Lepetit / Moreno-Noguer /
+// Fua; BSD-style notice in that file; OpenCV is Apache-2.0) so that results match the reference's solvePnPRansac calls --
+// see NOTICE.  Written for this repository; no OpenCV source is included.
 #pragma once
 
 #include "vo_linalg.h"

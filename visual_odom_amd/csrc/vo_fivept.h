@@ -11,6 +11,9 @@
 //   -> cv::solvePoly (Durand-Kerner sweeps from the powers of 1 + i, 300 iterations)
 //   -> per real root: (x, y) from the null vector of B(z) (3 x 3 SVD), E normalised to unit norm.
 // VO_HD like the rest of the pose math, so tests/host_check can run the exact device code on the CPU.
+// Attribution: follows the operation order of OpenCV's modules/calib3d/src/five-point.cpp (Nister's five-point algorithm,
+// derived from Bo Li's implementation; BSD-style notice in that file; OpenCV is Apache-2.0) -- see NOTICE.  Written for
+// this repository; no OpenCV source is included.
 #pragma once
 
 #include "vo_linalg.h"

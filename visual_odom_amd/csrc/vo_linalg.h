@@ -8,6 +8,8 @@
 // (core/src/lapack.cpp) which the reference reaches through cv::triangulatePoints and
 // cv::solvePnPRansac (reference main.cpp:170, visualOdometry.cpp:176), so that with
 // -ffp-contract=off the device results track the CPU path to the last bits.
+// Attribution: JacobiSVD / back-substitution follow the operation order of OpenCV's modules/core/src/lapack.cpp
+// (Apache-2.0) -- see NOTICE.  Written for this repository; no OpenCV source is included.
 #pragma once
 
 #include <float.h>
