@@ -169,18 +169,16 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
         memcpy(im.lvl[0] + (ptrdiff_t)y * p.ls[0], img + (size_t)y * w, w);
     Quad quad{0, 0, 0, 0};
     const int fcap = 1 << 17;
-    std::vector<uint16_t> score((size_t)w * h, 0xBEEF);
-    std::vector<int> rowcnt(h, -1), fages(fcap, 0);
+    std::vector<int> rowcnt(h, 0), rowoff(h, -1), fages(fcap, 0);
     std::vector<float2> feat(fcap);
     memcpy(feat.data(), tracked, sizeof(float2) * n_tracked);
     memcpy(fages.data(), ages_in, sizeof(int) * n_ages);
     int n_new = -1, n_out = -1;
-    launch((w + 63) / 64, (h + 3) / 4, 1, 256, [&] { fast_score_kernel(&im, &quad, &do_detect, threshold, score.data()); });
     const int segs = (w + 63) / 64;
     std::vector<unsigned long long> nmsmask((size_t)h * segs, 0xDEADBEEFDEADBEEFull);
-    launch(h, 1, 1, 256, [&] { fast_nms_mask_kernel(score.data(), w, h, &do_detect, nonmax, nmsmask.data(), segs, rowcnt.data()); });
-    launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), h, &do_detect, &n_new); });
-    launch(h, 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowcnt.data(), &n_tracked, fcap, feat.data()); });
+    launch(segs, (h + 15) / 16, 1, 256, [&] { fast_tile_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
+    launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), rowoff.data(), h, &do_detect, &n_new); });
+    launch(h, 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowoff.data(), &n_tracked, fcap, feat.data()); });
     if (bucket_size <= 0) {
         const int k = n_new < out_cap ? n_new : out_cap;
         memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);

@@ -84,9 +84,9 @@ struct vo_ctx {
     // detection / bucketing (VO_STAGE_DETECT)
     vo_detect_params dprm;
     int fcap = 0;                  // capacity of the carried + detected feature list of a frame
-    uint16_t *d_score = nullptr;   // [B][max_h][max_w] FAST corner flag << 8 | score
     unsigned long long *d_nmsmask = nullptr; // [B][max_h][ceil(max_w / 64)] NMS keep ballots
-    int *d_rowcnt = nullptr;       // [B][max_h]
+    int *d_rowcnt = nullptr;       // [B][max_h] corners per image row (zero between launches)
+    int *d_rowoff = nullptr;       // [B][max_h] exclusive row offsets
     int *d_detect = nullptr, *d_ntracked = nullptr, *d_nnew = nullptr; // [B]
     float2 *d_feat = nullptr;      // [B][fcap] carried features, then the new corners
     int *d_fages = nullptr;        // [B][fcap] ages of d_feat (zero beyond the uploaded ages)
@@ -316,7 +316,7 @@ void vo_destroy(vo_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
-                    c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_score, c->d_nmsmask, c->d_rowcnt, c->d_detect,
+                    c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_rowoff, c->d_nmsmask, c->d_rowcnt, c->d_detect,
                     c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages, c->d_pts_det[0], c->d_pts_det[1],
                     c->d_npts_det[0], c->d_npts_det[1], c->d_ages_det[0], c->d_ages_det[1], c->d_overflow};
     for (void *p : ptrs)
@@ -482,9 +482,10 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->fcap = max_pts * 4 > 16384 ? max_pts * 4 : 16384;
     if ((long long)max_w * max_h / 16 > c->fcap)
         c->fcap = (int)((long long)max_w * max_h / 16);
-    ok = ok && dmalloc(&c->d_score, B * (size_t)max_w * max_h) == hipSuccess;
     ok = ok && dmalloc(&c->d_nmsmask, B * (size_t)max_h * ((max_w + 63) / 64)) == hipSuccess;
     ok = ok && dmalloc(&c->d_rowcnt, B * (size_t)max_h) == hipSuccess;
+    ok = ok && dmalloc(&c->d_rowoff, B * (size_t)max_h) == hipSuccess;
+    ok = ok && hipMemset(c->d_rowcnt, 0, B * (size_t)max_h * sizeof(int)) == hipSuccess;
     ok = ok && dmalloc(&c->d_detect, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_ntracked, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_nnew, B) == hipSuccess;
@@ -940,8 +941,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                           c->w, c->h, bs, fpb, c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
                           c->d_overflow, B, c->stream);
         } else {
-            launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax, c->d_score,
-                                 c->d_nmsmask, c->d_rowcnt, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
+            launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, B, c->w, c->h, t, c->dprm.fast_nonmax,
+                                 c->d_nmsmask, c->d_rowcnt, c->d_rowoff, c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, bs, fpb,
                                  c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
                                  c->d_overflow, c->stream);
         }
@@ -1725,7 +1726,7 @@ int vo_seq_step(vo_ctx *c)
         if (c->w > 4096)
             return fail(c, VO_ERR_ARG, "vo_seq_step: detection handles images up to 4096 pixels wide");
         launch_fast_corners(c->d_imgs, q.d_quads + (size_t)r * q.S, nullptr, q.S, c->w, c->h, t, c->dprm.fast_nonmax,
-                            c->d_score, c->d_nmsmask, c->d_rowcnt, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
+                            c->d_nmsmask, c->d_rowcnt, c->d_rowoff, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
                             q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
         VO_HIP_TRY(c, hipEventRecord(q.ev_fast[r], q.copy));
         q.fast_pending[r] = true;
@@ -1985,7 +1986,7 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     c->h_ntracked[0] = 0;
     c->detect_uploaded = false;
     threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
-    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_score, c->d_nmsmask, c->d_rowcnt,
+    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_nmsmask, c->d_rowcnt, c->d_rowoff,
                          c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
                          nullptr, nullptr, 0, nullptr, nullptr, c->stream);
     VO_HIP_TRY(c, hipGetLastError());

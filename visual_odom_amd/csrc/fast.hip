@@ -17,10 +17,10 @@
 //     ages array is longer than the points array (new corners then inherit stale ages).
 //
 // Kernels:
-//   fast_score_kernel    thread per pixel of the level-0 image already resident for LK:
-//                        16 circle pixels -> 2 x 16-bit masks -> 9-contiguous test by shift-and,
-//                        cornerScore<16> for corners; u16 map (corner flag << 8 | score)
-//   fast_nms_mask_kernel workgroup per image row: NMS predicate once, one 64-bit ballot per 64-pixel segment, row count
+//   fast_tile_kernel     workgroup per 64 x 16 tile of the level-0 image already resident for LK: pixels staged in
+//                        LDS; per position 16 circle pixels -> 2 x 16-bit masks -> 9-contiguous test by shift-and,
+//                        cornerScore<16> for corners; NMS predicate on the LDS score tile, one 64-bit ballot per
+//                        64-pixel row segment, row counts by atomicAdd
 //   fast_rowscan_kernel  workgroup per frame: exclusive scan of the row counts
 //   fast_nms_write_kernel workgroup per image row: (x, y) at rows_before + rank from the stored ballots (row-major)
 //   bucket_kernel        workgroup per frame.  The sequential bucket fill is restated as order
@@ -101,77 +101,78 @@ __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int str
     return (-b0 - 1) & 0xff;
 }
 
-// grid (ceil(w / 64), ceil(h / 4), n_frames), 256 threads
-__global__ __launch_bounds__(256) void fast_score_kernel(const PyrImage *__restrict__ imgs,
-                                                         const Quad *__restrict__ quads,
-                                                         const int *__restrict__ detect, int threshold,
-                                                         uint16_t *__restrict__ score /* [B][h][w] */)
+// Fused score + non-maximum suppression, one 256-thread workgroup per 64 x 16 pixel tile (round 2; the first version
+// was a thread-per-pixel score kernel -- 17 global byte loads per pixel -- writing a u16 score map that a second kernel
+// read back nine times: 0.77 + 0.49 ms per 256 KITTI frames, the map alone 239 MB):
+//   A  the tile's pixels + 4-pixel apron (80 x 24 bytes, origin (x0 - 4, y0 - 4): 4-byte aligned in the bordered
+//      level-0 image, always inside its allocation) go to LDS with dword loads;
+//   B  corner test + cornerScore<16> of the 66 x 18 positions of the tile and its 1-pixel halo, reading the circle
+//      pixels from LDS (positions inside FAST's 3-pixel image margin or outside the image score 0 like the map did);
+//   C  keep predicate of the 64 x 16 tile positions (corner, score strictly above its 8 neighbours'), one 64-bit
+//      ballot per row segment stored exactly where fast_nms_write_kernel expects it, row counts by atomicAdd (the
+//      row-scan pass turns them into offsets and zeroes them again).
+// Results are identical to the two-kernel form by construction (same predicate, same neighbour scores).
+constexpr int FT_W = 64, FT_H = 16;                 // output tile
+constexpr int FT_PW = FT_W + 16, FT_PH = FT_H + 8;  // pixel tile in LDS (bytes x rows)
+constexpr int FT_SW = FT_W + 2, FT_SH = FT_H + 2;   // score tile incl. the 1-pixel halo
+constexpr int FAST_MAX_SEGS = 64;                   // 64-pixel segments per row: images up to 4096 pixels wide
+
+__global__ __launch_bounds__(256) void fast_tile_kernel(const PyrImage *__restrict__ imgs,
+                                                        const Quad *__restrict__ quads,
+                                                        const int *__restrict__ detect /* or null = every frame */,
+                                                        int threshold, int nonmax,
+                                                        unsigned long long *__restrict__ mask /* [B][h][segs] */,
+                                                        int segs, int *__restrict__ rowcnt /* [B][h], zero on entry */)
 {
-    const int frame = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PH * FT_PW];
+    __shared__ uint16_t s_sc[FT_SH * FT_SW];
+    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (detect && !detect[frame])
         return;
     const PyrImage &im = imgs[quads[frame].l0];
     const int w = im.w[0], h = im.h[0], stride = im.stride[0];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h)
-        return;
-    uint16_t out = 0;
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-        bool corner;
-        const int s = fast_score(im.lvl[0] + (ptrdiff_t)y * stride + x, stride, threshold, &corner);
-        if (corner)
-            out = (uint16_t)(0x100 | s);
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const VO_GLOBAL uint8_t *__restrict__ base =
+        (const VO_GLOBAL uint8_t *)im.lvl[0] + ((ptrdiff_t)(y0 - 4) * stride + (x0 - 4));
+    for (int i = tid; i < FT_PH * (FT_PW / 4); i += 256) {
+        const int row = i / (FT_PW / 4), c = i - row * (FT_PW / 4);
+        *reinterpret_cast<uint32_t *>(&s_px[row * FT_PW + 4 * c]) =
+            *reinterpret_cast<const VO_GLOBAL uint32_t *>(base + ((ptrdiff_t)row * stride + 4 * c));
     }
-    score[((size_t)frame * h + y) * w + x] = out;
-}
-
-// Non-maximum suppression + row-major compaction in two passes without re-reading the score map:
-//   fast_nms_mask_kernel   grid (h, n_frames), 256 threads: every wavefront takes 64-pixel segments of the row
-//                          (s = wave, wave + 4, ...), evaluates the keep predicate (corner, score strictly above its 8
-//                          neighbours') and stores the 64-bit ballot of the segment; the row count is the popcount sum
-//   fast_rowscan_kernel    row counts -> exclusive offsets (row-major order = cv::FAST's keypoint order)
-//   fast_nms_write_kernel  grid (h, n_frames): segment prefix from the stored ballots, each kept pixel writes
-//                          (x, y) at rows_before + segments_before + its rank inside the ballot
-// One barrier per workgroup in each pass (the first version evaluated the predicate twice and synchronised three
-// times per 256 pixels).
-constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
-
-__global__ __launch_bounds__(256) void fast_nms_mask_kernel(const uint16_t *__restrict__ score, int w, int h,
-                                                             const int *__restrict__ detect, int nonmax,
-                                                             unsigned long long *__restrict__ mask /* [B][h][segs] */,
-                                                             int segs, int *__restrict__ rowcnt /* [B][h] */)
-{
-    __shared__ int s_wave[4];
-    const int frame = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (detect && !detect[frame])
-        return;
-    const uint16_t *__restrict__ row = score + ((size_t)frame * h + y) * w;
-    unsigned long long *__restrict__ mrow = mask + ((size_t)frame * h + y) * segs;
-    const bool inner = y >= 3 && y < h - 3;
-    int cnt = 0;
-    for (int s = wv; s < segs; s += 4) {
-        const int x = s * 64 + lane;
+    __syncthreads();
+    for (int i = tid; i < FT_SW * FT_SH; i += 256) {
+        const int sy = i / FT_SW, sx = i - sy * FT_SW;
+        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        uint16_t out = 0;
+        if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3) {
+            bool corner;
+            const int sc = fast_score(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold, &corner);
+            if (corner)
+                out = (uint16_t)(0x100 | sc);
+        }
+        s_sc[i] = out;
+    }
+    __syncthreads();
+    for (int ly = wv; ly < FT_H; ly += 4) { // a wavefront = one 64-pixel row segment
+        const int gy = y0 + ly;
+        if (gy >= h)
+            break;
+        const uint16_t *__restrict__ r = &s_sc[(ly + 1) * FT_SW + lane + 1];
+        const int c = r[0];
         bool keep = false;
-        if (inner && x >= 3 && x < w - 3) {
-            const int c = row[x];
-            if (c & 0x100) {
-                const int sc = c & 0xff;
-                keep = !nonmax || (sc > (row[x + 1] & 0xff) && sc > (row[x - 1] & 0xff) &&
-                                   sc > (row[x - w - 1] & 0xff) && sc > (row[x - w] & 0xff) &&
-                                   sc > (row[x - w + 1] & 0xff) && sc > (row[x + w - 1] & 0xff) &&
-                                   sc > (row[x + w] & 0xff) && sc > (row[x + w + 1] & 0xff));
-            }
+        if (c & 0x100) {
+            const int sc = c & 0xff;
+            keep = !nonmax || (sc > (r[1] & 0xff) && sc > (r[-1] & 0xff) && sc > (r[-FT_SW - 1] & 0xff) &&
+                               sc > (r[-FT_SW] & 0xff) && sc > (r[-FT_SW + 1] & 0xff) && sc > (r[FT_SW - 1] & 0xff) &&
+                               sc > (r[FT_SW] & 0xff) && sc > (r[FT_SW + 1] & 0xff));
         }
         const unsigned long long m = VO_BALLOT(keep);
-        if (lane == 0)
-            mrow[s] = m;
-        cnt += VO_POPCLL(m);
+        if (lane == 0) {
+            mask[((size_t)frame * h + gy) * segs + blockIdx.x] = m;
+            if (m)
+                atomicAdd(&rowcnt[(size_t)frame * h + gy], (int)VO_POPCLL(m));
+        }
     }
-    if (lane == 0)
-        s_wave[wv] = cnt;
-    __syncthreads();
-    if (tid == 0)
-        rowcnt[(size_t)frame * h + y] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
 __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long long *__restrict__ mask, int segs,
@@ -207,8 +208,9 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
     }
 }
 
-// one 256-thread workgroup per frame: rowcnt -> exclusive offsets, n_new = total (0 when not detecting)
-__global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ rowcnt, int h,
+// one 256-thread workgroup per frame: row counts -> exclusive offsets (separate array), n_new = total (0 when not
+// detecting); the counts are zeroed again for the next fast_tile_kernel launch
+__global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ rowcnt, int *__restrict__ rowoff, int h,
                                                            const int *__restrict__ detect,
                                                            int *__restrict__ n_new)
 {
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ row
         return;
     }
     int *__restrict__ rc = rowcnt + (size_t)frame * h;
+    int *__restrict__ ro = rowoff + (size_t)frame * h;
     const int per = (h + 255) / 256, r0 = tid * per, r1 = min(h, r0 + per);
     int sum = 0;
     for (int r = r0; r < r1; r++)
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ row
     int acc = s_part[tid];
     for (int r = r0; r < r1; r++) {
         const int t = rc[r];
-        rc[r] = acc;
+        ro[r] = acc;
+        rc[r] = 0;
         acc += t;
     }
 }
@@ -370,19 +374,18 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
 // cv::FAST of every frame's left t0 image: corners in row-major order at out[frame][base ...], count in n_new[frame]
 // (base = n_tracked[frame] when given -- the combined list -- else 0)
 void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w, int h,
-                         int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask, int *d_rowcnt,
+                         int threshold, int nonmax, unsigned long long *d_nmsmask, int *d_rowcnt, int *d_rowoff,
                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_out, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
-    hipLaunchKernelGGL(fast_score_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_frames), dim3(256), 0, stream, d_imgs,
-                       d_quads, d_detect, threshold, d_score);
-    const int segs = (w + 63) / 64;
-    hipLaunchKernelGGL(fast_nms_mask_kernel, dim3(h, n_frames), dim3(256), 0, stream, d_score, w, h, d_detect, nonmax,
-                       d_nmsmask, segs, d_rowcnt);
-    hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, h, d_detect, d_nnew);
+    const int segs = (w + FT_W - 1) / FT_W;
+    hipLaunchKernelGGL(fast_tile_kernel, dim3(segs, (h + FT_H - 1) / FT_H, n_frames), dim3(256), 0, stream, d_imgs,
+                       d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
+    hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, d_rowoff, h, d_detect,
+                       d_nnew);
     hipLaunchKernelGGL(fast_nms_write_kernel, dim3(h, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
-                       d_rowcnt, d_ntracked, cap, d_out);
+                       d_rowoff, d_ntracked, cap, d_out);
 }
 
 void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_ages, const int *d_ntracked,
@@ -396,13 +399,13 @@ void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_a
 }
 
 void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
-                          int h, int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask,
-                          int *d_rowcnt,
+                          int h, int threshold, int nonmax, unsigned long long *d_nmsmask,
+                          int *d_rowcnt, int *d_rowoff,
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
                           const int *d_active, int *d_overflow, hipStream_t stream)
 {
-    launch_fast_corners(d_imgs, d_quads, d_detect, n_frames, w, h, threshold, nonmax, d_score, d_nmsmask, d_rowcnt,
+    launch_fast_corners(d_imgs, d_quads, d_detect, n_frames, w, h, threshold, nonmax, d_nmsmask, d_rowcnt, d_rowoff,
                         d_ntracked, d_nnew, cap, d_feat, stream);
     if (bucket_size > 0)
         launch_bucket(d_feat, nullptr, d_ages, d_ntracked, d_nnew, cap, w, h, bucket_size, fpb, d_out_pts, d_out_ages,

@@ -102,13 +102,13 @@ void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
 void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
-                          int h, int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask,
-                          int *d_rowcnt,
+                          int h, int threshold, int nonmax, unsigned long long *d_nmsmask,
+                          int *d_rowcnt, int *d_rowoff,
                           const int *d_ntracked, int *d_nnew, int cap, float2 *d_feat, const int *d_ages,
                           int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages, int *d_out_n, int out_cap,
                           const int *d_active, int *d_overflow, hipStream_t stream);
 void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w, int h,
-                         int threshold, int nonmax, uint16_t *d_score, unsigned long long *d_nmsmask, int *d_rowcnt,
+                         int threshold, int nonmax, unsigned long long *d_nmsmask, int *d_rowcnt, int *d_rowoff,
                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_out, hipStream_t stream);
 void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_ages, const int *d_ntracked,
                    const int *d_nnew, int cap, int w, int h, int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages,
