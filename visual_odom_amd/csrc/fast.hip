@@ -34,6 +34,17 @@
 
 namespace vo {
 
+// (acc << 1) | (x < 0): one v_alignbit_b32 shifts a comparison's sign bit into a ring mask (a compare + select + or
+// per bit cost 2.5 x as much issue time, profiles/r02_valu_issue_cost.txt)
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
+    return __builtin_amdgcn_alignbit(acc, (uint32_t)x, 31);
+#else
+    return (acc << 1) | ((uint32_t)x >> 31);
+#endif
+}
+
 __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int stride, int threshold, bool *corner)
 {
     // Bresenham circle of radius 3, the 16 offsets of FAST_t<16> starting at (0, 3), clockwise
@@ -55,11 +66,13 @@ __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int str
     d[13] = v - p[stride - 3];
     d[14] = v - p[2 * stride - 2];
     d[15] = v - p[3 * stride - 1];
-    uint32_t mb = 0, md = 0; // d > t : circle pixel darker than the centre; -d > t : brighter
+    // d > t : circle pixel darker than the centre; -d > t : brighter.  The bits enter from the low end, i.e. the ring is
+    // stored mirrored -- "9 contiguous" does not care about orientation.
+    uint32_t mb = 0, md = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        mb |= (uint32_t)(d[k] > threshold) << k;
-        md |= (uint32_t)(-d[k] > threshold) << k;
+        mb = shift_in_sign(mb, threshold - d[k]);
+        md = shift_in_sign(md, threshold + d[k]);
     }
     // >= 9 contiguous set bits on the 16-bit ring
     auto ring9 = [](uint32_t m) {
