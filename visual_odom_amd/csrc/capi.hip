@@ -248,7 +248,6 @@ hipError_t dmalloc(T **p, size_t n)
 } // namespace
 
 static int sync_all(vo_ctx *c);
-static int ensure_stream(vo_ctx *c, hipStream_t *st);
 
 static void seq_free(vo_ctx *c)
 {
@@ -397,11 +396,9 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         int least = 0, greatest = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp2, hipStreamNonBlocking, greatest) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
-        // stream_pnp2 (second pose stream of small batches) and stream_em (mono_rotation) are created on first use: the
-        // runtime multiplexes a process's streams onto a few hardware queues (4 by default), and every stream that
-        // exists shifts that mapping -- a second vo_ctx in the same process was measured at 1.6 instead of 0.63 ms per
-        // lock-step step for exactly that reason (gpurun_out/r2_11 notes) -- so a context only owns the streams it uses
+        ok = ok && hipStreamCreateWithPriority(&c->stream_em, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     for (auto &ev : c->ev_trk_free)
         ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -995,11 +992,6 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
     const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded && c->pose2_max > 0 &&
                                   (long long)B * (c->max_pts_set > 0 ? c->max_pts_set : 1) <= c->pose2_max;
-    if (two_pose_streams && (c->cur & 1)) {
-        int rcs = ensure_stream(c, &c->stream_pnp2);
-        if (rcs != VO_OK)
-            return rcs;
-    }
     hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
@@ -1067,11 +1059,6 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             ep.max_iters = EM_MAX_ITERS;
             // its own stream: the two chains only share their inputs, and together they would outlast the LK
             // launch they hide behind
-            if (!c->serial_pose) {
-                int rcs = ensure_stream(c, &c->stream_em);
-                if (rcs != VO_OK)
-                    return rcs;
-            }
             hipStream_t es = c->serial_pose ? c->stream : c->stream_em;
             VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
             launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
@@ -1106,17 +1093,6 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     return VO_OK;
 }
 
-// a high-priority stream created on first use
-static int ensure_stream(vo_ctx *c, hipStream_t *st)
-{
-    if (*st)
-        return VO_OK;
-    int least = 0, greatest = 0;
-    VO_HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    VO_HIP_TRY(c, hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest));
-    return VO_OK;
-}
-
 // both streams idle (every getter and every synchronous entry point ends with this)
 static int sync_all(vo_ctx *c)
 {
@@ -1124,10 +1100,8 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_filter));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
-    if (c->stream_pnp2)
-        VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp2));
-    if (c->stream_em)
-        VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp2));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
     if (c->seq.copy)
         VO_HIP_TRY(c, hipStreamSynchronize(c->seq.copy));
     return VO_OK;
