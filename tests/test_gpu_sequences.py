@@ -99,7 +99,7 @@ class _DeviceImages:
             self.hip = ctypes.CDLL("libamdhip64.so.7")  # already mapped by libvo_hip.so
         except OSError:
             self.hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
-        self.ptrs = []
+        self.ptrs, self.host = [], []
 
     def upload(self, img):
         C = self.C
@@ -110,10 +110,23 @@ class _DeviceImages:
         self.ptrs.append(p)
         return p.value
 
+    def pinned(self, img):
+        """a page-locked host copy (hipHostMalloc) as a numpy view"""
+        C = self.C
+        img = np.ascontiguousarray(img, np.uint8)
+        p = C.c_void_p()
+        assert self.hip.hipHostMalloc(C.byref(p), C.c_size_t(img.size), 0) == 0
+        view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(img.size,)).reshape(img.shape)
+        view[...] = img
+        self.host.append(p)
+        return view
+
     def free(self):
         for p in self.ptrs:
             self.hip.hipFree(p)
-        self.ptrs = []
+        for p in self.host:
+            self.hip.hipHostFree(p)
+        self.ptrs, self.host = [], []
 
 
 def test_lockstep_ring_of_two_six_per_bucket_against_the_oracle_chain(volib, orc, small_world):
@@ -217,6 +230,43 @@ def test_long_sequence_kitti_size_against_the_reference_loop(volib, orc, kitti_w
         assert ate < 0.02 * float(odometry.trajectory_distances(gt)[-1])
         assert summ is not None and summ["t_err_percent"] < 3.0
     finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_lockstep_pinned_sources_and_mono_rotation(volib, orc, small_world, mono):
+    """three slots fed the same sequence from page-locked host memory (read by the GPU over PCIe), pageable memory and,
+    in one call, vo_seq_push_pairs; with trackingFrame2Frame's mono_rotation both ways (rotation from recoverPose,
+    integrated on the device), against the reference's own loop"""
+    from visual_odom_amd import odometry
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref was not shipped")
+    n = 7
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    ctx = volib.Context(0, w, h, 4096, 3)
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, 3, w, h, ctx=ctx, ring=3, max_steps=16, mono_rotation=mono)
+        loop = orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3], mono_rotation=mono)
+        di = _DeviceImages()
+        pin = [(di.pinned(L[k]), di.pinned(R[k])) for k in range(n)]
+        for k in range(n):
+            vo.push(0, pin[k][0], pin[k][1], pinned=True)
+            table = ctx.seq_pair_table([1, 2], [L[k].ctypes.data, pin[k][0].ctypes.data], [R[k].ctypes.data, pin[k][1].ctypes.data])
+            ctx.seq_push_pairs(table, w, 0)          # pageable path for both (page-locked memory is valid pageable input)
+            vo.step()
+            loop.process(L[k], R[k])
+        for s in range(3):
+            _check_state(vo, s, loop, ("end", mono))
+            traj = vo.trajectory(s)
+            assert len(traj) == n and odometry.ate_rmse(traj, loop.trajectory) <= 1e-6
+            log = vo.log(s)
+            assert not any(r["flags"] & (volib.SEQ_F_TOO_FEW | volib.SEQ_F_NO_ESSENTIAL) for r in log)
+            assert np.abs(log[-1]["R"] - loop.rotation).max() <= (1e-9 if mono else 1e-6)
+        di.free()
+    finally:
+        ctx.set_params(mono_rotation=0)
         ctx.close()
 
 

@@ -839,6 +839,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if ((stages & (VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) && !c->have_P)
         return fail(c, VO_ERR_STATE, "vo_batch_run: projection matrices not set");
     VO_HIP_TRY(c, hipSetDevice(c->device));
+    (void)hipGetLastError(); // the launch check at the end must report THIS call's launches, not a stale error of the thread
     const int B = c->n_frames, cap = c->cap;
     const bool touches_pose = (stages & (VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) != 0;
     vo_ctx::PoseBufs &pb = c->pb[c->cur];
