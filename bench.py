@@ -188,7 +188,8 @@ def main(argv=None):
     ap.add_argument("--frames", type=int, default=256,
                     help="batch mode: frame quadruples per step per GPU (a 256-frame sequence batch = 514 images, "
                          "1.8 GB of pyramids + Scharr images)")
-    ap.add_argument("--seqs", type=int, default=256, help="sequence mode: independent sequences per GPU (one frame each per step)")
+    ap.add_argument("--seqs", "--S", dest="seqs", type=int, default=256,
+                    help="sequence mode: independent sequences per GPU (one frame each per step)")
     ap.add_argument("--ring", type=int, default=3, choices=[2, 3], help="sequence mode: stereo pairs resident per sequence")
     ap.add_argument("--ingest", default="device", choices=["device", "pinned", "host"],
                     help="sequence mode: where the new stereo pairs come from (device = resident in HBM)")
