@@ -189,6 +189,11 @@ void orc_lk_set_iteration_log(int *buf, int n)
     g_iter_log = buf;
     g_iter_log_n = n;
 }
+/* optional: for every (level, point) the first iteration j after which the window corner is bit-identical to the one
+ * after iteration j - p, and that period p (0 = the orbit never repeats exactly): buf [levels][n][2]
+ * (tools/lk_cycle_study.py: could iterations of non-converging features be skipped exactly?) */
+static int *g_cycle_log;
+void orc_lk_set_cycle_log(int *buf) { g_cycle_log = buf; }
 /* histogram of the inner-iteration count of every (point, level) solve since the last reset:
  * hist[k] = solves that executed k iterations (k = 0..100); used to size the GPU kernel's loops */
 static long long g_iter_hist[101];
@@ -305,6 +310,8 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
         nextY -= halfWin;
         float prevDX = 0, prevDY = 0;
         int my_iters = 0;
+        float histX[128], histY[128];
+        int cyc_j = 0, cyc_p = 0;
         for (int j = 0; j < maxCount; j++) {
             int inx = cv_floor_f(nextX), iny = cv_floor_f(nextY);
             if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
@@ -353,6 +360,15 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
             nextY += dy;
             nextPts[2 * ptidx] = nextX + halfWin;
             nextPts[2 * ptidx + 1] = nextY + halfWin;
+            if (g_cycle_log && j < 128) {
+                histX[j] = nextX;
+                histY[j] = nextY;
+                for (int pp = 1; pp <= 12 && pp <= j && !cyc_p; pp++)
+                    if (memcmp(&histX[j - pp], &nextX, 4) == 0 && memcmp(&histY[j - pp], &nextY, 4) == 0) {
+                        cyc_j = j;
+                        cyc_p = pp;
+                    }
+            }
             /* Point2f::ddot -> double */
             if ((double)dx * dx + (double)dy * dy <= epsilon)
                 break;
@@ -370,6 +386,10 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
         g_iter_hist[my_iters]++;
         if (g_iter_log && ptidx < g_iter_log_n)
             g_iter_log[(size_t)level * g_iter_log_n + ptidx] = my_iters;
+        if (g_cycle_log && g_iter_log && ptidx < g_iter_log_n) {
+            g_cycle_log[((size_t)level * g_iter_log_n + ptidx) * 2] = cyc_j;
+            g_cycle_log[((size_t)level * g_iter_log_n + ptidx) * 2 + 1] = cyc_p;
+        }
 
         /* status[ptidx] && err && level == 0 && !(flags & OPTFLOW_LK_GET_MIN_EIGENVALS) */
         if (status[ptidx] && err && level == 0) {
