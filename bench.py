@@ -362,9 +362,9 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     K, W = args.steps, args.warmup
     ctx = _lib.Context(local_dev, w, h, 4096, S)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
+    ctx.batch_set_detect_params(features_per_bucket=per_bucket)
     ctx.seq_configure(S, w, h, args.ring, K + W + 8)
     ctx.batch_set_projection(*world.proj_matrices())
-    ctx.batch_set_detect_params(features_per_bucket=per_bucket)
 
     def feed(s, k):  # rendered pair sequence s shows at its k-th pair: same street, every sequence phase-shifted
         return tri(k + s, Q)

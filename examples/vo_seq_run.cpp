@@ -81,12 +81,12 @@ int main(int argc, char **argv)
         fprintf(stderr, "vo_create failed: no HIP device (there is no CPU fallback)\n");
         return 2;
     }
-    CHECK(vo_seq_configure(ctx, S, w, h, /*ring*/ 3, max_frames + 1));
-    CHECK(vo_batch_set_projection(ctx, P_l, P_r));
     vo_detect_params dp;
     vo_default_detect_params(&dp);
     dp.features_per_bucket = per_bucket;
-    CHECK(vo_batch_set_detect_params(ctx, &dp));
+    CHECK(vo_batch_set_detect_params(ctx, &dp)); // before vo_seq_configure: they decide how a step is scheduled
+    CHECK(vo_seq_configure(ctx, S, w, h, /*ring*/ 3, max_frames + 1));
+    CHECK(vo_batch_set_projection(ctx, P_l, P_r));
 
     std::vector<char> live(S, 1);
     for (int id = 0; id < max_frames; id++) {

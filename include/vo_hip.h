@@ -242,8 +242,9 @@ int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double 
  *              vo_seq_step(ctx)                                        asynchronous
  *   A sequence processes a frame in a step iff it received a pair for this step AND for the previous one (its
  *   first pair only builds pyramids, main.cpp:110-113); a sequence that receives nothing simply pauses.
- *   Detection / LK / RANSAC parameters: vo_set_params (before vo_seq_configure), vo_batch_set_detect_params,
- *   vo_batch_set_projection.
+ *   Detection / LK / RANSAC parameters: vo_set_params and vo_batch_set_detect_params before vo_seq_configure (or at
+ *   least before the first vo_seq_step: with few sequences FAST runs on a pair's left image as soon as the pair is on
+ *   the device, one step before its corners are needed), vo_batch_set_projection before the first step.
  * ------------------------------------------------------------------------------------------ */
 #define VO_SEQ_ROW 27          /* doubles per trajectory row: frame_pose 3x4 (12), rvec (3), tvec (3), rotation (9) */
 #define VO_SEQ_INFO 8          /* ints per row: n_bucketed, n_circ, n_tracked, n_inliers, pnp_status, flags,

@@ -134,9 +134,9 @@ class MultiSequenceOdometry:
         self._own = ctx is None
         self.n_seq = n_seq
         self.ctx.set_params(mono_rotation=int(bool(mono_rotation)))
+        self.ctx.batch_set_detect_params(**detect_kw)   # before configure: they decide how a step is scheduled
         self.ctx.seq_configure(n_seq, width, height, ring, max_steps)
         self.ctx.batch_set_projection(P_l, P_r)
-        self.ctx.batch_set_detect_params(**detect_kw)
 
     def close(self):
         if self._own:
