@@ -38,10 +38,10 @@ if has lkprobe; then
     stamp "LK probe: parity subset, two bench lines, VALU count"
     timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_config.py -m gpu -x -q -k "lk or circular or bench_configuration or track_frame" 2>&1 | tail -2
     for i in 1 2; do
-        timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/probe_bench_$i.json" 2>/dev/null
+        timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/probe_bench_$i.json" 2>/dev/null
         python -c "import json; b=json.load(open('$OUT/probe_bench_$i.json')); print('  %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
     done
-    (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/probe_pmc" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > /dev/null 2>&1)
+    (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d "$OUT/probe_pmc" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > /dev/null 2>&1)
     python - <<PY
 import glob, csv
 from collections import defaultdict
@@ -102,13 +102,13 @@ if has seqab; then
         python -c "import json,sys; b=json.load(open('$OUT/ab_seq_${S}_bigpose.json')); print('  512-reg pose:    %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
     done
     stamp "A/B batch kitti374: 128-register pose kernels forced"
-    VO_CROWDED_MIN=1 VO_CROWDED_MIN_PTS=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 > "$OUT/ab_kitti374_crowded.json" 2>/dev/null
+    VO_CROWDED_MIN=1 VO_CROWDED_MIN_PTS=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 --no-replay-leg > "$OUT/ab_kitti374_crowded.json" 2>/dev/null
     python -c "import json,sys; b=json.load(open('$OUT/ab_kitti374_crowded.json')); print('  kitti374 crowded: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
 fi
 if has posewaves; then
     for WV in 1 2 4; do
         stamp "pose kernels at $WV waves per SIMD"
-        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 > "$OUT/pw_kitti374_$WV.json" 2>/dev/null
+        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 --validate 0 --sustain 0 --no-replay-leg > "$OUT/pw_kitti374_$WV.json" 2>/dev/null
         python -c "import json; b=json.load(open('$OUT/pw_kitti374_$WV.json')); print('  batch kitti374 : %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
         for S in 16 64 256; do
             VO_POSE_WAVES=$WV timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/pw_seq_${S}_$WV.json" 2>/dev/null
@@ -116,7 +116,7 @@ if has posewaves; then
         done
         VO_POSE_WAVES=$WV timeout 300 python bench.py --mode sequences --workload kitti2000 --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/pw_seq2000_$WV.json" 2>/dev/null
         python -c "import json; b=json.load(open('$OUT/pw_seq2000_$WV.json')); print('  seq2000 S=256   : %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
-        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pw_default_$WV.json" 2>/dev/null
+        VO_POSE_WAVES=$WV timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/pw_default_$WV.json" 2>/dev/null
         python -c "import json; b=json.load(open('$OUT/pw_default_$WV.json')); print('  batch kitti2000: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
     done
 fi
@@ -150,7 +150,7 @@ fi
 if has prof; then
     cd /tmp
     stamp "rocprofv3 kernel trace (overlapped, as benched)"
-    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_overlap" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/prof_overlap.log" 2>&1
+    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_overlap" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/prof_overlap.log" 2>&1
     stamp "rocprofv3 kernel trace (sequence mode)"
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_seq" -- python "$ROOT/bench.py" --mode sequences --workload kitti374 --seqs 256 --steps 10 --warmup 2 --no-cpu-baseline --validate 0 > "$OUT/prof_seq.log" 2>&1
     cd "$ROOT"
@@ -158,11 +158,11 @@ fi
 if has pmc; then
     cd /tmp
     stamp "rocprofv3 pmc SQ pass (LK instruction counts)"
-    timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_sq.log" 2>&1
+    timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/pmc_sq.log" 2>&1
     stamp "rocprofv3 pmc FETCH_SIZE"
-    timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_fetch.log" 2>&1
+    timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/pmc_fetch.log" 2>&1
     stamp "rocprofv3 pmc WRITE_SIZE"
-    timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 > "$OUT/pmc_write.log" 2>&1
+    timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg > "$OUT/pmc_write.log" 2>&1
     cd "$ROOT"
 fi
 stamp "done"
