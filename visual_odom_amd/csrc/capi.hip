@@ -1668,6 +1668,8 @@ int vo_seq_step(vo_ctx *c)
         return fail(c, VO_ERR_STATE, "vo_seq_step before vo_seq_configure");
     if (!c->have_P)
         return fail(c, VO_ERR_STATE, "vo_seq_step: projection matrices not set");
+    if (q.step > q.max_steps) // a sequence's first step yields no row: max_steps rows need max_steps + 1 steps
+        return fail(c, VO_ERR_STATE, "vo_seq_step: trajectory capacity (max_steps of vo_seq_configure) exhausted");
     VO_HIP_TRY(c, hipSetDevice(c->device));
     int rc = seq_begin_step(c);
     if (rc != VO_OK)
