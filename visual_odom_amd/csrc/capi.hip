@@ -106,7 +106,7 @@ struct vo_ctx {
     // against 44.2 k -> only from 256 on.
     int seq_crowded_min = 256;
     int pose_waves_forced = 0;         // VO_POSE_WAVES = 1 / 2 / 4: developer A/B of the pose kernels' register budget
-    long long pose_medium_min = 32768; // frames x points from which the 256-register pose kernels are used
+    long long pose_medium_min = 128;   // frames per run from which the 256-register pose kernels are used (VO_POSE_MEDIUM_MIN)
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
@@ -194,19 +194,23 @@ inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
 {
     return frames * pts >= c->crowded_min && pts >= c->crowded_min_pts;
 }
-// Register budget of the f64 PnP kernels as waves per SIMD (pnp.hip): 1 = 512 registers (fastest alone: small batches,
-// the drop-in calls), 2 = 256 registers from ~32 k point-frames per run on -- a 512-register wave needs a whole SIMD to
-// itself and makes the next run's pyramid / detection kernels wait, a 256-register wave leaves half of it to them.
-// Measured (gpurun_out/r2_06, frames/s at 1 / 2 / 4 waves): 256-frame batch at 340 points 59.2 k / 69.6 k / 46.6 k;
-// at 2040 points 18.8 k / 19.7 k / 18.6 k; lock-step loop with 256 sequences 42.6 k / 49.2 k / 44.3 k, with 64
-// sequences 41.3 k / 32.8 k / 22.3 k, with 16 sequences 15.7 k / 14.0 k / 10.2 k.  The 128-register instantiation
-// round 1 used for crowded batches is never the best one any more and stays reachable through VO_POSE_WAVES = 4 only.
+// Register budget of the f64 PnP kernels as waves per SIMD (pnp.hip): 1 = 512 registers (fastest alone), 2 = 256
+// registers from 128 frames per run on.  The chain's work grows with the number of FRAMES (128 hypotheses each); with
+// many frames its 512-register waves -- each needs a whole SIMD to itself -- keep the next run's pyramid / detection
+// kernels waiting, a 256-register wave leaves half a SIMD to them; with few frames the chain is the long pole and the
+// fastest kernels win whatever LK does beside them.
+// Measured (gpurun_out/r2_06, r2_14; frames/s at 1 / 2 / 4 waves): 256-frame batch at 340 points 59.2 k / 69.6 k / 46.6 k,
+// at 2040 points 18.8 k / 19.7 k / 18.6 k; lock-step loop with 256 sequences 42.6 k / 49.2 k / 44.3 k, 64 sequences
+// 41.3 k / 32.8 k / 22.3 k, 16 sequences 15.7 k / 14.0 k / 10.2 k; 16 frames x 4000 points at 1080p (BASELINE config 4)
+// 5.76 k / 5.25 k / 3.56 k.  The 128-register instantiation round 1 used for crowded batches is never the best one any
+// more and stays reachable through VO_POSE_WAVES = 4 only.
 inline int pose_waves(const vo_ctx *c, long long frames, int pts, bool crowded)
 {
     (void)crowded;
+    (void)pts;
     if (c->pose_waves_forced)
         return c->pose_waves_forced;
-    return frames * (pts > 0 ? pts : 1) >= c->pose_medium_min ? 2 : 1;
+    return frames >= c->pose_medium_min ? 2 : 1;
 }
 // the current feature set (see vo_ctx::pts_sel)
 inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
