@@ -29,9 +29,10 @@ def bench_inputs():
     return bench, S, world, lefts, rights, pts
 
 
-def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs):
+def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs, monkeypatch):
     bench, S, world, lefts, rights, pts = bench_inputs
     B = 64
+    monkeypatch.setenv("VO_POSE_WAVES", "2")  # what the 256-frame benchmark batch selects (>= 128 frames per run)
     ctx = volib.Context(0, world.w, world.h, 8192, B)
     try:
         frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
