@@ -95,7 +95,7 @@ fi
 if has seqab; then
     for S in 1 8 64 256; do
         stamp "A/B seq S=$S: second pose stream off"
-        VO_POSE2_MAX=0 timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/ab_seq_${S}_onepose.json" 2>/dev/null
+        VO_POSE2_FRAMES=0 timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/ab_seq_${S}_onepose.json" 2>/dev/null
         python -c "import json,sys; b=json.load(open('$OUT/ab_seq_${S}_onepose.json')); print('  one pose stream: %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), {k: round(v,3) for k,v in b['config']['stage_ms'].items()})"
         stamp "A/B seq S=$S: 512-register pose kernels"
         VO_SEQ_CROWDED_MIN=100000 timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/ab_seq_${S}_bigpose.json" 2>/dev/null

@@ -99,7 +99,11 @@ struct vo_ctx {
     // the two buffer sets anyway; giving each set its own stream lets two chains overlap.  Large batches keep one
     // stream (two were measured slower there).
     hipStream_t stream_pnp2 = nullptr;
-    long long pose2_max = 16384;   // frames x points up to which the second pose stream is used (VO_POSE2_MAX; 0 = never)
+    // Frames per run up to which the second pose stream (and, in the lock-step loop, the prepare stream) is used
+    // (VO_POSE2_FRAMES; 0 = never).  Measured, lock-step loop, both on against both off (gpurun_out r2 sweep): 374 points
+    // per frame 24 / 32 / 48 sequences +46 % / +35 % / +11 %, 64: -9 %; ~2000 points per frame 8 / 16 / 32 sequences
+    // +28 % / +13 % / +7 %, 64: -7 %.  The crossover follows the number of frames, not frames x points.
+    int pose2_frames = 48;
     // sequences from which the lock-step loop takes the 128-register pose kernels (VO_SEQ_CROWDED_MIN).  Measured at the
     // reference-default load (gpurun_out/r2_04): 64 sequences 41.3 k frames/s with the 512-register kernels against
     // 22.4 k with the 128-register ones (their chain then takes 5.5 ms and throttles the loop); 256 sequences 42.1 k
@@ -417,9 +421,9 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
             c->crowded_min_pts = atoi(ep);
         const char *e = getenv("VO_SERIAL_POSE");
         c->serial_pose = e && e[0] == '1';
-        const char *e2 = getenv("VO_POSE2_MAX");
+        const char *e2 = getenv("VO_POSE2_FRAMES");
         if (e2)
-            c->pose2_max = atoll(e2);
+            c->pose2_frames = atoi(e2);
         const char *e3 = getenv("VO_SEQ_CROWDED_MIN");
         if (e3)
             c->seq_crowded_min = atoi(e3);
@@ -995,8 +999,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded && c->pose2_max > 0 &&
-                                  (long long)B * (c->max_pts_set > 0 ? c->max_pts_set : 1) <= c->pose2_max;
+    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded && B <= c->pose2_frames;
     hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
@@ -1467,12 +1470,11 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     // 8 sequences 9.3 k -> 12.3 k); with many sequences the GPU is saturated, the step costs the sum of its kernels
     // either way and the extra concurrency only disturbs them (64 sequences 41.3 k -> 35.8 k, 256: 49.2 k -> 46.7 k;
     // gpurun_out/r2_06, r2_07).  So: prepare stream (highest priority -- its short memory-bound kernels have to find
-    // SIMD slots between the running step's LK waves) up to ~16 k point-frames per step, plain copy stream above.
+    // SIMD slots between the running step's LK waves) up to pose2_frames sequences (the same crossover as the second
+    // pose stream, measured together), plain copy stream above.
     {
-        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : h / 10;
-        const long long cells = bs > 0 ? (long long)(h / bs + 1) * (w / bs + 1) : 1;
         const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
-        q.prep = e ? e[0] != '0' : (long long)n_seq * cells * c->dprm.features_per_bucket <= c->pose2_max;
+        q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames;
     }
     int least = 0, greatest = 0;
     bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
