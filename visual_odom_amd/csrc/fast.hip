@@ -45,11 +45,11 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, int x)
 #endif
 }
 
-__device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int stride, int threshold, bool *corner)
+// the 16 differences centre - circle pixel: Bresenham circle of radius 3, the 16 offsets of FAST_t<16> starting at (0, 3),
+// clockwise
+__device__ __forceinline__ void fast_ring(const uint8_t *__restrict__ p, int stride, int *__restrict__ d)
 {
-    // Bresenham circle of radius 3, the 16 offsets of FAST_t<16> starting at (0, 3), clockwise
     const int v = p[0];
-    int d[25];
     d[0] = v - p[3 * stride];
     d[1] = v - p[3 * stride + 1];
     d[2] = v - p[2 * stride + 2];
@@ -66,6 +66,13 @@ __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int str
     d[13] = v - p[stride - 3];
     d[14] = v - p[2 * stride - 2];
     d[15] = v - p[3 * stride - 1];
+}
+
+// FastFeatureDetector TYPE_9_16 corner test: >= 9 contiguous circle pixels all brighter than p + t or all darker than p - t
+__device__ __forceinline__ bool fast_is_corner(const uint8_t *__restrict__ p, int stride, int threshold)
+{
+    int d[16];
+    fast_ring(p, stride, d);
     // d > t : circle pixel darker than the centre; -d > t : brighter.  The bits enter from the low end, i.e. the ring is
     // stored mirrored -- "9 contiguous" does not care about orientation.
     uint32_t mb = 0, md = 0;
@@ -83,13 +90,17 @@ __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int str
         x &= m >> 8;
         return x != 0;
     };
-    *corner = ring9(mb) || ring9(md);
-    if (!*corner)
-        return 0;
+    return ring9(mb) || ring9(md);
+}
+
+// cornerScore<16> (features2d/src/fast_score.cpp) of a position that passed fast_is_corner
+__device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, int stride, int threshold)
+{
+    int d[25];
+    fast_ring(p, stride, d);
 #pragma unroll
     for (int k = 16; k < 25; k++)
         d[k] = d[k - 16];
-    // cornerScore<16> (features2d/src/fast_score.cpp)
     int a0 = threshold;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
@@ -119,8 +130,12 @@ __device__ __forceinline__ int fast_score(const uint8_t *__restrict__ p, int str
 // read back nine times: 0.77 + 0.49 ms per 256 KITTI frames, the map alone 239 MB):
 //   A  the tile's pixels + 4-pixel apron (80 x 24 bytes, origin (x0 - 4, y0 - 4): 4-byte aligned in the bordered
 //      level-0 image, always inside its allocation) go to LDS with dword loads;
-//   B  corner test + cornerScore<16> of the 66 x 18 positions of the tile and its 1-pixel halo, reading the circle
-//      pixels from LDS (positions inside FAST's 3-pixel image margin or outside the image score 0 like the map did);
+//   B1 corner test of the 66 x 18 positions of the tile and its 1-pixel halo, reading the circle pixels from LDS
+//      (positions inside FAST's 3-pixel image margin or outside the image are no corners); the positions that pass are
+//      appended to a list in LDS (one LDS atomic per wavefront and round, ballot ranks);
+//   B2 cornerScore<16> of the listed positions only, on densely packed lanes.  The score is ~4 x the work of the corner
+//      test and only a few per cent of the positions are corners, but in the one-pass form nearly every wavefront held
+//      at least one corner and so executed it for all 64 lanes (1.02 ms per 256 KITTI frames, round-2 trace);
 //   C  keep predicate of the 64 x 16 tile positions (corner, score strictly above its 8 neighbours'), one 64-bit
 //      ballot per row segment stored exactly where fast_nms_write_kernel expects it, row counts by atomicAdd (the
 //      row-scan pass turns them into offsets and zeroes them again).
@@ -139,6 +154,8 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const PyrImage *__restri
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PH * FT_PW];
     __shared__ uint16_t s_sc[FT_SH * FT_SW];
+    __shared__ uint16_t s_list[FT_SH * FT_SW]; // positions (index into s_sc) that passed the corner test
+    __shared__ int s_ncorner;
     const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (detect && !detect[frame])
         return;
@@ -153,17 +170,33 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const PyrImage *__restri
             *reinterpret_cast<const VO_GLOBAL uint32_t *>(base + ((ptrdiff_t)row * stride + 4 * c));
     }
     __syncthreads();
-    for (int i = tid; i < FT_SW * FT_SH; i += 256) {
-        const int sy = i / FT_SW, sx = i - sy * FT_SW;
-        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        uint16_t out = 0;
-        if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3) {
-            bool corner;
-            const int sc = fast_score(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold, &corner);
-            if (corner)
-                out = (uint16_t)(0x100 | sc);
+    if (tid == 0)
+        s_ncorner = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < FT_SW * FT_SH; i0 += 256) { // wave-uniform trip count: the ballot needs all lanes
+        const int i = i0 + tid;
+        bool corner = false;
+        if (i < FT_SW * FT_SH) {
+            const int sy = i / FT_SW, sx = i - sy * FT_SW;
+            const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3)
+                corner = fast_is_corner(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold);
+            s_sc[i] = 0;
         }
-        s_sc[i] = out;
+        const unsigned long long m = VO_BALLOT(corner);
+        int base = 0;
+        if (lane == 0 && m)
+            base = atomicAdd(&s_ncorner, (int)VO_POPCLL(m));
+        base = uni(base);
+        if (corner)
+            s_list[base + (int)VO_POPCLL(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int ncorner = s_ncorner;
+    for (int k = tid; k < ncorner; k += 256) {
+        const int i = s_list[k];
+        const int sy = i / FT_SW, sx = i - sy * FT_SW;
+        s_sc[i] = (uint16_t)(0x100 | fast_corner_score(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold));
     }
     __syncthreads();
     for (int ly = wv; ly < FT_H; ly += 4) { // a wavefront = one 64-pixel row segment
