@@ -35,6 +35,10 @@ struct uint4 {
     uint32_t x, y, z, w;
 };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct uint2 {
+    uint32_t x, y;
+};
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct EmuIdx {
     unsigned x, y, z;
 };

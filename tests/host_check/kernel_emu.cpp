@@ -51,9 +51,60 @@ void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
                 emu::run_block(threads, x, y, z, body);
 }
 
+// the PYRAMID stage of capi.hip's run_stages with the emulated kernels
+void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
+{
+    using namespace vo;
+    auto fill = [&](int l) {
+        launch(border_fill_blocks(p.ls[l], p.lh[l]), n_img, 1, 256, [&] { border_fill_kernel(d_imgs, l); });
+    };
+    fill(0);
+    for (int l = 0; l + 1 < p.levels; l++) {
+        launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
+        fill(l + 1);
+    }
+    const ScharrTiles st = scharr_tiles(p.levels, p.lw, p.lh);
+    launch(st.first[p.levels], n_img, 1, 256, [&] { scharr_kernel(d_imgs, p.levels, st); });
+}
+
 } // namespace
 
 extern "C" {
+
+// the whole bordered allocation of one level of one image after the emulated pyramid build: rows -VO_BY .. h + VO_BY - 1,
+// `stride` bytes / dwords each starting at column -VO_BX (pixels poisoned with 0xA5 before the build, derivatives zero)
+int ke_bordered_level(const uint8_t *img, int w, int h, int max_level, int level, uint8_t *pix_out, uint32_t *der_out,
+                      int cap, int *lvl_w, int *lvl_h, int *lvl_stride)
+{
+    using namespace vo;
+    Plan p = plan(w, h, max_level);
+    if (level < 0 || level >= p.levels)
+        return -1;
+    std::vector<uint8_t> pix(p.total, 0xA5);
+    std::vector<uint32_t> der(p.total, 0);
+    PyrImage im;
+    memset(&im, 0, sizeof(im));
+    for (int l = 0; l < p.levels; l++) {
+        size_t org = p.off[l] + (size_t)VO_BY * p.ls[l] + VO_BX;
+        im.lvl[l] = pix.data() + org;
+        im.der[l] = der.data() + org;
+        im.w[l] = p.lw[l];
+        im.h[l] = p.lh[l];
+        im.stride[l] = p.ls[l];
+    }
+    for (int y = 0; y < h; y++)
+        memcpy(im.lvl[0] + (ptrdiff_t)y * p.ls[0], img + (size_t)y * w, w);
+    build_pyramids(p, &im, 1);
+    const int n = p.ls[level] * (p.lh[level] + 2 * VO_BY);
+    if (n > cap)
+        return -2;
+    memcpy(pix_out, pix.data() + p.off[level], n);
+    memcpy(der_out, der.data() + p.off[level], 4 * (size_t)n);
+    *lvl_w = p.lw[level];
+    *lvl_h = p.lh[level];
+    *lvl_stride = p.ls[level];
+    return p.levels;
+}
 
 // imgs: n_img images of w x h (contiguous).  Builds every pyramid with the emulated kernels.
 // lvl_out / der_out (optional): interior of level `want_level` of image 0 (w_l*h_l bytes / dwords).
@@ -81,22 +132,7 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
             memcpy(tab[i].lvl[0] + (ptrdiff_t)y * p.ls[0], imgs + ((size_t)i * h + y) * w, w);
     }
     const PyrImage *d_imgs = tab.data();
-    auto fill = [&](int l) {
-        launch(p.lh[l] + 2 * VO_BY, n_img, 1, 64, [&] { border_fill_kernel(d_imgs, l); });
-    };
-    fill(0);
-    for (int l = 0; l + 1 < p.levels; l++) {
-        launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
-        fill(l + 1);
-    }
-    {
-        ScharrTiles st = {};
-        for (int l = 0; l < p.levels; l++) {
-            st.tiles_x[l] = (p.lw[l] + 255) / 256;
-            st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((p.lh[l] + 3) / 4);
-        }
-        launch(st.first[p.levels], n_img, 1, 256, [&] { scharr_kernel(d_imgs, p.levels, st); });
-    }
+    build_pyramids(p, d_imgs, n_img);
 
     if (want_level >= 0 && want_level < p.levels) {
         const int l = want_level;

@@ -71,6 +71,46 @@ def test_emulated_pyramid_and_scharr_match_oracle(kemu, orc, shape):
         assert np.array_equal(r["der"], packed), l
 
 
+@pytest.mark.parametrize("shape", [(100, 203), (61, 96), (48, 45)])
+def test_emulated_borders(kemu, orc, shape):
+    """every pixel of the bordered allocation that a kernel may read: REFLECT_101 of the level around it (VO_BY rows above /
+    below, VO_BX columns left, at least VO_BY right -- the fill runs to the end of the row), derivatives zero outside the
+    image (calcSharrDeriv's constant border of the derivative image, which LK reads for off-image windows)"""
+    BX, BY = 32, 24
+    rng = np.random.default_rng(shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    ref = orc.build_pyramid(img, 3)
+    h, w = shape
+    for l in range(len(ref)):
+        cap = 4 << 20
+        pix, der = np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+        lw, lh, ls = C.c_int(0), C.c_int(0), C.c_int(0)
+        levels = kemu.ke_bordered_level(vp(img), w, h, 3, l, vp(pix), vp(der), cap, C.byref(lw), C.byref(lh), C.byref(ls))
+        if levels <= l:
+            break
+        lw, lh, ls = lw.value, lh.value, ls.value
+        assert (lh, lw) == ref[l].shape and ls % 16 == 0 and ls - BX - lw >= BY
+        pix = pix[:ls * (lh + 2 * BY)].reshape(lh + 2 * BY, ls)
+        der = der[:ls * (lh + 2 * BY)].reshape(lh + 2 * BY, ls)
+        right = ls - BX - lw
+
+        def refl(n, lo, hi):   # cv::borderInterpolate(BORDER_REFLECT_101), repeated for levels narrower than the border
+            idx = np.arange(lo, hi)
+            if n == 1:
+                return np.zeros_like(idx)
+            period = 2 * (n - 1)
+            idx = np.mod(idx, period)
+            return np.where(idx >= n, period - idx, idx)
+        expect = ref[l][refl(lh, -BY, lh + BY)][:, refl(lw, -BX, lw + right)]
+        assert np.array_equal(pix, expect), l
+        inside = np.zeros_like(der, bool)
+        inside[BY:BY + lh, BX:BX + lw] = True
+        assert not der[~inside].any(), l
+        d = orc.scharr(ref[l]).astype(np.int64) * 4
+        packed = ((d[..., 0] & 0xffff) | ((d[..., 1] & 0xffff) << 16)).astype(np.uint32)
+        assert np.array_equal(der[BY:BY + lh, BX:BX + lw], packed), l
+
+
 def _oracle_hops(orc, L0, R0, L1, R1, pts, **kw):
     p1, s1, _ = orc.calc_optical_flow_pyr_lk(L0, R0, pts, **kw)
     p2, s2, _ = orc.calc_optical_flow_pyr_lk(R0, R1, p1, **kw)

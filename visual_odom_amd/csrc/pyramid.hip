@@ -8,54 +8,84 @@
 //   pyrDown: horizontal [1 4 6 4 1] in int, vertical [1 4 6 4 1], (v + 128) >> 8, REFLECT_101 on the
 //   level itself; Scharr: 3x3 unnormalised, REFLECT_101 (= reading the level's own border).
 //
-// Kernels (all HBM-streaming; see DESIGN.md for the byte counts):
-//   border_fill_kernel  writes the REFLECT_101 border of one level from its interior (workgroup per row)
-//   pyr_down_kernel     one 256-thread workgroup -> 64 x 16 output tile; the 136 x 35 source tile is
-//                       staged in LDS with aligned dword loads (the source border makes every tile an
-//                       in-bounds read), u16 horizontal partials in LDS, 4 pixels per 32-bit store
-//   scharr_kernel       4 pixels per thread: three unaligned 8-byte row loads, one 16-byte store of
+// Kernels (all HBM-streaming; see DESIGN.md for the byte counts).  Round 2 rewrote all three -- the first versions were
+// instruction-bound far below the memory rate (byte-granular loads / stores, one LDS byte read per filter tap, 64-bit
+// shifts to pull pixels apart): 512 KITTI images took 0.11-0.17 + 0.20 + 0.60 ms, against 0.02 / 0.07 / 0.35 ms of HBM time:
+//   border_fill_kernel  one thread per 32-bit word that holds a REFLECT_101 border pixel of one level (all words of the
+//                       rows above / below the image, the left / right border words of image rows): words inside the
+//                       image span are aligned word copies of the reflected row, the rest gathers 4 reflected bytes
+//   pyr_down_kernel     one 256-thread workgroup -> 64 x 16 output tile; the 144 x 35 source tile is staged in LDS with
+//                       16-byte loads (the source border makes every tile an in-bounds read); horizontal [1 4 6 4 1]:
+//                       a thread reads 16 bytes and forms 4 partials with v_alignbyte_b32 + v_dot4_u32_u8 (u16 in LDS);
+//                       vertical: packed 16-bit multiply-adds (the sum + 128 stays below 2^16), 4 pixels per 32-bit store
+//   scharr_kernel       8 pixels per thread: three unaligned 12-byte row loads, the pixels lifted into u16 pairs
+//                       (v_perm_b32), the separable form t0 = 3 (above + below) + 10 row, t1 = below - above in packed
+//                       16-bit arithmetic with the x4 pre-scale folded into the constants, two 16-byte stores of
 //                       (4*Ix | 4*Iy << 16) x 4
 #include "vo_kernels.h"
 #include "vo_lkmath.h"
 
 namespace vo {
 
-struct __attribute__((packed, aligned(1))) U8x8 {
-    uint32_t lo, hi;
+struct __attribute__((packed, aligned(1))) U8x12 {
+    uint32_t a, b, c;
+};
+struct __attribute__((packed, aligned(4))) U32x4 {
+    uint32_t a, b, c, d;
 };
 
 // ---------------------------------------------------------------------------------------------------
-// one 64-thread workgroup per bordered row: rows above / below the image copy a whole reflected row,
-// image rows only write their VO_BX left and (stride - VO_BX - w) right border pixels
-__global__ __launch_bounds__(64) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
+// Border words of one level.  Work items: first the 2 * VO_BY rows above / below the image (stride / 4 words each), then,
+// per image row, the VO_BX / 4 words left of the image and the words from the one holding pixel w - 1 (or starting at w)
+// to the end of the row.  A word that straddles the image edge rewrites its interior bytes with the values they already have.
+constexpr int BF_MAX_ROW_WORDS = VO_BX / 4 + 11; // right border < 40 pixels + up to 3 interior ones (level_stride, capi.hip)
+
+inline unsigned border_fill_blocks(int stride, int h)
+{
+    return (unsigned)((2 * VO_BY * (stride / 4) + h * BF_MAX_ROW_WORDS + 255) / 256);
+}
+
+__global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
 {
     const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
     VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
-    const int y = (int)blockIdx.x - VO_BY; // -VO_BY .. h + VO_BY - 1
-    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
-    VO_GLOBAL uint8_t *__restrict__ dst = p + (ptrdiff_t)y * stride;
-    const int right = stride - VO_BX - w; // >= VO_BY
-    if (y >= 0 && y < h) {
-        for (int i = threadIdx.x; i < VO_BX + right; i += 64) {
-            const int x = i < VO_BX ? i - VO_BX : w + (i - VO_BX);
-            dst[x] = src[reflect101(x, w)];
-        }
+    const int wpr = stride >> 2;                                // words per bordered row
+    const int xr0 = w & ~3;                                     // first word with a right-border pixel
+    const int nb = VO_BX / 4 + ((stride - VO_BX - xr0) >> 2);   // border words of an image row
+    const int n_out = 2 * VO_BY * wpr;
+    int item = (int)(blockIdx.x * 256 + threadIdx.x);
+    int y, x0;
+    if (item < n_out) {
+        const int r = item / wpr;
+        y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
+        x0 = 4 * (item - r * wpr) - VO_BX;
     } else {
-        for (int x = (int)threadIdx.x - VO_BX; x < stride - VO_BX; x += 64)
-            dst[x] = src[reflect101(x, w)];
+        item -= n_out;
+        const int r = item / nb, k = item - r * nb;
+        if (r >= h)
+            return;
+        y = r;
+        x0 = k < VO_BX / 4 ? 4 * k - VO_BX : xr0 + 4 * (k - VO_BX / 4);
     }
+    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
+    uint32_t v;
+    if (x0 >= 0 && x0 + 3 < w)
+        v = *(const VO_GLOBAL uint32_t *)(src + x0);
+    else
+        v = (uint32_t)src[reflect101(x0, w)] | (uint32_t)src[reflect101(x0 + 1, w)] << 8 |
+            (uint32_t)src[reflect101(x0 + 2, w)] << 16 | (uint32_t)src[reflect101(x0 + 3, w)] << 24;
+    *(VO_GLOBAL uint32_t *)(p + (ptrdiff_t)y * stride + x0) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------
 constexpr int PD_TW = 64, PD_TH = 16;             // output tile
-constexpr int PD_SW = 136, PD_SH = 2 * PD_TH + 3; // source tile (bytes x rows), x origin = 2*ox-4
-constexpr int PD_SSTRIDE = 140;                   // LDS row stride of the source tile (bytes)
+constexpr int PD_SW = 144, PD_SH = 2 * PD_TH + 3; // source tile (bytes x rows), x origin = 2*ox-4; LDS row stride = PD_SW
 
 __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restrict__ imgs, int level)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[PD_SH * PD_SSTRIDE];
-    __shared__ uint16_t s_h[PD_SH * PD_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[PD_SH * PD_SW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[PD_SH * PD_TW];
 
     const PyrImage &im = imgs[blockIdx.z];
     const int sh = im.h[level], sstride = im.stride[level];
@@ -66,52 +96,81 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     if (ox >= dw || oy >= dh)
         return;
     const int tid = threadIdx.x;
-    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;   // >= -4 / -2: inside the source border
+    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;        // >= -4 / -2: inside the source border
     const int xmax = sstride - VO_BX, ymax = sh + VO_BY; // first column / row outside the allocation
 
-    // 35 rows x 34 dwords, coalesced along rows; columns / rows past the allocation are never used
-    // by a valid output pixel (those need source x <= 2 dw <= w + 1, y <= h + 1) and read as 0
-    for (int i = tid; i < PD_SH * (PD_SW / 4); i += 256) {
-        const int r = i / (PD_SW / 4), c = i - r * (PD_SW / 4);
-        const int x = sx0 + 4 * c, y = sy0 + r;
-        uint32_t v = 0;
-        if (x + 4 <= xmax && y < ymax)
-            v = *(const VO_GLOBAL uint32_t *)(src + (ptrdiff_t)y * sstride + x);
-        *reinterpret_cast<uint32_t *>(&s_src[r * PD_SSTRIDE + 4 * c]) = v;
+    // 35 rows x 9 x 16 bytes, coalesced along rows; columns / rows past the allocation are never used by a valid output
+    // pixel (those need source x <= 2 dw <= w + 1, y <= h + 1) and read as 0
+    for (int i = tid; i < PD_SH * (PD_SW / 16); i += 256) {
+        const int r = i / (PD_SW / 16), c = i - r * (PD_SW / 16);
+        const int x = sx0 + 16 * c, y = sy0 + r;
+        const VO_GLOBAL uint8_t *g = src + (ptrdiff_t)y * sstride + x;
+        U32x4 v = {0, 0, 0, 0};
+        if (y < ymax) {
+            if (x + 16 <= xmax) {
+                v = *(const VO_GLOBAL U32x4 *)g;
+            } else {
+                if (x + 4 <= xmax)
+                    v.a = *(const VO_GLOBAL uint32_t *)g;
+                if (x + 8 <= xmax)
+                    v.b = *(const VO_GLOBAL uint32_t *)(g + 4);
+                if (x + 12 <= xmax)
+                    v.c = *(const VO_GLOBAL uint32_t *)(g + 8);
+            }
+        }
+        *reinterpret_cast<uint4 *>(&s_src[r * PD_SW + 16 * c]) = make_uint4(v.a, v.b, v.c, v.d);
     }
     __syncthreads();
 
-    // horizontal 5-tap; output column x reads source columns 2x-2 .. 2x+2 = tile columns 2x+2 .. 2x+6
-    for (int i = tid; i < PD_SH * PD_TW; i += 256) {
-        const int r = i / PD_TW, x = i - r * PD_TW;
-        const uint8_t *p = &s_src[r * PD_SSTRIDE + 2 * x + 2];
-        s_h[i] = (uint16_t)(p[2] * 6 + (p[1] + p[3]) * 4 + p[0] + p[4]);
+    // horizontal 5-tap, 4 outputs per thread: output column x reads source columns 2x-2 .. 2x+2 = tile columns 2x+2 .. 2x+6,
+    // i.e. outputs x4 .. x4+3 read bytes 2+2k .. 6+2k (k = 0..3) of the 16 bytes at tile column 2*x4
+    for (int i = tid; i < PD_SH * (PD_TW / 4); i += 256) {
+        const int r = i / (PD_TW / 4), q = i - r * (PD_TW / 4);
+        const uint2 lo = *reinterpret_cast<const uint2 *>(&s_src[r * PD_SW + 8 * q]);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(&s_src[r * PD_SW + 8 * q + 8]);
+        const uint32_t w0 = lo.x, w1 = lo.y, w2 = hi.x, w3 = hi.y;
+        const uint32_t taps = 0x04060401u; // weights of bytes 0..3 of the aligned group; the fifth tap is the next byte
+        const uint32_t h0 = udot4(alignbyte(w1, w0, 2), taps, udot4(w1, 0x00010000u, 0));
+        const uint32_t h1 = udot4(w1, taps, udot4(w2, 0x00000001u, 0));
+        const uint32_t h2 = udot4(alignbyte(w2, w1, 2), taps, udot4(w2, 0x00010000u, 0));
+        const uint32_t h3 = udot4(w2, taps, udot4(w3, 0x00000001u, 0));
+        *reinterpret_cast<uint2 *>(&s_h[r * PD_TW + 4 * q]) = make_uint2(h0 | h1 << 16, h2 | h3 << 16);
     }
     __syncthreads();
 
-    // vertical 5-tap; thread -> (row y, 4 adjacent columns); columns >= dw land in the right border
-    // (stride - VO_BX - dw >= VO_BY there) and are overwritten by border_fill_kernel afterwards
+    // vertical 5-tap; thread -> (row y, 4 adjacent columns) as two packed u16 pairs: 6 q2 + 4 (q1 + q3) + q0 + q4 + 128
+    // <= 65408 fits 16 bits, the result is its high byte.  Columns >= dw land in the right border (stride - VO_BX - dw
+    // >= VO_BY there) and are overwritten by border_fill_kernel afterwards
     const int y = tid >> 4, x4 = (tid & 15) * 4;
     if (oy + y < dh && ox + x4 < dw) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint16_t *q = &s_h[(2 * y) * PD_TW + x4 + k];
-            int v = q[2 * PD_TW] * 6 + (q[PD_TW] + q[3 * PD_TW]) * 4 + q[0] + q[4 * PD_TW];
-            packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
-        }
-        *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = packed;
+        const uint16_t *q = &s_h[(2 * y) * PD_TW + x4];
+        const uint2 q0 = *reinterpret_cast<const uint2 *>(q), q1 = *reinterpret_cast<const uint2 *>(q + PD_TW),
+                    q2 = *reinterpret_cast<const uint2 *>(q + 2 * PD_TW), q3 = *reinterpret_cast<const uint2 *>(q + 3 * PD_TW),
+                    q4 = *reinterpret_cast<const uint2 *>(q + 4 * PD_TW);
+        const uint32_t va = pk_mad_u16(q2.x, 6, pk_mad_u16(pk_add_u16(q1.x, q3.x), 4, pk_add_u16(pk_add_u16(q0.x, q4.x), 0x00800080u)));
+        const uint32_t vb = pk_mad_u16(q2.y, 6, pk_mad_u16(pk_add_u16(q1.y, q3.y), 4, pk_add_u16(pk_add_u16(q0.y, q4.y), 0x00800080u)));
+        *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = perm_b32(vb, va, 0x07050301u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// all levels of all images in one launch: blockIdx.y = image, blockIdx.x = tile of 256 x 4 pixels numbered
+// all levels of all images in one launch: blockIdx.y = image, blockIdx.x = tile of 512 x 4 pixels numbered
 // level by level (every image of the table has the same geometry, so the per-level tile counts are launch
 // constants: no workgroup is launched for tiles a smaller level does not have)
 struct ScharrTiles {
     int first[VO_MAX_LEVELS + 1]; // first[l] = tiles of the levels before l
     int tiles_x[VO_MAX_LEVELS];
 };
+
+inline ScharrTiles scharr_tiles(int n_levels, const int *lw, const int *lh)
+{
+    ScharrTiles st = {};
+    for (int l = 0; l < n_levels; l++) {
+        st.tiles_x[l] = (lw[l] + 511) / 512;
+        st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((lh[l] + 3) / 4);
+    }
+    return st;
+}
 
 __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict__ imgs, int n_levels, ScharrTiles st)
 {
@@ -122,38 +181,54 @@ __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict_
     const int ty = tile / st.tiles_x[level], tx = tile - ty * st.tiles_x[level];
     const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
-    const int x4 = (int)(tx * 64 + (threadIdx.x & 63)) * 4;
+    const int x8 = (int)(tx * 64 + (threadIdx.x & 63)) * 8;
     const int y = (int)(ty * 4 + (threadIdx.x >> 6));
-    if (x4 >= w || y >= h)
+    if (x8 >= w || y >= h)
         return;
-    const VO_GLOBAL uint8_t *__restrict__ p = (const VO_GLOBAL uint8_t *)im.lvl[level] + (ptrdiff_t)y * stride + x4 - 1; // pixel (x4-1, y)
-    const U8x8 a = *(const VO_GLOBAL U8x8 *)(p - stride);
-    const U8x8 b = *(const VO_GLOBAL U8x8 *)(p);
-    const U8x8 c = *(const VO_GLOBAL U8x8 *)(p + stride);
-    const uint64_t ra = ((uint64_t)a.hi << 32) | a.lo, rb = ((uint64_t)b.hi << 32) | b.lo,
-                   rc = ((uint64_t)c.hi << 32) | c.lo;
-    uint32_t out[4];
+    // bytes j = 0..9 of the three rows = columns x8 - 1 + j (the reads end at column x8 + 10 <= w + 9: right border)
+    const VO_GLOBAL uint8_t *__restrict__ p = (const VO_GLOBAL uint8_t *)im.lvl[level] + (ptrdiff_t)y * stride + x8 - 1;
+    const U8x12 ra = *(const VO_GLOBAL U8x12 *)(p - stride);
+    const U8x12 rb = *(const VO_GLOBAL U8x12 *)(p);
+    const U8x12 rc = *(const VO_GLOBAL U8x12 *)(p + stride);
+    // column pairs (j, j + 1), j = 0, 2, 4, 6, 8 as u16 lanes
+    const uint32_t EVEN = 0x0c010c00u, ODD = 0x0c030c02u;
+    uint32_t T[5], U[5]; // T = 4 t0 = 12 (above + below) + 40 row (<= 16320), U = t1 = below - above
+#define VO_SCHARR_COLS(pi, word, sel)                                                              \
+    {                                                                                              \
+        const uint32_t a = perm_b32(0, ra.word, sel), b = perm_b32(0, rb.word, sel), c = perm_b32(0, rc.word, sel); \
+        T[pi] = pk_mad_u16(b, 40, pk_mad_u16(pk_add_u16(a, c), 12, 0));                            \
+        U[pi] = pk_sub_i16(c, a);                                                                  \
+    }
+    VO_SCHARR_COLS(0, a, EVEN) VO_SCHARR_COLS(1, a, ODD) VO_SCHARR_COLS(2, b, EVEN) VO_SCHARR_COLS(3, b, ODD)
+    VO_SCHARR_COLS(4, c, EVEN)
+#undef VO_SCHARR_COLS
+    // pixel m = 0..7 has its centre in column j = m + 1:  4 Ix = T[j + 1] - T[j - 1],  4 Iy = 12 (U[j - 1] + U[j + 1]) + 40 U[j]
+    uint32_t out[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int s = 8 * k;
-        out[k] = scharr4_packed((int)((ra >> s) & 0xff), (int)((ra >> (s + 8)) & 0xff), (int)((ra >> (s + 16)) & 0xff),
-                                (int)((rb >> s) & 0xff), (int)((rb >> (s + 16)) & 0xff), (int)((rc >> s) & 0xff),
-                                (int)((rc >> (s + 8)) & 0xff), (int)((rc >> (s + 16)) & 0xff));
+        const uint32_t ix = pk_sub_i16(T[k + 1], T[k]);
+        const uint32_t mid = alignbyte(U[k + 1], U[k], 2); // (U[2k + 1], U[2k + 2])
+        const uint32_t iy = pk_mad_u16(mid, 40, pk_mad_u16(pk_add_u16(U[k], U[k + 1]), 12, 0));
+        out[2 * k] = perm_b32(iy, ix, VO_SEL_LO16);
+        out[2 * k + 1] = perm_b32(iy, ix, VO_SEL_HI16);
     }
-    // pixels >= w of the last quad fall into the (zero) right border: keep them zero
+    // pixels >= w of the last group fall into the (zero) right border: keep them zero
+    if (x8 + 8 > w) {
 #pragma unroll
-    for (int k = 1; k < 4; k++)
-        if (x4 + k >= w)
-            out[k] = 0;
-    *(VO_GLOBAL uint4 *)((VO_GLOBAL uint32_t *)im.der[level] + (ptrdiff_t)y * stride + x4) = make_uint4(out[0], out[1], out[2], out[3]);
+        for (int k = 1; k < 8; k++)
+            if (x8 + k >= w)
+                out[k] = 0;
+    }
+    VO_GLOBAL uint4 *o = (VO_GLOBAL uint4 *)((VO_GLOBAL uint32_t *)im.der[level] + (ptrdiff_t)y * stride + x8);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
 #ifndef VO_HOST_EMUL
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream)
 {
-    (void)stride;
-    dim3 grid(h + 2 * VO_BY, n_images);
-    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(64), 0, stream, d_imgs, level);
+    dim3 grid(border_fill_blocks(stride, h), n_images);
+    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)
@@ -165,11 +240,7 @@ void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, in
 void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh,
                    hipStream_t stream)
 {
-    ScharrTiles st = {};
-    for (int l = 0; l < n_levels; l++) {
-        st.tiles_x[l] = (lw[l] + 255) / 256;
-        st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((lh[l] + 3) / 4);
-    }
+    const ScharrTiles st = scharr_tiles(n_levels, lw, lh);
     dim3 grid(st.first[n_levels], n_images);
     hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
 }

@@ -104,6 +104,52 @@ VO_HD uint32_t pk_lshr1_u16(uint32_t a)
 #endif
 }
 
+// v_dot4_u32_u8: sum of the four unsigned byte products + c
+VO_HD uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    uint32_t r = c;
+    for (int i = 0; i < 4; i++)
+        r += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
+    return r;
+#endif
+}
+
+// packed 16-bit lanes, wrapping: v_pk_add_u16, v_pk_mul_lo_u16, v_pk_mad_u16 (the low 16 bits of a product or sum do
+// not depend on signedness, so the same instructions serve int16 lanes)
+VO_HD uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+#else
+    return (((a & 0xffff) + (b & 0xffff)) & 0xffff) | (((a >> 16) + (b >> 16)) << 16);
+#endif
+}
+
+VO_HD uint32_t pk_mad_u16(uint32_t a, uint32_t k /* both lanes */, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 kk = {(unsigned short)k, (unsigned short)k};
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * kk + __builtin_bit_cast(u16x2, c)));
+#else
+    return (((a & 0xffff) * k + (c & 0xffff)) & 0xffff) | ((((a >> 16) * k + (c >> 16)) & 0xffff) << 16);
+#endif
+}
+
+// v_alignbyte_b32 / v_alignbit_b32: the 8-byte value {hi:lo} shifted right by `bytes` bytes, low dword
+VO_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t bytes /* 0..3 */)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, bytes);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * bytes));
+#endif
+}
+
 // ---- selectors ------------------------------------------------------------------------------------
 // bytes k and k+1 of the 8 loaded bytes into the high byte of the two u16 lanes (256*p[k], 256*p[k+1])
 #define VO_SEL_PIX(k) (0x0cu | ((uint32_t)(k) << 8) | (0x0cu << 16) | ((uint32_t)((k) + 1) << 24))
