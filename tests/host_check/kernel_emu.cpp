@@ -42,6 +42,8 @@ Plan plan(int w, int h, int max_level)
     return p;
 }
 
+int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead
+
 template <typename F>
 void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
 {
@@ -106,6 +108,8 @@ int ke_bordered_level(const uint8_t *img, int w, int h, int max_level, int level
     return p.levels;
 }
 
+void ke_set_lk_pair(int on) { g_lk_pair = on; }
+
 // imgs: n_img images of w x h (contiguous).  Builds every pyramid with the emulated kernels.
 // lvl_out / der_out (optional): interior of level `want_level` of image 0 (w_l*h_l bytes / dwords).
 // Then tracks pts [n][2] through the quad (0,1,2,3) with the emulated LK kernel.
@@ -157,10 +161,19 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     prm.full_chain = full_chain;
     std::vector<float2> out((size_t)4 * n);
     const int cap = n, n_frames = 1, fpg = 1, parts = 8, ppp = (n + parts - 1) / parts;
-    for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
-        emu::run_block(64, b, 0, 0, [&] {
-            lk_circular_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(), status, prm);
-        });
+    if (g_lk_pair) {
+        const int ppp2 = ((n + 1) / 2 + parts - 1) / parts; // pairs per part
+        for (unsigned b = 0; b < (unsigned)(8 * ppp2); b++) {
+            emu::run_block(64, b, 0, 0, [&] {
+                lk_circular_pair_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp2, out.data(), status, prm);
+            });
+        }
+    } else {
+        for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
+            emu::run_block(64, b, 0, 0, [&] {
+                lk_circular_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(), status, prm);
+            });
+        }
     }
     memcpy(trk, out.data(), sizeof(float2) * 4 * (size_t)n);
     return p.levels;

@@ -119,7 +119,15 @@ def _oracle_hops(orc, L0, R0, L1, R1, pts, **kw):
     return np.stack([p1, p2, p3, p4]), np.stack([s1, s2, s3, s4])
 
 
-def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq):
+@pytest.fixture(params=[0, 1], ids=["one-feature-per-wave", "two-features-per-wave"])
+def lk_variant(request, kemu):
+    """the LK emulation tests run on lk_circular_kernel and on lk_circular_pair_kernel"""
+    kemu.ke_set_lk_pair(request.param)
+    yield request.param
+    kemu.ke_set_lk_pair(0)
+
+
+def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq, lk_variant):
     s = small_seq
     imgs = [s["L"][0], s["R"][0], s["L"][1], s["R"][1]]
     border = np.array([[0, 0], [479, 159], [2.5, 80.25], [476.2, 10.7], [240, 1.1], [250.4, 158.9],
@@ -143,7 +151,7 @@ def test_emulated_lk_kernel_bit_exact(kemu, orc, small_seq):
     assert np.array_equal(keep_full, keep_early) and 0 < keep_full.sum() < len(pts)
 
 
-def test_emulated_lk_large_motion_and_params(kemu, orc):
+def test_emulated_lk_large_motion_and_params(kemu, orc, lk_variant):
     """big flow (search tile re-fetched mid-iteration), fractional / out-of-image start points,
     non-reference parameters"""
     from test_oracle_images import smooth_image
@@ -160,7 +168,7 @@ def test_emulated_lk_large_motion_and_params(kemu, orc):
     assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
 
 
-def test_emulated_lk_negative_bilinear_weight(kemu, orc):
+def test_emulated_lk_negative_bilinear_weight(kemu, orc, lk_variant):
     """regression found on the MI355X: the three rounded bilinear weights can add up to 2^14 + 1, which
     makes iw11 = -1; feature 133 of the large-motion GPU test walks through such an iteration"""
     from test_oracle_images import smooth_image

@@ -114,6 +114,7 @@ struct vo_ctx {
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool serial_pose = false;
+    bool lk_pair = false; // VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip), same results
     long long crowded_min = 65536; // frames x points from which the 128-register pose kernels are used (VO_CROWDED_MIN)
     int crowded_min_pts = 1024;    // ... and points per frame (VO_CROWDED_MIN_PTS)
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
@@ -421,6 +422,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
             c->crowded_min_pts = atoi(ep);
         const char *e = getenv("VO_SERIAL_POSE");
         c->serial_pose = e && e[0] == '1';
+        const char *elp = getenv("VO_LK_PAIR");
+        c->lk_pair = elp && elp[0] == '1';
         const char *e2 = getenv("VO_POSE2_FRAMES");
         if (e2)
             c->pose2_frames = atoi(e2);
@@ -976,8 +979,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        launch_lk_circular(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
-                           c->d_status2[wset], lp, c->stream);
+        (c->lk_pair ? launch_lk_circular_pair : launch_lk_circular)(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap,
+                                                                    c->max_pts_set, B, c->d_trk2[wset],
+                                                                    c->d_status2[wset], lp, c->stream);
         c->trk_last = wset;
         c->trk_next = wset ^ 1;
         if (sq.on) { // the ring slots holding this step's pairs may be overwritten once this LK has finished

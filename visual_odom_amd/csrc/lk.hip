@@ -373,6 +373,341 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TWO FEATURES PER WAVEFRONT ("build and measure the 2-features-per-wave variant").
+// 65 % of the iteration's VALU slots above are wave-uniform arithmetic replicated over 64 lanes (weights, reduction tail,
+// 2 x 2 solve, convergence).  Here a wavefront tracks two features of one frame, one per 32-lane half: lane hl of a half owns
+// the row segments 2 hl and 2 hl + 1 (14 pixels), so the per-pixel work per feature is unchanged while the uniform part and
+// the reduction tree are shared by two features.  The halves run in lock step per (hop, level): a level's Gauss-Newton loop
+// runs until both halves have stopped (a stopped half only idles: every state update is predicated), cell entries (tile
+// test, lift of the pixel pairs) happen when either half needs one.  All per-feature quantities are per-lane values that
+// are uniform within a half; only the images, the level and the iteration counter stay wave-uniform.  The arithmetic of a
+// running half is operation for operation that of lk_circular_kernel (same helpers, same expressions), so the results are
+// bit-identical (tests: CPU emulator vs oracle, GPU vs the one-feature kernel).
+//
+// per-half exact sums of two per-lane int32 partials (|v| < 2^29: 14 products per lane), as f32 rounded once from the exact
+// integer.  v_permlane16_swap folds a | b into the row pairs (even rows: a, odd rows: b), one quad step keeps the 4-value sums
+// below 2^31, then the signed-high / unsigned-low halves finish the 16-lane rows (3 DPP steps each); one fma recombines
+// and a second swap hands every lane of a half both totals.
+__device__ __forceinline__ void half_sum2_exact_f32(int a, int b, float &fa, float &fb)
+{
+    VO_PERMLANE16_SWAP(a, b);
+    int t = a + b;
+    t = dpp_add<VO_DPP_QUAD_XOR1, 0xf>(t);
+    int hi = t >> 16, lo = t & 0xffff;
+    hi = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(hi);
+    lo = dpp_add<VO_DPP_QUAD_XOR2, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_HALF_MIRROR, 0xf>(lo);
+    hi = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(hi);
+    lo = dpp_add<VO_DPP_ROW_MIRROR, 0xf>(lo);
+    const float res = fmaf((float)hi, 65536.f, (float)lo);
+    int x = __float_as_int(res), y = x;
+    VO_PERMLANE16_SWAP(x, y); // x: the even row's value (a) in both rows of a pair, y: the odd row's (b)
+    fa = __int_as_float(x);
+    fb = __int_as_float(y);
+}
+
+#ifndef VO_LK_PAIR_ATTRS
+#define VO_LK_PAIR_ATTRS __launch_bounds__(64, 4)
+#endif
+__global__ VO_LK_PAIR_ATTRS void lk_circular_pair_kernel(const PyrImage *__restrict__ imgs,
+                                                         const Quad *__restrict__ quads,
+                                                         const float2 *__restrict__ pts_in,
+                                                         const int *__restrict__ n_pts, int cap, int n_frames,
+                                                         int fpg /* 1, 2, 4 or 8 */, int ppp /* PAIRS per part */,
+                                                         float2 *__restrict__ trk,     // [B][4][cap]
+                                                         uint8_t *__restrict__ status, // [B][4][cap]
+                                                         LkParams prm)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_jt[2 * LK_JT_H * LK_JT_W];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int grp = slot / ppp, fi = slot - grp * ppp;
+    const int frame = grp * fpg + (xcd & (fpg - 1));
+    if (frame >= n_frames)
+        return;
+    const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
+    const int f = 2 * ((xcd / fpg) * ppp + fi) + half;
+    bool act = f < n_pts[frame]; // this half still tracks its feature
+    if (VO_BALLOT(act) == 0ull)
+        return;
+    // lane -> two (row, 7-pixel segment) slots; slot 63 (second slot of lane 31) owns no pixel: it duplicates slot 62's
+    // pixel addresses and reads its Scharr samples from the all-zero border corner
+    const int sA = 2 * hl, sB = 2 * hl + 1;
+    const bool liveB = sB < 63;
+    const int sBc = liveB ? sB : 62;
+    const int rA = sA / 3, cA = 7 * (sA - 3 * rA), rB = sBc / 3, cB = 7 * (sBc - 3 * rB);
+    const int offA = rA * LK_JT_W + cA, offB = rB * LK_JT_W + cB;
+    uint8_t *const tile = s_jt + half * (LK_JT_H * LK_JT_W);
+
+    const Quad q = quads[frame];
+    const float halfWin = (LK_WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps_lo = (float)(prm.epsilon * 0.999999), eps_hi = (float)(prm.epsilon * 1.000001);
+    const float min_eig_n = prm.min_eig * (1.001f * (float)(2 * LK_WIN * LK_WIN));
+
+    float2 p = make_float2(0.f, 0.f);
+    if (act)
+        p = pts_in[(size_t)frame * cap + f];
+    float prevPtX = p.x, prevPtY = p.y;
+
+    for (int hop = 0; hop < 4; hop++) {
+        const int pi = hop == 0 ? q.l0 : hop == 1 ? q.r0 : hop == 2 ? q.r1 : q.l1;
+        const int ni = hop == 0 ? q.r0 : hop == 1 ? q.r1 : hop == 2 ? q.l1 : q.l0;
+        const PyrImage &I = imgs[pi];
+        const PyrImage &J = imgs[ni];
+        float outX = 0.f, outY = 0.f;
+        int st = 1;
+
+        for (int level = prm.max_level; level >= 0; level--) {
+            const float scale = __int_as_float((127 - level) << 23);
+            float prevX = prevPtX * scale, prevY = prevPtY * scale;
+            float nextX, nextY;
+            if (level == prm.max_level) {
+                nextX = prevX;
+                nextY = prevY;
+            } else {
+                nextX = outX * 2.f;
+                nextY = outY * 2.f;
+            }
+            outX = nextX;
+            outY = nextY;
+
+            const int iw = I.w[level], ih = I.h[level], istride = I.stride[level];
+            const int jw = J.w[level], jh = J.h[level], jstride = J.stride[level];
+            const VO_GLOBAL uint8_t *__restrict__ Iimg = (const VO_GLOBAL uint8_t *)I.lvl[level];
+            const VO_GLOBAL uint32_t *__restrict__ Ider = (const VO_GLOBAL uint32_t *)I.der[level];
+            const VO_GLOBAL uint8_t *__restrict__ Jimg = (const VO_GLOBAL uint8_t *)J.lvl[level];
+
+            prevX -= halfWin;
+            prevY -= halfWin;
+            const float fpx = floorf(prevX), fpy = floorf(prevY);
+            const int ipx = (int)fpx, ipy = (int)fpy;
+            const bool in = act && !(ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih);
+            if (act && !in && level == 0)
+                st = 0;
+            if (VO_BALLOT(in) == 0ull)
+                continue;
+            uint32_t wt, wb;
+            lk_weights(prevX - fpx, prevY - fpy, wt, wb);
+
+            // ---- template of both slots + structure tensor (a half that sits this level out reads window (0, 0)) ----
+            uint32_t IxA[4], IyA[4], IxB[4], IyB[4];
+            int a11, a12, a22, c1, c2;
+            {
+                const int ipxs = in ? ipx : 0, ipys = in ? ipy : 0;
+                const ptrdiff_t org = (ptrdiff_t)VO_BY * istride + VO_BX;
+                const VO_GLOBAL uint8_t *Ib = Iimg - org;
+                const VO_GLOBAL uint8_t *Db = (const VO_GLOBAL uint8_t *)(Ider - org);
+                const uint32_t drow = 4u * (uint32_t)istride;
+#define VO_LK_SLOT(r, c0, live, Ixp, Iyp, FIRST)                                                                       \
+    {                                                                                                                  \
+        const uint32_t o = (uint32_t)((ipys + (r) + VO_BY) * istride + ipxs + (c0) + VO_BX);                           \
+        const uint32_t od = (live) ? 4u * o : 0u;                                                                      \
+        const LkU2 t = *(const VO_GLOBAL LkU2 *)(Ib + o);                                                              \
+        const LkU2 u = *(const VO_GLOBAL LkU2 *)(Ib + (o + (uint32_t)istride));                                        \
+        const LkU4 dt0 = *(const VO_GLOBAL LkU4 *)(Db + od);                                                           \
+        const LkU4 dt1 = *(const VO_GLOBAL LkU4 *)(Db + (od + 16u));                                                   \
+        const LkU4 db0 = *(const VO_GLOBAL LkU4 *)(Db + (od + drow));                                                  \
+        const LkU4 db1 = *(const VO_GLOBAL LkU4 *)(Db + (od + drow + 16u));                                            \
+        const uint32_t dt[8] = {dt0.a, dt0.b, dt0.c, dt0.d, dt1.a, dt1.b, dt1.c, dt1.d};                               \
+        const uint32_t db[8] = {db0.a, db0.b, db0.c, db0.d, db1.a, db1.b, db1.c, db1.d};                               \
+        uint32_t Ip[4];                                                                                                \
+        bilinear7_u8(t.lo, t.hi, u.lo, u.hi, wt, wb, Ip);                                                              \
+        bilinear7_deriv(dt, db, wt, wb, Ixp, Iyp);                                                                     \
+        _Pragma("unroll") for (int m = 0; m < 4; m++)                                                                  \
+        {                                                                                                              \
+            if ((FIRST) && m == 0) {                                                                                   \
+                a11 = sdot2_first(Ixp[0], Ixp[0], 0);                                                                  \
+                a12 = sdot2_first(Ixp[0], Iyp[0], 0);                                                                  \
+                a22 = sdot2_first(Iyp[0], Iyp[0], 0);                                                                  \
+                c1 = sdot2_first(Ip[0], Ixp[0], 0);                                                                    \
+                c2 = sdot2_first(Ip[0], Iyp[0], 0);                                                                    \
+            } else {                                                                                                   \
+                a11 = sdot2(Ixp[m], Ixp[m], a11);                                                                      \
+                a12 = sdot2(Ixp[m], Iyp[m], a12);                                                                      \
+                a22 = sdot2(Iyp[m], Iyp[m], a22);                                                                      \
+                c1 = sdot2(Ip[m], Ixp[m], c1);                                                                         \
+                c2 = sdot2(Ip[m], Iyp[m], c2);                                                                         \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+                VO_LK_SLOT(rA, cA, true, IxA, IyA, true)
+                VO_LK_SLOT(rB, cB, liveB, IxB, IyB, false)
+#undef VO_LK_SLOT
+            }
+            float A11, A12, A22, unused;
+            half_sum2_exact_f32(a11, a12, A11, A12);
+            half_sum2_exact_f32(a22, 0, A22, unused);
+            A11 *= FLT_SCALE;
+            A12 *= FLT_SCALE;
+            A22 *= FLT_SCALE;
+
+            float D = A11 * A22 - A12 * A12;
+            // min-eigenvalue test: the conservative quick form of lk_circular_kernel, the exact expression where it does not decide
+            const float t = A22 + A11;
+            const float s2 = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+            const float u = t - (min_eig_n + t * 3.814697265625e-6f);
+            bool eig_ok = u > 0.f && s2 < u * u * 0.9999f;
+            if (VO_BALLOT(in && !eig_ok) != 0ull) {
+                const float minEig = (t - sqrtf(s2)) / (float)(2 * LK_WIN * LK_WIN);
+                eig_ok = eig_ok || !(minEig < prm.min_eig); // the quick form implies the exact one
+            }
+            const bool ok = in && eig_ok && !(D < FLT_EPSILON);
+            if (in && !ok && level == 0)
+                st = 0;
+            if (VO_BALLOT(ok) == 0ull)
+                continue;
+            D = 1.f / D;
+            const float A11s = A11 * FLT_SCALE, A12s = A12 * FLT_SCALE, A22s = A22 * FLT_SCALE;
+            const int nc1 = -c1, nc2 = -c2;
+
+            nextX -= halfWin;
+            nextY -= halfWin;
+            float prevDX = 0.f, prevDY = 0.f;
+            int jx0 = 0, jy0 = 0, offT = 0;
+            bool have_tile = false;
+            const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
+
+            int j = 0; // iterations done at this level: the same for every half that still runs
+            float fnx = floorf(nextX), fny = floorf(nextY);
+            bool run = ok && prm.max_count > 0;
+            bool entry = run; // this half has to (re-)enter a pixel cell before its next iteration
+            uint32_t JtA[7], JbA[7], JtB[7], JbB[7];
+            while (VO_BALLOT(run) != 0ull) {
+                if (VO_BALLOT(entry) != 0ull) {
+                    const int inx = (int)fnx, iny = (int)fny;
+                    const bool oob = entry && (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh);
+                    if (oob) {
+                        if (level == 0)
+                            st = 0;
+                        run = false;
+                    }
+                    const bool e2 = entry && !oob;
+                    const bool need = e2 && (!have_tile || inx < jx0 || inx + LK_WIN + 1 > jx0 + LK_JT_W || iny < jy0 ||
+                                             iny + LK_WIN + 1 > jy0 + LK_JT_H);
+                    if (VO_BALLOT(need) != 0ull) {
+                        if (need) {
+                            jx0 = (inx - 12) & ~3;
+                            jy0 = iny - 9;
+                            jx0 = jx0 < -VO_BX ? -VO_BX : jx0 > jx_max ? jx_max : jx0;
+                            jy0 = jy0 < -VO_BY ? -VO_BY : jy0 > jy_max ? jy_max : jy0;
+                        }
+                        __syncthreads(); // single-wave workgroup: orders the LDS reads before the refill
+                        if (need) {
+                            const VO_GLOBAL uint8_t *tb = Jimg + ((ptrdiff_t)jy0 * jstride + jx0);
+                            for (int c = hl; c < LK_JT_H * (LK_JT_W / 16); c += 32) {
+                                const int row = c / (LK_JT_W / 16), col = c - row * (LK_JT_W / 16);
+                                const LkU4 v = *(const VO_GLOBAL LkU4 *)(tb + (uint32_t)(row * jstride + 16 * col));
+                                *reinterpret_cast<uint4 *>(&tile[row * LK_JT_W + 16 * col]) = make_uint4(v.a, v.b, v.c, v.d);
+                            }
+                            have_tile = true;
+                        }
+                        __syncthreads();
+                    }
+                    if (e2)
+                        offT = (iny - jy0) * LK_JT_W + (inx - jx0);
+                    {
+                        // every lane lifts its current cell again (a half that did not move re-reads the same bytes; a
+                        // half without a tile reads offset 0 and never uses the result)
+                        const LkU2 tA = *reinterpret_cast<const LkU2 *>(&tile[offT + offA]);
+                        const LkU2 uA = *reinterpret_cast<const LkU2 *>(&tile[offT + offA + LK_JT_W]);
+                        const LkU2 tB = *reinterpret_cast<const LkU2 *>(&tile[offT + offB]);
+                        const LkU2 uB = *reinterpret_cast<const LkU2 *>(&tile[offT + offB + LK_JT_W]);
+                        lift7(tA.lo, tA.hi, JtA);
+                        lift7(uA.lo, uA.hi, JbA);
+                        lift7(tB.lo, tB.hi, JtB);
+                        lift7(uB.lo, uB.hi, JbB);
+                    }
+                    entry = false;
+                    if (VO_BALLOT(run) == 0ull)
+                        break;
+                }
+                lk_weights(nextX - fnx, nextY - fny, wt, wb);
+                int b1, b2;
+                {
+                    uint32_t Jp[4];
+                    blend7(JtA, JbA, wt, wb, Jp);
+                    b1 = sdot2_first(Jp[0], IxA[0], nc1);
+                    b2 = sdot2_first(Jp[0], IyA[0], nc2);
+#pragma unroll
+                    for (int m = 1; m < 4; m++) {
+                        b1 = sdot2(Jp[m], IxA[m], b1);
+                        b2 = sdot2(Jp[m], IyA[m], b2);
+                    }
+                    blend7(JtB, JbB, wt, wb, Jp);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        b1 = sdot2(Jp[m], IxB[m], b1);
+                        b2 = sdot2(Jp[m], IyB[m], b2);
+                    }
+                }
+                float fb1, fb2;
+                half_sum2_exact_f32(b1, b2, fb1, fb2);
+                const float dx = (A12s * fb2 - A22s * fb1) * D;
+                const float dy = (A12s * fb1 - A11s * fb2) * D;
+                if (run) {
+                    nextX += dx;
+                    nextY += dy;
+                    outX = nextX + halfWin;
+                    outY = nextY + halfWin;
+                    const float n2 = fmaf(dy, dy, dx * dx);
+                    bool stop = false;
+                    if (!(n2 > eps_hi))
+                        stop = n2 < eps_lo || (double)dx * dx + (double)dy * dy <= prm.epsilon;
+                    if (!stop && j > 0 && fabsf(dx + prevDX) <= 0.01f && fabsf(dy + prevDY) <= 0.01f) {
+                        outX -= dx * 0.5f;
+                        outY -= dy * 0.5f;
+                        stop = true;
+                    }
+                    prevDX = dx;
+                    prevDY = dy;
+                    if (stop)
+                        run = false;
+                }
+                if (++j >= prm.max_count)
+                    run = false;
+                if (run) {
+                    const uint32_t ua = (uint32_t)__float_as_int(nextX - fnx), ub = (uint32_t)__float_as_int(nextY - fny);
+                    if ((ua > ub ? ua : ub) >= 0x3f800000u) { // the corner left the cell
+                        fnx = floorf(nextX);
+                        fny = floorf(nextY);
+                        entry = true;
+                    }
+                }
+            }
+
+            // final in-bounds check OpenCV performs at level 0 when an err vector is requested
+            if (ok && st && level == 0) {
+                const int fx = (int)floorf(outX - halfWin), fy = (int)floorf(outY - halfWin);
+                if (fx < -LK_WIN || fx >= jw || fy < -LK_WIN || fy >= jh)
+                    st = 0;
+            }
+        }
+
+        if (act && hl == 0) {
+            trk[((size_t)frame * 4 + hop) * cap + f] = make_float2(outX, outY);
+            status[((size_t)frame * 4 + hop) * cap + f] = (uint8_t)st;
+        }
+        // a feature deleteUnmatchFeaturesCircle is going to drop stops here (see lk_circular_kernel)
+        const bool dead = st == 0 || outX < 0.f || outY < 0.f || (hop == 0 && (p.x < 0.f || p.y < 0.f));
+        if (act && dead && !prm.full_chain && hop < 3) {
+            if (hl == 0)
+                for (int k = hop + 1; k < 4; k++) {
+                    trk[((size_t)frame * 4 + k) * cap + f] = make_float2(-1.f, -1.f);
+                    status[((size_t)frame * 4 + k) * cap + f] = 0;
+                }
+            act = false;
+        }
+        if (VO_BALLOT(act) == 0ull)
+            return;
+        prevPtX = outX;
+        prevPtY = outY;
+    }
+}
+
 #ifndef VO_HOST_EMUL
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
@@ -386,6 +721,20 @@ void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float
     const int groups = (n_frames + fpg - 1) / fpg;
     dim3 grid((unsigned)(8 * groups * ppp));
     hipLaunchKernelGGL(lk_circular_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames,
+                       fpg, ppp, d_trk, d_status, prm);
+}
+
+void launch_lk_circular_pair(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
+                             int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
+                             const LkParams &prm, hipStream_t stream)
+{
+    if (max_pts <= 0 || n_frames <= 0)
+        return;
+    const int fpg = n_frames >= 8 ? 8 : n_frames >= 4 ? 4 : n_frames >= 2 ? 2 : 1;
+    const int parts = 8 / fpg, pairs = (max_pts + 1) / 2, ppp = (pairs + parts - 1) / parts;
+    const int groups = (n_frames + fpg - 1) / fpg;
+    dim3 grid((unsigned)(8 * groups * ppp));
+    hipLaunchKernelGGL(lk_circular_pair_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames,
                        fpg, ppp, d_trk, d_status, prm);
 }
 
