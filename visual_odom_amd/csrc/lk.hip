@@ -383,7 +383,7 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
 // test, lift of the pixel pairs) happen when either half needs one.  All per-feature quantities are per-lane values that
 // are uniform within a half; only the images, the level and the iteration counter stay wave-uniform.  The arithmetic of a
 // running half is operation for operation that of lk_circular_kernel (same helpers, same expressions), so the results are
-// bit-identical (tests: CPU emulator vs oracle, GPU vs the one-feature kernel).
+// bit-identical (tests: the CPU emulator run of this source and the GPU run against the one-feature kernel).
 //
 // per-half exact sums of two per-lane int32 partials (|v| < 2^29: 14 products per lane), as f32 rounded once from the exact
 // integer.  v_permlane16_swap folds a | b into the row pairs (even rows: a, odd rows: b), one quad step keeps the 4-value sums
