@@ -57,16 +57,16 @@ void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
 void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 {
     using namespace vo;
-    auto fill = [&](int l) {
-        launch(border_fill_blocks(p.ls[l], p.lh[l]), n_img, 1, 256, [&] { border_fill_kernel(d_imgs, l); });
-    };
-    fill(0);
-    for (int l = 0; l + 1 < p.levels; l++) {
-        launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
-        fill(l + 1);
+    // the order of capi.hip: level 0's border + Scharr image, the pyr_down chain, then the other levels
+    for (int first = 0, last = 1; first < p.levels; first = last, last = p.levels) {
+        if (first == 1)
+            for (int l = 0; l + 1 < p.levels; l++)
+                launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
+        const BorderBlocks bb = border_blocks(first, last, p.ls, p.lh);
+        launch(bb.first[last], n_img, 1, 256, [&] { border_fill_kernel(d_imgs, last, bb); });
+        const ScharrTiles st = scharr_tiles(first, last, p.lw, p.lh);
+        launch(st.first[last], n_img, 1, 256, [&] { scharr_kernel(d_imgs, last, st); });
     }
-    const ScharrTiles st = scharr_tiles(p.levels, p.lw, p.lh);
-    launch(st.first[p.levels], n_img, 1, 256, [&] { scharr_kernel(d_imgs, p.levels, st); });
 }
 
 } // namespace

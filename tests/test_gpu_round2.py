@@ -186,14 +186,14 @@ def test_two_features_per_wave_lk_kernel_is_bit_identical(volib, monkeypatch, sm
         monkeypatch.setenv("VO_LK_PAIR", pair)
         ctx = volib.Context(0, w, h, 4096, 3)
         try:
-            ctx.batch_configure(6, w, h, 3)
-            for k in range(3):
-                ctx.batch_upload_image(2 * k, s["L"][k])
-                ctx.batch_upload_image(2 * k + 1, s["R"][k])
-            ctx.batch_set_quads([[0, 1, 2, 3], [4, 5, 2, 3], [4, 5, 4, 5]])
             res = []
             for full in (1, 0):
                 ctx.set_params(lk_full_chain=full)
+                ctx.batch_configure(6, w, h, 3)
+                for k in range(3):
+                    ctx.batch_upload_image(2 * k, s["L"][k])
+                    ctx.batch_upload_image(2 * k + 1, s["R"][k])
+                ctx.batch_set_quads([[0, 1, 2, 3], [4, 5, 2, 3], [4, 5, 4, 5]])
                 for k in range(3):
                     ctx.batch_set_points(k, pts[k])
                 ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)

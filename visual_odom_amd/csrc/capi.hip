@@ -874,12 +874,15 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
-            launch_border_fill(tab, ni, 0, c->lstride[0], c->lh[0], pyrs);
-            for (int l = 0; l + 1 < c->levels; l++) {
-                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], pyrs);
-                launch_border_fill(tab, ni, l + 1, c->lstride[l + 1], c->lh[l + 1], pyrs);
-            }
-            launch_scharr(tab, ni, c->levels, c->lw, c->lh, pyrs);
+            // Level 0 first, with the two kernels that use no LDS: in steady state the pose solve of the previous run starts
+            // on the pose stream at about this moment, and two of its EPnP workgroups fill a CU's LDS (pnp.hip, launch_pnp)
+            // -- an LDS-using kernel launched now would wait ~0.6 ms for them, these two do not.
+            launch_border_fill(tab, ni, 0, 1, c->lstride, c->lh, pyrs);
+            launch_scharr(tab, ni, 0, 1, c->lw, c->lh, pyrs);
+            for (int l = 0; l + 1 < c->levels; l++)
+                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], pyrs); // reflects on its own: needs no border
+            launch_border_fill(tab, ni, 1, c->levels, c->lstride, c->lh, pyrs);
+            launch_scharr(tab, ni, 1, c->levels, c->lw, c->lh, pyrs);
             std::fill(c->img_stale.begin() + c->pyr_first, c->img_stale.begin() + c->pyr_first + ni, (uint8_t)0);
         }
     }

@@ -23,6 +23,7 @@
 #include "vo_epnp.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 // Register budget of the two f64-heavy kernels, as minimum waves per SIMD (launch_bounds' second
 // argument), a template parameter with two instantiations:
@@ -504,7 +505,19 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
         return;
     const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
     const dim3 eg(RANSAC_CHUNK / 64, n_frames);
-    const size_t lds = (144 + 12) * 64 * sizeof(double);
+    // The 12 x 12 matrices of 64 hypotheses take 78 KB of LDS, so two such workgroups fill a CU's 160 KB completely and no
+    // other kernel that uses LDS at all (pyr_down, FAST, LK with 1.9 KB per wave) can start a workgroup there until one of
+    // them retires: when the chain starts on an idle GPU, the next LDS-using kernel of the tracking stream sits behind it
+    // for ~0.6 ms (round-2 trace of the lock-step loop, 256 sequences).  Capping the solver at ONE workgroup per CU by asking
+    // for more than half of the LDS (VO_EPNP_LDS_KB=82) was measured and is worse -- the chain gets longer than two steps:
+    // reference-default batch 67.6 k -> 56.9 k frames/s, 128 sequences 51.5 k -> 48.9 k, 256 sequences unchanged -- so the
+    // tracking stream instead starts each step with its LDS-free kernels (capi.hip, PYRAMID stage).
+    static const size_t lds = [] {
+        size_t need = (144 + 12) * 64 * sizeof(double), want = 0;
+        if (const char *e = getenv("VO_EPNP_LDS_KB"))
+            want = (size_t)atoi(e) * 1024;
+        return want > need ? want : need;
+    }();
     for (int k = 0; k < n_chunks; k++) {
         hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm.iters, k, subsets, state);

@@ -11,13 +11,16 @@
 // Kernels (all HBM-streaming; see DESIGN.md for the byte counts).  Round 2 rewrote all three -- the first versions were
 // instruction-bound far below the memory rate (byte-granular loads / stores, one LDS byte read per filter tap, 64-bit
 // shifts to pull pixels apart): 512 KITTI images took 0.11-0.17 + 0.20 + 0.60 ms, against 0.02 / 0.07 / 0.35 ms of HBM time:
-//   border_fill_kernel  one thread per 32-bit word that holds a REFLECT_101 border pixel of one level (all words of the
-//                       rows above / below the image, the left / right border words of image rows): words inside the
-//                       image span are aligned word copies of the reflected row, the rest gathers 4 reflected bytes
 //   pyr_down_kernel     one 256-thread workgroup -> 64 x 16 output tile; the 144 x 35 source tile is staged in LDS with
-//                       16-byte loads (the source border makes every tile an in-bounds read); horizontal [1 4 6 4 1]:
+//                       16-byte loads (rows through REFLECT_101, the two reflected columns an edge tile needs patched in
+//                       LDS: a level's border is never read here, so the three launches only depend on each other);
+//                       horizontal [1 4 6 4 1]:
 //                       a thread reads 16 bytes and forms 4 partials with v_alignbyte_b32 + v_dot4_u32_u8 (u16 in LDS);
 //                       vertical: packed 16-bit multiply-adds (the sum + 128 stays below 2^16), 4 pixels per 32-bit store
+//   border_fill_kernel  after the last pyr_down, ALL levels in one launch: one thread per 32-bit word that holds a
+//                       REFLECT_101 border pixel (all words of the rows above / below the image, the left / right border
+//                       words of image rows): words inside the image span are aligned word copies of the reflected row,
+//                       the rest gathers 4 reflected bytes
 //   scharr_kernel       8 pixels per thread: three unaligned 12-byte row loads, the pixels lifted into u16 pairs
 //                       (v_perm_b32), the separable form t0 = 3 (above + below) + 10 row, t1 = below - above in packed
 //                       16-bit arithmetic with the x4 pre-scale folded into the constants, two 16-byte stores of
@@ -40,13 +43,25 @@ struct __attribute__((packed, aligned(4))) U32x4 {
 // to the end of the row.  A word that straddles the image edge rewrites its interior bytes with the values they already have.
 constexpr int BF_MAX_ROW_WORDS = VO_BX / 4 + 11; // right border < 40 pixels + up to 3 interior ones (level_stride, capi.hip)
 
-inline unsigned border_fill_blocks(int stride, int h)
+// all levels of all images in one launch (nothing on the path reads a level's border before the whole pyramid exists --
+// pyr_down_kernel reflects on its own): blockIdx.y = image, blockIdx.x = 256-word block numbered level by level
+struct BorderBlocks {
+    int first[VO_MAX_LEVELS + 1]; // first[l] = blocks of the levels before l
+};
+
+inline BorderBlocks border_blocks(int first_level, int n_levels, const int *lstride, const int *lh)
 {
-    return (unsigned)((2 * VO_BY * (stride / 4) + h * BF_MAX_ROW_WORDS + 255) / 256);
+    BorderBlocks bb = {}; // levels below first_level get no blocks
+    for (int l = first_level; l < n_levels; l++)
+        bb.first[l + 1] = bb.first[l] + (2 * VO_BY * (lstride[l] / 4) + lh[l] * BF_MAX_ROW_WORDS + 255) / 256;
+    return bb;
 }
 
-__global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__restrict__ imgs, int level)
+__global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__restrict__ imgs, int n_levels, BorderBlocks bb)
 {
+    int level = 0; // bb.first[l + 1] == bb.first[l] for levels that are not part of this launch
+    while (level + 1 < n_levels && (int)blockIdx.x >= bb.first[level + 1])
+        level++;
     const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
     VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
@@ -54,7 +69,7 @@ __global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__rest
     const int xr0 = w & ~3;                                     // first word with a right-border pixel
     const int nb = VO_BX / 4 + ((stride - VO_BX - xr0) >> 2);   // border words of an image row
     const int n_out = 2 * VO_BY * wpr;
-    int item = (int)(blockIdx.x * 256 + threadIdx.x);
+    int item = (int)(((int)blockIdx.x - bb.first[level]) * 256 + threadIdx.x);
     int y, x0;
     if (item < n_out) {
         const int r = item / wpr;
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     __shared__ __attribute__((aligned(16))) uint16_t s_h[PD_SH * PD_TW];
 
     const PyrImage &im = imgs[blockIdx.z];
-    const int sh = im.h[level], sstride = im.stride[level];
+    const int sw = im.w[level], sh = im.h[level], sstride = im.stride[level];
     const int dw = im.w[level + 1], dh = im.h[level + 1], dstride = im.stride[level + 1];
     const VO_GLOBAL uint8_t *__restrict__ src = (const VO_GLOBAL uint8_t *)im.lvl[level];
     VO_GLOBAL uint8_t *__restrict__ dst = (VO_GLOBAL uint8_t *)im.lvl[level + 1];
@@ -96,31 +111,51 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     if (ox >= dw || oy >= dh)
         return;
     const int tid = threadIdx.x;
-    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;        // >= -4 / -2: inside the source border
-    const int xmax = sstride - VO_BX, ymax = sh + VO_BY; // first column / row outside the allocation
+    const int sx0 = 2 * ox - 4, sy0 = 2 * oy - 2;        // >= -4 / -2
+    const int xmax = sstride - VO_BX;                    // first column outside the allocation
 
-    // 35 rows x 9 x 16 bytes, coalesced along rows; columns / rows past the allocation are never used by a valid output
-    // pixel (those need source x <= 2 dw <= w + 1, y <= h + 1) and read as 0
+    // 35 rows x 9 x 16 bytes, coalesced along rows.  The source level's border is NOT read as data (it may not exist yet:
+    // the borders of all levels are filled in one pass after the last pyr_down): rows outside the image are fetched from
+    // their REFLECT_101 row, the up to two columns a valid output needs left / right of the image are patched in LDS below.
+    // Bytes of border columns that do get loaded are unspecified and never used; columns past the allocation read as 0.
     for (int i = tid; i < PD_SH * (PD_SW / 16); i += 256) {
         const int r = i / (PD_SW / 16), c = i - r * (PD_SW / 16);
-        const int x = sx0 + 16 * c, y = sy0 + r;
+        const int x = sx0 + 16 * c, y = reflect101(sy0 + r, sh);
         const VO_GLOBAL uint8_t *g = src + (ptrdiff_t)y * sstride + x;
         U32x4 v = {0, 0, 0, 0};
-        if (y < ymax) {
-            if (x + 16 <= xmax) {
-                v = *(const VO_GLOBAL U32x4 *)g;
-            } else {
-                if (x + 4 <= xmax)
-                    v.a = *(const VO_GLOBAL uint32_t *)g;
-                if (x + 8 <= xmax)
-                    v.b = *(const VO_GLOBAL uint32_t *)(g + 4);
-                if (x + 12 <= xmax)
-                    v.c = *(const VO_GLOBAL uint32_t *)(g + 8);
-            }
+        if (x + 16 <= xmax) {
+            v = *(const VO_GLOBAL U32x4 *)g;
+        } else {
+            if (x + 4 <= xmax)
+                v.a = *(const VO_GLOBAL uint32_t *)g;
+            if (x + 8 <= xmax)
+                v.b = *(const VO_GLOBAL uint32_t *)(g + 4);
+            if (x + 12 <= xmax)
+                v.c = *(const VO_GLOBAL uint32_t *)(g + 8);
         }
         *reinterpret_cast<uint4 *>(&s_src[r * PD_SW + 16 * c]) = make_uint4(v.a, v.b, v.c, v.d);
     }
     __syncthreads();
+    // REFLECT_101 columns: outputs read source columns 2x - 2 .. 2x + 2 with x < dw = (sw + 1) / 2, i.e. -2 .. sw + 1 at most;
+    // tile column = source column + 4 - 2 ox.  (sw - 2, sw - 3 lie inside the tile whenever sw or sw + 1 is needed: the
+    // last tile has 2 ox <= sw - 1.)
+    const bool left = ox == 0, right = sw + 4 - 2 * ox < PD_SW;
+    if (left || right) {
+        if (tid < PD_SH) {
+            uint8_t *row = &s_src[tid * PD_SW];
+            if (left) {
+                row[2] = row[4 + reflect101(-2, sw)];
+                row[3] = row[4 + reflect101(-1, sw)];
+            }
+            if (right) {
+                const int c = sw + 4 - 2 * ox; // tile column of source column sw
+                row[c] = row[c - sw + reflect101(sw, sw)];
+                if (c + 1 < PD_SW)
+                    row[c + 1] = row[c - sw + reflect101(sw + 1, sw)];
+            }
+        }
+        __syncthreads();
+    }
 
     // horizontal 5-tap, 4 outputs per thread: output column x reads source columns 2x-2 .. 2x+2 = tile columns 2x+2 .. 2x+6,
     // i.e. outputs x4 .. x4+3 read bytes 2+2k .. 6+2k (k = 0..3) of the 16 bytes at tile column 2*x4
@@ -162,12 +197,12 @@ struct ScharrTiles {
     int tiles_x[VO_MAX_LEVELS];
 };
 
-inline ScharrTiles scharr_tiles(int n_levels, const int *lw, const int *lh)
+inline ScharrTiles scharr_tiles(int first_level, int n_levels, const int *lw, const int *lh)
 {
-    ScharrTiles st = {};
+    ScharrTiles st = {}; // levels below first_level get no tiles
     for (int l = 0; l < n_levels; l++) {
         st.tiles_x[l] = (lw[l] + 511) / 512;
-        st.first[l + 1] = st.first[l] + st.tiles_x[l] * ((lh[l] + 3) / 4);
+        st.first[l + 1] = st.first[l] + (l < first_level ? 0 : st.tiles_x[l] * ((lh[l] + 3) / 4));
     }
     return st;
 }
@@ -225,10 +260,14 @@ __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict_
 }
 
 #ifndef VO_HOST_EMUL
-void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream)
+void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lstride,
+                        const int *lh, hipStream_t stream)
 {
-    dim3 grid(border_fill_blocks(stride, h), n_images);
-    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(256), 0, stream, d_imgs, level);
+    if (first_level >= n_levels)
+        return;
+    const BorderBlocks bb = border_blocks(first_level, n_levels, lstride, lh);
+    dim3 grid(bb.first[n_levels], n_images);
+    hipLaunchKernelGGL(border_fill_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, bb);
 }
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)
@@ -237,10 +276,12 @@ void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, in
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
 
-void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh,
+void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lw, const int *lh,
                    hipStream_t stream)
 {
-    const ScharrTiles st = scharr_tiles(n_levels, lw, lh);
+    if (first_level >= n_levels)
+        return;
+    const ScharrTiles st = scharr_tiles(first_level, n_levels, lw, lh);
     dim3 grid(st.first[n_levels], n_images);
     hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
 }

@@ -94,9 +94,10 @@ struct EmBufs {
     uint8_t *mask = nullptr;              // [B][cap]
 };
 
-void launch_border_fill(const PyrImage *d_imgs, int n_images, int level, int stride, int h, hipStream_t stream);
+void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lstride,
+                        const int *lh, hipStream_t stream);
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
-void launch_scharr(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh,
+void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lw, const int *lh,
                    hipStream_t stream);
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
