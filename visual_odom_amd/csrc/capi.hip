@@ -113,6 +113,7 @@ struct vo_ctx {
     long long pose_medium_min = 128;   // frames per run from which the 256-register pose kernels are used (VO_POSE_MEDIUM_MIN)
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
+    bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
     bool serial_pose = false;
     bool lk_pair = false; // VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip), same results
     long long crowded_min = 65536; // frames x points from which the 128-register pose kernels are used (VO_CROWDED_MIN)
@@ -121,6 +122,7 @@ struct vo_ctx {
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
     // 1241 x 376 image measured, tools/latency_mode.py)
     uint8_t *h_stage = nullptr;
+    uint8_t *h_gather = nullptr, *d_gather = nullptr; // vo_track_frame's result buffer: host memory, and its device address
     size_t stage_slot = 0; // bytes per slot, VO_STAGE_SLOTS slots
     int stage_next = 0;
     int ransac_cap = 0;
@@ -367,6 +369,8 @@ void vo_destroy(vo_ctx *c)
         (void)hipStreamDestroy(c->stream_em);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
+    if (c->h_gather)
+        (void)hipHostFree(c->h_gather);
     for (auto &e : c->ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -455,6 +459,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     }
     c->stage_slot = (size_t)level_stride(max_w) * max_h;
     ok = ok && hipHostMalloc((void **)&c->h_stage, c->stage_slot * VO_STAGE_SLOTS, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_gather, frame_gather_bytes(c->cap), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void **)&c->d_gather, c->h_gather, 0) == hipSuccess;
     ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_der, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
@@ -607,6 +613,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     std::fill(c->h_ntracked.begin(), c->h_ntracked.end(), 0);
     std::fill(c->img_stale.begin(), c->img_stale.end(), 0);
     std::fill(c->h_quads.begin(), c->h_quads.end(), Quad{0, 0, 0, 0});
+    c->quads_set = false;
     VO_HIP_TRY(c, hipMemsetAsync(c->d_quads, 0, sizeof(Quad) * c->max_frames, c->stream));
     VO_HIP_TRY(c, hipMemsetAsync(c->d_overflow, 0, sizeof(int) * c->max_frames, c->stream));
     c->detect_uploaded = false; // the per-frame detect flags on the device belong to the previous batch shape
@@ -677,10 +684,13 @@ int vo_batch_set_quads(vo_ctx *c, const int32_t *quads4, int n_frames)
             return fail(c, VO_ERR_ARG, "vo_batch_set_quads: image index out of range");
     if (c->seq.on)
         return fail(c, VO_ERR_STATE, "vo_batch_set_quads inside the sequence loop");
+    if (c->quads_set && memcmp(c->h_quads.data(), quads4, sizeof(Quad) * n_frames) == 0)
+        return VO_OK; // the table on the device already says so (the single-frame calls set {0, 1, 2, 3} every time)
     VO_HIP_TRY(c, hipSetDevice(c->device));
     VO_HIP_TRY(c, hipMemcpyAsync(c->d_quads, quads4, sizeof(Quad) * n_frames, hipMemcpyHostToDevice, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(c->h_quads.data(), quads4, sizeof(Quad) * n_frames);
+    c->quads_set = true;
     return VO_OK;
 }
 
@@ -806,6 +816,8 @@ int vo_batch_set_projection(vo_ctx *c, const float *P_l, const float *P_r)
 {
     if (!c || !P_l || !P_r)
         return VO_ERR_ARG;
+    if (c->have_P && memcmp(c->h_P, P_l, 12 * sizeof(float)) == 0 && memcmp(c->h_P + 12, P_r, 12 * sizeof(float)) == 0)
+        return VO_OK; // unchanged since the last call (every vo_track_frame passes the same calibration)
     memcpy(c->h_P, P_l, 12 * sizeof(float));
     memcpy(c->h_P + 12, P_r, 12 * sizeof(float));
     VO_HIP_TRY(c, hipSetDevice(c->device));
@@ -2073,11 +2085,74 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     rc = run_stages(c, VO_STAGE_ALL, false);
     if (rc != VO_OK)
         return rc;
-    rc = vo_batch_get_filtered(c, 0, out_l0, out_r0, out_l1, out_r1, xyz_out, keep_idx, n_out, keep_idx_circ,
-                               n_circ);
-    if (rc != VO_OK)
-        return rc;
-    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ false);
+    // Results: one kernel behind the pose solve gathers the counts, the PnpResult and every output array into one
+    // host-visible buffer, one synchronisation, host copies from there -- instead of eleven device-to-host copies and
+    // four rounds of stream synchronisation through vo_batch_get_filtered + vo_batch_get_pose (0.25 of the call's 1.45 ms).
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    const bool mono = c->prm.mono_rotation && c->em_ready;
+    FrameGather g;
+    g.nA = c->d_nA;
+    g.nB = pb.nB;
+    g.outB = pb.outB;
+    g.xyz = pb.xyz;
+    g.idxB = pb.idxB;
+    g.idxA = c->d_idxA;
+    g.inliers = pb.inliers;
+    g.result = pb.results;
+    g.em = mono ? pb.em_results : nullptr;
+    g.cap = c->cap;
+    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0)); // `done` covers the filter, both pose chains
+    launch_frame_gather(g, c->d_gather, c->stream);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint8_t *hb = c->h_gather;
+    int hdr[3];
+    memcpy(hdr, hb, sizeof(hdr));
+    const int M = hdr[0], K = hdr[1];
+    PnpResult r;
+    memcpy(&r, hb + 16, sizeof(r));
+    const size_t cap = (size_t)c->cap;
+    const uint8_t *arr = hb + VO_GATHER_HEADER;
+    float *outs[4] = {out_l0, out_r0, out_l1, out_r1};
+    for (int k = 0; k < 4; k++)
+        if (outs[k] && K > 0)
+            memcpy(outs[k], arr + (size_t)k * cap * 8, (size_t)K * 8);
+    const uint8_t *ax = arr + 4 * cap * 8, *ak = ax + cap * 12, *ac = ak + cap * 4, *ai = ac + cap * 4;
+    if (xyz_out && K > 0)
+        memcpy(xyz_out, ax, (size_t)K * 12);
+    if (keep_idx && K > 0)
+        memcpy(keep_idx, ak, (size_t)K * 4);
+    if (keep_idx_circ && M > 0)
+        memcpy(keep_idx_circ, ac, (size_t)M * 4);
+    if (n_out)
+        *n_out = K;
+    if (n_circ)
+        *n_circ = M;
+    // the pose, by the rules of vo_batch_get_pose / fetch_pose
+    if (r.status >= 0) {
+        if (rvec_io)
+            memcpy(rvec_io, r.rvec, sizeof(r.rvec));
+        if (tvec_io)
+            memcpy(tvec_io, r.tvec, sizeof(r.tvec));
+        if (R_out && !c->prm.mono_rotation)
+            memcpy(R_out, r.R, sizeof(r.R)); // `if (!mono_rotation) Rodrigues(rvec, rotation)` (visualOdometry.cpp:186-189)
+    }
+    int em_status = 1;
+    if (mono) {
+        EmResult e;
+        memcpy(&e, hb + 256, sizeof(e));
+        if (e.status == 1 && R_out)
+            memcpy(R_out, e.R, sizeof(e.R));
+        em_status = e.status;
+    }
+    if (inliers && r.n_inliers > 0)
+        memcpy(inliers, ai, (size_t)r.n_inliers * 4);
+    if (n_inliers)
+        *n_inliers = r.n_inliers;
+    if (r.status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached solvePnPRansac");
+    if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
+        return VO_NO_ESSENTIAL;
+    return r.status == 1 ? VO_OK : VO_NO_MODEL;
 }
 
 } // extern "C"

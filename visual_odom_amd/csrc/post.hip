@@ -126,6 +126,45 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float *__restric
     o[2] = out[2];
 }
 
+// see FrameGather (vo_kernels.h); `out` is page-locked host memory mapped into the device's address space
+__global__ __launch_bounds__(256) void frame_gather_kernel(FrameGather g, uint8_t *__restrict__ out)
+{
+    const int K = g.nB[0], M = g.nA[0], cap = g.cap;
+    const PnpResult r = g.result[0];
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid == 0) {
+        int *h = reinterpret_cast<int *>(out);
+        h[0] = M;
+        h[1] = K;
+        h[2] = g.em ? 1 : 0;
+        *reinterpret_cast<PnpResult *>(out + 16) = r;
+        if (g.em)
+            *reinterpret_cast<EmResult *>(out + 256) = g.em[0];
+    }
+    float2 *o2 = reinterpret_cast<float2 *>(out + VO_GATHER_HEADER);
+    float *ox = reinterpret_cast<float *>(o2 + 4 * (size_t)cap);
+    int32_t *ok = reinterpret_cast<int32_t *>(ox + 3 * (size_t)cap), *oc = ok + cap, *oi = oc + cap;
+    for (int i = tid; i < K; i += nth) {
+#pragma unroll
+        for (int row = 0; row < 4; row++)
+            o2[(size_t)row * cap + i] = g.outB[(size_t)row * cap + i];
+        ox[3 * i] = g.xyz[3 * i];
+        ox[3 * i + 1] = g.xyz[3 * i + 1];
+        ox[3 * i + 2] = g.xyz[3 * i + 2];
+        ok[i] = g.idxB[i];
+    }
+    for (int i = tid; i < M; i += nth)
+        oc[i] = g.idxA[i];
+    const int ninl = r.n_inliers < cap ? r.n_inliers : cap;
+    for (int i = tid; i < ninl; i += nth)
+        oi[i] = g.inliers[i];
+}
+
+void launch_frame_gather(const FrameGather &g, uint8_t *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(frame_gather_kernel, dim3(8), dim3(256), 0, stream, g, out);
+}
+
 void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
                     int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
                     int n_frames, hipStream_t stream)

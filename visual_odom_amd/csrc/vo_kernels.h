@@ -128,6 +128,21 @@ void launch_seq_carry(const int *active, const float2 *outB, const int *nB, cons
 void launch_seq_integrate(const int *active, const PnpResult *results, const EmResult *em, double *pose,
                           double *traj, SeqFrameInfo *info, int *n_rows, int max_steps, int n_seq,
                           hipStream_t stream);
+// Everything vo_track_frame returns for its one frame, gathered by one kernel into one host-visible buffer (layout: a
+// 512-byte header -- nA, nB, has_em at bytes 0 / 4 / 8, the PnpResult at byte 16, the EmResult at byte 256 -- then fixed
+// capacity arrays l0, r0, l1, r1 [cap] float2, xyz [cap][3] float, keep_idx, keep_idx_circ, inliers [cap] int32).
+struct FrameGather {
+    const int *nA, *nB;
+    const float2 *outB; // [4][cap]
+    const float *xyz;
+    const int32_t *idxB, *idxA, *inliers;
+    const PnpResult *result;
+    const EmResult *em; // null unless mono_rotation
+    int cap;
+};
+constexpr size_t VO_GATHER_HEADER = 512;
+inline size_t frame_gather_bytes(int cap) { return VO_GATHER_HEADER + (size_t)cap * (4 * 8 + 12 + 3 * 4); }
+void launch_frame_gather(const FrameGather &g, uint8_t *out, hipStream_t stream);
 void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
                     int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
                     int n_frames, hipStream_t stream);
