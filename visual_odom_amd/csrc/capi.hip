@@ -211,12 +211,23 @@ inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
 // 41.3 k / 32.8 k / 22.3 k, 16 sequences 15.7 k / 14.0 k / 10.2 k; 16 frames x 4000 points at 1080p (BASELINE config 4)
 // 5.76 k / 5.25 k / 3.56 k.  The 128-register instantiation round 1 used for crowded batches is never the best one any
 // more and stays reachable through VO_POSE_WAVES = 4 only.
+// The lock-step loop between pose2_frames and 96 sequences at a light point load (<= 40 k point-frames per step, i.e. the
+// reference-default bucketing): there the second pose stream + prepare stream still pay, but only together with the
+// 256-register pose kernels.  Measured late in round 2 (frames/s, one pose stream + 512 registers = the rule outside the
+// band | both streams + 512 | both + 256): 64 sequences 41.7 k | 43.2 k | 45.3 k, 96 sequences 51.4 k | 47.2 k | 52.9 k,
+// 128 sequences 57.2 k (256 registers, one stream) | 46.5 k | 53.4 k -> the band ends at 96; at ~2000 points per frame
+// 64 sequences 20.0 k | - | 19.2 k -> light loads only.
+inline bool seq_light_band(const vo_ctx *c, long long frames, long long pts_bound)
+{
+    return c->pose2_frames > 0 && frames > c->pose2_frames && frames <= 96 && frames * pts_bound <= 40000;
+}
 inline int pose_waves(const vo_ctx *c, long long frames, int pts, bool crowded)
 {
     (void)crowded;
-    (void)pts;
     if (c->pose_waves_forced)
         return c->pose_waves_forced;
+    if (c->seq.on && seq_light_band(c, frames, pts))
+        return 2;
     return frames >= c->pose_medium_min ? 2 : 1;
 }
 // the current feature set (see vo_ctx::pts_sel)
@@ -1018,7 +1029,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded && B <= c->pose2_frames;
+    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded &&
+                                  (B <= c->pose2_frames || (c->seq.on && seq_light_band(c, B, c->max_pts_set)));
     hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
@@ -1492,8 +1504,10 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     // SIMD slots between the running step's LK waves) up to pose2_frames sequences (the same crossover as the second
     // pose stream, measured together), plain copy stream above.
     {
+        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : h / 10;
+        const long long cells = bs > 0 ? (long long)(h / bs + 1) * (w / bs + 1) : 1;
         const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
-        q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames;
+        q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames || seq_light_band(c, n_seq, cells * c->dprm.features_per_bucket);
     }
     int least = 0, greatest = 0;
     bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
