@@ -17,10 +17,10 @@
 //                       horizontal [1 4 6 4 1]:
 //                       a thread reads 16 bytes and forms 4 partials with v_alignbyte_b32 + v_dot4_u32_u8 (u16 in LDS);
 //                       vertical: packed 16-bit multiply-adds (the sum + 128 stays below 2^16), 4 pixels per 32-bit store
-//   border_fill_kernel  after the last pyr_down, ALL levels in one launch: one thread per 32-bit word that holds a
-//                       REFLECT_101 border pixel (all words of the rows above / below the image, the left / right border
-//                       words of image rows): words inside the image span are aligned word copies of the reflected row,
-//                       the rest gathers 4 reflected bytes
+//   border_fill_kernel  a range of levels in one launch: one thread per 16-byte chunk that holds a REFLECT_101 border
+//                       pixel (all chunks of the rows above / below the image, the left / right border chunks of image
+//                       rows): chunks inside the image span are aligned copies of the reflected row, the rest gathers
+//                       16 reflected bytes
 //   scharr_kernel       8 pixels per thread: three unaligned 12-byte row loads, the pixels lifted into u16 pairs
 //                       (v_perm_b32), the separable form t0 = 3 (above + below) + 10 row, t1 = below - above in packed
 //                       16-bit arithmetic with the x4 pre-scale folded into the constants, two 16-byte stores of
@@ -43,10 +43,16 @@ struct __attribute__((packed, aligned(4))) U32x4 {
 // Border words of one level.  Work items: first the 2 * VO_BY rows above / below the image (stride / 4 words each), then,
 // per image row, the VO_BX / 4 words left of the image and the words from the one holding pixel w - 1 (or starting at w)
 // to the end of the row.  A word that straddles the image edge rewrites its interior bytes with the values they already have.
-constexpr int BF_MAX_ROW_WORDS = VO_BX / 4 + 11; // right border < 40 pixels + up to 3 interior ones (level_stride, capi.hip)
+constexpr int BF_MAX_ROW_CHUNKS = VO_BX / 16 + 4; // right border < 40 pixels + up to 15 interior ones (level_stride, capi.hip)
 
-// all levels of all images in one launch (nothing on the path reads a level's border before the whole pyramid exists --
-// pyr_down_kernel reflects on its own): blockIdx.y = image, blockIdx.x = 256-word block numbered level by level
+// One launch covers a range of levels of all images (nothing on the path reads a level's border before the whole pyramid
+// exists -- pyr_down_kernel reflects on its own): blockIdx.y = image, blockIdx.x = 256-chunk block numbered level by level.
+// Work items are 16-byte chunks (rows start 16-byte aligned, the stride is a multiple of 16): first all chunks of the
+// 2 * VO_BY rows above / below the image, then, per image row, the VO_BX / 16 chunks left of the image and the chunks from
+// the one holding pixel w - 1 (or starting at w) to the end of the row.  A chunk that lies inside the image span is an
+// aligned 16-byte copy of the reflected row, any other gathers its 16 reflected bytes (a chunk that straddles the image
+// edge rewrites its interior bytes with the values they already have).  (One 32-bit word per thread, the first round-2
+// version, was bound by the latency of its one load: 0.11 ms for level 0 of 512 KITTI images.)
 struct BorderBlocks {
     int first[VO_MAX_LEVELS + 1]; // first[l] = blocks of the levels before l
 };
@@ -55,7 +61,7 @@ inline BorderBlocks border_blocks(int first_level, int n_levels, const int *lstr
 {
     BorderBlocks bb = {}; // levels below first_level get no blocks
     for (int l = first_level; l < n_levels; l++)
-        bb.first[l + 1] = bb.first[l] + (2 * VO_BY * (lstride[l] / 4) + lh[l] * BF_MAX_ROW_WORDS + 255) / 256;
+        bb.first[l + 1] = bb.first[l] + (2 * VO_BY * (lstride[l] / 16) + lh[l] * BF_MAX_ROW_CHUNKS + 255) / 256;
     return bb;
 }
 
@@ -67,32 +73,41 @@ __global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__rest
     const PyrImage &im = imgs[blockIdx.y];
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
     VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
-    const int wpr = stride >> 2;                                // words per bordered row
-    const int xr0 = w & ~3;                                     // first word with a right-border pixel
-    const int nb = VO_BX / 4 + ((stride - VO_BX - xr0) >> 2);   // border words of an image row
-    const int n_out = 2 * VO_BY * wpr;
+    const int cpr = stride >> 4;                                 // chunks per bordered row
+    const int xr0 = w & ~15;                                     // first chunk with a right-border pixel
+    const int nb = VO_BX / 16 + ((stride - VO_BX - xr0) >> 4);   // border chunks of an image row
+    const int n_out = 2 * VO_BY * cpr;
     int item = (int)(((int)blockIdx.x - bb.first[level]) * 256 + threadIdx.x);
     int y, x0;
     if (item < n_out) {
-        const int r = item / wpr;
+        const int r = item / cpr;
         y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
-        x0 = 4 * (item - r * wpr) - VO_BX;
+        x0 = 16 * (item - r * cpr) - VO_BX;
     } else {
         item -= n_out;
         const int r = item / nb, k = item - r * nb;
         if (r >= h)
             return;
         y = r;
-        x0 = k < VO_BX / 4 ? 4 * k - VO_BX : xr0 + 4 * (k - VO_BX / 4);
+        x0 = k < VO_BX / 16 ? 16 * k - VO_BX : xr0 + 16 * (k - VO_BX / 16);
     }
     const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
-    uint32_t v;
-    if (x0 >= 0 && x0 + 3 < w)
-        v = *(const VO_GLOBAL uint32_t *)(src + x0);
-    else
-        v = (uint32_t)src[reflect101(x0, w)] | (uint32_t)src[reflect101(x0 + 1, w)] << 8 |
-            (uint32_t)src[reflect101(x0 + 2, w)] << 16 | (uint32_t)src[reflect101(x0 + 3, w)] << 24;
-    *(VO_GLOBAL uint32_t *)(p + (ptrdiff_t)y * stride + x0) = v;
+    uint32_t v[4];
+    if (x0 >= 0 && x0 + 15 < w) {
+        const U32x4 t = *(const VO_GLOBAL U32x4 *)(src + x0);
+        v[0] = t.a;
+        v[1] = t.b;
+        v[2] = t.c;
+        v[3] = t.d;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = x0 + 4 * q;
+            v[q] = (uint32_t)src[reflect101(x, w)] | (uint32_t)src[reflect101(x + 1, w)] << 8 |
+                   (uint32_t)src[reflect101(x + 2, w)] << 16 | (uint32_t)src[reflect101(x + 3, w)] << 24;
+        }
+    }
+    *(VO_GLOBAL uint4 *)(p + (ptrdiff_t)y * stride + x0) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------
