@@ -42,6 +42,7 @@ Plan plan(int w, int h, int max_level)
     return p;
 }
 
+int g_fast_big = 0; // ke_set_fast_big: tile form of the FAST kernel (0: 64 x 16, 1: 64 x 32, 2: 128 x 32)
 int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead
 
 template <typename F>
@@ -109,6 +110,7 @@ int ke_bordered_level(const uint8_t *img, int w, int h, int max_level, int level
 }
 
 void ke_set_lk_pair(int on) { g_lk_pair = on; }
+void ke_set_fast_big(int on) { g_fast_big = on; }
 
 // imgs: n_img images of w x h (contiguous).  Builds every pyramid with the emulated kernels.
 // lvl_out / der_out (optional): interior of level `want_level` of image 0 (w_l*h_l bytes / dwords).
@@ -225,7 +227,12 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
     int n_new = -1, n_out = -1;
     const int segs = (w + 63) / 64;
     std::vector<unsigned long long> nmsmask((size_t)h * segs, 0xDEADBEEFDEADBEEFull);
-    launch(segs, (h + 15) / 16, 1, 256, [&] { fast_tile_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
+    if (g_fast_big == 1)
+        launch(segs, (h + 31) / 32, 1, 256, [&] { fast_tile_tall_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
+    else if (g_fast_big == 2)
+        launch((segs + 1) / 2, (h + 31) / 32, 1, 256, [&] { fast_tile_big_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
+    else
+        launch(segs, (h + 15) / 16, 1, 256, [&] { fast_tile_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
     launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), rowoff.data(), h, &do_detect, &n_new); });
     launch((h + 3) / 4, 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowoff.data(), &n_tracked, fcap, feat.data()); });
     if (bucket_size <= 0) {

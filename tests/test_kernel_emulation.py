@@ -194,7 +194,15 @@ def ke_detect(lib, img, tracked=None, ages=None, threshold=20, nonmax=1, detect=
     return out_p[:n].copy(), out_a[:n].copy()
 
 
-def test_emulated_fast_matches_oracle(kemu, orc, small_seq):
+@pytest.fixture(params=[0, 1, 2], ids=["tile-64x16", "tile-64x32", "tile-128x32"])
+def fast_variant(request, kemu):
+    """the FAST emulation tests run on all three tile forms of the kernel"""
+    kemu.ke_set_fast_big(request.param)
+    yield request.param
+    kemu.ke_set_fast_big(0)
+
+
+def test_emulated_fast_matches_oracle(kemu, orc, small_seq, fast_variant):
     img = small_seq["L"][0]
     for thr, nonmax in ((20, 1), (35, 0), (0, 1)):
         got, _ = ke_detect(kemu, img, threshold=thr, nonmax=nonmax)
@@ -208,7 +216,7 @@ def test_emulated_fast_matches_oracle(kemu, orc, small_seq):
     assert len(ke_detect(kemu, flat)[0]) == 0
 
 
-def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq):
+def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq, fast_variant):
     """bucket.cpp / feature.cpp:206-253 quirks: aliased last column, duplicate emission, slot-0 overwrite,
     age >= 10 dropped, ages longer than points (stale ages inherited by new corners)"""
     img = small_seq["L"][0]

@@ -17,7 +17,7 @@
 //     ages array is longer than the points array (new corners then inherit stale ages).
 //
 // Kernels:
-//   fast_tile_kernel     workgroup per 64 x 16 tile of the level-0 image already resident for LK: pixels staged in
+//   fast_tile_kernel     workgroup per 64 x 16 (fast_tile_tall_kernel: 64 x 32) tile of the level-0 image already resident for LK: pixels staged in
 //                        LDS; per position 16 circle pixels -> 2 x 16-bit masks -> 9-contiguous test by shift-and,
 //                        cornerScore<16> for corners; NMS predicate on the LDS score tile, one 64-bit ballot per
 //                        64-pixel row segment, row counts by atomicAdd
@@ -32,6 +32,7 @@
 #include "vo_kernels.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace vo {
 
@@ -67,6 +68,29 @@ __device__ __forceinline__ void fast_ring(const uint8_t *__restrict__ p, int str
     d[13] = v - p[stride - 3];
     d[14] = v - p[2 * stride - 2];
     d[15] = v - p[3 * stride - 1];
+}
+
+// Necessary condition of the TYPE_9_16 test on the four compass pixels of the circle (ring positions 0, 4, 8, 12): any 9
+// contiguous ring positions contain two NEIGHBOURING compass positions, so a corner has two neighbouring compass pixels
+// that are both brighter than p + t or both darker than p - t.  5 LDS bytes and ~25 instructions instead of 17 and ~100;
+// 8.7 % of the positions of the benchmark's frames pass (3.6 % are corners).
+__device__ __forceinline__ bool fast_compass_candidate(const uint8_t *__restrict__ p, int stride, int threshold)
+{
+    const int v = p[0], hi = v + threshold, lo = v - threshold;
+    const int c0 = p[3 * stride], c4 = p[3], c8 = p[-3 * stride], c12 = p[-3];
+    uint32_t mb = 0, md = 0; // bit 3 .. 0 = compass position 0, 4, 8, 12
+    mb = shift_in_sign(mb, hi - c0);
+    md = shift_in_sign(md, c0 - lo);
+    mb = shift_in_sign(mb, hi - c4);
+    md = shift_in_sign(md, c4 - lo);
+    mb = shift_in_sign(mb, hi - c8);
+    md = shift_in_sign(md, c8 - lo);
+    mb = shift_in_sign(mb, hi - c12);
+    md = shift_in_sign(md, c12 - lo);
+    // two neighbours on the 4-ring, both polarities at once: bits 0-3 bright, 8-11 dark, each doubled by 4 for the wrap
+    uint32_t m = mb | md << 8;
+    m |= m << 4;
+    return ((m & (m >> 1)) & 0x0f0fu) != 0;
 }
 
 // FastFeatureDetector TYPE_9_16 corner test: >= 9 contiguous circle pixels all brighter than p + t or all darker than p - t
@@ -131,9 +155,12 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, 
 // read back nine times: 0.77 + 0.49 ms per 256 KITTI frames, the map alone 239 MB):
 //   A  the tile's pixels + 4-pixel apron (80 x 24 bytes, origin (x0 - 4, y0 - 4): 4-byte aligned in the bordered
 //      level-0 image, always inside its allocation) go to LDS with dword loads;
-//   B1 corner test of the 66 x 18 positions of the tile and its 1-pixel halo, reading the circle pixels from LDS
-//      (positions inside FAST's 3-pixel image margin or outside the image are no corners); the positions that pass are
-//      appended to a list in LDS (one LDS atomic per wavefront and round, ballot ranks);
+//   B0 compass test (a necessary condition on 4 of the 16 circle pixels) of the 66 x 18 positions of the tile and its
+//      1-pixel halo, reading the pixels from LDS (positions inside FAST's 3-pixel image margin or outside the image are no
+//      corners); the positions that pass are appended to a list in LDS (one LDS atomic per wavefront and round, ballot
+//      ranks);
+//   B1 the full corner test of the listed candidates (8.7 % of the positions on the benchmark's frames), corners to a
+//      second list;
 //   B2 cornerScore<16> of the listed positions only, on densely packed lanes.  The score is ~4 x the work of the corner
 //      test and only a few per cent of the positions are corners, but in the one-pass form nearly every wavefront held
 //      at least one corner and so executed it for all 64 lanes (1.02 ms per 256 KITTI frames, round-2 trace);
@@ -141,10 +168,112 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, 
 //      ballot per row segment stored exactly where fast_nms_write_kernel expects it, row counts by atomicAdd (the
 //      row-scan pass turns them into offsets and zeroes them again).
 // Results are identical to the two-kernel form by construction (same predicate, same neighbour scores).
-constexpr int FT_W = 64, FT_H = 16;                 // output tile
-constexpr int FT_PW = FT_W + 16, FT_PH = FT_H + 8;  // pixel tile in LDS (bytes x rows)
-constexpr int FT_SW = FT_W + 2, FT_SH = FT_H + 2;   // score tile incl. the 1-pixel halo
-constexpr int FAST_MAX_SEGS = 64;                   // 64-pixel segments per row: images up to 4096 pixels wide
+// Tile size: a template parameter, chosen by launch_fast_corners (64 x 16 for fewer than 8 frames, 64 x 32 above; 128 x 32
+// was measured and is slower).  The list phases B1 / B2 keep one or two wavefronts of the workgroup busy for ~100 / ~500
+// instructions whatever the tile size (a 64 x 16 tile holds ~100 candidates and ~40 corners on the benchmark's frames).
+constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
+
+template <int SEGS, int H>
+__device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs, const Quad *__restrict__ quads,
+                                               const int *__restrict__ detect, int threshold, int nonmax,
+                                               unsigned long long *__restrict__ mask, int segs, int *__restrict__ rowcnt)
+{
+    constexpr int W = 64 * SEGS;               // output tile W x H
+    constexpr int PW = W + 16, PH = H + 8;     // pixel tile in LDS (bytes x rows)
+    constexpr int SW = W + 2, SH = H + 2;      // score tile incl. the 1-pixel halo
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[PH * PW];
+    __shared__ uint16_t s_sc[SH * SW];
+    __shared__ uint16_t s_cand[SH * SW]; // positions (index into s_sc) that passed the compass test
+    __shared__ uint16_t s_list[SH * SW]; // ... and the corner test
+    __shared__ int s_ncand, s_ncorner;
+    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (detect && !detect[frame])
+        return;
+    const PyrImage &im = imgs[quads[frame].l0];
+    const int w = im.w[0], h = im.h[0], stride = im.stride[0];
+    const int x0 = blockIdx.x * W, y0 = blockIdx.y * H;
+    const VO_GLOBAL uint8_t *__restrict__ base = (const VO_GLOBAL uint8_t *)im.lvl[0] + (x0 - 4);
+    const int last_row = h + VO_BY - 1; // rows past the bordered allocation are never used: read the last one instead
+    for (int i = tid; i < PH * (PW / 4); i += 256) {
+        const int row = i / (PW / 4), c = i - row * (PW / 4);
+        const int gy = y0 - 4 + row < last_row ? y0 - 4 + row : last_row;
+        *reinterpret_cast<uint32_t *>(&s_px[row * PW + 4 * c]) =
+            *reinterpret_cast<const VO_GLOBAL uint32_t *>(base + ((ptrdiff_t)gy * stride + 4 * c));
+    }
+    if (tid == 0)
+        s_ncand = s_ncorner = 0;
+    __syncthreads();
+    // B0: compass test of every position, candidates to a list (ballot ranks, one LDS atomic per wavefront and round)
+    for (int i0 = 0; i0 < SW * SH; i0 += 256) { // wave-uniform trip count: the ballot needs all lanes
+        const int i = i0 + tid;
+        bool cand = false;
+        if (i < SW * SH) {
+            const int sy = i / SW, sx = i - sy * SW;
+            const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3)
+                cand = fast_compass_candidate(&s_px[(sy + 3) * PW + sx + 3], PW, threshold);
+            s_sc[i] = 0;
+        }
+        const unsigned long long m = VO_BALLOT(cand);
+        int base_k = 0;
+        if (lane == 0 && m)
+            base_k = atomicAdd(&s_ncand, (int)VO_POPCLL(m));
+        base_k = uni(base_k);
+        if (cand)
+            s_cand[base_k + (int)VO_POPCLL(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // B1: the full corner test on the candidates only, corners to a second list
+    const int ncand = s_ncand;
+    for (int k0 = 0; k0 < ncand; k0 += 256) {
+        const int k = k0 + tid;
+        bool corner = false;
+        int i = 0;
+        if (k < ncand) {
+            i = s_cand[k];
+            const int sy = i / SW, sx = i - sy * SW;
+            corner = fast_is_corner(&s_px[(sy + 3) * PW + sx + 3], PW, threshold);
+        }
+        const unsigned long long m = VO_BALLOT(corner);
+        int base_k = 0;
+        if (lane == 0 && m)
+            base_k = atomicAdd(&s_ncorner, (int)VO_POPCLL(m));
+        base_k = uni(base_k);
+        if (corner)
+            s_list[base_k + (int)VO_POPCLL(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    // B2: cornerScore of the corners
+    const int ncorner = s_ncorner;
+    for (int k = tid; k < ncorner; k += 256) {
+        const int i = s_list[k];
+        const int sy = i / SW, sx = i - sy * SW;
+        s_sc[i] = (uint16_t)(0x100 | fast_corner_score(&s_px[(sy + 3) * PW + sx + 3], PW, threshold));
+    }
+    __syncthreads();
+    // C: a wavefront = one 64-pixel row segment of the tile
+    for (int q = wv; q < H * SEGS; q += 4) {
+        const int ly = q / SEGS, sg = q - ly * SEGS;
+        const int gy = y0 + ly, seg = (int)blockIdx.x * SEGS + sg;
+        if (gy >= h || seg >= segs)
+            continue;
+        const uint16_t *__restrict__ r = &s_sc[(ly + 1) * SW + sg * 64 + lane + 1];
+        const int c = r[0];
+        bool keep = false;
+        if (c & 0x100) {
+            const int sc = c & 0xff;
+            keep = !nonmax || (sc > (r[1] & 0xff) && sc > (r[-1] & 0xff) && sc > (r[-SW - 1] & 0xff) &&
+                               sc > (r[-SW] & 0xff) && sc > (r[-SW + 1] & 0xff) && sc > (r[SW - 1] & 0xff) &&
+                               sc > (r[SW] & 0xff) && sc > (r[SW + 1] & 0xff));
+        }
+        const unsigned long long m = VO_BALLOT(keep);
+        if (lane == 0) {
+            mask[((size_t)frame * h + gy) * segs + seg] = m;
+            if (m)
+                atomicAdd(&rowcnt[(size_t)frame * h + gy], (int)VO_POPCLL(m));
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void fast_tile_kernel(const PyrImage *__restrict__ imgs,
                                                         const Quad *__restrict__ quads,
@@ -153,73 +282,25 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const PyrImage *__restri
                                                         unsigned long long *__restrict__ mask /* [B][h][segs] */,
                                                         int segs, int *__restrict__ rowcnt /* [B][h], zero on entry */)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PH * FT_PW];
-    __shared__ uint16_t s_sc[FT_SH * FT_SW];
-    __shared__ uint16_t s_list[FT_SH * FT_SW]; // positions (index into s_sc) that passed the corner test
-    __shared__ int s_ncorner;
-    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (detect && !detect[frame])
-        return;
-    const PyrImage &im = imgs[quads[frame].l0];
-    const int w = im.w[0], h = im.h[0], stride = im.stride[0];
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    const VO_GLOBAL uint8_t *__restrict__ base =
-        (const VO_GLOBAL uint8_t *)im.lvl[0] + ((ptrdiff_t)(y0 - 4) * stride + (x0 - 4));
-    for (int i = tid; i < FT_PH * (FT_PW / 4); i += 256) {
-        const int row = i / (FT_PW / 4), c = i - row * (FT_PW / 4);
-        *reinterpret_cast<uint32_t *>(&s_px[row * FT_PW + 4 * c]) =
-            *reinterpret_cast<const VO_GLOBAL uint32_t *>(base + ((ptrdiff_t)row * stride + 4 * c));
-    }
-    __syncthreads();
-    if (tid == 0)
-        s_ncorner = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < FT_SW * FT_SH; i0 += 256) { // wave-uniform trip count: the ballot needs all lanes
-        const int i = i0 + tid;
-        bool corner = false;
-        if (i < FT_SW * FT_SH) {
-            const int sy = i / FT_SW, sx = i - sy * FT_SW;
-            const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3)
-                corner = fast_is_corner(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold);
-            s_sc[i] = 0;
-        }
-        const unsigned long long m = VO_BALLOT(corner);
-        int base = 0;
-        if (lane == 0 && m)
-            base = atomicAdd(&s_ncorner, (int)VO_POPCLL(m));
-        base = uni(base);
-        if (corner)
-            s_list[base + (int)VO_POPCLL(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-    }
-    __syncthreads();
-    const int ncorner = s_ncorner;
-    for (int k = tid; k < ncorner; k += 256) {
-        const int i = s_list[k];
-        const int sy = i / FT_SW, sx = i - sy * FT_SW;
-        s_sc[i] = (uint16_t)(0x100 | fast_corner_score(&s_px[(sy + 3) * FT_PW + sx + 3], FT_PW, threshold));
-    }
-    __syncthreads();
-    for (int ly = wv; ly < FT_H; ly += 4) { // a wavefront = one 64-pixel row segment
-        const int gy = y0 + ly;
-        if (gy >= h)
-            break;
-        const uint16_t *__restrict__ r = &s_sc[(ly + 1) * FT_SW + lane + 1];
-        const int c = r[0];
-        bool keep = false;
-        if (c & 0x100) {
-            const int sc = c & 0xff;
-            keep = !nonmax || (sc > (r[1] & 0xff) && sc > (r[-1] & 0xff) && sc > (r[-FT_SW - 1] & 0xff) &&
-                               sc > (r[-FT_SW] & 0xff) && sc > (r[-FT_SW + 1] & 0xff) && sc > (r[FT_SW - 1] & 0xff) &&
-                               sc > (r[FT_SW] & 0xff) && sc > (r[FT_SW + 1] & 0xff));
-        }
-        const unsigned long long m = VO_BALLOT(keep);
-        if (lane == 0) {
-            mask[((size_t)frame * h + gy) * segs + blockIdx.x] = m;
-            if (m)
-                atomicAdd(&rowcnt[(size_t)frame * h + gy], (int)VO_POPCLL(m));
-        }
-    }
+    fast_tile_body<1, 16>(imgs, quads, detect, threshold, nonmax, mask, segs, rowcnt);
+}
+
+__global__ __launch_bounds__(256) void fast_tile_tall_kernel(const PyrImage *__restrict__ imgs,
+                                                             const Quad *__restrict__ quads,
+                                                             const int *__restrict__ detect, int threshold, int nonmax,
+                                                             unsigned long long *__restrict__ mask, int segs,
+                                                             int *__restrict__ rowcnt)
+{
+    fast_tile_body<1, 32>(imgs, quads, detect, threshold, nonmax, mask, segs, rowcnt);
+}
+
+__global__ __launch_bounds__(256) void fast_tile_big_kernel(const PyrImage *__restrict__ imgs,
+                                                            const Quad *__restrict__ quads,
+                                                            const int *__restrict__ detect, int threshold, int nonmax,
+                                                            unsigned long long *__restrict__ mask, int segs,
+                                                            int *__restrict__ rowcnt)
+{
+    fast_tile_body<2, 32>(imgs, quads, detect, threshold, nonmax, mask, segs, rowcnt);
 }
 
 // Corner list from the stored ballots: a wavefront per image row (4 rows per workgroup), a lane per 64-pixel segment.  The
@@ -429,9 +510,22 @@ void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int 
 {
     if (n_frames <= 0)
         return;
-    const int segs = (w + FT_W - 1) / FT_W;
-    hipLaunchKernelGGL(fast_tile_kernel, dim3(segs, (h + FT_H - 1) / FT_H, n_frames), dim3(256), 0, stream, d_imgs,
-                       d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
+    const int segs = (w + 63) / 64;
+    // tile form 0: 64 x 16, 1: 64 x 32, 2: 128 x 32 (VO_FAST_TILE forces one).  Measured per 256 KITTI frames in the lock-step
+    // loop: detection stage 0.67 / 0.58 / 0.94 ms -- the 64 x 32 tile amortises the two list phases (one or two busy
+    // wavefronts per workgroup) over twice the full-width work, the 128 x 32 tile's 32 KB of LDS costs more occupancy than
+    // that saves.  Fewer than 8 frames keep the small tile (more workgroups than CUs for one 1241 x 376 image).
+    static const int forced = [] { const char *e = getenv("VO_FAST_TILE"); return e ? atoi(e) : -1; }();
+    const int tile = forced >= 0 ? forced : n_frames >= 8 ? 1 : 0;
+    if (tile == 2)
+        hipLaunchKernelGGL(fast_tile_big_kernel, dim3((segs + 1) / 2, (h + 31) / 32, n_frames), dim3(256), 0, stream, d_imgs,
+                           d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
+    else if (tile == 1)
+        hipLaunchKernelGGL(fast_tile_tall_kernel, dim3(segs, (h + 31) / 32, n_frames), dim3(256), 0, stream, d_imgs,
+                           d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
+    else
+        hipLaunchKernelGGL(fast_tile_kernel, dim3(segs, (h + 15) / 16, n_frames), dim3(256), 0, stream, d_imgs,
+                           d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
     hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, d_rowoff, h, d_detect,
                        d_nnew);
     hipLaunchKernelGGL(fast_nms_write_kernel, dim3((h + 3) / 4, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
