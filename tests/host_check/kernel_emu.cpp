@@ -109,6 +109,37 @@ int ke_bordered_level(const uint8_t *img, int w, int h, int max_level, int level
     return p.levels;
 }
 
+// Exhaustive check of the FAST pre-test: for every assignment of {similar, brighter, darker} to the 16 circle pixels
+// (3^16 rings) the full TYPE_9_16 test implies the compass test.  Returns the number of violations; *n_corners = rings that
+// are corners, *n_candidates = rings that pass the compass test.
+long long ke_fast_compass_exhaustive(long long *n_corners, long long *n_candidates)
+{
+    using namespace vo;
+    static const int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    static const int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    uint8_t patch[7 * 7];
+    const int stride = 7, threshold = 20;
+    long long bad = 0, corners = 0, cands = 0, total = 1;
+    for (int k = 0; k < 16; k++)
+        total *= 3;
+    for (long long code = 0; code < total; code++) {
+        memset(patch, 100, sizeof(patch));
+        long long c = code;
+        for (int k = 0; k < 16; k++, c /= 3) {
+            const int s = (int)(c % 3);
+            patch[(3 + dy[k]) * stride + 3 + dx[k]] = s == 0 ? 100 : s == 1 ? 121 : 79; // just beyond the threshold
+        }
+        const uint8_t *p = &patch[3 * stride + 3];
+        const bool corner = fast_is_corner(p, stride, threshold), cand = fast_compass_candidate(p, stride, threshold);
+        corners += corner;
+        cands += cand;
+        bad += corner && !cand;
+    }
+    *n_corners = corners;
+    *n_candidates = cands;
+    return bad;
+}
+
 void ke_set_lk_pair(int on) { g_lk_pair = on; }
 void ke_set_fast_big(int on) { g_fast_big = on; }
 

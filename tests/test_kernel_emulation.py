@@ -252,3 +252,53 @@ def test_exact_wave_sums_at_the_extremes(kemu):
         kemu.ke_wave_sums(vp(a), vp(b), vp(c), vp(out))
         ref = [np.float32(int(x.astype(np.int64).sum())) for x in (a, b, a, b, c)]
         assert [bits(o) for o in out] == [bits(r) for r in ref], k
+
+
+def test_fast_compass_pretest_is_necessary_exhaustive(kemu):
+    """the pre-test fast_tile_kernel compacts on (two neighbouring compass pixels both brighter or both darker) must never
+    reject a TYPE_9_16 corner: checked on all 3^16 = 43 046 721 brighter / darker / similar ring patterns with the real
+    device functions; the counts pin the corner test itself (rings with >= 9 contiguous equal non-similar states)"""
+    nc, nk = C.c_longlong(0), C.c_longlong(0)
+    kemu.ke_fast_compass_exhaustive.restype = C.c_longlong
+    bad = kemu.ke_fast_compass_exhaustive(C.byref(nc), C.byref(nk))
+    assert bad == 0
+    # independent count of the corner rings: cyclic ternary strings of length 16 with a run of >= 9 equal non-zero symbols
+    def corner_rings():
+        total = 0
+        for sym in (1, 2):
+            for run in range(9, 17):
+                if run == 16:
+                    total += 1
+                else:
+                    # a maximal run of exactly `run` symbols starting at one of 16 rotations, bounded by a different symbol
+                    # on both sides (the same cell when run == 15), the remaining cells free; runs >= 9 cannot occur twice
+                    free = 16 - run - 2
+                    total += 16 * (2 * 3 ** 0 if run == 15 else 2 * 2 * 3 ** free)
+        return total
+    assert nc.value == corner_rings()
+    assert nk.value > nc.value
+
+
+@pytest.mark.parametrize("pattern", ["white", "black", "columns", "rows", "checker"])
+def test_emulated_pyramid_extremes(kemu, orc, pattern):
+    """the packed 16-bit arithmetic of pyr_down_kernel (6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408) and scharr_kernel
+    (|4 Ix|, |4 Iy| <= 16320) at the ends of their ranges"""
+    h, w = 90, 150
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = {"white": np.full((h, w), 255), "black": np.zeros((h, w)), "columns": (xx % 2) * 255, "rows": (yy % 2) * 255,
+           "checker": ((xx + yy) % 2) * 255}[pattern].astype(np.uint8)
+    ref = orc.build_pyramid(img, 3)
+    levels = ke_run(kemu, [img], want_level=0)["levels"]   # the plan stops before a level of 21 pixels or fewer
+    assert levels == 3
+    for l in range(levels):
+        r = ke_run(kemu, [img], want_level=l)
+        assert np.array_equal(r["lvl"], ref[l]), l
+        d = orc.scharr(ref[l]).astype(np.int64) * 4
+        packed = ((d[..., 0] & 0xffff) | ((d[..., 1] & 0xffff) << 16)).astype(np.uint32)
+        assert np.array_equal(r["der"], packed), l
+    # a vertical / horizontal step edge of full contrast: the largest derivative the Scharr image can hold
+    step = np.zeros((h, w), np.uint8)
+    step[:, w // 2:] = 255
+    r = ke_run(kemu, [step], want_level=0)
+    ix = (r["der"] & 0xffff).astype(np.uint16).view(np.int16)
+    assert ix.max() == 16320
