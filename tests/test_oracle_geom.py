@@ -170,3 +170,30 @@ def test_solve_pnp_ransac_no_model(orc):
     uv = rng.uniform([0, 0], [1241, 376], (60, 2)).astype(np.float32)
     rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(X, uv, K_KITTI)
     assert rc == 0 and len(inl) == 0 and dbg[0] == 500
+
+
+def test_pnp_refinement_is_the_least_squares_minimum_scipy_finds(orc):
+    """independent check of the final solvePnP(ITERATIVE) refinement (CvLevMarq restated in oracle/orc_pnp.c, the chain the
+    device's select_refine_kernel mirrors): on the RANSAC inliers, scipy's own trust-region least-squares solver -- numpy
+    projection, scipy rotation vectors, numerical Jacobian: no code shared with the oracle -- started from the oracle's
+    pose must not move it, and started from the planted pose must arrive at it"""
+    from scipy.optimize import least_squares
+    fx, fy, cx, cy = K_KITTI[0, 0], K_KITTI[1, 1], K_KITTI[0, 2], K_KITTI[1, 2]
+    # (moderate outlier shares only: the refinement starts from the LAST hypothesis RANSAC evaluated -- rvec / tvec are shared
+    # buffers in solvePnPRansac -- and with half of the points wrong that start can be too far off for 20 iterations)
+    for n, frac, noise, seed in ((600, 0.3, 0.15, 21), (300, 0.0, 0.3, 22), (1500, 0.2, 0.1, 23), (60, 0.1, 0.05, 24)):
+        X, uv, r, t, _ = planted_problem(orc, n, frac, noise, seed)
+        rc, rv, tv, inl, _ = orc.solve_pnp_ransac(X, uv, K_KITTI)
+        assert rc == 1 and len(inl) >= 0.4 * n
+        Xi, ui = X[inl].astype(np.float64), uv[inl].astype(np.float64)
+
+        def residual(p):
+            Xc = Xi @ Rotation.from_rotvec(p[:3]).as_matrix().T + p[3:]
+            return np.concatenate([Xc[:, 0] / Xc[:, 2] * fx + cx - ui[:, 0], Xc[:, 1] / Xc[:, 2] * fy + cy - ui[:, 1]])
+        mine = np.concatenate([rv, tv])
+        for start in (mine, np.concatenate([r, t])):
+            sol = least_squares(residual, start, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, x_scale=[1e-3] * 3 + [1e-2] * 3)
+            # CvLevMarq stops at 20 iterations or a relative step of FLT_EPSILON: agreement far below the 1e-6 rad / 1e-5 m
+            # the GPU-vs-oracle pose tolerance works with
+            assert np.allclose(sol.x[:3], rv, rtol=0, atol=2e-7) and np.allclose(sol.x[3:], tv, rtol=0, atol=5e-6), (n, sol.x - mine)
+            assert np.sum(sol.fun ** 2) <= np.sum(residual(mine) ** 2) * (1 + 1e-9)
