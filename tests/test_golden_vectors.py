@@ -62,3 +62,35 @@ def test_product_reproduces_the_known_answers(gpu_ctx, kat):
     assert np.array_equal(bits(fast), bits(kat["fast_l0"]))
     bp, ba = gpu_ctx.detect_bucket(L0, np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
     assert np.array_equal(bits(bp), bits(kat["bucket_pts"])) and np.array_equal(ba, kat["bucket_ages"])
+
+
+def test_oracle_against_opencv_golden_if_present(orc):
+    """tools/opencv_crosscheck.py --write-golden, run on a machine that has cv2, leaves tests/golden/opencv_<version>.npz:
+    cv2's own outputs on the seeded synthetic pair.  When such a file is committed the oracle is held to it here (the bars
+    of DESIGN.md section 6); this container has no OpenCV, so without the file the test skips and parity stays unpinned."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "opencv_*.npz")))
+    if not files:
+        pytest.skip("no OpenCV-provenance golden file: tools/opencv_crosscheck.py --write-golden has not been run where cv2 exists")
+    from visual_odom_amd import synth
+    for path in files:
+        g = np.load(path)
+        world = synth.StereoWorld(seed=int(g["seed"]), width=1241, height=376, fx=718.856, cx=607.1928, cy=185.2157, bf=-386.1448)
+        L, R, _, _ = world.render_sequence(2)
+        pts = synth.select_keypoints(L[0], bucket=37, per_bucket=6)
+        assert np.array_equal(pts, g["pts"]), "the synthetic inputs changed since %s was written" % path
+        assert np.array_equal(orc.fast_detect(L[0], 20, True), g["fast"])
+        p = pts
+        for hop, (a, b) in enumerate([(L[0], R[0]), (R[0], R[1]), (R[1], L[1]), (L[1], L[0])]):
+            q, st, _ = orc.calc_optical_flow_pyr_lk(a, b, p)
+            both = (st == 1) & (g["lk_status%d" % hop] == 1)
+            assert (st != g["lk_status%d" % hop]).mean() <= 0.002, hop
+            assert np.abs(q[both] - g["lk_hop%d" % hop][both]).max() <= 1e-3, hop   # f32 SIMD accumulation in x86 builds
+            p = q
+        P_l, P_r = world.proj_matrices()
+        cm = orc.circular_matching(L[0], R[0], L[1], R[1], pts)
+        (l0, r0, l1, r1), _ = orc.check_valid_and_remove(cm["l0"], cm["r0"], cm["l1"], cm["r1"], cm["l0_ret"])
+        xyz = orc.triangulate(P_l, P_r, l0, r0)
+        assert (np.abs(xyz - g["xyz"]) / np.abs(xyz).max(1, keepdims=True)).max() <= 1e-5
+        rc, rv, tv, _, _ = orc.solve_pnp_ransac(xyz, l1, world.K())
+        assert rc == 1 and np.abs(rv - g["rvec"]).max() <= 1e-6 and np.abs(tv - g["tvec"]).max() <= 1e-6
