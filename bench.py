@@ -40,6 +40,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+N_GPUS = 1  # distinct GPUs this job runs on (set in main)
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
@@ -55,21 +56,31 @@ WORKLOADS = {
 }
 
 
+_RENDERED = {}  # (w, h, seed, n_quads) -> rendered sequence: the legs of one run share their images
+
+
 def build_inputs(workload, n_quads, seed):
     from visual_odom_amd import synth
     w, h, per_bucket, max_level, _ = WORKLOADS[workload]
-    if (w, h) == (synth.KITTI_W, synth.KITTI_H):
-        world = synth.StereoWorld(seed=seed)
-    else:
-        world = synth.StereoWorld(seed=seed, width=w, height=h, fx=synth.KITTI_FX * w / synth.KITTI_W,
-                                  cx=w / 2.0 - 0.5, cy=h / 2.0 - 0.5, bf=synth.KITTI_BF * w / synth.KITTI_W)
-    lefts, rights, poses, _ = world.render_sequence(n_quads + 1)
+    key = (w, h, seed, n_quads)
+    if key not in _RENDERED:
+        if (w, h) == (synth.KITTI_W, synth.KITTI_H):
+            world = synth.StereoWorld(seed=seed)
+        else:
+            world = synth.StereoWorld(seed=seed, width=w, height=h, fx=synth.KITTI_FX * w / synth.KITTI_W,
+                                      cx=w / 2.0 - 0.5, cy=h / 2.0 - 0.5, bf=synth.KITTI_BF * w / synth.KITTI_W)
+        lefts, rights, poses, _ = world.render_sequence(n_quads + 1)
+        _RENDERED[key] = (world, lefts, rights, {})
+    world, lefts, rights, pts_cache = _RENDERED[key]
+    if (workload.startswith("hd4000"), per_bucket) in pts_cache:
+        return world, lefts, rights, pts_cache[(workload.startswith("hd4000"), per_bucket)], max_level
     bucket = h // 10
     if workload.startswith("hd4000"):
         pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket, min_dist=3)[:4000]
                for k in range(n_quads + 1)]
     else:
         pts = [synth.select_keypoints(lefts[k], bucket=bucket, per_bucket=per_bucket) for k in range(n_quads + 1)]
+    pts_cache[(workload.startswith("hd4000"), per_bucket)] = pts
     return world, lefts, rights, pts, max_level
 
 
@@ -100,7 +111,7 @@ def setup_batch(ctx, world, lefts, rights, pts, B, S, dev_imgs=None):
     return frame_pts
 
 
-def validate_frames(ctx, frames, lefts, rights, frame_pts, world, S, full=True, cache=None):
+def validate_frames(ctx, frames, lefts, rights, frame_pts, world, S, full=True, cache=None, max_level=3):
     """Pulls the results of `frames` out of the batch and holds them to the oracle (the checker -- outside any timed
     region): circular-matching survivors and the tracks that reach triangulation BIT-EXACT, triangulation <= 1e-5
     relative, RANSAC control flow and inlier set identical, rvec / tvec <= 1e-6.  Returns the number of frames
@@ -114,7 +125,7 @@ def validate_frames(ctx, frames, lefts, rights, frame_pts, world, S, full=True, 
     for b in frames:
         a, c = tri(b, S), tri(b + 1, S)
         if (a, c) not in cache:
-            ref = orc.circular_matching(lefts[a], rights[a], lefts[c], rights[c], frame_pts[b])
+            ref = orc.circular_matching(lefts[a], rights[a], lefts[c], rights[c], frame_pts[b], max_level=max_level)
             (l0, r0, l1, r1), _ = orc.check_valid_and_remove(ref["l0"], ref["r0"], ref["l1"], ref["r1"], ref["l0_ret"])
             rec = dict(keep=ref["keep_idx"], l0=l0, r0=r0, l1=l1, r1=r1)
             if full and len(l0) >= 5:
@@ -212,7 +223,22 @@ def main(argv=None):
     ap.add_argument("--selftest-replicas", action="store_true",
                     help="CPU-only self-test of the N > 1 control flow (rank discovery, process group, barrier, max-over-ranks "
                          "time / summed frames, rank-0 JSON): no GPU work, fabricated per-rank timings (tests/test_replicas_gloo.py)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default run only: skip the additional legs reported in `configs` (BASELINE config 2 = LK only, the "
+                         "reference-default 374-point load, config 4 = 1080p / 4000 points at maxLevel 3 and 4)")
+    ap.add_argument("--hd-frames", type=int, default=128, help="frames per step of the config-4 legs")
     args = ap.parse_args(argv)
+
+    # --gpus N is a promise about the line that gets printed: n_gpus = N ranks, one per GPU.  Launched by
+    # torch.distributed.run the environment says the same thing; launched bare with N > 1 this process starts the N ranks
+    # itself; anything else is refused -- `--gpus 8` never prints `n_gpus: 1`.
+    env_ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus != env_ws:
+        if "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+            raise SystemExit("bench.py: --gpus %d contradicts the launcher's WORLD_SIZE=%d" % (args.gpus, env_ws))
+        return spawn_ranks(args, sys.argv[1:] if argv is None else list(argv))
 
     import torch
     from visual_odom_amd import replicas
@@ -223,7 +249,7 @@ def main(argv=None):
             dist.barrier()
         elapsed, frames_total = replicas.aggregate(dist, 1.0 + 0.25 * rank, args.frames * args.steps)
         out = {"metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features", "value": frames_total / elapsed,
-               "unit": "frames/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+               "unit": "frames/s", "n_gpus": world_size, "ranks": world_size, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "data": "SELFTEST of the multi-rank control flow: no GPU work, fabricated timings -- not a measurement"}
         if rank == 0:
@@ -235,7 +261,15 @@ def main(argv=None):
     dist = replicas.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    local_dev = local_rank % torch.cuda.device_count()  # one GPU per rank on a real node
+    global N_GPUS
+    n_dev = torch.cuda.device_count()
+    if world_size > n_dev and os.environ.get("VO_ALLOW_SHARED_GPU") != "1":
+        # (VO_ALLOW_SHARED_GPU=1 + VO_DIST_BACKEND=gloo: smoke test of the N > 1 control flow on fewer GPUs; the line then
+        # reports n_gpus = the GPUs actually used and `ranks` = the processes)
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s) -- n_gpus would not be the number of GPUs used"
+                         % (world_size, n_dev))
+    N_GPUS = min(world_size, n_dev)
+    local_dev = local_rank % n_dev  # one GPU per rank on a real node
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
 
@@ -245,9 +279,12 @@ def main(argv=None):
         if dist is not None:
             dist.barrier()
 
+    default_run = args.mode == "batch" and args.workload == "kitti2000" and args.stages == "full" and \
+        not args.mono_rotation and args.frames >= 256
     replay_leg = args.mode == "batch" and not args.no_replay_leg and args.workload.startswith("kitti") and \
         not args.mono_rotation and args.frames >= 256
-    kept = [] if replay_leg else None
+    config_legs = default_run and not args.no_configs and world_size == 1
+    kept = [] if (replay_leg or config_legs) else None
     if args.mode == "sequences":
         out = run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas)
     else:
@@ -260,12 +297,55 @@ def main(argv=None):
         a2.mode, a2.seqs, a2.ring, a2.ingest, a2.no_cpu_baseline = "sequences", 256, 3, "device", True
         a2.validate = min(args.validate, 2)
         rep = run_sequences(a2, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=kept[0])
-        kept[0].close()
         if rank == 0 and out is not None and rep is not None:
             out["exact_replay"] = {"value": rep["value"], "unit": rep["unit"], "ms_per_step": rep["ms_per_step"],
                                    "steps": rep["steps"], "validated_frames": rep["validated_frames"],
                                    "sequences_per_gpu": 256, "points_per_frame": rep["config"]["points_per_frame"],
-                                   "mode": rep["config"]["mode"], "stage_ms": rep["config"]["stage_ms"]}
+                                   "mode": rep["config"]["mode"], "stage_ms": rep["config"]["stage_ms"],
+                                   "roofline": rep["roofline"]}
+    if config_legs:
+        # every other BASELINE configuration in the same driver-run line: same code path, fewer
+        # steps, each leg validated against the oracle after its timed loop.  The KITTI-size legs reuse the headline's
+        # context; the 1080p legs need a bigger one, created after the first is destroyed (it gets the same HIP streams
+        # back from the library's per-device pool).
+        import copy
+        legs = []
+
+        def leg(name, baseline_config, ctx, **over):
+            a = copy.copy(args)
+            a.no_cpu_baseline, a.sustain, a.steps, a.warmup, a.validate = True, 0.0, 10, 2, 2
+            for k, v in over.items():
+                setattr(a, k, v)
+            r = run_batch(a, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=ctx)
+            legs.append({"name": name, "baseline_config": baseline_config, "workload": r["config"]["workload"],
+                         "stages": r["config"]["stages"], "value": r["value"], "unit": r["unit"],
+                         "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                         "frames_per_step": r["config"]["frames_per_step_per_gpu"],
+                         "points_per_frame": r["config"]["points_per_frame"], "validated_frames": r["validated_frames"],
+                         "stage_ms": r["config"]["stage_ms"], "roofline": r["roofline"]})
+
+        leg("config2_lk_only", 2, kept[0], stages="lk")
+        leg("reference_default_374", 3, kept[0], workload="kitti374", steps=20)
+        kept[0].close()
+        kept[0] = None
+        from visual_odom_amd import _lib
+        hd = _lib.Context(local_dev, 1920, 1080, 8192, args.hd_frames)
+        try:
+            leg("config4_1080p_4000_maxlevel3", 4, hd, workload="hd4000", frames=args.hd_frames, quads=4, steps=8)
+            leg("config4_1080p_4000_maxlevel4", 4, hd, workload="hd4000l4", frames=args.hd_frames, quads=4, steps=8)
+        finally:
+            hd.close()
+        if out is not None:
+            if "exact_replay" in out:
+                er = out["exact_replay"]
+                legs.append({"name": "exact_replay_256_sequences", "baseline_config": 3, "workload": out["config"]["workload"],
+                             "stages": "detect+full", "value": er["value"], "unit": er["unit"], "ms_per_step": er["ms_per_step"],
+                             "steps": er["steps"], "warmup": args.warmup, "frames_per_step": er["sequences_per_gpu"],
+                             "points_per_frame": er["points_per_frame"], "validated_frames": er["validated_frames"],
+                             "stage_ms": er["stage_ms"], "roofline": er["roofline"]})
+            out["configs"] = legs
+    if kept and kept[0] is not None:
+        kept[0].close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -274,13 +354,15 @@ def main(argv=None):
     return out
 
 
-def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, keep_ctx=None):
+def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, keep_ctx=None, ctx=None):
     from visual_odom_amd import _lib
     B, S = args.frames, min(args.quads, args.frames)
     # every rank renders its own sequence (seed by rank) = independent sequences, one per GPU
     world, lefts, rights, pts, max_level = build_inputs(args.workload, S, 20260925 + rank)
     w, h = world.w, world.h
-    ctx = _lib.Context(local_dev, w, h, 8192, B)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = _lib.Context(local_dev, w, h, 8192, B)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
     n_images = 2 * (B + 1)
     # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
@@ -322,7 +404,8 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     validated = 0
     if args.validate > 0 and rank == 0:
         picks = sorted({int(round(x)) for x in np.linspace(0, B - 1, max(args.validate, 2))})
-        validated = validate_frames(ctx, picks, lefts, rights, frame_pts, world, S, full=args.stages != "lk")
+        validated = validate_frames(ctx, picks, lefts, rights, frame_pts, world, S, full=args.stages != "lk",
+                                    max_level=max_level)
     sustained = None
     if args.sustain > 0:
         n_sus = max(K, int(np.ceil(args.sustain / max(elapsed / K, 1e-6))))
@@ -348,7 +431,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     if rank == 0:
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features",
-            "value": fps, "unit": "frames/s", "n_gpus": world_size, "steps": K, "warmup": args.warmup,
+            "value": fps, "unit": "frames/s", "n_gpus": N_GPUS, "ranks": world_size, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
             "validated_frames": validated, "sustained": sustained,
@@ -360,19 +443,24 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes,
                        "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
-            "roofline": {"bound": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
+            # `frac` stays the contract's figure -- algorithmic bytes / launch time / HBM peak -- but what BINDS the kernel
+            # is VALU issue (profiles/r02_lk_issue_bound.md: 13.2 k VALU instructions per feature at 4 SIMD-cycles each =
+            # the launch time; measured HBM traffic is half the algorithmic bytes), so `bound` says that
+            "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": measured_traffic(args.workload, B) if profiled_config else None,
-                         # the contract prices the kernel against HBM; what binds it is VALU issue (profile-derived,
-                         # IMPORTED from the committed PMC pass of this same command, not measured in this run)
+                         # profile-derived, IMPORTED from the committed PMC pass of this same command, not measured in this run
                          "valu_issue_imported": measured_issue(args.workload, B) if profiled_config else None,
-                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch},
+                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
+                         "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1),
+                         "other_stages": pyramid_roofline(ctx, w, h, n_images, stage_ms)},
         }
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(lefts, rights, pts, world, min(args.cpu_frames, S), args.stages)
+    del dev_t
     if keep_ctx is not None:
-        keep_ctx.append(ctx)  # the exact-replay leg reuses the context: a second context of the same process gets a
-    else:                     # different stream -> hardware-queue mapping and runs the loop measurably slower
+        keep_ctx.append(ctx)  # the exact-replay leg and the KITTI-size `configs` legs reuse the context
+    elif own_ctx:
         ctx.close()
     return out
 
@@ -449,7 +537,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     if rank == 0:
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features",
-            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world_size, "steps": K, "warmup": W,
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": N_GPUS, "ranks": world_size, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
             "validated_frames": validated,
@@ -465,9 +553,10 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                        "parallelism": "replicas x%d (%d sequences per GPU, no collective)" % (world_size, S),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes},
-            "roofline": {"bound": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
+            "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch},
+                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
+                         "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1)},
         }
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(lefts, rights, pts, world, min(args.cpu_frames, Q), "detect+full",
@@ -475,6 +564,49 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     if own_ctx:
         ctx.close()
     return out
+
+
+def pyramid_roofline(ctx, w, h, n_images, stage_ms):
+    """the pyramid stage against the HBM roof, next to the LK entry: its ALGORITHMIC bytes (every level read
+    once, every level >= 1 written once) and the bytes the stage moves BY DESIGN -- it also stores a 4-byte Scharr pixel
+    (2 x int16) per pyramid pixel, which 8d's model does not count"""
+    from visual_odom_amd import _lib
+    ms = float(stage_ms[_lib.STAGE_NAMES.index("pyramid")])
+    algo = float(ctx.model_bytes(w, h, 0)[0]) / 4.0 * n_images      # model_bytes()[0] is per frame = 4 images
+    lv, cw, ch, px = 0, w, h, 0
+    max_level = ctx.get_params().lk_max_level
+    while True:
+        px += cw * ch
+        nw, nh = (cw + 1) // 2, (ch + 1) // 2
+        if lv == max_level or nw <= 21 or nh <= 21:
+            break
+        cw, ch, lv = nw, nh, lv + 1
+    moved = algo + (px * 1.0 + px * 4.0) * n_images                  # + Scharr pass: read every level, write 4 B per pixel
+    return {"pyramid": {"bound": "hbm", "stage_ms": ms, "algorithmic_bytes": algo, "designed_bytes": moved,
+                        "achieved": algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                        "achieved_designed": moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": algo / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms > 0 else 0.0,
+                        "frac_designed": moved / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms > 0 else 0.0}}
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would"""
+    import socket
+    import subprocess
+    if not args.selftest_replicas:
+        import torch
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, n))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def measured_issue(workload, frames):

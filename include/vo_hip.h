@@ -241,7 +241,9 @@ int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double 
  *   per step:  vo_seq_push_pair(ctx, s, left, right, stride, pinned)  for every sequence that has a new pair
  *              vo_seq_step(ctx)                                        asynchronous
  *   A sequence processes a frame in a step iff it received a pair for this step AND for the previous one (its
- *   first pair only builds pyramids, main.cpp:110-113); a sequence that receives nothing simply pauses.
+ *   first pair only builds pyramids, main.cpp:110-113); a sequence that receives nothing pauses, and when it resumes
+ *   the first pair again only builds pyramids: the transition across the pause is dropped and the next processed frame
+ *   is flagged VO_SEQ_F_GAP.
  *   Detection / LK / RANSAC parameters: vo_set_params and vo_batch_set_detect_params before vo_seq_configure (or at
  *   least before the first vo_seq_step: with few sequences FAST runs on a pair's left image as soon as the pair is on
  *   the device, one step before its corners are needed), vo_batch_set_projection before the first step.
@@ -253,8 +255,18 @@ int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double 
 #define VO_SEQ_F_INTEGRATED 2  /* the motion passed the gates of main.cpp:201 / utils.cpp:80 and was integrated */
 #define VO_SEQ_F_TOO_FEW 4     /* fewer than 5 points reached solvePnPRansac (the reference asserts) */
 #define VO_SEQ_F_NO_ESSENTIAL 8
+#define VO_SEQ_F_GAP 16        /* first frame processed after the sequence had paused (no pair for >= 1 step): the motion
+                                  between the last pair before the pause and the first pair after it was never
+                                  estimated -- the carried features (tracked in the last pair before the pause) and
+                                  frame_pose are kept, the image pair restarts.  The reference's loop has no such
+                                  case (it reads consecutive files, main.cpp:123-158); a caller that wants a clean
+                                  restart calls vo_seq_reset(seq) instead of resuming. */
 int vo_seq_configure(vo_ctx *ctx, int n_seq, int w, int h, int ring, int max_steps);
-/* empty feature set, identity pose, no trajectory rows, no resident pair -- for sequence `seq`, or all if seq < 0 */
+/* empty feature set, identity pose, no trajectory rows, no resident pair -- for sequence `seq`, or all if seq < 0.
+ * seq < 0 also rewinds the loop's step counter (all max_steps rows of every sequence are available again) and clears
+ * the "a step failed half-way" state after which every vo_seq_push_pair / vo_seq_step returns VO_ERR_STATE.
+ * vo_seq_step refuses (VO_ERR_STATE, the pairs pushed for that step are dropped) when an active sequence has used up
+ * its max_steps rows; vo_seq_reset(seq) gives them back. */
 int vo_seq_reset(vo_ctx *ctx, int seq);
 /* the next stereo pair of sequence `seq` (8-bit gray, byte stride).  host_pinned = 0: pageable memory, staged
  * through the library's pinned buffers (the call returns when the images have been copied out of the caller's

@@ -93,8 +93,9 @@ def lk_last_iteration_count():
     return int(lib().orc_lk_last_iteration_count())
 
 
-def circular_matching(l0, r0, l1, r1, pts_l0, ages=None, nthreads=0):
-    """feature.cpp:118-148.  Returns dict with compacted arrays (M survivors)."""
+def circular_matching(l0, r0, l1, r1, pts_l0, ages=None, nthreads=0, max_level=3):
+    """feature.cpp:118-148.  Returns dict with compacted arrays (M survivors).  max_level: maxLevel of the four
+    calcOpticalFlowPyrLK calls (the reference's literal is 3)."""
     imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
     h, w = imgs[0].shape
     p0 = np.array(pts_l0, np.float32).reshape(-1, 2).copy()
@@ -110,9 +111,9 @@ def circular_matching(l0, r0, l1, r1, pts_l0, ages=None, nthreads=0):
         na = C.c_int(len(ages_a))
         if len(ages_a) == 0:
             ages_a = np.zeros(1, np.int32)
-    m = lib().orc_circular_matching(_vp(imgs[0]), _vp(imgs[1]), _vp(imgs[2]), _vp(imgs[3]), w, h,
-                                    _vp(p0), n, _vp(p1), _vp(p2), _vp(p3), _vp(p0r), _vp(ages_a),
-                                    C.byref(na), _vp(st), _vp(keep), nthreads)
+    m = lib().orc_circular_matching_lvl(_vp(imgs[0]), _vp(imgs[1]), _vp(imgs[2]), _vp(imgs[3]), w, h,
+                                        _vp(p0), n, _vp(p1), _vp(p2), _vp(p3), _vp(p0r), _vp(ages_a),
+                                        C.byref(na), _vp(st), _vp(keep), nthreads, int(max_level))
     return dict(l0=p0[:m].copy(), r0=p1[:m].copy(), r1=p2[:m].copy(), l1=p3[:m].copy(),
                 l0_ret=p0r[:m].copy(), ages=ages_a[:na.value].copy(), status4=st[:, :n].copy(),
                 keep_idx=keep[:m].copy(), n_out=m)

@@ -19,18 +19,29 @@ int orc_circular_matching(const uint8_t *l0, const uint8_t *r0, const uint8_t *l
                           float *p3, float *p0r, int *ages, int *n_ages, uint8_t *status4,
                           int *keep_idx, int nthreads)
 {
+    return orc_circular_matching_lvl(l0, r0, l1, r1, w, h, p0, n, p1, p2, p3, p0r, ages, n_ages, status4, keep_idx,
+                                     nthreads, 3);
+}
+
+/* the same with calcOpticalFlowPyrLK's maxLevel as a parameter (the reference hard-codes 3, feature.cpp:136-139;
+ * BASELINE config 4 asks for one more pyramid level) */
+int orc_circular_matching_lvl(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
+                              const uint8_t *r1, int w, int h, float *p0, int n, float *p1, float *p2,
+                              float *p3, float *p0r, int *ages, int *n_ages, uint8_t *status4,
+                              int *keep_idx, int nthreads, int max_level)
+{
     uint8_t *st = (uint8_t *)malloc(4 * (size_t)(n > 0 ? n : 1));
     float *err = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     uint8_t *s0 = st, *s1 = st + n, *s2 = st + 2 * n, *s3 = st + 3 * n;
     long long it = 0;
     /* feature.cpp:136-139: win 21, maxLevel 3, COUNT+EPS(30, 0.01), flags 0, minEig 0.001 */
-    orc_calc_optical_flow_pyr_lk(l0, r0, w, h, p0, n, p1, s0, err, 21, 3, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(l0, r0, w, h, p0, n, p1, s0, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(r0, r1, w, h, p1, n, p2, s1, err, 21, 3, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(r0, r1, w, h, p1, n, p2, s1, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(r1, l1, w, h, p2, n, p3, s2, err, 21, 3, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(r1, l1, w, h, p2, n, p3, s2, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(l1, l0, w, h, p3, n, p0r, s3, err, 21, 3, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(l1, l0, w, h, p3, n, p0r, s3, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
     it += orc_lk_last_iteration_count();
     (void)it;
     if (status4)

@@ -60,6 +60,12 @@ int orc_circular_matching(const uint8_t *l0, const uint8_t *r0, const uint8_t *l
                           float *pts_r0, float *pts_r1, float *pts_l1, float *pts_l0_ret,
                           int *ages, int *n_ages, uint8_t *status4, int *keep_idx,
                           int nthreads);
+/* same, maxLevel of the four calcOpticalFlowPyrLK calls as a parameter (reference: 3) */
+int orc_circular_matching_lvl(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
+                              const uint8_t *r1, int w, int h, float *pts_l0, int n,
+                              float *pts_r0, float *pts_r1, float *pts_l1, float *pts_l0_ret,
+                              int *ages, int *n_ages, uint8_t *status4, int *keep_idx,
+                              int nthreads, int max_level);
 
 /* visualOdometry.cpp:44-77,119-125 : checkValidMatch(thr) + removeInvalidPoints x4.
  * Compacts the four arrays in place, returns K.  valid (optional, m) gets the mask. */

@@ -100,11 +100,18 @@ def _build_example(name):
     exe = os.path.join(out_dir, name)
     src = os.path.join(ROOT, "examples", name + ".cpp")
     libdir = os.path.join(ROOT, "visual_odom_amd")
-    deps = [src, os.path.join(ROOT, "include", "vo_hip.h"), os.path.join(libdir, "libvo_hip.so")]
+    deps = [src, os.path.join(ROOT, "include", "vo_hip.h"), os.path.join(libdir, "libvo_hip.so"),
+            os.path.join(ROOT, "examples", "vo_io.h"), os.path.join(ROOT, "examples", "vo_seq_host.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(ROOT, "include"), "-L" + libdir,
-                               "-lvo_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+                               "-lvo_hip", "-lz", "-lpthread", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
+
+
+@pytest.fixture(scope="session")
+def vo_multi_gpu_binary():
+    """examples/vo_multi_gpu.cpp (one host thread + one vo_ctx per GPU, sequences sharded, no collective), built with g++"""
+    return _build_example("vo_multi_gpu")
 
 
 @pytest.fixture(scope="session")
@@ -126,5 +133,5 @@ def vo_run_binary():
     deps = [src, os.path.join(ROOT, "include", "vo_hip.h"), os.path.join(libdir, "libvo_hip.so")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", src, "-I" + os.path.join(ROOT, "include"), "-L" + libdir,
-                               "-lvo_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+                               "-lvo_hip", "-lz", "-lpthread", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe

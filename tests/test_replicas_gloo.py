@@ -71,3 +71,41 @@ def test_bench_multi_rank_launch_line():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 16 * 4 / 1.25) < 1e-9      # frames of both ranks / the slower rank's time
     assert "SELFTEST" in out["data"]
+
+
+def _run_bench(args, env=None, launcher_ranks=0):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if launcher_ranks:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += [os.path.join(root, "bench.py")] + args
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=e)
+
+
+def test_bench_gpus_flag_cannot_misreport():
+    """`python bench.py --gpus N` launched WITHOUT torch.distributed.run starts its N ranks itself
+    (and the line says n_gpus = N); a --gpus that contradicts the launcher's WORLD_SIZE is refused; more ranks than
+    GPUs is refused -- `n_gpus: 1` is never printed for `--gpus 8`"""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "16", "--selftest-replicas"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and abs(out["value"] - 2 * 16 * 4 / 1.25) < 1e-9
+    # the launcher says 2 ranks, the flag says 4
+    r = _run_bench(["--gpus", "4", "--selftest-replicas"], launcher_ranks=2)
+    assert r.returncode != 0 and "contradicts" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # no GPU in this container: a real (non-selftest) multi-GPU request must fail, not fall back to fewer GPUs
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "8"])
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

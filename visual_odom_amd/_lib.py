@@ -14,7 +14,7 @@ SO_PATH = os.path.join(HERE, "libvo_hip.so")
 VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW, VO_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
 VO_NO_MODEL, VO_NO_ESSENTIAL = 1, 2
 SEQ_ROW, SEQ_INFO = 27, 8
-SEQ_F_ACTIVE, SEQ_F_INTEGRATED, SEQ_F_TOO_FEW, SEQ_F_NO_ESSENTIAL = 1, 2, 4, 8
+SEQ_F_ACTIVE, SEQ_F_INTEGRATED, SEQ_F_TOO_FEW, SEQ_F_NO_ESSENTIAL, SEQ_F_GAP = 1, 2, 4, 8, 16
 SEQ_INFO_NAMES = ("n_bucketed", "n_circ", "n_tracked", "n_inliers", "pnp_status", "flags", "ransac_iters", "overflow")
 STAGE_PYRAMID, STAGE_LK, STAGE_FILTER, STAGE_TRIANGULATE, STAGE_PNP, STAGE_ALL = 1, 2, 4, 8, 16, 31
 STAGE_DETECT = 32

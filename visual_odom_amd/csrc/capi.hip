@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,11 +22,18 @@ using namespace vo;
 #define VO_EV_PER_RUN (VO_NUM_STAGES + 3)
 #define VO_SEQ_MAX_RING 3
 
+// the HIP streams of one context (pooled per device, see acquire_streams)
+struct StreamSet {
+    hipStream_t stream = nullptr, pnp = nullptr, pnp2 = nullptr, filter = nullptr, em = nullptr, copy = nullptr;
+    int id = 0; // creation rank on its device: the pool hands out the oldest free set first
+};
+
 struct vo_ctx {
     int device = 0;
+    StreamSet streams;
     int max_w = 0, max_h = 0, cap = 0, max_frames = 0, max_images = 0;
     vo_params prm;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // tracking stream; all streams belong to `streams` (pooled per device)
     hipEvent_t ev[VO_EV_PER_RUN] = {}; // [0..3] tracking stream (3 stages), [4..7] post stream (3 stages)
     std::vector<hipEvent_t> ring; // VO_EVENT_SLOTS x (VO_EV_PER_RUN) for vo_batch_run_slot
     std::string err;
@@ -146,6 +154,9 @@ struct vo_ctx {
         SeqFrameInfo *d_info = nullptr; // [S][max_steps]
         int *d_rows = nullptr, *d_rows_carry = nullptr, *d_nages = nullptr; // [S]
         std::vector<uint8_t> pushed, had_prev; // pair pushed for the pending step / for the previous step
+        std::vector<uint8_t> ever, gap;        // has had a pair since its reset / resumes after a pause (VO_SEQ_F_GAP)
+        std::vector<int> h_rows;               // frames processed per sequence since its reset (host mirror of d_rows)
+        bool broken = false;                   // a step failed after it had consumed its pairs: vo_seq_reset(-1) first
         hipStream_t copy = nullptr;
         hipEvent_t ev_upload = nullptr, ev_carry = nullptr, ev_integ = nullptr;
         bool integ_pending = false;
@@ -267,6 +278,75 @@ hipError_t dmalloc(T **p, size_t n)
     return hipMalloc((void **)p, n * sizeof(T));
 }
 
+// HIP streams of a context come from a per-device pool and go back to it in vo_destroy (they are never destroyed).
+// Why: the runtime multiplexes a process's streams onto a few hardware queues in creation order, and which of a
+// context's streams share a queue moves the latency-bound modes by 25 % (round-2 measurement: the SECOND vo_ctx of a
+// process ran a one-sequence step in 0.80 instead of 0.63 ms).  A context created after another one was destroyed
+// (bench.py's legs, a test session, a service that reconfigures) now gets the very same streams -- same mapping, same
+// speed; contexts that are alive at the same time (one per host thread, examples/vo_multi_gpu.cpp) get a set each.
+constexpr int VO_MAX_DEVICES = 64;
+std::mutex g_pool_mu;
+std::vector<StreamSet> g_pool[VO_MAX_DEVICES];
+int g_pool_created[VO_MAX_DEVICES] = {};
+
+bool acquire_streams(int device, StreamSet *out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (device < VO_MAX_DEVICES && !g_pool[device].empty()) {
+            // the set that was created first: a process that only ever has one context alive always runs on the same streams
+            size_t best = 0;
+            for (size_t i = 1; i < g_pool[device].size(); i++)
+                if (g_pool[device][i].id < g_pool[device][best].id)
+                    best = i;
+            *out = g_pool[device][best];
+            g_pool[device].erase(g_pool[device].begin() + best);
+            return true;
+        }
+    }
+    StreamSet s;
+    if (device < VO_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        s.id = g_pool_created[device]++;
+    }
+    bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    // the post-LK streams carry a few hundred waves next to LK's hundred thousand: at equal priority
+    // their kernels trickle in behind LK's workgroups (pose chain 1.1 ms alone, 5-10 ms next to LK) and
+    // the next run ends up waiting for them, so they get the highest stream priority
+    int least = 0, greatest = 0;
+    ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&s.pnp, hipStreamNonBlocking, greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&s.pnp2, hipStreamNonBlocking, greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&s.filter, hipStreamNonBlocking, greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&s.em, hipStreamNonBlocking, greatest) == hipSuccess;
+    *out = s;
+    return ok;
+}
+
+// the lock-step loop's copy / prepare stream, created the first time a context of this set needs it (highest priority:
+// when it carries the prepare work its short memory-bound kernels have to find SIMD slots between the running step's LK
+// waves; when it only carries the ingest kernel the priority does not matter)
+bool ensure_copy_stream(StreamSet *s)
+{
+    if (s->copy)
+        return true;
+    int least = 0, greatest = 0;
+    return hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+           hipStreamCreateWithPriority(&s->copy, hipStreamNonBlocking, greatest) == hipSuccess;
+}
+
+void release_streams(int device, const StreamSet &s)
+{
+    hipStream_t all[] = {s.stream, s.pnp, s.pnp2, s.filter, s.em, s.copy};
+    for (hipStream_t st : all)
+        if (st)
+            (void)hipStreamSynchronize(st);
+    if (!s.stream || device >= VO_MAX_DEVICES)
+        return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool[device].push_back(s);
+}
+
 } // namespace
 
 static int sync_all(vo_ctx *c);
@@ -299,7 +379,7 @@ static void seq_free(vo_ctx *c)
         if (e)
             (void)hipEventDestroy(e);
     if (q.copy)
-        (void)hipStreamDestroy(q.copy);
+        (void)hipStreamSynchronize(q.copy); // belongs to the context's stream set, not to the loop
     q = vo_ctx::Seq();
 }
 
@@ -337,6 +417,8 @@ void vo_destroy(vo_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)sync_all(c); // nothing of this context may still run on streams that go back to the pool
     void *ptrs[] = {c->d_der, c->d_pix, c->d_imgs, c->d_quads, c->d_pts, c->d_trk2[0], c->d_trk2[1], c->d_outA,
                     c->d_status2[0], c->d_status2[1], c->d_npts, c->d_nA, c->d_idxA, c->d_P, c->d_rowoff, c->d_nmsmask, c->d_rowcnt, c->d_detect,
                     c->d_ntracked, c->d_nnew, c->d_feat, c->d_fages, c->d_ages, c->d_pts_det[0], c->d_pts_det[1],
@@ -370,14 +452,6 @@ void vo_destroy(vo_ctx *c)
     for (auto &ev : c->ev_trk_free)
         if (ev)
             (void)hipEventDestroy(ev);
-    if (c->stream_pnp)
-        (void)hipStreamDestroy(c->stream_pnp);
-    if (c->stream_pnp2)
-        (void)hipStreamDestroy(c->stream_pnp2);
-    if (c->stream_filter)
-        (void)hipStreamDestroy(c->stream_filter);
-    if (c->stream_em)
-        (void)hipStreamDestroy(c->stream_em);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
     if (c->h_gather)
@@ -388,8 +462,7 @@ void vo_destroy(vo_ctx *c)
     for (auto &e : c->ring)
         if (e)
             (void)hipEventDestroy(e);
-    if (c->stream)
-        (void)hipStreamDestroy(c->stream);
+    release_streams(c->device, c->streams); // synchronises them; back to the per-device pool
     delete c;
 }
 
@@ -412,18 +485,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     vo_default_params(&c->prm);
     c->ransac_cap = 1000;
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    // the post-LK streams carry a few hundred waves next to LK's hundred thousand: at equal priority
-    // their kernels trickle in behind LK's workgroups (pose chain 1.1 ms alone, 5-10 ms next to LK) and
-    // the next run ends up waiting for them, so they get the highest stream priority
-    {
-        int least = 0, greatest = 0;
-        ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp, hipStreamNonBlocking, greatest) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->stream_pnp2, hipStreamNonBlocking, greatest) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->stream_filter, hipStreamNonBlocking, greatest) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->stream_em, hipStreamNonBlocking, greatest) == hipSuccess;
-    }
+    bool ok = acquire_streams(device, &c->streams);
+    c->stream = c->streams.stream;
+    c->stream_pnp = c->streams.pnp;
+    c->stream_pnp2 = c->streams.pnp2;
+    c->stream_filter = c->streams.filter;
+    c->stream_em = c->streams.em;
     for (auto &ev : c->ev_trk_free)
         ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
     // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
@@ -1509,10 +1576,8 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
         const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
         q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames || seq_light_band(c, n_seq, cells * c->dprm.features_per_bucket);
     }
-    int least = 0, greatest = 0;
-    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-    ok = ok && (q.prep ? hipStreamCreateWithPriority(&q.copy, hipStreamNonBlocking, greatest)
-                       : hipStreamCreateWithFlags(&q.copy, hipStreamNonBlocking)) == hipSuccess;
+    bool ok = ensure_copy_stream(&c->streams);
+    q.copy = c->streams.copy;
     ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
     ok = ok && dmalloc(&q.d_ncorn, (size_t)ring * S) == hipSuccess;
     ok = ok && hipMemset(q.d_ncorn, 0, sizeof(int) * ring * S) == hipSuccess;
@@ -1553,6 +1618,9 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     VO_HIP_TRY(c, hipMemset(q.d_info, 0, sizeof(SeqFrameInfo) * S * (size_t)max_steps));
     q.pushed.assign(S, 0);
     q.had_prev.assign(S, 0);
+    q.ever.assign(S, 0);
+    q.gap.assign(S, 0);
+    q.h_rows.assign(S, 0);
     q.step = 0;
     q.on = true;
     return vo_seq_reset(c, -1);
@@ -1567,7 +1635,7 @@ int vo_seq_reset(vo_ctx *c, int seq)
         return fail(c, VO_ERR_STATE, "vo_seq_reset before vo_seq_configure");
     if (seq >= q.S)
         return fail(c, VO_ERR_ARG, "vo_seq_reset: bad sequence");
-    if (q.begun && q.n_ing > 0)
+    if (q.begun && q.n_ing > 0 && !(q.broken && seq < 0))
         return fail(c, VO_ERR_STATE, "vo_seq_reset between vo_seq_push_pair and vo_seq_step");
     int rc = sync_all(c);
     if (rc != VO_OK)
@@ -1576,7 +1644,24 @@ int vo_seq_reset(vo_ctx *c, int seq)
     double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int s = s0; s < s1; s++) {
         VO_HIP_TRY(c, hipMemcpy(q.d_pose + (size_t)s * 16, eye, sizeof(eye), hipMemcpyHostToDevice));
-        q.pushed[s] = q.had_prev[s] = 0;
+        q.pushed[s] = q.had_prev[s] = q.ever[s] = q.gap[s] = 0;
+        q.h_rows[s] = 0;
+    }
+    if (seq < 0) {
+        // everything is idle (sync_all above) and no sequence has a resident pair any more: the loop starts over -- ring
+        // slot 0, event slot 0, all max_steps trajectory rows available again (a long-lived context that recycles its
+        // sequences never runs out of steps)
+        q.step = 0;
+        q.begun = q.staged = q.broken = false;
+        q.n_ing = 0;
+        q.carry_pending = q.integ_pending = false;
+        for (auto &b : q.slot_busy)
+            b = false;
+        for (auto &b : q.fast_pending)
+            b = false;
+        for (auto &b : q.step_pending)
+            b = false;
+        q.stage_busy[0] = q.stage_busy[1] = false;
     }
     const size_t n = (size_t)(s1 - s0);
     VO_HIP_TRY(c, hipMemset(q.d_rows + s0, 0, sizeof(int) * n));
@@ -1614,6 +1699,8 @@ static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int
     vo_ctx::Seq &q = c->seq;
     if (!q.on)
         return fail(c, VO_ERR_STATE, "vo_seq_push_pair before vo_seq_configure");
+    if (q.broken)
+        return fail(c, VO_ERR_STATE, "vo_seq_push_pair: a previous vo_seq_step failed half-way; vo_seq_reset(ctx, -1) first");
     if (seq < 0 || seq >= q.S || !left || !right || stride < c->w)
         return fail(c, VO_ERR_ARG, "vo_seq_push_pair: bad sequence / image / stride");
     if (q.pushed[seq])
@@ -1707,20 +1794,51 @@ int vo_seq_step(vo_ctx *c)
         return fail(c, VO_ERR_STATE, "vo_seq_step before vo_seq_configure");
     if (!c->have_P)
         return fail(c, VO_ERR_STATE, "vo_seq_step: projection matrices not set");
-    if (q.step > q.max_steps) // a sequence's first step yields no row: max_steps rows need max_steps + 1 steps
-        return fail(c, VO_ERR_STATE, "vo_seq_step: trajectory capacity (max_steps of vo_seq_configure) exhausted");
+    if (q.broken)
+        return fail(c, VO_ERR_STATE, "vo_seq_step: a previous step failed half-way; vo_seq_reset(ctx, -1) first");
+    // everything that can be refused is refused BEFORE the step consumes its pairs
+    {
+        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
+        const int fpb = c->dprm.features_per_bucket;
+        if (bs < 1 || fpb < 1 || fpb > 8 || (long long)(c->h / bs + 1) * (c->w / bs + 1) > 1024)
+            return fail(c, VO_ERR_ARG, "vo_seq_step: bucket grid beyond 1024 cells / 8 features per bucket");
+        if (c->w > 4096)
+            return fail(c, VO_ERR_ARG, "vo_seq_step: detection handles images up to 4096 pixels wide");
+    }
+    for (int s = 0; s < q.S; s++)
+        if (q.pushed[s] && q.had_prev[s] && q.h_rows[s] >= q.max_steps) {
+            // refuse the step and drop its pending pairs: the loop stays usable (trajectories can be read,
+            // vo_seq_reset(s) gives the sequence its rows back)
+            for (int k = 0; k < q.S; k++)
+                q.pushed[k] = 0;
+            q.begun = false;
+            q.n_ing = 0;
+            return fail(c, VO_ERR_STATE, "vo_seq_step: a sequence's trajectory capacity (max_steps of vo_seq_configure) is "
+                                         "exhausted; the pairs pushed for this step were dropped");
+        }
     VO_HIP_TRY(c, hipSetDevice(c->device));
     int rc = seq_begin_step(c);
     if (rc != VO_OK)
         return rc;
     const int slot = (int)(q.step % VO_SEQ_INFLIGHT);
     const int r = (int)(q.step % q.ring);
-    // a sequence processes a frame iff it has a pair for this step and had one for the previous step
+    // a sequence processes a frame iff it has a pair for this step and had one for the previous step.  A sequence that
+    // RESUMES after steps without a pair restarts its image pair (this pair only builds pyramids) but keeps its carried
+    // features and pose -- a case the reference's loop does not have; its next processed frame carries VO_SEQ_F_GAP
+    // (active value 3) so that the missing transition is on record.
     int *act = q.h_active + (size_t)slot * q.S;
     int n_active = 0;
     for (int s = 0; s < q.S; s++) {
-        act[s] = (q.pushed[s] && q.had_prev[s]) ? 1 : 0;
-        n_active += act[s];
+        const bool on = q.pushed[s] && q.had_prev[s];
+        if (q.pushed[s] && !q.had_prev[s] && q.ever[s])
+            q.gap[s] = 1;
+        act[s] = on ? (q.gap[s] ? 3 : 1) : 0;
+        if (on) {
+            q.gap[s] = 0;
+            q.h_rows[s]++;
+        }
+        n_active += on;
+        q.ever[s] |= q.pushed[s];
         q.had_prev[s] = q.pushed[s];
         q.pushed[s] = 0;
     }
@@ -1758,24 +1876,36 @@ int vo_seq_step(vo_ctx *c)
         stages |= VO_STAGE_DETECT | VO_STAGE_LK | VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP;
     }
     rc = run_stages(c, stages, true, &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_EV_PER_RUN)]);
-    if (rc != VO_OK)
-        return rc;
-    if (q.prep) {
+    if (rc == VO_OK && q.prep) {
         // FAST + non-maximum suppression of the new pairs' left images, for the NEXT step's appendNewFeatures: on the
         // prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
-        if (c->w > 4096)
-            return fail(c, VO_ERR_ARG, "vo_seq_step: detection handles images up to 4096 pixels wide");
         launch_fast_corners(c->d_imgs, q.d_quads + (size_t)r * q.S, nullptr, q.S, c->w, c->h, t, c->dprm.fast_nonmax,
                             c->d_nmsmask, c->d_rowcnt, c->d_rowoff, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
                             q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
-        VO_HIP_TRY(c, hipEventRecord(q.ev_fast[r], q.copy));
+        hipError_t e1 = hipEventRecord(q.ev_fast[r], q.copy);
         q.fast_pending[r] = true;
-        VO_HIP_TRY(c, hipGetLastError());
+        hipError_t e2 = hipGetLastError();
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            c->err = std::string("vo_seq_step: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+            rc = VO_ERR_HIP;
+        }
     }
-    // end of the step = end of its last stream: the pose stream when a frame was processed
-    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream : c->stream));
+    if (rc != VO_OK) {
+        // the step has consumed its pairs and part of it may be running: wait for the device, then refuse everything
+        // until the caller starts over -- the ring / staging slots of this step must not be rewritten under it
+        const std::string why = c->err;
+        (void)sync_all(c);
+        c->err = why;
+        q.broken = true;
+        return rc;
+    }
+    // end of the step = end of its last stream: the pose stream when a frame was processed; without a processed frame
+    // the step's work is the ingest + pyramids (+ FAST) -- on the prepare stream when there is one
+    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream
+                                                  : q.prep               ? q.copy
+                                                                         : c->stream));
     q.step_pending[slot] = true;
     q.step++;
     return VO_OK;

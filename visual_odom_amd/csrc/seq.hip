@@ -95,7 +95,7 @@ __global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpRe
         return;
     const PnpResult r = results[f];
     double *P = pose + (size_t)f * 16;
-    int flags = VO_SEQ_F_ACTIVE;
+    int flags = VO_SEQ_F_ACTIVE | ((active[f] & 2) ? VO_SEQ_F_GAP : 0);
     float euler[3] = {0.f, 0.f, 0.f};
     double R[9], t[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
     for (int k = 0; k < 9; k++)

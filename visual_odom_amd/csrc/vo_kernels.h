@@ -80,6 +80,7 @@ struct SeqIngest {
 #define VO_SEQ_F_INTEGRATED 2
 #define VO_SEQ_F_TOO_FEW 4
 #define VO_SEQ_F_NO_ESSENTIAL 8
+#define VO_SEQ_F_GAP 16
 #endif
 
 #ifndef VO_HOST_EMUL
