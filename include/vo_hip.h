@@ -26,7 +26,8 @@ extern "C" {
 #define VO_ERR_ARG (-1)      /* bad argument / size beyond the capacity given to vo_create */
 #define VO_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define VO_ERR_STATE (-3)    /* call order violated (e.g. run before configure) */
-#define VO_ERR_TOO_FEW (-4)  /* fewer than 5 correspondences reached PnP (OpenCV would CV_Assert) */
+#define VO_ERR_TOO_FEW (-4)  /* fewer than 4 correspondences reached solvePnPRansac (OpenCV would CV_Assert), fewer
+                                than 5 reached findEssentialMat */
 #define VO_ERR_OVERFLOW (-5) /* detection / bucketing produced more features than the capacity given to vo_create:
                                 the stored result is truncated and differs from the reference's -- never silent */
 /* positive return codes of the pose calls: the call worked, the reference's algorithm reported a failure */
@@ -116,7 +117,10 @@ int vo_triangulate(vo_ctx *ctx, const float *P_l, const float *P_r, const float 
  * f64[9] row-major) = Rodrigues(rvec).  inliers (optional, int32[n]) / n_inliers as cv::Mat
  * inliers.  Iterations / threshold / confidence come from vo_params.
  * R_out is Rodrigues(rvec) whatever vo_params.mono_rotation says (that flag belongs to vo_track_frame).
- * Returns VO_OK when a model was found, VO_NO_MODEL when RANSAC found none (OpenCV returns false). */
+ * Returns VO_OK when a model was found, VO_NO_MODEL when RANSAC found none (OpenCV returns false).
+ * Point counts: n >= 6 RANSAC over 5-point EPnP + refinement; n == 5 EPnP on all five; n == 4 OpenCV's P3P switch
+ * (`npoints == 4 -> SOLVEPNP_P3P`, solvePnP's answer as is, all four points inliers; without a P3P solution
+ * VO_NO_MODEL with rvec_io / tvec_io UNTOUCHED, as solvePnP leaves them); n < 4 VO_ERR_TOO_FEW. */
 int vo_pnp_ransac(vo_ctx *ctx, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers);
 
@@ -131,7 +135,8 @@ int vo_essential_pose(vo_ctx *ctx, const float *pts0_xy, const float *pts1_xy, i
                       int *n_good);
 /* Replaces cv::FAST as called by featureDetectionFast() -- feature.cpp:39-47: TYPE_9_16 corners of an
  * 8-bit image in row-major order.  pts_out [2 * cap]; *n_out = corners found (may exceed cap, in which
- * case only the first cap are written). */
+ * case only the first cap are written).  VO_ERR_OVERFLOW when the corners exceed the context's own corner-list
+ * capacity max(4 * max_pts, 16384, max_w * max_h / 16) although the caller's cap would have held them. */
 int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
                    float *pts_out, int cap, int *n_out);
 
@@ -253,7 +258,7 @@ int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double 
                                   ransac_iters, overflow */
 #define VO_SEQ_F_ACTIVE 1      /* flags */
 #define VO_SEQ_F_INTEGRATED 2  /* the motion passed the gates of main.cpp:201 / utils.cpp:80 and was integrated */
-#define VO_SEQ_F_TOO_FEW 4     /* fewer than 5 points reached solvePnPRansac (the reference asserts) */
+#define VO_SEQ_F_TOO_FEW 4     /* fewer than 4 points reached solvePnPRansac (the reference asserts) */
 #define VO_SEQ_F_NO_ESSENTIAL 8
 #define VO_SEQ_F_GAP 16        /* first frame processed after the sequence had paused (no pair for >= 1 step): the motion
                                   between the last pair before the pause and the first pair after it was never

@@ -169,6 +169,35 @@ def solve_pnp_ransac(xyz, uv, K, rvec=None, tvec=None, iterations=500, reproj=0.
     return rc, rv, tv, inl[:ninl.value].copy(), dbg
 
 
+def solve_p3p(xyz, uv, K):
+    """solvePnP(SOLVEPNP_P3P) on exactly 4 points (orc_p3p.c): (n_solutions, rvecs [n][3], tvecs [n][3]) in solveP3P's
+    final order (the first one is what solvePnPRansac returns)"""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(4, 3)
+    uv = np.ascontiguousarray(uv, np.float32).reshape(4, 2)
+    K = np.ascontiguousarray(K, np.float32).reshape(3, 3)
+    rv, tv = np.zeros(3), np.zeros(3)
+    rvs, tvs = np.zeros((4, 3)), np.zeros((4, 3))
+    n = lib().orc_solve_p3p(_vp(xyz), _vp(uv), _vp(K), _vp(rv), _vp(tv), _vp(rvs), _vp(tvs))
+    return n, rvs[:n].copy(), tvs[:n].copy()
+
+
+def p3p_solve(K4, uv, xyz, p4p=True):
+    """p3p::solve on f64 data: K4 = (fx, fy, cx, cy), uv [4][2] pixels, xyz [4][3]; returns (R [n][3][3], t [n][3])"""
+    K4 = np.ascontiguousarray(K4, np.float64).reshape(4)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(4, 2)
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(4, 3)
+    R, t = np.zeros((4, 3, 3)), np.zeros((4, 3))
+    n = lib().orc_p3p_solve(_vp(K4), _vp(uv), _vp(xyz), int(p4p), _vp(R), _vp(t))
+    return R[:n].copy(), t[:n].copy()
+
+
+def solve_deg4(a, b, c, d, e):
+    x = np.zeros(4)
+    lib().orc_solve_deg4.argtypes = [C.c_double] * 5 + [C.c_void_p]
+    n = lib().orc_solve_deg4(a, b, c, d, e, _vp(x))
+    return x[:n].copy()
+
+
 def rodrigues(r):
     r = np.ascontiguousarray(r, np.float64)
     if r.size == 3:

@@ -703,8 +703,26 @@ int orc_solve_pnp_ransac(const float *xyz, const float *uv, int n, const float *
         *n_inliers = 0;
     if (n < 4)
         return -1; /* CV_Assert(npoints >= 4) */
-    if (n == 4)
-        return -2; /* P3P kernel: never reached by the reference in practice, not restated */
+    if (n == 4) {
+        /* `else if (npoints == 4) { model_points = 4; ransac_kernel_method = SOLVEPNP_P3P; }` and, model_points being
+         * npoints, `return solvePnP(opoints, ipoints, ..., SOLVEPNP_P3P)`: no RANSAC loop, no refinement (orc_p3p.c) */
+        int ns = orc_solve_p3p(xyz, uv, K, rvec, tvec, NULL, NULL);
+        if (dbg) {
+            dbg[0] = 1;
+            dbg[1] = ns > 0 ? 0 : -1;
+            dbg[2] = ns > 0 ? 4 : 0;
+            dbg[3] = 0;
+            dbg[4] = ns;
+        }
+        if (ns <= 0)
+            return 0; /* solvePnP returned false: rvec / tvec untouched, inliers released */
+        if (inliers)
+            for (int i = 0; i < 4; i++)
+                inliers[i] = i;
+        if (n_inliers)
+            *n_inliers = 4;
+        return 1;
+    }
     if (n == model_points) {
         /* solvePnP(opoints, ipoints, ..., ransac_kernel_method) on all points */
         double R[3][3], t[3];

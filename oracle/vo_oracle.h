@@ -91,6 +91,14 @@ int orc_solve_pnp_ransac(const float *xyz, const float *uv, int n, const float *
                          double *rvec, double *tvec, int iterations_count,
                          float reprojection_error, double confidence, int32_t *inliers,
                          int *n_inliers, double *dbg);
+/* solvePnPRansac with exactly 4 points = solvePnP(SOLVEPNP_P3P) (orc_p3p.c): number of solutions (0: rvec / tvec
+ * untouched); rvecs / tvecs (optional, [4][3]): all solutions in solveP3P's final order */
+int orc_solve_p3p(const float *xyz, const float *uv, const float *K, double *rvec, double *tvec, double *rvecs,
+                  double *tvecs);
+/* p3p::solve: image points in pixels (f64), K4 = fx fy cx cy; up to 4 poses R [4][9], t [4][3] */
+int orc_p3p_solve(const double *K4, const double *uv, const double *xyz, int p4p, double *R_out, double *t_out);
+/* polynom_solver.cpp solve_deg4: real roots of a x^4 + b x^3 + c x^2 + d x + e */
+int orc_solve_deg4(double a, double b, double c, double d, double e, double *x);
 void orc_rodrigues_vec2mat(const double *rvec, double *R /*9*/, double *dRdr /*27 or NULL*/);
 void orc_rodrigues_mat2vec(const double *R, double *rvec);
 /* EPnP on n>=4 correspondences; K as f32 3x3; uv already in pixels (f32) */

@@ -8,6 +8,7 @@
 #include "../../visual_odom_amd/csrc/vo_fivept.h"
 #include "../../visual_odom_amd/csrc/vo_linalg.h"
 #include "../../visual_odom_amd/csrc/vo_lkmath.h"
+#include "../../visual_odom_amd/csrc/vo_p3p.h"
 #include "../../visual_odom_amd/csrc/vo_tri.h"
 
 extern "C" {
@@ -15,6 +16,12 @@ void hc_epnp5(const float *xyz5, const float *uv5, const float *K, double *rvec,
 {
     vo::epnp5_solve(xyz5, uv5, K, rvec, tvec);
 }
+// solvePnPRansac's four-point case (vo_p3p.h): number of P3P solutions, rvec / tvec of the first sorted one
+int hc_p3p4(const float *xyz4, const float *uv4, const float *K, double *rvec, double *tvec)
+{
+    return vo::p3p4_solve(xyz4, uv4, K, rvec, tvec);
+}
+int hc_p3p_deg4(double a, double b, double c, double d, double e, double *x) { return vo::p3p_deg4(a, b, c, d, e, x); }
 void hc_rodrigues_v2m(const double *r, double *R, double *J) { vo::rodrigues_v2m(r, R, J); }
 void hc_rodrigues_m2v(const double *R, double *r) { vo::rodrigues_m2v(R, r); }
 void hc_triangulate(const float *Pl, const float *Pr, const float *pl, const float *pr, int n, float *xyz)

@@ -142,7 +142,14 @@ def test_real_photograph_through_every_stage(volib, orc):
     l0, r0, l1, r1 = quad
     h, w = l0.shape
     P_l, P_r = synth.proj_matrices(**cs.REAL_CALIB)
-    ctx = volib.Context(0, w, h, 8192, 1)
+    small = volib.Context(0, w, h, 1024, 1)   # corner list of 23 156 entries (w h / 16) < the 45 905 corners below
+    try:
+        with pytest.raises(volib.VoError) as e:
+            small.fast_detect(l0, 7, False, cap=1 << 17)
+        assert e.value.code == volib.VO_ERR_OVERFLOW  # never a silently truncated list
+    finally:
+        small.close()
+    ctx = volib.Context(0, w, h, 16384, 1)
     try:
         for img in (l0, r0, l1):
             for nonmax in (True, False):

@@ -260,3 +260,39 @@ def test_second_context_runs_at_the_speed_of_the_first(volib, small_world):
     c = step_ms()
     print("one-sequence step: first context %.3f ms, second %.3f ms, third %.3f ms" % (a, b, c))
     assert min(b, c) <= 1.15 * a
+
+
+def test_pnp_ransac_with_exactly_four_points_is_opencv_p3p_switch(volib, orc):
+    """visualOdometry.cpp:176 with K = 4 survivors: OpenCV's `npoints == 4 -> SOLVEPNP_P3P`, solvePnP's answer as is.
+    p3p_kernel against oracle/orc_p3p.c: same solution (pow / acos / cos are the device's, so to rounding -- stated bar
+    1e-9 relative on these well-conditioned quadruples, 1e-6 absolute like every other pose test), inliers 0..3, no
+    refinement; a quadruple without a P3P solution leaves rvec / tvec untouched and reports VO_NO_MODEL"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_p3p import planted, KM
+    ctx = volib.Context(0, 1241, 376, 1024, 4)
+    try:
+        rng = np.random.default_rng(5)
+        worst, diffs = 0.0, []
+        for k in range(200):
+            X, uv, rv, t = planted(rng, noise=0.3 if k % 2 else 0.0)
+            Xf, uvf = np.ascontiguousarray(X, np.float32), np.ascontiguousarray(uv, np.float32)
+            rc, r_o, t_o, inl, dbg = orc.solve_pnp_ransac(Xf, uvf, KM, rvec=[0.5, 0.5, 0.5], tvec=[3, 3, 3])
+            found, r_g, t_g, R_g, inl_g = ctx.pnp_ransac(Xf, uvf, KM, rvec=[0.5, 0.5, 0.5], tvec=[3, 3, 3])
+            assert found == (rc == 1), k
+            assert np.array_equal(inl_g, inl)
+            if rc == 1:
+                assert list(inl) == [0, 1, 2, 3]
+                d = max(np.abs(r_g - r_o).max(), np.abs(t_g - t_o).max())
+                worst = max(worst, d)
+                diffs.append(d)
+                assert np.allclose(R_g, orc.rodrigues(r_g), atol=1e-12)
+            else:  # untouched
+                assert np.array_equal(r_g, [0.5, 0.5, 0.5]) and np.array_equal(t_g, [3, 3, 3])
+                assert np.allclose(R_g, orc.rodrigues(np.array([0.5, 0.5, 0.5])), atol=1e-12)
+        # the quartic's closed form amplifies the last-ulp differences of the device's pow / acos / cos near double
+        # roots (the solver's known conditioning, tests/test_p3p.py), hence quantiles: the bulk agrees to rounding
+        print("P3P on the device vs the checker: median %.3g, 90 %% %.3g, worst %.3g over %d quadruples"
+              % (np.median(diffs), np.percentile(diffs, 90), worst, len(diffs)))
+        assert len(diffs) > 150 and np.median(diffs) <= 1e-9 and np.percentile(diffs, 90) <= 1e-6
+    finally:
+        ctx.close()

@@ -4,6 +4,7 @@
 #include "../../include/vo_hip.h"
 #include "vo_kernels.h"
 #include "vo_integrate.h"
+#include "vo_linalg.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -24,7 +25,8 @@ using namespace vo;
 
 // the HIP streams of one context (pooled per device, see acquire_streams)
 struct StreamSet {
-    hipStream_t stream = nullptr, pnp = nullptr, pnp2 = nullptr, filter = nullptr, em = nullptr, copy = nullptr;
+    hipStream_t stream = nullptr, pnp = nullptr, pnp2 = nullptr, filter = nullptr, em = nullptr;
+    hipStream_t copy = nullptr, prep = nullptr; // lock-step loop: plain copy stream / highest-priority prepare stream
     int id = 0; // creation rank on its device: the pool hands out the oldest free set first
 };
 
@@ -323,21 +325,27 @@ bool acquire_streams(int device, StreamSet *out)
     return ok;
 }
 
-// the lock-step loop's copy / prepare stream, created the first time a context of this set needs it (highest priority:
-// when it carries the prepare work its short memory-bound kernels have to find SIMD slots between the running step's LK
-// waves; when it only carries the ingest kernel the priority does not matter)
-bool ensure_copy_stream(StreamSet *s)
+// The lock-step loop's copy stream, created the first time a context of this set needs it.  Two flavours: the PREPARE
+// stream has the highest priority (it carries the new pairs' pyramids and FAST besides the ingest kernel, short
+// memory-bound kernels that have to find SIMD slots between the running step's LK waves); the plain COPY stream only
+// carries the ingest kernel and keeps the default priority -- at the highest priority that kernel runs into the current
+// step's pyramid / detection / LK kernels and costs each ~0.2 ms at 256 sequences (measured, round 3: 22.4 k -> 21.1 k
+// frames/s).
+hipStream_t ensure_copy_stream(StreamSet *s, bool prepare)
 {
-    if (s->copy)
-        return true;
+    hipStream_t &st = prepare ? s->prep : s->copy;
+    if (st)
+        return st;
     int least = 0, greatest = 0;
-    return hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-           hipStreamCreateWithPriority(&s->copy, hipStreamNonBlocking, greatest) == hipSuccess;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    ok = ok && (prepare ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest)
+                        : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) == hipSuccess;
+    return ok ? st : nullptr;
 }
 
 void release_streams(int device, const StreamSet &s)
 {
-    hipStream_t all[] = {s.stream, s.pnp, s.pnp2, s.filter, s.em, s.copy};
+    hipStream_t all[] = {s.stream, s.pnp, s.pnp2, s.filter, s.em, s.copy, s.prep};
     for (hipStream_t st : all)
         if (st)
             (void)hipStreamSynchronize(st);
@@ -1365,7 +1373,12 @@ static int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, doubl
     PnpResult r;
     VO_HIP_TRY(c, hipMemcpyAsync(&r, pb.results + frame, sizeof(r), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (r.status >= 0) {
+    if (r.status == 0 && r.lm_iters < 0) {
+        // four points, P3P without a solution: solvePnP returned false and never wrote rvec / tvec -- the caller's
+        // buffers stay as they are; the reference then still runs Rodrigues(rvec, rotation) on what rvec holds
+        if (R && rvec && (pnp_rotation || !c->prm.mono_rotation))
+            rodrigues_v2m(rvec, R, nullptr);
+    } else if (r.status >= 0) {
         if (rvec)
             memcpy(rvec, r.rvec, sizeof(r.rvec));
         if (tvec)
@@ -1576,8 +1589,8 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
         const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
         q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames || seq_light_band(c, n_seq, cells * c->dprm.features_per_bucket);
     }
-    bool ok = ensure_copy_stream(&c->streams);
-    q.copy = c->streams.copy;
+    q.copy = ensure_copy_stream(&c->streams, q.prep);
+    bool ok = q.copy != nullptr;
     ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
     ok = ok && dmalloc(&q.d_ncorn, (size_t)ring * S) == hipSuccess;
     ok = ok && hipMemset(q.d_ncorn, 0, sizeof(int) * ring * S) == hipSuccess;
@@ -2091,7 +2104,7 @@ static int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out
     if (n_inliers)
         *n_inliers = ninl;
     if (status < 0)
-        return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached solvePnPRansac");
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
     if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
         return VO_NO_ESSENTIAL;
     return status == 1 ? VO_OK : VO_NO_MODEL;
@@ -2170,6 +2183,9 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     if (k > 0)
         VO_HIP_TRY(c, hipMemcpy(pts_out, c->d_feat, sizeof(float2) * k, hipMemcpyDeviceToHost));
     *n_out = n;
+    if (n > c->fcap && cap > c->fcap) // the caller's buffer would have held them, the context's corner list does not
+        return fail(c, VO_ERR_OVERFLOW, "vo_fast_detect: more corners than the context's corner-list capacity "
+                                        "(max(4 x max_pts, 16384, max_w x max_h / 16)): only that many were written");
     return VO_OK;
 }
 
@@ -2272,7 +2288,10 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     if (n_circ)
         *n_circ = M;
     // the pose, by the rules of vo_batch_get_pose / fetch_pose
-    if (r.status >= 0) {
+    if (r.status == 0 && r.lm_iters < 0) { // P3P without a solution: rvec / tvec untouched (see get_pose_impl)
+        if (R_out && rvec_io && !c->prm.mono_rotation)
+            rodrigues_v2m(rvec_io, R_out, nullptr);
+    } else if (r.status >= 0) {
         if (rvec_io)
             memcpy(rvec_io, r.rvec, sizeof(r.rvec));
         if (tvec_io)
@@ -2293,7 +2312,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     if (n_inliers)
         *n_inliers = r.n_inliers;
     if (r.status < 0)
-        return fail(c, VO_ERR_TOO_FEW, "fewer than 5 correspondences reached solvePnPRansac");
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
     if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
         return VO_NO_ESSENTIAL;
     return r.status == 1 ? VO_OK : VO_NO_MODEL;

@@ -15,12 +15,15 @@
 //                              squared error <= thr^2, wave sum -> inlier count
 //   4. ransac_replay_kernel    one thread per frame continues "keep first strictly better,
 //                              niters = RANSACUpdateNumIters(...)" over the new counts
+//   (frames with exactly 4 points take no part in 1-5: OpenCV switches to P3P and returns solvePnP's answer
+//    directly -- p3p_kernel, one thread per frame, vo_p3p.h)
 //   5. select_refine_kernel    one workgroup per frame: winning hypothesis and the last one OpenCV
 //                              would have evaluated (its pose is the start of the final refinement
 //                              because rvec/tvec are shared buffers), inlier mask, the CvLevMarq
 //                              state machine with block-wide reductions of J^T J / J^T e, rvec -> R.
 #include "vo_kernels.h"
 #include "vo_epnp.h"
+#include "vo_p3p.h"
 
 #include <float.h>
 #include <stdlib.h>
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
     PnpResult &res = results[frame];
     if (count < 5) {
         if (tid == 0) {
-            res.status = count == 4 ? -2 : -1; // CV_Assert(npoints >= 4) / P3P path not provided
+            res.status = -1; // CV_Assert(npoints >= 4); exactly 4 points: p3p_kernel overwrites this record
             res.n_inliers = 0;
             res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
         }
@@ -489,6 +492,46 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
     }
 }
 
+// solvePnPRansac with exactly four correspondences: `npoints == 4 -> model_points = 4, SOLVEPNP_P3P`, and model_points
+// being npoints the call IS solvePnP(P3P): first of solveP3P's sorted solutions, no refinement, all four points inliers;
+// no solution -> false, rvec / tvec untouched (lm_iters = -1 marks "pose buffers untouched" for the host side and the
+// lock-step loop), inliers released.  One thread per frame; frames with any other count return at once.
+__global__ void p3p_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv, size_t uv_stride,
+                           const int *__restrict__ n_pts, int cap, int n_frames, PnpParams prm,
+                           int32_t *__restrict__ inliers, PnpResult *__restrict__ results)
+{
+    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (frame >= n_frames || n_pts[frame] != 4)
+        return;
+    float x4[12], u4[8];
+    for (int i = 0; i < 4; i++) {
+        const float *p = xyz + ((size_t)frame * cap + i) * 3;
+        x4[3 * i] = p[0];
+        x4[3 * i + 1] = p[1];
+        x4[3 * i + 2] = p[2];
+        const float2 q = uv[frame * uv_stride + i];
+        u4[2 * i] = q.x;
+        u4[2 * i + 1] = q.y;
+    }
+    PnpResult &res = results[frame];
+    double rv[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
+    const int ns = p3p4_solve(x4, u4, prm.K, rv, tv);
+    for (int k = 0; k < 3; k++) {
+        res.rvec[k] = rv[k];
+        res.tvec[k] = tv[k];
+    }
+    rodrigues_v2m(rv, res.R, nullptr);
+    res.niters = 1;
+    res.max_good = ns > 0 ? 4 : 0;
+    res.best_iter = ns > 0 ? 0 : -1;
+    res.lm_iters = ns > 0 ? 0 : -1;
+    res.n_inliers = ns > 0 ? 4 : 0;
+    res.status = ns > 0 ? 1 : 0;
+    if (ns > 0)
+        for (int i = 0; i < 4; i++)
+            inliers[(size_t)frame * cap + i] = i;
+}
+
 void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
                            RansacState *rstate, hipStream_t stream)
 {
@@ -544,6 +587,8 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
     else
         hipLaunchKernelGGL(select_refine_kernel<1>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, inliers, results);
+    hipLaunchKernelGGL(p3p_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
+                       n_frames, prm, inliers, results);
 }
 
 } // namespace vo

@@ -100,12 +100,22 @@ __global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpRe
     double R[9], t[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
     for (int k = 0; k < 9; k++)
         R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    const int row = n_rows[f];
     if (r.status < 0) {
         flags |= VO_SEQ_F_TOO_FEW; // the reference's solvePnPRansac asserts here; the pose stays
     } else {
         for (int k = 0; k < 3; k++) {
             t[k] = r.tvec[k];
             rv[k] = r.rvec[k];
+        }
+        if (r.status == 0 && r.lm_iters < 0) {
+            // four points and P3P found no solution: solvePnP returned false with the shared buffers UNTOUCHED --
+            // rvec is the zeros of visualOdometry.cpp:162, `translation` is still the previous frame's (main.cpp:82)
+            const bool have_prev = row > 0 && row <= max_steps;
+            for (int k = 0; k < 3; k++) {
+                rv[k] = 0;
+                t[k] = have_prev ? traj[((size_t)f * max_steps + row - 1) * VO_SEQ_ROW + 15 + k] : 0.0;
+            }
         }
         bool have_R = true;
         if (em) { // mono_rotation: rotation = recoverPose's (visualOdometry.cpp:146-157)
@@ -118,13 +128,13 @@ __global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpRe
                 flags |= VO_SEQ_F_NO_ESSENTIAL; // recoverPose throws on the empty E in the reference
             }
         } else {
-            for (int k = 0; k < 9; k++)
-                R[k] = r.R[k];
+            if (!(r.status == 0 && r.lm_iters < 0)) // (untouched: R stays Rodrigues(0) = identity)
+                for (int k = 0; k < 9; k++)
+                    R[k] = r.R[k];
         }
         if (have_R && integrate_odometry(P, R, t, euler))
             flags |= VO_SEQ_F_INTEGRATED;
     }
-    const int row = n_rows[f];
     if (row < max_steps) {
         double *o = traj + ((size_t)f * max_steps + row) * VO_SEQ_ROW;
         for (int k = 0; k < 12; k++)

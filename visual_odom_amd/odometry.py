@@ -73,7 +73,7 @@ class StereoOdometry:
         rec = dict(n_bucketed=len(pts), n_tracked=len(out["l1"]), n_inliers=len(out["inliers"]), rc=out["rc"],
                    rvec=out["rvec"].copy(), tvec=out["tvec"].copy(), integrated=False)
         if out["rc"] == _lib.VO_ERR_TOO_FEW:
-            raise _lib.VoError(out["rc"], "fewer than 5 correspondences reached solvePnPRansac (the reference asserts here)")
+            raise _lib.VoError(out["rc"], "fewer than 4 correspondences reached solvePnPRansac (the reference asserts here)")
         if self.mono_rotation and self.ctx.batch_get_essential(0, 0)["status"] != 1:
             raise _lib.VoError(1, "findEssentialMat found no model (the reference's recoverPose throws on the empty E)")
         self.rotation, self.translation = out["R"], out["tvec"]
