@@ -49,6 +49,8 @@ WORKLOADS = {
                                    "(bucket=rows/10, 6 per bucket), maxLevel 3"),
     "kitti374": (1241, 376, 1, 3, "KITTI-00-shaped 1241x376 stereo, reference-default bucketing "
                                   "(1 per bucket, <=374 pts), maxLevel 3"),
+    "zed374": (1280, 720, 1, 3, "calibration/zed.yaml-shaped 1280x720 stereo, reference-default bucketing (1 per bucket), maxLevel 3"),
+    "rgbd374": (640, 480, 1, 3, "calibration/rgbd.yaml-shaped 640x480 stereo, reference-default bucketing (1 per bucket), maxLevel 3"),
     "hd4000": (1920, 1080, 60, 3, "synthetic 1920x1080 stereo, 4000 keypoints/frame fed at the boundary "
                                   "(60 per bucket, 3 px spacing, first 4000), maxLevel 3"),
     "hd4000l4": (1920, 1080, 60, 4, "synthetic 1920x1080 stereo, 4000 keypoints/frame fed at the boundary "
@@ -227,6 +229,9 @@ def main(argv=None):
                     help="default run only: skip the additional legs reported in `configs` (BASELINE config 2 = LK only, the "
                          "reference-default 374-point load, config 4 = 1080p / 4000 points at maxLevel 3 and 4)")
     ap.add_argument("--hd-frames", type=int, default=128, help="frames per step of the config-4 legs")
+    ap.add_argument("--schedule", default=None,
+                    help="pin the pose-chain schedule instead of letting the library probe it: pose_waves,pose_streams,prepare "
+                         "(vo_set_schedule: 0 / 0 / -1 = probe); tools/schedule_sweep.py uses it to hold the probe to every candidate")
     args = ap.parse_args(argv)
 
     # --gpus N is a promise about the line that gets printed: n_gpus = N ranks, one per GPU.  Launched by
@@ -322,7 +327,7 @@ def main(argv=None):
                          "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
                          "frames_per_step": r["config"]["frames_per_step_per_gpu"],
                          "points_per_frame": r["config"]["points_per_frame"], "validated_frames": r["validated_frames"],
-                         "stage_ms": r["config"]["stage_ms"], "roofline": r["roofline"]})
+                         "schedule": r["config"]["schedule"], "stage_ms": r["config"]["stage_ms"], "roofline": r["roofline"]})
 
         leg("config2_lk_only", 2, kept[0], stages="lk")
         leg("reference_default_374", 3, kept[0], workload="kitti374", steps=20)
@@ -364,6 +369,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     if own_ctx:
         ctx = _lib.Context(local_dev, w, h, 8192, B)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
+    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()
     n_images = 2 * (B + 1)
     # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
     dev_t = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev),
@@ -440,6 +446,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                        "frames_per_step_per_gpu": B, "pyramids_per_step_per_gpu": n_images,
                        "points_per_frame": float(np.mean([len(p) for p in frame_pts])),
                        "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,
+                       "schedule": ctx.get_schedule(),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes,
                        "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
@@ -477,6 +484,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     if own_ctx:
         ctx = _lib.Context(local_dev, w, h, 4096, S)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
+    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()
     ctx.batch_set_detect_params(features_per_bucket=per_bucket)
     ctx.seq_configure(S, w, h, args.ring, K + W + 8)
     ctx.batch_set_projection(*world.proj_matrices())
@@ -551,6 +559,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                        "frames_per_step_per_gpu": S, "pyramids_per_step_per_gpu": 2 * S,
                        "points_per_frame": pts_per_launch / S, "integrated_fraction": float(integrated),
                        "parallelism": "replicas x%d (%d sequences per GPU, no collective)" % (world_size, S),
+                       "schedule": ctx.get_schedule(),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes},
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,

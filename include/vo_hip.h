@@ -88,6 +88,25 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
 void vo_destroy(vo_ctx *ctx);
 const char *vo_last_error(const vo_ctx *ctx);
 int vo_set_params(vo_ctx *ctx, const vo_params *p);
+
+/* How the pose chain (PnP / RANSAC, f64) is scheduled next to the tracking stages (pyramids, FAST, LK).  None of the
+ * three knobs changes a result.  By default (all "probe") the first run of a new (mode, image size, frames per run,
+ * point-load) key times the candidates on the caller's own data -- a batch run is idempotent; a lock-step step is
+ * repeated without the two kernels that advance its state -- keeps the fastest and remembers it for the process.  That
+ * first run therefore takes about a dozen runs' time.  Pin a knob to skip its probe (all three pinned: no probe at
+ * all).  The reference has no counterpart: its calls are synchronous CPU code.
+ *   pose_waves    register budget of the pose kernels in waves per SIMD: 1 = 512 registers, 2 = 256; 0 = probe
+ *   pose_streams  1 or 2 pose streams (2: the chains of consecutive runs overlap); 0 = probe
+ *   prepare       lock-step loop: pyramids + FAST of the new pairs one step ahead on a prepare stream; -1 = probe */
+typedef struct vo_schedule {
+    int pose_waves;
+    int pose_streams;
+    int prepare;
+} vo_schedule;
+/* s == NULL: probe everything (the default) */
+int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
+/* the schedule the next run will use; *probed (optional) = 1 when it came out of a probe of this key */
+int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
 int vo_get_params(const vo_ctx *ctx, vo_params *p);
 
 /* ------------------------------------------------------------------------------------------

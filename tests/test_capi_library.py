@@ -124,3 +124,21 @@ def test_cpp_host_program_builds_and_fails_loudly_without_gpu(vo_run_binary, tmp
     r = subprocess.run([vo_run_binary, str(d), "300", "48", "32", "-100", "2", str(tmp_path / "p.txt")],
                        capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_product_library_reads_no_environment_variable():
+    """the fourteen getenv switches and the measured-slower kernel variants live in the developer build
+    (python -m visual_odom_amd.build --dev -> libvo_hip_dev.so, -DVO_DEV_VARIANTS) only: libvo_hip.so does not even import
+    getenv, and does not contain the two-features-per-wavefront LK kernel, the 128-register pose kernels or the 128 x 32 FAST tile"""
+    import subprocess
+    from visual_odom_amd import build
+    so = build.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    blob = open(so, "rb").read()
+    for name in (b"lk_circular_pair_kernel", b"fast_tile_big_kernel"):
+        assert name not in blob, name
+    assert b"lk_circular_kernel" in blob and b"p3p_kernel" in blob
+    # kernel symbols are mangled: epnp_kernel<4> / select_refine_kernel<4> = ...ILi4EE...
+    assert b"epnp_kernelILi4EE" not in blob and b"select_refine_kernelILi4EE" not in blob
+    assert b"epnp_kernelILi2EE" in blob and b"epnp_kernelILi1EE" in blob

@@ -309,7 +309,7 @@ def test_batch_ragged_equals_single(gpu_ctx, volib, orc, small_world, small_seq)
         assert np.array_equal(got["keep_idx_circ"], ref["keep_idx"])
         assert np.array_equal(bits(got["l1"]), bits(l1)) and np.array_equal(bits(got["r1"]), bits(r1))
         pose = gpu_ctx.batch_get_pose(f)
-        if len(l0) >= 5:
+        if len(l0) >= 4:  # 4 survivors (the 7-point set): OpenCV's P3P switch, here without a solution -> status 0
             xyz = orc.triangulate(P_l, P_r, l0, r0)
             rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(xyz, l1, small_world.K())
             assert pose["status"] == rc and np.array_equal(pose["inliers"], inl)
@@ -425,7 +425,7 @@ def test_batch_detect_stage_feeds_lk(gpu_ctx, volib, orc, small_world, small_seq
             got = gpu_ctx.batch_get_filtered(f)
             assert np.array_equal(got["keep_idx_circ"], ref["keep_idx"])
             assert np.array_equal(bits(got["l1"]), bits(l1)) and np.array_equal(bits(got["r0"]), bits(r0))
-            if len(l0) >= 5:
+            if len(l0) >= 4:
                 xyz = orc.triangulate(P_l, P_r, l0, r0)
                 rc, rv, tv, inl, _ = orc.solve_pnp_ransac(xyz, l1, small_world.K())
                 pose = gpu_ctx.batch_get_pose(f)

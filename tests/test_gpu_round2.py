@@ -169,42 +169,3 @@ def test_config4_as_written_1080p_4000_points_max_level_4(volib, orc):
             assert np.array_equal(g1[k], g2[k])
     finally:
         ctx.close()
-
-
-def test_two_features_per_wave_lk_kernel_is_bit_identical(volib, monkeypatch, small_seq):
-    """VERDICT r01 item 3 asked for the 2-features-per-wavefront LK variant to be built and measured: lk_circular_pair_kernel
-    (VO_LK_PAIR=1).  Same tracks and status bytes as lk_circular_kernel on odd and even numbers of points (a wavefront with
-    an empty half), points off the image and a batch of several frames (forward, backward and a static quadruple), in both
-    retirement modes."""
-    s = small_seq
-    h, w = s["L"][0].shape
-    rng = np.random.default_rng(11)
-    extra = np.stack([rng.uniform(-30, w + 30, 40), rng.uniform(-30, h + 30, 40)], 1).astype(np.float32)
-    pts = [np.vstack([s["pts"][k % 2], extra])[:len(s["pts"][k % 2]) + 40 - (k % 2)] for k in range(3)]
-    out = {}
-    for pair in ("0", "1"):
-        monkeypatch.setenv("VO_LK_PAIR", pair)
-        ctx = volib.Context(0, w, h, 4096, 3)
-        try:
-            res = []
-            for full in (1, 0):
-                ctx.set_params(lk_full_chain=full)
-                ctx.batch_configure(6, w, h, 3)
-                for k in range(3):
-                    ctx.batch_upload_image(2 * k, s["L"][k])
-                    ctx.batch_upload_image(2 * k + 1, s["R"][k])
-                ctx.batch_set_quads([[0, 1, 2, 3], [4, 5, 2, 3], [4, 5, 4, 5]])
-                for k in range(3):
-                    ctx.batch_set_points(k, pts[k])
-                ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
-                ctx.batch_sync()
-                res.append([ctx.batch_get_tracks(k, len(pts[k])) for k in range(3)])
-            out[pair] = res
-        finally:
-            ctx.close()
-    for a, b in zip(out["0"], out["1"]):
-        for fa, fb in zip(a, b):
-            assert np.array_equal(fa["status4"], fb["status4"])
-            for key in ("r0", "r1", "l1", "l0_ret"):
-                assert np.array_equal(bits(fa[key]), bits(fb[key])), key          # bit for bit
-            assert fa["status4"].all(0).sum() > 100

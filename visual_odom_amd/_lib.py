@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libvo_hip.so")
+# VO_HIP_LIB: a developer build of the same library (python -m visual_odom_amd.build --dev -> libvo_hip_dev.so, the
+# measured-slower kernel variants and their environment switches compiled in) for tools/ -- never a different backend
+SO_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(HERE, "libvo_hip.so")
 
 VO_OK, VO_ERR_ARG, VO_ERR_HIP, VO_ERR_STATE, VO_ERR_TOO_FEW, VO_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
 VO_NO_MODEL, VO_NO_ESSENTIAL = 1, 2
@@ -32,7 +34,7 @@ EXPORTS = (
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
     "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_push_pairs", "vo_seq_step", "vo_seq_sync",
-    "vo_seq_get_state", "vo_seq_get_trajectory",
+    "vo_seq_get_state", "vo_seq_get_trajectory", "vo_set_schedule", "vo_get_schedule",
 )
 
 
@@ -47,6 +49,11 @@ class VoParams(C.Structure):
 class VoDetectParams(C.Structure):
     _fields_ = [("fast_threshold", C.c_int), ("fast_nonmax", C.c_int), ("redetect_below", C.c_int),
                 ("bucket_size", C.c_int), ("features_per_bucket", C.c_int)]
+
+
+class VoSchedule(C.Structure):
+    """vo_schedule (include/vo_hip.h): pose_waves 0 = probe / 1 / 2, pose_streams 0 = probe / 1 / 2, prepare -1 = probe / 0 / 1"""
+    _fields_ = [("pose_waves", C.c_int), ("pose_streams", C.c_int), ("prepare", C.c_int)]
 
 
 class VoError(RuntimeError):
@@ -144,6 +151,17 @@ class Context:
                 raise KeyError(k)
             setattr(p, k, v)
         self._chk(self.lib.vo_set_params(self.h, C.byref(p)))
+
+    def set_schedule(self, pose_waves=0, pose_streams=0, prepare=-1):
+        """pin knobs of the pose-chain schedule (0 / 0 / -1 = probe, the default); see vo_schedule in vo_hip.h"""
+        s = VoSchedule(int(pose_waves), int(pose_streams), int(prepare))
+        self._chk(self.lib.vo_set_schedule(self.h, C.byref(s)))
+
+    def get_schedule(self):
+        """the schedule the next run uses: dict(pose_waves, pose_streams, prepare, probed)"""
+        s, probed = VoSchedule(), C.c_int(0)
+        self._chk(self.lib.vo_get_schedule(self.h, C.byref(s), C.byref(probed)))
+        return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, probed=bool(probed.value))
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):

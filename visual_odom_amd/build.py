@@ -1,6 +1,12 @@
 """Build libvo_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m visual_odom_amd.build [--force]
+    python -m visual_odom_amd.build [--force] [--dev]
+
+--dev additionally builds libvo_hip_dev.so with -DVO_DEV_VARIANTS: the same library plus the kernel variants that were
+built, measured and lost (two-features-per-wavefront LK, 128-register pose kernels, 128 x 32 FAST tile, ordinary-store
+Scharr) and the environment switches that select them (VO_LK_PAIR, VO_POSE_WAVES via vo_set_schedule(4), VO_FAST_TILE,
+VO_SCHARR_NT, VO_EPNP_LDS_KB, VO_SERIAL_POSE).  tools/ uses it (VO_HIP_LIB=.../libvo_hip_dev.so); the product library has
+none of them and reads no environment variable.
 
 Flags that matter for parity: -ffp-contract=off (no FMA contraction: the f32 2x2 LK solve and the
 f64 pose math must round like the CPU path) and correctly rounded f32 divide / sqrt.
@@ -24,9 +30,11 @@ def _newer(target, deps):
     return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
-    flags = list(FLAGS)
+def build(force=False, verbose=False, dev=False):
+    obj_dir = OBJ + ("_dev" if dev else "")
+    so = SO.replace("libvo_hip.so", "libvo_hip_dev.so") if dev else SO
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = list(FLAGS) + (["-DVO_DEV_VARIANTS"] if dev else [])
     if os.environ.get("VO_LK_ATTRS"):  # developer A/B of the LK kernel's register caps
         flags.append("-DVO_LK_ATTRS=" + os.environ["VO_LK_ATTRS"])
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -34,7 +42,7 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or not _newer(obj, [src] + headers):
             jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
@@ -51,10 +59,12 @@ def build(force=False, verbose=False):
         for msg in ex.map(run, jobs):
             if verbose and msg.strip():
                 print(msg)
-    if force or jobs or not _newer(SO, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
-    return SO
+    if force or jobs or not _newer(so, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    return so
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -106,28 +108,32 @@ struct vo_ctx {
     // second pose stream: in a SMALL batch the pose chain is a few latency-bound waves (1.0-1.3 ms for one frame) and
     // longer than the tracking stages of the next run, so back-to-back runs were throttled by it (lock-step loop with
     // one sequence: 1.35 ms per step, of which 1.3 ms waiting behind the previous step's chain).  Runs alternate between
-    // the two buffer sets anyway; giving each set its own stream lets two chains overlap.  Large batches keep one
-    // stream (two were measured slower there).
+    // the two buffer sets anyway; giving each set its own stream lets two chains overlap.  Whether that pays is part of
+    // the SCHEDULE, which is probed, not looked up (see Schedule below).
     hipStream_t stream_pnp2 = nullptr;
-    // Frames per run up to which the second pose stream (and, in the lock-step loop, the prepare stream) is used
-    // (VO_POSE2_FRAMES; 0 = never).  Measured, lock-step loop, both on against both off (gpurun_out r2 sweep): 374 points
-    // per frame 24 / 32 / 48 sequences +46 % / +35 % / +11 %, 64: -9 %; ~2000 points per frame 8 / 16 / 32 sequences
-    // +28 % / +13 % / +7 %, 64: -7 %.  The crossover follows the number of frames, not frames x points.
-    int pose2_frames = 48;
-    // sequences from which the lock-step loop takes the 128-register pose kernels (VO_SEQ_CROWDED_MIN).  Measured at the
-    // reference-default load (gpurun_out/r2_04): 64 sequences 41.3 k frames/s with the 512-register kernels against
-    // 22.4 k with the 128-register ones (their chain then takes 5.5 ms and throttles the loop); 256 sequences 42.1 k
-    // against 44.2 k -> only from 256 on.
-    int seq_crowded_min = 256;
-    int pose_waves_forced = 0;         // VO_POSE_WAVES = 1 / 2 / 4: developer A/B of the pose kernels' register budget
-    long long pose_medium_min = 128;   // frames per run from which the 256-register pose kernels are used (VO_POSE_MEDIUM_MIN)
+    // How the pose chain is scheduled next to the tracking stages -- three knobs, none of which changes a result:
+    //   waves   register budget of the f64 pose kernels as waves per SIMD: 1 = 512 registers (fastest alone, but such a
+    //           wave only starts on a completely empty SIMD and keeps the next run's kernels waiting), 2 = 256 registers
+    //   streams 1 or 2 pose streams (2: the chains of consecutive runs overlap)
+    //   prep    lock-step loop only: the new pairs' pyramids + FAST of their left images on the prepare stream, one step
+    //           ahead and off the tracking stream's critical path
+    // Round 2 chose them from a table of constants fitted on two point loads at one image size (48 frames, a 49-96
+    // sequence band, 65 536 point-frames ...), which sent every other shape wherever the table happened to put it.  Now
+    // the first run of a new (mode, image size, frames, point-load) key PROBES the candidates on the caller's own data --
+    // a batch run is idempotent, a lock-step step is re-run without its state-carrying kernels -- keeps the fastest and
+    // remembers it for the process (tune_*).  vo_set_schedule() pins any knob instead.
+    struct Schedule {
+        int waves = 2, streams = 1, prep = 1;
+    } sched;
+    vo_schedule pin = {0, 0, -1};    // 0 / 0 / -1 = probe
+    long long sched_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0}; // key `sched` was resolved for
+    bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
+    bool tuning = false;             // inside a probe: run_stages must not start another one
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
-    bool serial_pose = false;
-    bool lk_pair = false; // VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip), same results
-    long long crowded_min = 65536; // frames x points from which the 128-register pose kernels are used (VO_CROWDED_MIN)
-    int crowded_min_pts = 1024;    // ... and points per frame (VO_CROWDED_MIN_PTS)
+    bool serial_pose = false; // -DVO_DEV_VARIANTS + VO_SERIAL_POSE=1: the whole chain on the tracking stream (profiling)
+    bool lk_pair = false;     // -DVO_DEV_VARIANTS + VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip)
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
     // PCIe as ONE contiguous copy (a pitched copy from pageable memory moves row by row: 3.3 ms per
     // 1241 x 376 image measured, tools/latency_mode.py)
@@ -176,12 +182,14 @@ struct vo_ctx {
         // their pyramids, and FAST + non-maximum suppression of their LEFT images -- the corners the NEXT step's
         // appendNewFeatures needs (visualOdometry.cpp:95-101 detects on imageLeft_t0, i.e. on the pair that arrived one
         // step earlier).  Per step the tracking stream is left with: bucketing -> LK -> filter -> carry.
-        bool prep = true;                 // VO_SEQ_PREP = 0: everything on the tracking stream (round-2 first version)
+        // (whether the prepare stream is used is vo_ctx::sched.prep; `copy` below is the stream the step's ingest kernel
+        // goes to: the prepare stream when it is, a plain copy stream when not)
         float2 *d_corners = nullptr;      // [ring][S][fcap] FAST corners of the left image in each ring slot
         int *d_ncorn = nullptr;           // [ring][S]
         hipEvent_t ev_pyr = nullptr;      // pyramids of the pending step built (prep stream)
         hipEvent_t ev_fast[VO_SEQ_MAX_RING] = {}; // corners of ring slot r ready (prep stream)
         bool fast_pending[VO_SEQ_MAX_RING] = {};
+        bool have_corners[VO_SEQ_MAX_RING] = {}; // d_corners of ring slot r belongs to the pair now in that slot
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
         int n_ing = 0;
         bool begun = false, staged = false;
@@ -208,41 +216,9 @@ int fail(vo_ctx *ctx, int code, const char *msg)
 }
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
-// "crowded": the LK launch of a batch keeps every SIMD full for long enough that a 512-register pose wave would
-// starve next to it -> the 128-register instantiations of the f64 pose kernels (see run_stages)
-inline bool is_crowded(const vo_ctx *c, long long frames, int pts)
-{
-    return frames * pts >= c->crowded_min && pts >= c->crowded_min_pts;
-}
-// Register budget of the f64 PnP kernels as waves per SIMD (pnp.hip): 1 = 512 registers (fastest alone), 2 = 256
-// registers from 128 frames per run on.  The chain's work grows with the number of FRAMES (128 hypotheses each); with
-// many frames its 512-register waves -- each needs a whole SIMD to itself -- keep the next run's pyramid / detection
-// kernels waiting, a 256-register wave leaves half a SIMD to them; with few frames the chain is the long pole and the
-// fastest kernels win whatever LK does beside them.
-// Measured (gpurun_out/r2_06, r2_14; frames/s at 1 / 2 / 4 waves): 256-frame batch at 340 points 59.2 k / 69.6 k / 46.6 k,
-// at 2040 points 18.8 k / 19.7 k / 18.6 k; lock-step loop with 256 sequences 42.6 k / 49.2 k / 44.3 k, 64 sequences
-// 41.3 k / 32.8 k / 22.3 k, 16 sequences 15.7 k / 14.0 k / 10.2 k; 16 frames x 4000 points at 1080p (BASELINE config 4)
-// 5.76 k / 5.25 k / 3.56 k.  The 128-register instantiation round 1 used for crowded batches is never the best one any
-// more and stays reachable through VO_POSE_WAVES = 4 only.
-// The lock-step loop between pose2_frames and 96 sequences at a light point load (<= 40 k point-frames per step, i.e. the
-// reference-default bucketing): there the second pose stream + prepare stream still pay, but only together with the
-// 256-register pose kernels.  Measured late in round 2 (frames/s, one pose stream + 512 registers = the rule outside the
-// band | both streams + 512 | both + 256): 64 sequences 41.7 k | 43.2 k | 45.3 k, 96 sequences 51.4 k | 47.2 k | 52.9 k,
-// 128 sequences 57.2 k (256 registers, one stream) | 46.5 k | 53.4 k -> the band ends at 96; at ~2000 points per frame
-// 64 sequences 20.0 k | - | 19.2 k -> light loads only.
-inline bool seq_light_band(const vo_ctx *c, long long frames, long long pts_bound)
-{
-    return c->pose2_frames > 0 && frames > c->pose2_frames && frames <= 96 && frames * pts_bound <= 40000;
-}
-inline int pose_waves(const vo_ctx *c, long long frames, int pts, bool crowded)
-{
-    (void)crowded;
-    if (c->pose_waves_forced)
-        return c->pose_waves_forced;
-    if (c->seq.on && seq_light_band(c, frames, pts))
-        return 2;
-    return frames >= c->pose_medium_min ? 2 : 1;
-}
+// register budget of the pose kernels for the stand-alone calls (vo_pnp_ransac, vo_essential_pose): nothing runs beside
+// them, so the full 512 registers unless the caller pinned the other variant
+inline int standalone_waves(const vo_ctx *c) { return c->pin.pose_waves ? c->pin.pose_waves : 1; }
 // the current feature set (see vo_ctx::pts_sel)
 inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
 inline int *cur_npts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_npts : c->d_npts_det[c->pts_sel]; }
@@ -501,32 +477,17 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->stream_em = c->streams.em;
     for (auto &ev : c->ev_trk_free)
         ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-    // profiling aid: VO_SERIAL_POSE=1 enqueues the pose solve on the tracking stream (no overlap), so
-    // that a kernel trace shows every kernel's stand-alone duration
+#ifdef VO_DEV_VARIANTS
+    // developer build only (python -m visual_odom_amd.build --dev -> libvo_hip_dev.so): VO_SERIAL_POSE=1 enqueues the pose
+    // solve on the tracking stream (no overlap), so that a kernel trace shows every kernel's stand-alone duration;
+    // VO_LK_PAIR=1 selects the measured-slower two-features-per-wavefront LK kernel
     {
-        const char *ec = getenv("VO_CROWDED_MIN");
-        if (ec)
-            c->crowded_min = atoll(ec);
-        const char *ep = getenv("VO_CROWDED_MIN_PTS");
-        if (ep)
-            c->crowded_min_pts = atoi(ep);
         const char *e = getenv("VO_SERIAL_POSE");
         c->serial_pose = e && e[0] == '1';
         const char *elp = getenv("VO_LK_PAIR");
         c->lk_pair = elp && elp[0] == '1';
-        const char *e2 = getenv("VO_POSE2_FRAMES");
-        if (e2)
-            c->pose2_frames = atoi(e2);
-        const char *e3 = getenv("VO_SEQ_CROWDED_MIN");
-        if (e3)
-            c->seq_crowded_min = atoi(e3);
-        const char *e4 = getenv("VO_POSE_WAVES");
-        if (e4 && (atoi(e4) == 1 || atoi(e4) == 2 || atoi(e4) == 4))
-            c->pose_waves_forced = atoi(e4);
-        const char *e5 = getenv("VO_POSE_MEDIUM_MIN");
-        if (e5)
-            c->pose_medium_min = atoll(e5);
     }
+#endif
     for (auto &e : c->ev)
         ok = ok && hipEventCreate(&e) == hipSuccess;
     c->ring.assign((size_t)VO_EVENT_SLOTS * (VO_EV_PER_RUN), nullptr);
@@ -667,6 +628,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
         c->pyr_count = n_images;
         return VO_OK;
     }
+    c->sched_key[0] = -1; // a new shape: the schedule is resolved again at its first run
     plan_levels(c, w, h);
     if (c->img_bytes * (size_t)n_images > c->pix_capacity)
         return fail(c, VO_ERR_ARG, "vo_batch_configure: pyramid storage exceeds capacity");
@@ -939,7 +901,9 @@ static int ensure_em(vo_ctx *c)
     return VO_OK;
 }
 
-static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr)
+// dry (lock-step loop, schedule probe): everything but the two kernels that advance a sequence's state (seq_carry,
+// seq_integrate) -- the step can then be repeated any number of times
+static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool dry = false)
 {
     if (!evs)
         evs = c->ev;
@@ -952,17 +916,9 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     const int B = c->n_frames, cap = c->cap;
     const bool touches_pose = (stages & (VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP)) != 0;
     vo_ctx::PoseBufs &pb = c->pb[c->cur];
-    // "crowded": the LK launch of this batch keeps every SIMD full for long enough that a 512-register pose wave
-    // would starve next to it -> 128-register instantiations of the f64 pose kernels.  That takes many point-frames
-    // AND many points per frame: 256 frames x 340 points are 87 k point-frames, but LK is over in 2.4 ms and the
-    // pose chain is the long pole there -- the fast (512-register) kernels give 59 k instead of 53 k frames/s
-    // (gpurun_out/r59)
-    // (the lock-step loop has DETECT on its critical path and the pose chain off it: from a few dozen sequences on, a
-    // 512-register pose wave -- which needs a whole SIMD to itself -- keeps the pyramid / detection kernels of the next
-    // step waiting: bucket_kernel 0.54 ms instead of 0.02 behind select_refine_kernel<1>, profiles/r02)
-    const bool crowded = is_crowded(c, B, c->max_pts_set) || (c->seq.on && B >= c->seq_crowded_min); // essential-matrix kernels
+    const bool crowded = c->sched.waves >= 2; // essential-matrix kernels: their reduced-register variant goes with the PnP one
     vo_ctx::Seq &sq = c->seq;
-    const bool prep = sq.on && sq.prep; // lock-step loop: pyramids (and, from vo_seq_step, FAST) on the prepare stream
+    const bool prep = sq.on && c->sched.prep; // lock-step loop: pyramids (and, from vo_seq_step, FAST) on the prepare stream
     hipStream_t pyrs = prep ? sq.copy : c->stream;
     int e = 0;
     if (timed)
@@ -1025,12 +981,15 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                 sq.carry_pending = false;
             }
             const int rp = (int)((sq.step - 1) % sq.ring); // ring slot of this step's t0 pair
-            if (prep && sq.fast_pending[rp]) {              // its corners come from the prepare stream, one step ago
-                VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_fast[rp], 0));
-                sq.fast_pending[rp] = false;
-            }
+            const bool ahead = prep && sq.have_corners[rp]; // its corners were detected one step ago on the prepare stream
+            for (int r2 = 0; r2 < sq.ring; r2++)
+                if (sq.fast_pending[r2] && (r2 == rp || !ahead)) {
+                    // (inline detection shares the FAST scratch buffers with a look-ahead pass that may still run)
+                    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, sq.ev_fast[r2], 0));
+                    sq.fast_pending[r2] = false;
+                }
             launch_seq_prepare(seq_active, c->d_ntracked, c->dprm.redetect_below, c->d_detect,
-                               prep ? sq.d_ncorn + (size_t)rp * sq.S : nullptr, c->d_nnew, B, c->stream);
+                               ahead ? sq.d_ncorn + (size_t)rp * sq.S : nullptr, c->d_nnew, B, c->stream);
             c->detect_uploaded = false;
         } else {
             bool changed = false;
@@ -1048,7 +1007,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
         int t = c->dprm.fast_threshold;
         t = t < 0 ? 0 : t > 255 ? 255 : t;
-        if (prep) {
+        if (prep && sq.have_corners[(sq.step - 1) % sq.ring]) {
             const int rp = (int)((sq.step - 1) % sq.ring);
             launch_bucket(c->d_feat, sq.d_corners + (size_t)rp * sq.S * c->fcap, c->d_fages, c->d_ntracked, c->d_nnew, c->fcap,
                           c->w, c->h, bs, fpb, c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
@@ -1080,9 +1039,14 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
-        (c->lk_pair ? launch_lk_circular_pair : launch_lk_circular)(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap,
-                                                                    c->max_pts_set, B, c->d_trk2[wset],
-                                                                    c->d_status2[wset], lp, c->stream);
+#ifdef VO_DEV_VARIANTS
+        if (c->lk_pair)
+            launch_lk_circular_pair(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
+                                    c->d_status2[wset], lp, c->stream);
+        else
+#endif
+            launch_lk_circular(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
+                               c->d_status2[wset], lp, c->stream);
         c->trk_last = wset;
         c->trk_next = wset ^ 1;
         if (sq.on) { // the ring slots holding this step's pairs may be overwritten once this LK has finished
@@ -1104,8 +1068,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && !crowded &&
-                                  (B <= c->pose2_frames || (c->seq.on && seq_light_band(c, B, c->max_pts_set)));
+    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && c->sched.streams == 2;
     hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
@@ -1122,7 +1085,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (stages & VO_STAGE_FILTER) {
         launch_compact(cur_pts(c), c->d_trk2[c->trk_last], c->d_status2[c->trk_last], cur_npts(c), cap,
                        c->prm.consistency_threshold, c->d_outA, c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
-        if (sq.on) { // currentVOFeatures of every sequence after this frame (seq.hip)
+        if (sq.on && !dry) { // currentVOFeatures of every sequence after this frame (seq.hip)
             launch_seq_carry(seq_active, pb.outB, pb.nB, c->d_idxA, c->d_nA, cur_ages(c), cur_npts(c), cap, c->fcap,
                              c->d_feat, c->d_fages, c->d_ntracked, c->d_overflow, sq.d_rows_carry, sq.d_nages, sq.d_info,
                              sq.max_steps, B, fs);
@@ -1180,10 +1143,10 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.rstate, pb.inliers, pb.results, pose_waves(c, B, c->max_pts_set, crowded), ps);
+                   pb.rstate, pb.inliers, pb.results, c->sched.waves, ps);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
-        if (sq.on) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
+        if (sq.on && !dry) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
             if (sq.integ_pending) // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it
                 VO_HIP_TRY(c, hipStreamWaitEvent(ps, sq.ev_integ, 0));
             launch_seq_integrate(seq_active, pb.results, c->prm.mono_rotation ? pb.em_results : nullptr, sq.d_pose,
@@ -1216,8 +1179,260 @@ static int sync_all(vo_ctx *c)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_pnp2));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream_em));
-    if (c->seq.copy)
-        VO_HIP_TRY(c, hipStreamSynchronize(c->seq.copy));
+    if (c->streams.copy)
+        VO_HIP_TRY(c, hipStreamSynchronize(c->streams.copy));
+    if (c->streams.prep)
+        VO_HIP_TRY(c, hipStreamSynchronize(c->streams.prep));
+    return VO_OK;
+}
+
+/* ------------------------------------- schedule probe ------------------------------------ */
+namespace {
+
+struct TuneKey {
+    long long k[8];
+    bool operator<(const TuneKey &o) const
+    {
+        for (int i = 0; i < 8; i++)
+            if (k[i] != o.k[i])
+                return k[i] < o.k[i];
+        return false;
+    }
+};
+std::mutex g_tune_mu;
+std::map<TuneKey, vo_ctx::Schedule> g_tuned; // per process: a second context of the same shape starts tuned
+
+// the point load a schedule was probed at, in half-octave buckets (1722 .. 2435 points share one): the single-frame
+// drop-in calls see a slightly different count every frame and must not probe every time
+int pts_bucket(long long pts) { return pts <= 0 ? 0 : (int)floor(2.0 * log2((double)pts) + 0.5); }
+
+TuneKey tune_key(const vo_ctx *c, int stages)
+{
+    long long pts = c->max_pts_set;
+    if (stages & VO_STAGE_DETECT) { // the bucketed count is only known on the device: its bound, like the launches
+        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
+        const long long cells = bs > 0 ? (long long)(c->h / bs + 1) * (c->w / bs + 1) : 1;
+        pts = cells * c->dprm.features_per_bucket < c->cap ? cells * c->dprm.features_per_bucket : c->cap;
+    }
+    TuneKey key;
+    key.k[0] = c->device;
+    key.k[1] = c->seq.on ? 1 : 0;
+    key.k[2] = c->w;
+    key.k[3] = c->h;
+    key.k[4] = c->levels;
+    key.k[5] = c->n_frames;
+    key.k[6] = pts_bucket(pts);
+    key.k[7] = (c->prm.mono_rotation ? 1 : 0) | ((stages & VO_STAGE_DETECT) ? 2 : 0);
+    return key;
+}
+
+void apply_pins(const vo_ctx *c, vo_ctx::Schedule *s)
+{
+    if (c->pin.pose_waves)
+        s->waves = c->pin.pose_waves;
+    if (c->pin.pose_streams)
+        s->streams = c->pin.pose_streams;
+    if (c->pin.prepare >= 0)
+        s->prep = c->pin.prepare;
+    if (c->prm.mono_rotation)
+        s->streams = 1; // the essential-matrix chain already runs next to the PnP chain on its own stream
+    if (!c->seq.on)
+        s->prep = 0;
+}
+
+bool all_pinned(const vo_ctx *c)
+{
+    return c->pin.pose_waves && (c->pin.pose_streams || c->prm.mono_rotation) && (!c->seq.on || c->pin.prepare >= 0);
+}
+
+} // namespace
+
+// make `s` the schedule the next run uses.  Moving the lock-step loop's ingest between the plain copy stream and the
+// prepare stream is only done with every stream idle (the ring slots, the FAST scratch buffers and the staging area are
+// ordered per stream).
+static int set_sched(vo_ctx *c, const vo_ctx::Schedule &s)
+{
+    if (c->seq.on && (s.prep != c->sched.prep || !c->seq.copy)) {
+        int rc = sync_all(c);
+        if (rc != VO_OK)
+            return rc;
+        c->seq.copy = ensure_copy_stream(&c->streams, s.prep != 0);
+        if (!c->seq.copy)
+            return fail(c, VO_ERR_HIP, "could not create the copy stream");
+        for (auto &b : c->seq.fast_pending)
+            b = false;
+        for (auto &b : c->seq.slot_busy)
+            b = false;
+        c->seq.stage_busy[0] = c->seq.stage_busy[1] = false;
+    }
+    c->sched = s;
+    return VO_OK;
+}
+
+// Resolve the schedule for the run that is about to be enqueued.  Returns 1 when this key has to be probed first
+// (nothing cached, not everything pinned), 0 when c->sched is settled, < 0 on error.
+static int sched_resolve(vo_ctx *c, int stages)
+{
+    const TuneKey key = tune_key(c, stages);
+    if (memcmp(key.k, c->sched_key, sizeof(key.k)) == 0)
+        return 0;
+    vo_ctx::Schedule s;
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) {
+            s = it->second;
+            found = true;
+        }
+    }
+    if (!found && !all_pinned(c) && !c->serial_pose)
+        return 1;
+    apply_pins(c, &s);
+    int rc = set_sched(c, s);
+    if (rc != VO_OK)
+        return rc;
+    memcpy(c->sched_key, key.k, sizeof(key.k));
+    c->sched_probed = found;
+    return 0;
+}
+
+// wall-clock milliseconds per run of M back-to-back runs (the pose chain of run i overlaps the tracking stages of run
+// i + 1 exactly as in steady state); the first, untimed run sizes M (>= 8 ms of work, 3 .. 16 runs)
+static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, double *ms_per_run)
+{
+    using clk = std::chrono::steady_clock;
+    int rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    auto t0 = clk::now();
+    rc = run_stages(c, stages, timed, evs, dry);
+    if (rc == VO_OK)
+        rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    const double warm = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    int M = warm > 0 ? (int)ceil(8.0 / warm) : 16;
+    M = M < 3 ? 3 : M > 16 ? 16 : M;
+    t0 = clk::now();
+    for (int i = 0; i < M && rc == VO_OK; i++)
+        rc = run_stages(c, stages, timed, evs, dry);
+    if (rc == VO_OK)
+        rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    *ms_per_run = std::chrono::duration<double, std::milli>(clk::now() - t0).count() / M;
+    return VO_OK;
+}
+
+// Probe every candidate the pins leave open on the data the caller is about to process, keep the fastest.
+// Batch mode: plain runs (a batch run is idempotent).  Lock-step loop: dry runs of the pending step.
+static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
+{
+    const TuneKey key = tune_key(c, stages);
+    std::vector<vo_ctx::Schedule> cands;
+    for (int waves = 1; waves <= 2; waves++)
+        for (int streams = 1; streams <= 2; streams++)
+            for (int prep = 1; prep >= 0; prep--) {
+                vo_ctx::Schedule s, t;
+                s.waves = waves;
+                s.streams = streams;
+                s.prep = prep;
+                t = s;
+                apply_pins(c, &t);
+                if (t.waves != s.waves || t.streams != s.streams || t.prep != s.prep)
+                    continue; // pinned away / not applicable
+                if (prep && !c->seq.have_corners[c->seq.on ? (c->seq.step - 1) % c->seq.ring : 0])
+                    continue; // no look-ahead corners for this step's t0 pair: the prepare variant cannot be shown
+                cands.push_back(s);
+            }
+    if (cands.empty()) {
+        vo_ctx::Schedule s;
+        apply_pins(c, &s);
+        cands.push_back(s);
+    }
+    c->tuning = true;
+    int rc = VO_OK, best = 0;
+    double best_ms = 0;
+    for (size_t i = 0; i < cands.size() && rc == VO_OK; i++) {
+        rc = set_sched(c, cands[i]);
+        double ms = 0;
+        if (rc == VO_OK)
+            rc = cands.size() > 1 ? probe_candidate(c, stages, timed, evs, dry, &ms) : VO_OK;
+        if (rc == VO_OK && (i == 0 || ms < best_ms)) {
+            best = (int)i;
+            best_ms = ms;
+        }
+    }
+    c->tuning = false;
+    if (rc != VO_OK)
+        return rc;
+    rc = set_sched(c, cands[best]);
+    if (rc != VO_OK)
+        return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tuned[key] = cands[best];
+    }
+    memcpy(c->sched_key, key.k, sizeof(key.k));
+    c->sched_probed = true;
+    return VO_OK;
+}
+
+// run_stages for the batch entry points: settles the schedule first (cached, pinned or probed) when the run has a pose chain
+static int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr)
+{
+    if ((stages & VO_STAGE_PNP) && !c->tuning && c->n_images > 0 && c->have_P) {
+        int need = sched_resolve(c, stages);
+        if (need < 0)
+            return need;
+        if (need) {
+            int rc = tune_schedule(c, stages, timed, evs, false);
+            if (rc != VO_OK)
+                return rc;
+        }
+    }
+    return run_stages(c, stages, timed, evs);
+}
+
+int vo_set_schedule(vo_ctx *c, const vo_schedule *s)
+{
+    if (!c)
+        return VO_ERR_ARG;
+    vo_schedule p = {0, 0, -1};
+    if (s)
+        p = *s;
+    const int max_waves =
+#ifdef VO_DEV_VARIANTS
+        4;
+#else
+        2;
+#endif
+    if (p.pose_waves < 0 || p.pose_waves == 3 || p.pose_waves > max_waves || p.pose_streams < 0 || p.pose_streams > 2 ||
+        p.prepare < -1 || p.prepare > 1)
+        return fail(c, VO_ERR_ARG, "vo_set_schedule: pose_waves 0 / 1 / 2, pose_streams 0 / 1 / 2, prepare -1 / 0 / 1");
+    int rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    c->pin = p;
+    c->sched_key[0] = -1; // resolved again at the next run
+    if (c->seq.on) {      // the lock-step loop reads sched between steps: apply what is pinned now
+        vo_ctx::Schedule sc = c->sched;
+        apply_pins(c, &sc);
+        rc = set_sched(c, sc);
+    }
+    return rc;
+}
+
+int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
+{
+    if (!c || !cur)
+        return VO_ERR_ARG;
+    cur->pose_waves = c->sched.waves;
+    cur->pose_streams = c->sched.streams;
+    cur->prepare = c->seq.on ? c->sched.prep : 0;
+    if (probed)
+        *probed = c->sched_probed ? 1 : 0;
     return VO_OK;
 }
 
@@ -1227,7 +1442,7 @@ int vo_batch_run(vo_ctx *c, int stages)
         return VO_ERR_ARG;
     if (c->seq.on)
         return fail(c, VO_ERR_STATE, "vo_batch_run inside the sequence loop: use vo_seq_step");
-    return run_stages(c, stages, false);
+    return run_stages_auto(c, stages, false);
 }
 
 int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
@@ -1236,7 +1451,7 @@ int vo_batch_run_timed(vo_ctx *c, int stages, float *ms)
         return VO_ERR_ARG;
     if (c->seq.on)
         return fail(c, VO_ERR_STATE, "vo_batch_run_timed inside the sequence loop: use vo_seq_step");
-    int rc = run_stages(c, stages, true);
+    int rc = run_stages_auto(c, stages, true);
     if (rc != VO_OK)
         return rc;
     rc = sync_all(c);
@@ -1253,7 +1468,7 @@ int vo_batch_run_slot(vo_ctx *c, int stages, int slot)
         return VO_ERR_ARG;
     if (c->seq.on)
         return fail(c, VO_ERR_STATE, "vo_batch_run_slot inside the sequence loop: use vo_seq_step");
-    return run_stages(c, stages, true, &c->ring[(size_t)slot * (VO_EV_PER_RUN)]);
+    return run_stages_auto(c, stages, true, &c->ring[(size_t)slot * (VO_EV_PER_RUN)]);
 }
 
 int vo_batch_slot_times(vo_ctx *c, int slot, float *ms)
@@ -1487,7 +1702,7 @@ int vo_essential_pose(vo_ctx *c, const float *pts0, const float *pts1, int n, do
     ep.threshold = threshold;
     ep.max_iters = EM_MAX_ITERS;
     launch_essential(pb.outB, pb.outB + 2 * cap, 4 * cap, pb.nB, c->cap, 1, ep, c->em, pb.em_results,
-                     /*crowded*/ is_crowded(c, 1, n), c->stream);
+                     /*crowded*/ standalone_waves(c) >= 2, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     int status = 0, good = 0;
     int rc = vo_batch_get_essential(c, 0, E, R, t, mask, n, nullptr, &good, &status, nullptr);
@@ -1577,20 +1792,39 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     q.ring = ring;
     q.max_steps = max_steps;
     // Prepare stream or plain copy stream?  Moving the pyramids and FAST off the tracking stream shortens a step's
-    // critical path, which is what a SMALL number of sequences is bound by (1 sequence 1.39 k -> 1.58 k frames/s,
+    // critical path, which is what a SMALL number of sequences is bound by (round 2: 1 sequence 1.39 k -> 1.58 k frames/s,
     // 8 sequences 9.3 k -> 12.3 k); with many sequences the GPU is saturated, the step costs the sum of its kernels
-    // either way and the extra concurrency only disturbs them (64 sequences 41.3 k -> 35.8 k, 256: 49.2 k -> 46.7 k;
-    // gpurun_out/r2_06, r2_07).  So: prepare stream (highest priority -- its short memory-bound kernels have to find
-    // SIMD slots between the running step's LK waves) up to pose2_frames sequences (the same crossover as the second
-    // pose stream, measured together), plain copy stream above.
+    // either way and the extra concurrency only disturbs them (64 sequences 41.3 k -> 35.8 k, 256: 49.2 k -> 46.7 k).
+    // Where the crossover lies depends on the image size and the point load, so it is part of the probed schedule: until
+    // the first full step has been probed the loop runs WITH the prepare stream (so that the look-ahead corners the
+    // prepare variant needs exist when the probe compares the two), unless this shape was probed before or is pinned.
+    bool ok = true;
     {
-        const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : h / 10;
-        const long long cells = bs > 0 ? (long long)(h / bs + 1) * (w / bs + 1) : 1;
-        const char *e = getenv("VO_SEQ_PREP"); // developer A/B: 0 / 1 force
-        q.prep = e ? e[0] != '0' : n_seq <= c->pose2_frames || seq_light_band(c, n_seq, cells * c->dprm.features_per_bucket);
+        c->seq.on = true; // (for the key; seq_free below has cleared it)
+        const TuneKey key = tune_key(c, VO_STAGE_ALL | VO_STAGE_DETECT);
+        c->seq.on = false;
+        vo_ctx::Schedule sc;
+        bool found = false;
+        {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tuned.find(key);
+            if (it != g_tuned.end()) {
+                sc = it->second;
+                found = true;
+            }
+        }
+        q.on = true;
+        apply_pins(c, &sc);
+        q.on = false;
+        c->sched = sc;
+        c->sched_probed = found;
+        if (found || all_pinned(c))
+            memcpy(c->sched_key, key.k, sizeof(key.k));
+        else
+            c->sched_key[0] = -1; // the first full step probes
+        q.copy = ensure_copy_stream(&c->streams, sc.prep != 0);
+        ok = q.copy != nullptr;
     }
-    q.copy = ensure_copy_stream(&c->streams, q.prep);
-    bool ok = q.copy != nullptr;
     ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
     ok = ok && dmalloc(&q.d_ncorn, (size_t)ring * S) == hipSuccess;
     ok = ok && hipMemset(q.d_ncorn, 0, sizeof(int) * ring * S) == hipSuccess;
@@ -1671,6 +1905,8 @@ int vo_seq_reset(vo_ctx *c, int seq)
         for (auto &b : q.slot_busy)
             b = false;
         for (auto &b : q.fast_pending)
+            b = false;
+        for (auto &b : q.have_corners)
             b = false;
         for (auto &b : q.step_pending)
             b = false;
@@ -1874,7 +2110,7 @@ int vo_seq_step(vo_ctx *c)
             q.staged = false;
         }
     }
-    if (!q.prep) {
+    if (!c->sched.prep) {
         VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
         VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
     }
@@ -1888,8 +2124,22 @@ int vo_seq_step(vo_ctx *c)
         c->quads_cur = q.d_quads + (size_t)((q.step - 1) % q.ring) * q.S;
         stages |= VO_STAGE_DETECT | VO_STAGE_LK | VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP;
     }
-    rc = run_stages(c, stages, true, &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_EV_PER_RUN)]);
-    if (rc == VO_OK && q.prep) {
+    hipEvent_t *step_evs = &c->ring[(size_t)(q.step % VO_EVENT_SLOTS) * (VO_EV_PER_RUN)];
+    rc = VO_OK;
+    if (n_active > 0 && 2 * n_active >= q.S && !c->tuning) {
+        // a step that shows the loop's real load: settle the schedule (cached / pinned / probed with dry runs of THIS
+        // step -- everything but seq_carry and seq_integrate, so the step can be repeated)
+        int need = sched_resolve(c, stages);
+        if (need < 0)
+            rc = need;
+        else if (need)
+            rc = tune_schedule(c, stages, true, step_evs, /*dry*/ true);
+    }
+    if (rc == VO_OK)
+        rc = run_stages(c, stages, true, step_evs);
+    if (rc == VO_OK && !c->sched.prep)
+        q.have_corners[r] = false; // the pair now in slot r has no look-ahead corners
+    if (rc == VO_OK && c->sched.prep) {
         // FAST + non-maximum suppression of the new pairs' left images, for the NEXT step's appendNewFeatures: on the
         // prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
         int t = c->dprm.fast_threshold;
@@ -1899,6 +2149,7 @@ int vo_seq_step(vo_ctx *c)
                             q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
         hipError_t e1 = hipEventRecord(q.ev_fast[r], q.copy);
         q.fast_pending[r] = true;
+        q.have_corners[r] = true;
         hipError_t e2 = hipGetLastError();
         if (e1 != hipSuccess || e2 != hipSuccess) {
             c->err = std::string("vo_seq_step: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
@@ -1917,7 +2168,7 @@ int vo_seq_step(vo_ctx *c)
     // end of the step = end of its last stream: the pose stream when a frame was processed; without a processed frame
     // the step's work is the ingest + pyramids (+ FAST) -- on the prepare stream when there is one
     VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream
-                                                  : q.prep               ? q.copy
+                                                  : c->sched.prep        ? q.copy
                                                                          : c->stream));
     q.step_pending[slot] = true;
     q.step++;
@@ -2135,7 +2386,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, pose_waves(c, 1, n, is_crowded(c, 1, n)), c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }
@@ -2242,7 +2493,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     rc = vo_batch_set_projection(c, P_l, P_r);
     if (rc != VO_OK)
         return rc;
-    rc = run_stages(c, VO_STAGE_ALL, false);
+    rc = run_stages_auto(c, VO_STAGE_ALL, false);
     if (rc != VO_OK)
         return rc;
     // Results: one kernel behind the pose solve gathers the counts, the PnpResult and every output array into one

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void fast_tile_tall_kernel(const PyrImage *__r
     fast_tile_body<1, 32>(imgs, quads, detect, threshold, nonmax, mask, segs, rowcnt);
 }
 
+#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL) // the 128 x 32 tile: measured slower than both product tiles (launch_fast_corners)
 __global__ __launch_bounds__(256) void fast_tile_big_kernel(const PyrImage *__restrict__ imgs,
                                                             const Quad *__restrict__ quads,
                                                             const int *__restrict__ detect, int threshold, int nonmax,
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256) void fast_tile_big_kernel(const PyrImage *__re
 {
     fast_tile_body<2, 32>(imgs, quads, detect, threshold, nonmax, mask, segs, rowcnt);
 }
+#endif
 
 // Corner list from the stored ballots: a wavefront per image row (4 rows per workgroup), a lane per 64-pixel segment.  The
 // lanes fetch the row's ballots with one coalesced load, the per-segment counts go through LDS for the lane's exclusive
@@ -515,12 +517,16 @@ void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int 
     // loop: detection stage 0.67 / 0.58 / 0.94 ms -- the 64 x 32 tile amortises the two list phases (one or two busy
     // wavefronts per workgroup) over twice the full-width work, the 128 x 32 tile's 32 KB of LDS costs more occupancy than
     // that saves.  Fewer than 8 frames keep the small tile (more workgroups than CUs for one 1241 x 376 image).
+    int tile = n_frames >= 8 ? 1 : 0;
+#ifdef VO_DEV_VARIANTS
     static const int forced = [] { const char *e = getenv("VO_FAST_TILE"); return e ? atoi(e) : -1; }();
-    const int tile = forced >= 0 ? forced : n_frames >= 8 ? 1 : 0;
+    tile = forced >= 0 ? forced : tile;
     if (tile == 2)
         hipLaunchKernelGGL(fast_tile_big_kernel, dim3((segs + 1) / 2, (h + 31) / 32, n_frames), dim3(256), 0, stream, d_imgs,
                            d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
-    else if (tile == 1)
+    else
+#endif
+    if (tile == 1)
         hipLaunchKernelGGL(fast_tile_tall_kernel, dim3(segs, (h + 31) / 32, n_frames), dim3(256), 0, stream, d_imgs,
                            d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
     else

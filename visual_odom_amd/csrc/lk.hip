@@ -373,6 +373,9 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
     }
 }
 
+// Developer variant: compiled into libvo_hip_dev.so (python -m visual_odom_amd.build --dev) and into the CPU emulator of
+// tests/host_check only -- measured 4-6 % slower than lk_circular_kernel, so the product library does not carry it.
+#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL)
 // ---------------------------------------------------------------------------------------------------------------------
 // TWO FEATURES PER WAVEFRONT ("build and measure the 2-features-per-wave variant").
 // 65 % of the iteration's VALU slots above are wave-uniform arithmetic replicated over 64 lanes (weights, reduction tail,
@@ -708,6 +711,7 @@ __global__ VO_LK_PAIR_ATTRS void lk_circular_pair_kernel(const PyrImage *__restr
     }
 }
 
+#endif // VO_DEV_VARIANTS || VO_HOST_EMUL
 #ifndef VO_HOST_EMUL
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
@@ -724,6 +728,7 @@ void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float
                        fpg, ppp, d_trk, d_status, prm);
 }
 
+#ifdef VO_DEV_VARIANTS
 void launch_lk_circular_pair(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                              int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                              const LkParams &prm, hipStream_t stream)
@@ -737,6 +742,7 @@ void launch_lk_circular_pair(const PyrImage *d_imgs, const Quad *d_quads, const 
     hipLaunchKernelGGL(lk_circular_pair_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames,
                        fpg, ppp, d_trk, d_status, prm);
 }
+#endif // VO_DEV_VARIANTS
 
 #endif // VO_HOST_EMUL
 

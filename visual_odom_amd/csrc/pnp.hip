@@ -557,17 +557,22 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
     // tracking stream instead starts each step with its LDS-free kernels (capi.hip, PYRAMID stage).
     static const size_t lds = [] {
         size_t need = (144 + 12) * 64 * sizeof(double), want = 0;
+#ifdef VO_DEV_VARIANTS
         if (const char *e = getenv("VO_EPNP_LDS_KB"))
             want = (size_t)atoi(e) * 1024;
+#endif
         return want > need ? want : need;
     }();
     for (int k = 0; k < n_chunks; k++) {
         hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm.iters, k, subsets, state);
+#ifdef VO_DEV_VARIANTS // the 128-register instantiation: never the best one since round 2
         if (waves >= 4)
             hipLaunchKernelGGL(epnp_kernel<4>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
                                k, models);
-        else if (waves == 2)
+        else
+#endif
+        if (waves >= 2)
             hipLaunchKernelGGL(epnp_kernel<2>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
                                k, models);
         else
@@ -578,10 +583,13 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
         hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
                            prm, k, counts, state);
     }
+#ifdef VO_DEV_VARIANTS
     if (waves >= 4)
         hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, inliers, results);
-    else if (waves == 2)
+    else
+#endif
+    if (waves >= 2)
         hipLaunchKernelGGL(select_refine_kernel<2>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, inliers, results);
     else

@@ -286,12 +286,14 @@ __device__ __forceinline__ void scharr_body(const PyrImage *__restrict__ imgs, i
     o[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
+#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL) // ordinary stores: the A/B partner of the product kernel below
 __global__ __launch_bounds__(256) void scharr_kernel(const PyrImage *__restrict__ imgs, int n_levels, ScharrTiles st)
 {
     scharr_body<false>(imgs, n_levels, st);
 }
+#endif
 
-// the same with non-temporal stores (what launch_scharr uses unless VO_SCHARR_NT=0)
+// the same with non-temporal stores: what launch_scharr uses
 __global__ __launch_bounds__(256) void scharr_nt_kernel(const PyrImage *__restrict__ imgs, int n_levels, ScharrTiles st)
 {
     scharr_body<true>(imgs, n_levels, st);
@@ -324,11 +326,14 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
     // non-temporal stores by default: the 4 bytes per pixel written here are 80 % of the pyramid stage's traffic and LK reads
     // a few per cent of them much later -- measured 0.58 -> 0.47 ms per 512 KITTI images, +1 ... +3 % frames/s in every
     // configuration (VO_SCHARR_NT=0 restores ordinary stores)
+#ifdef VO_DEV_VARIANTS
     static const bool nt = [] { const char *e = getenv("VO_SCHARR_NT"); return !(e && e[0] == '0'); }();
-    if (nt)
-        hipLaunchKernelGGL(scharr_nt_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
-    else
+    if (!nt) {
         hipLaunchKernelGGL(scharr_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(scharr_nt_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
 }
 
 #endif // VO_HOST_EMUL

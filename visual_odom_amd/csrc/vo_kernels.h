@@ -103,9 +103,11 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
+#ifdef VO_DEV_VARIANTS
 void launch_lk_circular_pair(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
+#endif
 void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,
                           int h, int threshold, int nonmax, unsigned long long *d_nmsmask,
                           int *d_rowcnt, int *d_rowoff,
