@@ -307,7 +307,7 @@ def main(argv=None):
                                    "steps": rep["steps"], "validated_frames": rep["validated_frames"],
                                    "sequences_per_gpu": 256, "points_per_frame": rep["config"]["points_per_frame"],
                                    "mode": rep["config"]["mode"], "stage_ms": rep["config"]["stage_ms"],
-                                   "roofline": rep["roofline"]}
+                                   "schedule": rep["config"]["schedule"], "roofline": rep["roofline"]}
     if config_legs:
         # every other BASELINE configuration in the same driver-run line: same code path, fewer
         # steps, each leg validated against the oracle after its timed loop.  The KITTI-size legs reuse the headline's
@@ -347,7 +347,7 @@ def main(argv=None):
                              "stages": "detect+full", "value": er["value"], "unit": er["unit"], "ms_per_step": er["ms_per_step"],
                              "steps": er["steps"], "warmup": args.warmup, "frames_per_step": er["sequences_per_gpu"],
                              "points_per_frame": er["points_per_frame"], "validated_frames": er["validated_frames"],
-                             "stage_ms": er["stage_ms"], "roofline": er["roofline"]})
+                             "schedule": er["schedule"], "stage_ms": er["stage_ms"], "roofline": er["roofline"]})
             out["configs"] = legs
     if kept and kept[0] is not None:
         kept[0].close()

@@ -346,13 +346,13 @@ def test_sequence_loop_guards(volib, small_world):
         assert ctx.seq_get_trajectory(1)[0].shape[0] == 0
         ctx.seq_reset(0)
         assert len(ctx.seq_get_state(0)[0]) == 0 and ctx.seq_get_trajectory(0)[0].shape[0] == 0
-        for k in range(7):                                # max_steps = 8 rows: steps 2 .. 8 still fit, the 10th call does not
+        for k in range(9):                                # max_steps = 8 rows PER SEQUENCE since its reset: 9 pairs fill them
             ctx.seq_push_pair(0, L[k % 2], R[k % 2])
             ctx.seq_step()
         ctx.seq_push_pair(0, L[1], R[1])
-        with pytest.raises(volib.VoError) as e:
+        with pytest.raises(volib.VoError) as e:          # a ninth row does not fit: the step is refused, its pair dropped
             ctx.seq_step()
-        assert e.value.code == volib.VO_ERR_STATE and ctx.seq_get_trajectory(0)[0].shape[0] == 6
+        assert e.value.code == volib.VO_ERR_STATE and ctx.seq_get_trajectory(0)[0].shape[0] == 8
         # the drop-in calls leave the loop cleanly
         got = ctx.circular_match(L[0], R[0], L[1], R[1], pts[:10])
         assert got["n_out"] <= 10

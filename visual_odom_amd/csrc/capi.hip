@@ -470,6 +470,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->ransac_cap = 1000;
     const size_t B = (size_t)max_frames, cap = (size_t)max_pts;
     bool ok = acquire_streams(device, &c->streams);
+    ok = ok && pnp_init_device(c->streams.stream) == 0;
     c->stream = c->streams.stream;
     c->stream_pnp = c->streams.pnp;
     c->stream_pnp2 = c->streams.pnp2;
@@ -1142,15 +1143,27 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
                              /*crowded*/ crowded, es);
             VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
-        launch_pnp(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                   pb.rstate, pb.inliers, pb.results, c->sched.waves, ps);
+        launch_pnp_ransac(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
+                          pb.rstate, c->sched.waves, ps);
         if (c->prm.mono_rotation)
-            VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains
-        if (sq.on && !dry) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each (seq.hip)
-            if (sq.integ_pending) // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it
+            VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
+        SeqTail tail;
+        if (sq.on && !dry) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each: inside
+                             // select_refine_kernel (vo_seqtail.h)
+            if (sq.integ_pending) // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it --
+                                  // only the refinement kernels of consecutive chains are ordered, their RANSAC parts overlap
                 VO_HIP_TRY(c, hipStreamWaitEvent(ps, sq.ev_integ, 0));
-            launch_seq_integrate(seq_active, pb.results, c->prm.mono_rotation ? pb.em_results : nullptr, sq.d_pose,
-                                 sq.d_traj, sq.d_info, sq.d_rows, sq.max_steps, B, ps);
+            tail.active = seq_active;
+            tail.em = c->prm.mono_rotation ? pb.em_results : nullptr;
+            tail.pose = sq.d_pose;
+            tail.traj = sq.d_traj;
+            tail.info = sq.d_info;
+            tail.n_rows = sq.d_rows;
+            tail.max_steps = sq.max_steps;
+        }
+        launch_pnp_refine(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.models, pb.rstate, pb.inliers,
+                          pb.results, c->sched.waves, tail, ps);
+        if (sq.on && !dry) {
             VO_HIP_TRY(c, hipEventRecord(sq.ev_integ, ps));
             sq.integ_pending = true;
         }
@@ -1293,7 +1306,7 @@ static int sched_resolve(vo_ctx *c, int stages)
     if (rc != VO_OK)
         return rc;
     memcpy(c->sched_key, key.k, sizeof(key.k));
-    c->sched_probed = found;
+    c->sched_probed = found && !all_pinned(c);
     return 0;
 }
 
@@ -1817,7 +1830,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
         apply_pins(c, &sc);
         q.on = false;
         c->sched = sc;
-        c->sched_probed = found;
+        c->sched_probed = found && !all_pinned(c);
         if (found || all_pinned(c))
             memcpy(c->sched_key, key.k, sizeof(key.k));
         else

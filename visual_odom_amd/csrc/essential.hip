@@ -270,7 +270,7 @@ void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const i
                        n_pts, cap, prm, eb.q0, eb.q1);
     const int n_chunks = (iters + EM_CHUNK - 1) / EM_CHUNK;
     for (int chunk = 0; chunk < n_chunks; chunk++) {
-        launch_ransac_subsets(n_pts, n_frames, iters, chunk, eb.subsets, eb.rstate, stream);
+        launch_ransac_subsets(n_pts, n_frames, iters, chunk * EM_CHUNK, EM_CHUNK, eb.subsets, eb.rstate, stream);
         if (crowded)
             hipLaunchKernelGGL(em_solve_kernel<4>, dim3(EM_CHUNK / 64, n_frames), dim3(64), 0, stream, eb.q0, eb.q1,
                                n_pts, cap, iters, chunk, eb.subsets, eb.rstate, eb.models, eb.nmodels);

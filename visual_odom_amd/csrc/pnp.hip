@@ -24,6 +24,9 @@
 #include "vo_kernels.h"
 #include "vo_epnp.h"
 #include "vo_p3p.h"
+#include "vo_seqtail.h"
+
+#include <mutex>
 
 #include <float.h>
 #include <stdlib.h>
@@ -50,60 +53,152 @@ namespace vo {
 
 constexpr int RANSAC_CHUNK = 128;
 
-// one thread per frame (the RNG stream is strictly sequential); n_frames threads in total.  Chunk k draws
-// the subsets of hypotheses [k * RANSAC_CHUNK, (k + 1) * RANSAC_CHUNK) continuing the frame's stream where
-// chunk k - 1 left it -- and only for frames whose adaptive iteration count still reaches that far.
-__global__ void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters, int chunk,
-                                       int32_t *__restrict__ subsets /* [B][iters][5] */,
-                                       RansacState *__restrict__ rstate)
+// ---- random 5-subsets: RANSACPointSetRegistrator::getSubset with cv::RNG(-1) ----
+// cv::RNG is a multiply-with-carry generator whose raw 32-bit outputs do not depend on anything the caller passes: the
+// stream of a solvePnPRansac call is the same in every call; only `next() % count` and the redraws of duplicates within
+// a subset depend on the frame.  So the raw stream is tabulated once per device (rng_table_kernel), and a WAVEFRONT
+// derives 64 subsets at a time from it: lane j first assumes that no earlier subset of the batch needed a redraw (its
+// draws start at position 5 j), every lane reports how many draws it consumed, an exclusive prefix sum gives the true
+// starts, lanes whose start moved recompute -- until nothing moves (lane 0 is right at once, every round settles at
+// least one more lane; with 340 points 3 % of the subsets redraw, so two or three rounds).  Round 2 replayed the stream
+// with one thread per frame: 0.14 ms at the head of every pose solve; this takes a few microseconds.
+// Exact by construction; a frame that would run past the table falls back to the serial generator.
+constexpr int RNG_TABLE = 1 << 15; // raw draws kept per device (128 KB): 500 subsets of 5 need ~2 600, 1 000 of them with 6 points ~9 000
+
+__global__ void rng_table_kernel(uint32_t *__restrict__ raw, int n)
 {
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    uint64_t state = 0xffffffffffffffffull; // cv::RNG rng((uint64)-1)
+    for (int i = 0; i < n; i++) {
+        state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+        raw[i] = (uint32_t)state;
+    }
+}
+
+// the serial generator (round 2's kernel body): subsets [first, last) continuing from stream position `pos`
+__device__ void subsets_serial(uint32_t pos, int first, int last, int count, int32_t *__restrict__ out, uint32_t *pos_out)
+{
+    uint64_t state = 0xffffffffffffffffull;
+    for (uint32_t i = 0; i < pos; i++)
+        state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+    const uint64_t recip = 0xFFFFFFFFFFFFFFFFull / (uint32_t)count + 1;
+    for (int it = first; it < last; it++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            int idx_i;
+            for (;;) {
+                state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+                pos++;
+                idx_i = (int)__umul64hi(recip * (uint32_t)state, (uint64_t)(uint32_t)count);
+                bool dup = false;
+                for (int k = 0; k < i; k++)
+                    dup |= idx[k] == idx_i;
+                if (!dup)
+                    break;
+            }
+            idx[i] = idx_i;
+        }
+        for (int i = 0; i < 5; i++)
+            out[it * 5 + i] = idx[i];
+    }
+    *pos_out = pos;
+}
+
+// one wavefront per frame.  The chunk [h0, h0 + hn) continues the frame's stream where the previous chunk left it
+// (RansacState::rng holds the stream POSITION), and only as far as the frame's adaptive iteration count still reaches.
+__global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters, int h0,
+                                                            int hn, const uint32_t *__restrict__ raw, int n_raw,
+                                                            int32_t *__restrict__ subsets /* [B][iters][5] */,
+                                                            RansacState *__restrict__ rstate)
+{
+    const int frame = blockIdx.x, lane = threadIdx.x;
     if (frame >= n_frames)
         return;
     RansacState st;
-    if (chunk == 0) {
+    if (h0 == 0) {
         st.it = 0;
         st.niters = iters > 1 ? iters : 1;
         st.max_good = 0;
         st.best = -1;
-        st.rng = 0xffffffffffffffffull; // cv::RNG rng((uint64)-1)
+        st.rng = 0;
     } else {
         st = rstate[frame];
     }
     const int count = n_pts[frame];
     int32_t *out = subsets + (size_t)frame * iters * 5;
-    if (count == 5 && chunk == 0) // model_points == npoints: solvePnP on all points in order
-        for (int i = 0; i < 5; i++)
-            out[i] = i;
+    if (count == 5 && h0 == 0 && lane < 5) // model_points == npoints: solvePnP on all points in order
+        out[lane] = lane;
     if (count > 5) {
-        const int first = chunk * RANSAC_CHUNK;
-        const int last = min(min(first + RANSAC_CHUNK, iters), st.niters);
-        uint64_t state = st.rng;
+        const int last = min(min(h0 + hn, iters), st.niters);
         // rng.uniform(0, count) = next() % count with a divisor that is fixed for the whole stream: Lemire's exact
-        // remainder by a precomputed 64-bit reciprocal (two multiplies) instead of a 32-bit division per draw --
-        // this single thread's chain of draws is the first 0.14 ms of every pose solve
+        // remainder by a precomputed 64-bit reciprocal (two multiplies) instead of a 32-bit division per draw
         const uint64_t recip = 0xFFFFFFFFFFFFFFFFull / (uint32_t)count + 1;
-        for (int it = first; it < last; it++) {
-            int idx[5];
-            for (int i = 0; i < 5; i++) {
-                int idx_i;
-                for (;;) {
-                    state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
-                    idx_i = (int)__umul64hi(recip * (uint32_t)state, (uint64_t)(uint32_t)count);
-                    bool dup = false;
-                    for (int k = 0; k < i; k++)
-                        dup |= idx[k] == idx_i;
-                    if (!dup)
-                        break;
+        uint32_t pos0 = (uint32_t)st.rng;
+        bool overflow = false;
+        int base = h0;
+        for (; base < last; base += 64) {
+            const int m = min(64, last - base);
+            const bool act = lane < m;
+            uint32_t off = pos0 + 5u * (uint32_t)lane, used = 0;
+            int idx[5] = {0, 0, 0, 0, 0};
+            bool dirty = act, ovf = false;
+            for (;;) {
+                if (dirty) {
+                    uint32_t p = off;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        int v = 0;
+                        for (;;) {
+                            if (p >= (uint32_t)n_raw) {
+                                ovf = true;
+                                break;
+                            }
+                            v = (int)__umul64hi(recip * raw[p++], (uint64_t)(uint32_t)count);
+                            bool dup = false;
+#pragma unroll
+                            for (int k = 0; k < 5; k++)
+                                dup |= (k < i) && idx[k] == v;
+                            if (!dup)
+                                break;
+                        }
+                        idx[i] = v;
+                    }
+                    used = p - off;
                 }
-                idx[i] = idx_i;
+                if (__any(ovf))
+                    break;
+                uint32_t incl = act ? used : 0u; // inclusive prefix sum over the wavefront
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if (lane >= d)
+                        incl += t;
+                }
+                const uint32_t start = pos0 + incl - (act ? used : 0u);
+                dirty = act && start != off;
+                off = start;
+                if (!__any(dirty)) {
+                    pos0 += __shfl(incl, 63, 64);
+                    break;
+                }
             }
-            for (int i = 0; i < 5; i++)
-                out[it * 5 + i] = idx[i];
+            if (__any(ovf)) {
+                overflow = true;
+                break;
+            }
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    out[(base + lane) * 5 + i] = idx[i];
+            }
         }
-        st.rng = state;
+        if (overflow && lane == 0) // past the table (never seen: it holds 3.5 x the worst expected demand)
+            subsets_serial(pos0, base, last, count, out, &pos0);
+        st.rng = pos0;
     }
-    rstate[frame] = st;
+    if (lane == 0)
+        rstate[frame] = st;
 }
 
 template <int WAVES>
@@ -111,7 +206,7 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
-                                                  const RansacState *__restrict__ rstate, int chunk,
+                                                  const RansacState *__restrict__ rstate, int h0, int hn,
                                                   double *__restrict__ models /* [B][iters][6] */)
 {
     // M^T M (12 x 12) + its column norms of every lane, lane-interleaved: element idx of lane l at
@@ -119,9 +214,9 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
     // (dynamic LDS, (144 + 12) * 64 doubles: with a static array the compiler derives one wave per SIMD
     // from the LDS footprint and spends all 512 registers, ignoring the launch bound above)
     extern __shared__ __attribute__((aligned(16))) double s_ut[];
-    const int frame = blockIdx.y, h = chunk * RANSAC_CHUNK + blockIdx.x * 64 + threadIdx.x;
+    const int frame = blockIdx.y, h = h0 + blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
-    if (count < 5)
+    if (count < 5 || h >= h0 + hn)
         return;
     // hypotheses beyond the iteration count the replay has already settled on are never looked at
     const int nh = count == 5 ? 1 : min(prm.iters, rstate[frame].niters);
@@ -166,10 +261,10 @@ __device__ __forceinline__ bool is_inlier(const double *R, const double *t, doub
 __global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   PnpParams prm, const double *__restrict__ models,
-                                                  const RansacState *__restrict__ rstate, int chunk,
+                                                  const RansacState *__restrict__ rstate, int h0,
                                                   int *__restrict__ counts /* [B][iters] */)
 {
-    const int frame = blockIdx.y, h = chunk * RANSAC_CHUNK + blockIdx.x, lane = threadIdx.x;
+    const int frame = blockIdx.y, h = h0 + blockIdx.x, lane = threadIdx.x;
     const int count = n_pts[frame];
     if (count <= 5 || h >= prm.iters || h >= rstate[frame].niters)
         return;
@@ -207,7 +302,7 @@ __device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int
 }
 
 // RANSACPointSetRegistrator::run on the vote counts, continued chunk by chunk: one thread per frame
-__global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int chunk,
+__global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int h_end,
                                       const int *__restrict__ counts, RansacState *__restrict__ rstate)
 {
     const int frame = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,7 +313,7 @@ __global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames
         return;
     RansacState st = rstate[frame];
     const int *cf = counts + (size_t)frame * prm.iters;
-    const int end = min((chunk + 1) * RANSAC_CHUNK, prm.iters);
+    const int end = min(h_end, prm.iters);
     int it = st.it;
     for (; it < st.niters && it < end; it++) {
         const int good = cf[it];
@@ -242,14 +337,13 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *__restrict__ xyz,
-                                                            const float2 *__restrict__ uv, size_t uv_stride,
-                                                            const int *__restrict__ n_pts, int cap,
-                                                            PnpParams prm, const double *__restrict__ models,
-                                                            const RansacState *__restrict__ rstate,
-                                                            int32_t *__restrict__ inliers /* [B][cap] */,
-                                                            PnpResult *__restrict__ results)
+// the work of one frame's workgroup (256 threads, all of them call it; every `return` below is block-uniform)
+__device__ __forceinline__ void select_refine_frame(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                    size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                    const PnpParams &prm, const double *__restrict__ models,
+                                                    const RansacState *__restrict__ rstate,
+                                                    int32_t *__restrict__ inliers /* [B][cap] */,
+                                                    PnpResult *__restrict__ results)
 {
     __shared__ int s_best, s_last, s_niters, s_maxgood, s_ninl;
     __shared__ int s_wave[4];
@@ -262,8 +356,8 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
     const int count = n_pts[frame];
     PnpResult &res = results[frame];
     if (count < 5) {
-        if (tid == 0) {
-            res.status = -1; // CV_Assert(npoints >= 4); exactly 4 points: p3p_kernel overwrites this record
+        if (tid == 0 && count != 4) { // (exactly 4 points: p3p_kernel has already written this frame's record)
+            res.status = -1;          // CV_Assert(npoints >= 4)
             res.n_inliers = 0;
             res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
         }
@@ -492,6 +586,24 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
     }
 }
 
+// one workgroup per frame.  Lock-step loop (tail.active != nullptr): thread 0 goes on with the tail of the reference's
+// frame loop for this sequence -- euler gates + integrateOdometryStereo + one trajectory row (vo_seqtail.h) -- instead of
+// a separate kernel behind the chain (round 2's seq_integrate_kernel: 7 us of work that waited up to 1.7 ms for a SIMD slot
+// next to the following step's LK waves).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *__restrict__ xyz,
+                                                            const float2 *__restrict__ uv, size_t uv_stride,
+                                                            const int *__restrict__ n_pts, int cap,
+                                                            PnpParams prm, const double *__restrict__ models,
+                                                            const RansacState *__restrict__ rstate,
+                                                            int32_t *__restrict__ inliers /* [B][cap] */,
+                                                            PnpResult *__restrict__ results, SeqTail tail)
+{
+    select_refine_frame(xyz, uv, uv_stride, n_pts, cap, prm, models, rstate, inliers, results);
+    if (tail.active && threadIdx.x == 0 && tail.active[blockIdx.x])
+        seq_integrate_frame(tail, blockIdx.x, results[blockIdx.x], tail.active[blockIdx.x]);
+}
+
 // solvePnPRansac with exactly four correspondences: `npoints == 4 -> model_points = 4, SOLVEPNP_P3P`, and model_points
 // being npoints the call IS solvePnP(P3P): first of solveP3P's sorted solutions, no refinement, all four points inliers;
 // no solution -> false, rvec / tvec untouched (lm_iters = -1 marks "pose buffers untouched" for the host side and the
@@ -532,29 +644,51 @@ __global__ void p3p_kernel(const float *__restrict__ xyz, const float2 *__restri
             inliers[(size_t)frame * cap + i] = i;
 }
 
-void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
-                           RansacState *rstate, hipStream_t stream)
+// the raw cv::RNG(-1) stream of the device the calling thread has selected (created on first use)
+static const uint32_t *rng_table(hipStream_t stream)
 {
-    hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, iters,
-                       chunk, subsets, rstate);
+    static std::mutex mu;
+    static uint32_t *tab[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tab[dev]) {
+        uint32_t *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(uint32_t) * RNG_TABLE) != hipSuccess)
+            return nullptr;
+        hipLaunchKernelGGL(rng_table_kernel, dim3(1), dim3(1), 0, stream, p, RNG_TABLE);
+        (void)hipStreamSynchronize(stream); // once per device and process: later launches on other streams read it
+        tab[dev] = p;
+    }
+    return tab[dev];
 }
 
-void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
-                const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, int waves /* 1, 2 or 4 per SIMD: 512 / 256 / 128 registers */,
-                hipStream_t stream)
+int pnp_init_device(hipStream_t stream) { return rng_table(stream) ? 0 : -1; }
+
+void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int h0, int hn, int32_t *subsets,
+                           RansacState *rstate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ransac_subsets_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, iters, h0, hn,
+                       rng_table(stream), RNG_TABLE, subsets, rstate);
+}
+
+// RANSAC hypotheses + votes + control-flow replay, everything up to the choice of the winner.  Two chunks: the first
+// RANSAC_CHUNK hypotheses (with >= 60 % inliers OpenCV stops before 128 iterations, so this is normally all), then ALL the
+// remaining ones at once for the frames whose adaptive iteration count reaches further -- round 2 went on in steps of
+// 128, i.e. 16 dependent launches per solve of which 12 found nothing to do.
+void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                       const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
+                       int waves /* 1 or 2 per SIMD: 512 / 256 registers */, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
-    const int n_chunks = (prm.iters + RANSAC_CHUNK - 1) / RANSAC_CHUNK;
-    const dim3 eg(RANSAC_CHUNK / 64, n_frames);
     // The 12 x 12 matrices of 64 hypotheses take 78 KB of LDS, so two such workgroups fill a CU's 160 KB completely and no
     // other kernel that uses LDS at all (pyr_down, FAST, LK with 1.9 KB per wave) can start a workgroup there until one of
     // them retires: when the chain starts on an idle GPU, the next LDS-using kernel of the tracking stream sits behind it
     // for ~0.6 ms (round-2 trace of the lock-step loop, 256 sequences).  Capping the solver at ONE workgroup per CU by asking
-    // for more than half of the LDS (VO_EPNP_LDS_KB=82) was measured and is worse -- the chain gets longer than two steps:
-    // reference-default batch 67.6 k -> 56.9 k frames/s, 128 sequences 51.5 k -> 48.9 k, 256 sequences unchanged -- so the
-    // tracking stream instead starts each step with its LDS-free kernels (capi.hip, PYRAMID stage).
+    // for more than half of the LDS (VO_EPNP_LDS_KB=82, developer build) was measured and is worse -- the chain gets longer
+    // than two steps -- so the tracking stream instead starts each step with its LDS-free kernels (capi.hip, PYRAMID stage).
     static const size_t lds = [] {
         size_t need = (144 + 12) * 64 * sizeof(double), want = 0;
 #ifdef VO_DEV_VARIANTS
@@ -563,40 +697,60 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 #endif
         return want > need ? want : need;
     }();
-    for (int k = 0; k < n_chunks; k++) {
-        hipLaunchKernelGGL(ransac_subsets_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
-                           prm.iters, k, subsets, state);
+    for (int h0 = 0; h0 < prm.iters;) {
+        const int hn = h0 == 0 ? min(RANSAC_CHUNK, prm.iters) : prm.iters - h0;
+        const dim3 eg((hn + 63) / 64, n_frames);
+        launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
 #ifdef VO_DEV_VARIANTS // the 128-register instantiation: never the best one since round 2
         if (waves >= 4)
             hipLaunchKernelGGL(epnp_kernel<4>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               k, models);
+                               h0, hn, models);
         else
 #endif
         if (waves >= 2)
             hipLaunchKernelGGL(epnp_kernel<2>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               k, models);
+                               h0, hn, models);
         else
             hipLaunchKernelGGL(epnp_kernel<1>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               k, models);
-        hipLaunchKernelGGL(vote_kernel, dim3(RANSAC_CHUNK, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts,
-                           cap, prm, models, state, k, counts);
-        hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames,
-                           prm, k, counts, state);
+                               h0, hn, models);
+        hipLaunchKernelGGL(vote_kernel, dim3(hn, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, prm, models,
+                           state, h0, counts);
+        hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, prm,
+                           h0 + hn, counts, state);
+        h0 += hn;
     }
+}
+
+// the four-point frames (P3P), then winner / inlier mask / Levenberg-Marquardt refinement / Rodrigues -- and, in the
+// lock-step loop, the pose integration of every sequence (tail)
+void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                       const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
+                       PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream)
+{
+    if (n_frames <= 0)
+        return;
+    hipLaunchKernelGGL(p3p_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
+                       n_frames, prm, inliers, results);
 #ifdef VO_DEV_VARIANTS
     if (waves >= 4)
         hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
-                           cap, prm, models, state, inliers, results);
+                           cap, prm, models, state, inliers, results, tail);
     else
 #endif
     if (waves >= 2)
         hipLaunchKernelGGL(select_refine_kernel<2>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
-                           cap, prm, models, state, inliers, results);
+                           cap, prm, models, state, inliers, results, tail);
     else
         hipLaunchKernelGGL(select_refine_kernel<1>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
-                           cap, prm, models, state, inliers, results);
-    hipLaunchKernelGGL(p3p_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
-                       n_frames, prm, inliers, results);
+                           cap, prm, models, state, inliers, results, tail);
+}
+
+void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream)
+{
+    launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream);
+    launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 
 } // namespace vo

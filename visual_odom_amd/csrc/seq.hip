@@ -11,11 +11,9 @@
 //                         survivors), ages = (bucketed ages + 1) compacted with the M >= K circular-matching survivors
 //                         -- the ages array keeps the longer length, so the next frame's first M - K new corners
 //                         inherit stale ages exactly like the reference
-//   seq_integrate_kernel  rotationMatrixToEulerAngles + gates + integrateOdometryStereo  main.cpp:196-208,
-//                         utils.cpp:57-131 (vo_integrate.h, the same code vo_integrate_odometry() runs on the host),
-//                         one trajectory row per processed frame
+//   (the pose tail -- rotationMatrixToEulerAngles + gates + integrateOdometryStereo, main.cpp:196-208, utils.cpp:57-131,
+//    one trajectory row per processed frame -- runs inside select_refine_kernel: vo_seqtail.h)
 #include "vo_kernels.h"
-#include "vo_integrate.h"
 
 namespace vo {
 
@@ -82,78 +80,6 @@ __global__ __launch_bounds__(256) void seq_carry_kernel(const int *__restrict__ 
     }
 }
 
-// one thread per sequence
-__global__ void seq_integrate_kernel(const int *__restrict__ active, const PnpResult *__restrict__ results,
-                                     const EmResult *__restrict__ em /* nullptr unless mono_rotation */,
-                                     double *__restrict__ pose /* [S][16] */,
-                                     double *__restrict__ traj /* [S][max_steps][VO_SEQ_ROW] */,
-                                     SeqFrameInfo *__restrict__ info, int *__restrict__ n_rows, int max_steps,
-                                     int n_seq)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_seq || !active[f])
-        return;
-    const PnpResult r = results[f];
-    double *P = pose + (size_t)f * 16;
-    int flags = VO_SEQ_F_ACTIVE | ((active[f] & 2) ? VO_SEQ_F_GAP : 0);
-    float euler[3] = {0.f, 0.f, 0.f};
-    double R[9], t[3] = {0, 0, 0}, rv[3] = {0, 0, 0};
-    for (int k = 0; k < 9; k++)
-        R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    const int row = n_rows[f];
-    if (r.status < 0) {
-        flags |= VO_SEQ_F_TOO_FEW; // the reference's solvePnPRansac asserts here; the pose stays
-    } else {
-        for (int k = 0; k < 3; k++) {
-            t[k] = r.tvec[k];
-            rv[k] = r.rvec[k];
-        }
-        if (r.status == 0 && r.lm_iters < 0) {
-            // four points and P3P found no solution: solvePnP returned false with the shared buffers UNTOUCHED --
-            // rvec is the zeros of visualOdometry.cpp:162, `translation` is still the previous frame's (main.cpp:82)
-            const bool have_prev = row > 0 && row <= max_steps;
-            for (int k = 0; k < 3; k++) {
-                rv[k] = 0;
-                t[k] = have_prev ? traj[((size_t)f * max_steps + row - 1) * VO_SEQ_ROW + 15 + k] : 0.0;
-            }
-        }
-        bool have_R = true;
-        if (em) { // mono_rotation: rotation = recoverPose's (visualOdometry.cpp:146-157)
-            const EmResult e = em[f];
-            if (e.status == 1) {
-                for (int k = 0; k < 9; k++)
-                    R[k] = e.R[k];
-            } else {
-                have_R = false;
-                flags |= VO_SEQ_F_NO_ESSENTIAL; // recoverPose throws on the empty E in the reference
-            }
-        } else {
-            if (!(r.status == 0 && r.lm_iters < 0)) // (untouched: R stays Rodrigues(0) = identity)
-                for (int k = 0; k < 9; k++)
-                    R[k] = r.R[k];
-        }
-        if (have_R && integrate_odometry(P, R, t, euler))
-            flags |= VO_SEQ_F_INTEGRATED;
-    }
-    if (row < max_steps) {
-        double *o = traj + ((size_t)f * max_steps + row) * VO_SEQ_ROW;
-        for (int k = 0; k < 12; k++)
-            o[k] = P[k];
-        for (int k = 0; k < 3; k++) {
-            o[12 + k] = rv[k];
-            o[15 + k] = t[k];
-        }
-        for (int k = 0; k < 9; k++)
-            o[18 + k] = R[k];
-        SeqFrameInfo &q = info[(size_t)f * max_steps + row];
-        q.n_inliers = r.status >= 0 ? r.n_inliers : 0;
-        q.pnp_status = r.status;
-        q.flags = flags;
-        q.ransac_iters = r.niters;
-    }
-    n_rows[f] = row + 1;
-}
-
 // One launch moves every new stereo pair of a step into its ring slot: block (x, y) copies 4 rows of image y (2 per
 // pushed pair).  Sources are row-major 8-bit images with a byte stride, in device memory or in page-locked host
 // memory the GPU reads over PCIe directly (one kernel instead of 2 S pitched copies: at S = 256 the 512
@@ -210,13 +136,6 @@ void launch_seq_carry(const int *active, const float2 *outB, const int *nB, cons
 {
     hipLaunchKernelGGL(seq_carry_kernel, dim3(n_seq), dim3(256), 0, stream, active, outB, nB, idxA, nA, ages,
                        n_bucketed, cap, fcap, feat, fages, n_tracked, overflow, n_rows_carry, n_ages, info, max_steps);
-}
-
-void launch_seq_integrate(const int *active, const PnpResult *results, const EmResult *em, double *pose, double *traj, SeqFrameInfo *info, int *n_rows, int max_steps, int n_seq,
-                          hipStream_t stream)
-{
-    hipLaunchKernelGGL(seq_integrate_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, active, results, em,
-                       pose, traj, info, n_rows, max_steps, n_seq);
 }
 
 } // namespace vo

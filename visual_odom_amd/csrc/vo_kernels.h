@@ -69,6 +69,17 @@ struct SeqFrameInfo {
     int ransac_iters; // RANSAC iterations OpenCV would have executed
     int overflow;     // detection / bucketing capacity exceeded in this frame (results truncated)
 };
+// what thread 0 of a sequence's select_refine_kernel workgroup needs to finish the frame in the lock-step loop
+// (vo_seqtail.h); active == nullptr: no tail (batch mode, stand-alone calls, schedule-probe dry runs)
+struct SeqTail {
+    const int *active = nullptr;   // [S] this step's activity (bit 1: first frame after a pause)
+    const EmResult *em = nullptr;  // mono_rotation: recoverPose results
+    double *pose = nullptr;        // [S][16] frame_pose
+    double *traj = nullptr;        // [S][max_steps][VO_SEQ_ROW]
+    SeqFrameInfo *info = nullptr;  // [S][max_steps]
+    int *n_rows = nullptr;         // [S]
+    int max_steps = 0;
+};
 // one pushed stereo pair of a step (seq_ingest_kernel): source images + first image-table index of its ring slot
 struct SeqIngest {
     const uint8_t *left, *right;
@@ -128,9 +139,6 @@ void launch_seq_carry(const int *active, const float2 *outB, const int *nB, cons
                       const int *ages, const int *n_bucketed, int cap, int fcap, float2 *feat, int *fages,
                       int *n_tracked, const int *overflow, int *n_rows_carry, int *n_ages, SeqFrameInfo *info,
                       int max_steps, int n_seq, hipStream_t stream);
-void launch_seq_integrate(const int *active, const PnpResult *results, const EmResult *em, double *pose,
-                          double *traj, SeqFrameInfo *info, int *n_rows, int max_steps, int n_seq,
-                          hipStream_t stream);
 // Everything vo_track_frame returns for its one frame, gathered by one kernel into one host-visible buffer (layout: a
 // 512-byte header -- nA, nB, has_em at bytes 0 / 4 / 8, the PnpResult at byte 16, the EmResult at byte 256 -- then fixed
 // capacity arrays l0, r0, l1, r1 [cap] float2, xyz [cap][3] float, keep_idx, keep_idx_circ, inliers [cap] int32).
@@ -155,8 +163,17 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream);
-void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int chunk, int32_t *subsets,
+void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                       const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
+                       hipStream_t stream);
+void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
+                       const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
+                       PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);
+// subsets of hypotheses [h0, h0 + hn) of every frame (cv::RNG(-1) stream, continued per frame)
+void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int h0, int hn, int32_t *subsets,
                            RansacState *rstate, hipStream_t stream);
+// per-device tables of the pose solve (the raw RNG stream); called by vo_create on the context's device
+int pnp_init_device(hipStream_t stream);
 void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
                       const EmParams &prm, const EmBufs &eb, EmResult *results, bool crowded, hipStream_t stream);
 
