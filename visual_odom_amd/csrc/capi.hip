@@ -1086,10 +1086,13 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     if (stages & VO_STAGE_FILTER) {
         launch_compact(cur_pts(c), c->d_trk2[c->trk_last], c->d_status2[c->trk_last], cur_npts(c), cap,
                        c->prm.consistency_threshold, c->d_outA, c->d_idxA, c->d_nA, pb.outB, pb.idxB, pb.nB, B, fs);
-        if (sq.on && !dry) { // currentVOFeatures of every sequence after this frame (seq.hip)
-            launch_seq_carry(seq_active, pb.outB, pb.nB, c->d_idxA, c->d_nA, cur_ages(c), cur_npts(c), cap, c->fcap,
-                             c->d_feat, c->d_fages, c->d_ntracked, c->d_overflow, sq.d_rows_carry, sq.d_nages, sq.d_info,
-                             sq.max_steps, B, fs);
+        if (sq.on) { // currentVOFeatures of every sequence after this frame (seq.hip)
+            if (!dry)
+                launch_seq_carry(seq_active, pb.outB, pb.nB, c->d_idxA, c->d_nA, cur_ages(c), cur_npts(c), cap, c->fcap,
+                                 c->d_feat, c->d_fages, c->d_ntracked, c->d_overflow, sq.d_rows_carry, sq.d_nages, sq.d_info,
+                                 sq.max_steps, B, fs);
+            // (a dry run keeps the DEPENDENCY -- the next run's detection waits for this run's filter like it waits for
+            // the carried features in a real step -- without the kernel that would advance the state)
             VO_HIP_TRY(c, hipEventRecord(sq.ev_carry, fs));
             sq.carry_pending = true;
         }
@@ -1310,31 +1313,62 @@ static int sched_resolve(vo_ctx *c, int stages)
     return 0;
 }
 
-// wall-clock milliseconds per run of M back-to-back runs (the pose chain of run i overlaps the tracking stages of run
-// i + 1 exactly as in steady state); the first, untimed run sizes M (>= 8 ms of work, 3 .. 16 runs)
+// FAST + non-maximum suppression of the pairs in ring slot r (this step's new pairs), for the NEXT step's
+// appendNewFeatures: on the prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
+static int seq_lookahead(vo_ctx *c, int r)
+{
+    vo_ctx::Seq &q = c->seq;
+    int t = c->dprm.fast_threshold;
+    t = t < 0 ? 0 : t > 255 ? 255 : t;
+    launch_fast_corners(c->d_imgs, q.d_quads + (size_t)r * q.S, nullptr, q.S, c->w, c->h, t, c->dprm.fast_nonmax,
+                        c->d_nmsmask, c->d_rowcnt, c->d_rowoff, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
+                        q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
+    VO_HIP_TRY(c, hipEventRecord(q.ev_fast[r], q.copy));
+    q.fast_pending[r] = true;
+    q.have_corners[r] = true;
+    VO_HIP_TRY(c, hipGetLastError());
+    return VO_OK;
+}
+
+// one run of the probe: the stages, plus -- lock-step loop with the prepare stream -- the look-ahead detection a real
+// step launches behind them (it recomputes the corners the real step will compute: idempotent)
+static int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
+{
+    int rc = run_stages(c, stages, timed, evs, dry);
+    if (rc == VO_OK && dry && c->seq.on && c->sched.prep)
+        rc = seq_lookahead(c, (int)(c->seq.step % c->seq.ring));
+    return rc;
+}
+
+// STEADY-STATE milliseconds per run: n and n + K back-to-back runs are timed and the difference is divided by K, so that
+// what every measurement has once -- the ramp-up and the last run's pose chain, which nothing overlaps -- cancels (timing
+// one short burst instead favours the schedule with the shortest lone chain: the first version of this probe picked the
+// 512-register kernels for 256 sequences, 10 % below the 256-register ones in the real loop).  K >= 12 ms of work, 4 .. 24.
 static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, double *ms_per_run)
 {
     using clk = std::chrono::steady_clock;
-    int rc = sync_all(c);
+    auto burst = [&](int n, double *ms) {
+        int rc = sync_all(c);
+        const auto t0 = clk::now();
+        for (int i = 0; i < n && rc == VO_OK; i++)
+            rc = probe_run(c, stages, timed, evs, dry);
+        if (rc == VO_OK)
+            rc = sync_all(c);
+        *ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        return rc;
+    };
+    double warm = 0, ta = 0, tb = 0;
+    int rc = burst(1, &warm);
     if (rc != VO_OK)
         return rc;
-    auto t0 = clk::now();
-    rc = run_stages(c, stages, timed, evs, dry);
+    int K = warm > 0 ? (int)ceil(12.0 / warm) : 24;
+    K = K < 4 ? 4 : K > 24 ? 24 : K;
+    rc = burst(3, &ta);
     if (rc == VO_OK)
-        rc = sync_all(c);
+        rc = burst(3 + K, &tb);
     if (rc != VO_OK)
         return rc;
-    const double warm = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-    int M = warm > 0 ? (int)ceil(8.0 / warm) : 16;
-    M = M < 3 ? 3 : M > 16 ? 16 : M;
-    t0 = clk::now();
-    for (int i = 0; i < M && rc == VO_OK; i++)
-        rc = run_stages(c, stages, timed, evs, dry);
-    if (rc == VO_OK)
-        rc = sync_all(c);
-    if (rc != VO_OK)
-        return rc;
-    *ms_per_run = std::chrono::duration<double, std::milli>(clk::now() - t0).count() / M;
+    *ms_per_run = (tb - ta) / K;
     return VO_OK;
 }
 
@@ -2152,23 +2186,8 @@ int vo_seq_step(vo_ctx *c)
         rc = run_stages(c, stages, true, step_evs);
     if (rc == VO_OK && !c->sched.prep)
         q.have_corners[r] = false; // the pair now in slot r has no look-ahead corners
-    if (rc == VO_OK && c->sched.prep) {
-        // FAST + non-maximum suppression of the new pairs' left images, for the NEXT step's appendNewFeatures: on the
-        // prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
-        int t = c->dprm.fast_threshold;
-        t = t < 0 ? 0 : t > 255 ? 255 : t;
-        launch_fast_corners(c->d_imgs, q.d_quads + (size_t)r * q.S, nullptr, q.S, c->w, c->h, t, c->dprm.fast_nonmax,
-                            c->d_nmsmask, c->d_rowcnt, c->d_rowoff, nullptr, q.d_ncorn + (size_t)r * q.S, c->fcap,
-                            q.d_corners + (size_t)r * q.S * c->fcap, q.copy);
-        hipError_t e1 = hipEventRecord(q.ev_fast[r], q.copy);
-        q.fast_pending[r] = true;
-        q.have_corners[r] = true;
-        hipError_t e2 = hipGetLastError();
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            c->err = std::string("vo_seq_step: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
-            rc = VO_ERR_HIP;
-        }
-    }
+    if (rc == VO_OK && c->sched.prep)
+        rc = seq_lookahead(c, r);
     if (rc != VO_OK) {
         // the step has consumed its pairs and part of it may be running: wait for the device, then refuse everything
         // until the caller starts over -- the ring / staging slots of this step must not be rewritten under it

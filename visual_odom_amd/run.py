@@ -99,6 +99,9 @@ def main(argv=None):
     ap.add_argument("--features-per-bucket", type=int, default=1, help="visualOdometry.cpp:107")
     ap.add_argument("--mono-rotation", action="store_true", help="trackingFrame2Frame(..., mono_rotation = true); main.cpp:181 passes false")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--decode-threads", type=int, default=8,
+                    help="image files of frame k + 1 are read and decoded by this many threads while step k is pushed and runs "
+                         "(PIL's decoders release the GIL); 0 = decode on the pushing thread like round 2")
     args = ap.parse_args(argv)
 
     from . import odometry
@@ -117,12 +120,39 @@ def main(argv=None):
                                         mono_rotation=args.mono_rotation, features_per_bucket=args.features_per_bucket)
     live = [True] * S
     n_read = [0] * S
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(args.decode_threads) if args.decode_threads > 0 else None
+
+    def prefetch(frame_id):
+        if pool is None or frame_id >= args.max_frames:
+            return {}
+        return {s: pool.submit(read_pair, d, frame_id) for s, d in enumerate(dirs) if live[s]}
+
+    t_start = time.perf_counter()
+    t_wait = 0.0
+    ahead = prefetch(1)
     for frame_id in range(args.max_frames):
         pushed = 0
+        cur, ahead = ahead, {}
+        pairs = {}
         for s, d in enumerate(dirs):
             if not live[s]:
                 continue
-            pair = first[s] if frame_id == 0 else read_pair(d, frame_id)
+            if frame_id == 0:
+                pairs[s] = first[s]
+            elif s in cur:
+                t0 = time.perf_counter()
+                pairs[s] = cur[s].result()
+                t_wait += time.perf_counter() - t0
+            else:
+                pairs[s] = read_pair(d, frame_id)
+        if frame_id > 0:  # the next frame's files are decoded while this step is pushed and runs
+            ahead = prefetch(frame_id + 1)
+        for s, d in enumerate(dirs):
+            if not live[s]:
+                continue
+            pair = pairs.get(s)
             if pair is None or pair[0].shape != (h, w):
                 live[s] = False   # the reference runs until imread fails (main.cpp:123, utils.cpp:178)
                 continue
@@ -133,6 +163,13 @@ def main(argv=None):
             break
         vo.step()                 # asynchronous: the next pairs are decoded while this step runs
     vo.sync()
+    elapsed = time.perf_counter() - t_start
+    if pool is not None:
+        pool.shutdown(wait=True, cancel_futures=True)
+    frames_done = sum(max(0, n - 1) for n in n_read)
+    print(dict(end_to_end_frames_per_s=frames_done / elapsed if elapsed > 0 else 0.0, frames=frames_done, seconds=elapsed,
+               sequences=S, decode_threads=args.decode_threads, seconds_waiting_for_decoders=t_wait,
+               note="from the image files: read + decode + upload + compute"), flush=True)
     results = []
     for s, d in enumerate(dirs):
         traj = vo.trajectory(s)
