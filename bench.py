@@ -446,7 +446,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                        "frames_per_step_per_gpu": B, "pyramids_per_step_per_gpu": n_images,
                        "points_per_frame": float(np.mean([len(p) for p in frame_pts])),
                        "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,
-                       "schedule": ctx.get_schedule(),
+                       "schedule": dict(ctx.get_schedule(), probe_ms=ctx.get_probe_log()),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes,
                        "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
@@ -559,7 +559,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                        "frames_per_step_per_gpu": S, "pyramids_per_step_per_gpu": 2 * S,
                        "points_per_frame": pts_per_launch / S, "integrated_fraction": float(integrated),
                        "parallelism": "replicas x%d (%d sequences per GPU, no collective)" % (world_size, S),
-                       "schedule": ctx.get_schedule(),
+                       "schedule": dict(ctx.get_schedule(), probe_ms=ctx.get_probe_log()),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes},
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,

@@ -107,6 +107,8 @@ typedef struct vo_schedule {
 int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
 /* the schedule the next run will use; *probed (optional) = 1 when it came out of a probe of this key */
 int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
+/* what the last probe run by this context measured: *n (<= 8) candidates and their steady-state milliseconds per run */
+int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands8, float *ms8, int *n);
 int vo_get_params(const vo_ctx *ctx, vo_params *p);
 
 /* ------------------------------------------------------------------------------------------

@@ -33,6 +33,13 @@ ORDER = [0, 1, 2, 3, 4, 3, 2, 1]  # ping-pong over the rendered pairs: always ad
 def run(what, per_bucket, n):
     from visual_odom_amd import _lib, odometry
     world, L, R, P_l, P_r, pts = inputs(per_bucket)
+    if what == "trackonly":  # for a kernel trace of vo_track_frame alone (tools/kernel_timeline.py)
+        ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+        for i in range(n):
+            k = i % 4
+            ctx.track_frame(L[k], R[k], L[k + 1], R[k + 1], pts[k], P_l, P_r)
+        print("  schedule", ctx.get_schedule(), ctx.get_probe_log())
+        return
     if what == "track":
         ctx = _lib.Context(0, world.w, world.h, 4096, 1)
         for k in range(4):

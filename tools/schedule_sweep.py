@@ -69,6 +69,7 @@ def main():
         best = max(pinned, key=pinned.get)
         rec["probe_fps"] = rec["runs"]["probe"]["fps"]
         rec["probe_pick"] = rec["runs"]["probe"]["schedule"]
+        rec["probe_ms"] = rec["runs"]["probe"]["schedule"].get("probe_ms")
         rec["best_pinned"] = best
         rec["best_pinned_fps"] = pinned[best]
         rec["worst_pinned_fps"] = min(pinned.values())

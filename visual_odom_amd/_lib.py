@@ -34,7 +34,7 @@ EXPORTS = (
     "vo_batch_sync", "vo_batch_get_tracks", "vo_batch_get_filtered", "vo_batch_get_pose",
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
     "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_push_pairs", "vo_seq_step", "vo_seq_sync",
-    "vo_seq_get_state", "vo_seq_get_trajectory", "vo_set_schedule", "vo_get_schedule",
+    "vo_seq_get_state", "vo_seq_get_trajectory", "vo_set_schedule", "vo_get_schedule", "vo_get_probe_log",
 )
 
 
@@ -162,6 +162,12 @@ class Context:
         s, probed = VoSchedule(), C.c_int(0)
         self._chk(self.lib.vo_get_schedule(self.h, C.byref(s), C.byref(probed)))
         return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, probed=bool(probed.value))
+
+    def get_probe_log(self):
+        """{"w,s,p": steady-state ms per run} as measured by the last schedule probe of this context ({} if none ran)"""
+        cands, ms, n = (VoSchedule * 8)(), (C.c_float * 8)(), C.c_int(0)
+        self._chk(self.lib.vo_get_probe_log(self.h, cands, ms, C.byref(n)))
+        return {"%d,%d,%d" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare): float(ms[i]) for i in range(n.value)}
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):

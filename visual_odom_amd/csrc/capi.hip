@@ -129,6 +129,10 @@ struct vo_ctx {
     long long sched_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0}; // key `sched` was resolved for
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
+    // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
+    int probe_n = 0;
+    vo_schedule probe_cand[8] = {};
+    float probe_ms[8] = {};
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
@@ -1410,7 +1414,12 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
             best = (int)i;
             best_ms = ms;
         }
+        if (i < 8) {
+            c->probe_cand[i] = vo_schedule{cands[i].waves, cands[i].streams, cands[i].prep};
+            c->probe_ms[i] = (float)ms;
+        }
     }
+    c->probe_n = (int)(cands.size() < 8 ? cands.size() : 8);
     c->tuning = false;
     if (rc != VO_OK)
         return rc;
@@ -1480,6 +1489,20 @@ int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
     cur->prepare = c->seq.on ? c->sched.prep : 0;
     if (probed)
         *probed = c->sched_probed ? 1 : 0;
+    return VO_OK;
+}
+
+int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands8, float *ms8, int *n)
+{
+    if (!c || !n)
+        return VO_ERR_ARG;
+    *n = c->probe_n;
+    for (int i = 0; i < c->probe_n; i++) {
+        if (cands8)
+            cands8[i] = c->probe_cand[i];
+        if (ms8)
+            ms8[i] = c->probe_ms[i];
+    }
     return VO_OK;
 }
 
