@@ -195,7 +195,7 @@ struct vo_ctx {
         bool fast_pending[VO_SEQ_MAX_RING] = {};
         bool have_corners[VO_SEQ_MAX_RING] = {}; // d_corners of ring slot r belongs to the pair now in that slot
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
-        int n_ing = 0;
+        int n_ing = 0, n_active = 0;    // pairs pushed for / sequences active in the pending step
         bool begun = false, staged = false;
     } seq;
 };
@@ -1317,6 +1317,41 @@ static int sched_resolve(vo_ctx *c, int stages)
     return 0;
 }
 
+// What the pending step's kernels read that comes from the host: the pushed pairs -> ring slot step % ring with ONE
+// kernel on the copy stream -- after the LK that still reads the slot's previous occupant (ring 2: the previous step's;
+// ring 3: the one before, long finished), next to the previous step's kernels -- and the step's activity flags.
+// dry (schedule probe): the same transfers again (same bytes to the same places), without the slot / staging bookkeeping.
+static int seq_enqueue_inputs(vo_ctx *c, bool dry)
+{
+    vo_ctx::Seq &q = c->seq;
+    const int slot = (int)(q.step % VO_SEQ_INFLIGHT), r = (int)(q.step % q.ring);
+    if (q.n_ing > 0) {
+        if (!dry && q.slot_busy[r]) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_slot_free[r], 0));
+            q.slot_busy[r] = false;
+        }
+        SeqIngest *d_tab = q.d_ing + (size_t)slot * q.S;
+        VO_HIP_TRY(c, hipMemcpyAsync(d_tab, q.h_ing + (size_t)slot * q.S, sizeof(SeqIngest) * q.n_ing,
+                                     hipMemcpyHostToDevice, q.copy));
+        launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
+                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.copy);
+        if (!dry && q.staged) {
+            const int g = (int)(q.step & 1);
+            VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));
+            q.stage_busy[g] = true;
+            q.staged = false;
+        }
+    }
+    if (!c->sched.prep) {
+        VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
+    }
+    if (q.n_active > 0)
+        VO_HIP_TRY(c, hipMemcpyAsync(q.d_active + (size_t)slot * q.S, q.h_active + (size_t)slot * q.S, sizeof(int) * q.S,
+                                     hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+
 // FAST + non-maximum suppression of the pairs in ring slot r (this step's new pairs), for the NEXT step's
 // appendNewFeatures: on the prepare stream behind their pyramids (fast_score reads level 0 only), while this step's LK runs
 static int seq_lookahead(vo_ctx *c, int r)
@@ -1338,7 +1373,9 @@ static int seq_lookahead(vo_ctx *c, int r)
 // step launches behind them (it recomputes the corners the real step will compute: idempotent)
 static int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
 {
-    int rc = run_stages(c, stages, timed, evs, dry);
+    int rc = dry && c->seq.on ? seq_enqueue_inputs(c, true) : VO_OK;
+    if (rc == VO_OK)
+        rc = run_stages(c, stages, timed, evs, dry);
     if (rc == VO_OK && dry && c->seq.on && c->sched.prep)
         rc = seq_lookahead(c, (int)(c->seq.step % c->seq.ring));
     return rc;
@@ -2161,36 +2198,15 @@ int vo_seq_step(vo_ctx *c)
         q.had_prev[s] = q.pushed[s];
         q.pushed[s] = 0;
     }
-    // this step's pairs -> ring slot r, on the copy stream: after the LK that still reads the slot's previous
-    // occupant (ring 2: the previous step's; ring 3: the one before, long finished), next to the previous step's kernels
-    if (q.n_ing > 0) {
-        if (q.slot_busy[r]) {
-            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_slot_free[r], 0));
-            q.slot_busy[r] = false;
-        }
-        SeqIngest *d_tab = q.d_ing + (size_t)slot * q.S;
-        VO_HIP_TRY(c, hipMemcpyAsync(d_tab, q.h_ing + (size_t)slot * q.S, sizeof(SeqIngest) * q.n_ing,
-                                     hipMemcpyHostToDevice, q.copy));
-        launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
-                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.copy);
-        if (q.staged) {
-            const int g = (int)(q.step & 1);
-            VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));
-            q.stage_busy[g] = true;
-            q.staged = false;
-        }
-    }
-    if (!c->sched.prep) {
-        VO_HIP_TRY(c, hipEventRecord(q.ev_upload, q.copy));
-        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, q.ev_upload, 0));
-    }
+    q.n_active = n_active;
+    rc = seq_enqueue_inputs(c, /*dry*/ false);
+    if (rc != VO_OK)
+        return rc;
     q.begun = false;
     c->pyr_first = r * q.S * 2;
     c->pyr_count = q.S * 2;
     int stages = VO_STAGE_PYRAMID;
     if (n_active > 0) {
-        VO_HIP_TRY(c, hipMemcpyAsync(q.d_active + (size_t)slot * q.S, act, sizeof(int) * q.S, hipMemcpyHostToDevice,
-                                     c->stream));
         c->quads_cur = q.d_quads + (size_t)((q.step - 1) % q.ring) * q.S;
         stages |= VO_STAGE_DETECT | VO_STAGE_LK | VO_STAGE_FILTER | VO_STAGE_TRIANGULATE | VO_STAGE_PNP;
     }
