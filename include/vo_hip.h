@@ -105,10 +105,16 @@ typedef struct vo_schedule {
 } vo_schedule;
 /* s == NULL: probe everything (the default) */
 int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
-/* the schedule the next run will use; *probed (optional) = 1 when it came out of a probe of this key */
+/* the schedule the next run will use; *probed (optional) = 1 when it came out of a probe of this key, 2 while the
+ * lock-step loop is still comparing the prepare knob over real steps (see below), 0 for defaults / pins.
+ * Lock-step loop: the probe's repeated runs of a step cannot include the two kernels that advance the sequences'
+ * state, and what they hide matters for the prepare knob; so after the probe that knob alone is settled over REAL
+ * steps -- the pick runs for 15 .. 51 steps, then its prepare-flipped twin, end-of-step GPU timestamps decide (two
+ * pipeline drains in the first ~100 steps of a loop; results never depend on any of it). */
 int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
-/* what the last probe run by this context measured: *n (<= 8) candidates and their steady-state milliseconds per run */
-int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands8, float *ms8, int *n);
+/* what the last probe run by this context measured: *n (<= 8) candidates and their steady-state milliseconds per run;
+ * real8[i] (optional) = 1 where the figure was re-measured over real steps of the lock-step loop */
+int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands8, float *ms8, int *real8, int *n);
 int vo_get_params(const vo_ctx *ctx, vo_params *p);
 
 /* ------------------------------------------------------------------------------------------

@@ -161,13 +161,15 @@ class Context:
         """the schedule the next run uses: dict(pose_waves, pose_streams, prepare, probed)"""
         s, probed = VoSchedule(), C.c_int(0)
         self._chk(self.lib.vo_get_schedule(self.h, C.byref(s), C.byref(probed)))
-        return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, probed=bool(probed.value))
+        return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, probed=bool(probed.value),
+                    settling=probed.value == 2)
 
     def get_probe_log(self):
         """{"w,s,p": steady-state ms per run} as measured by the last schedule probe of this context ({} if none ran)"""
-        cands, ms, n = (VoSchedule * 8)(), (C.c_float * 8)(), C.c_int(0)
-        self._chk(self.lib.vo_get_probe_log(self.h, cands, ms, C.byref(n)))
-        return {"%d,%d,%d" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare): float(ms[i]) for i in range(n.value)}
+        cands, ms, real, n = (VoSchedule * 8)(), (C.c_float * 8)(), (C.c_int * 8)(), C.c_int(0)
+        self._chk(self.lib.vo_get_probe_log(self.h, cands, ms, real, C.byref(n)))
+        return {"%d,%d,%d%s" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare, " (real steps)" if real[i] else ""):
+                float(ms[i]) for i in range(n.value)}
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):

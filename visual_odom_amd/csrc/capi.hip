@@ -129,10 +129,13 @@ struct vo_ctx {
     long long sched_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0}; // key `sched` was resolved for
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
+    Schedule ab_pick;                // lock-step loop: what the dry probe picked, while the prepare A/B is running
+    long long ab_key[8] = {};
     // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
     int probe_n = 0;
     vo_schedule probe_cand[8] = {};
     float probe_ms[8] = {};
+    int probe_real[8] = {};          // 1: probe_ms[i] was (re)measured over real steps of the lock-step loop
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
@@ -196,6 +199,11 @@ struct vo_ctx {
         bool have_corners[VO_SEQ_MAX_RING] = {}; // d_corners of ring slot r belongs to the pair now in that slot
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
         int n_ing = 0, n_active = 0;    // pairs pushed for / sequences active in the pending step
+        // A/B of the prepare stream over REAL steps (vo_seq_step): 1 = timing the dry probe's pick, 2 = timing its
+        // prepare-flipped twin, 3 = decided; ab_left counts down the phase's steps (3 untimed ramp steps + ab_n timed)
+        int ab_phase = 0, ab_left = 0, ab_n = 0;
+        hipEvent_t ev_ab[4] = {};
+
         bool begun = false, staged = false;
     } seq;
 };
@@ -355,6 +363,9 @@ static void seq_free(vo_ctx *c)
         (void)hipHostFree(q.h_stage);
     hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_pyr, q.ev_stage[0], q.ev_stage[1]};
     for (auto &e : q.ev_fast)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto &e : q.ev_ab)
         if (e)
             (void)hipEventDestroy(e);
     for (hipEvent_t e : evs)
@@ -1454,6 +1465,7 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
         if (i < 8) {
             c->probe_cand[i] = vo_schedule{cands[i].waves, cands[i].streams, cands[i].prep};
             c->probe_ms[i] = (float)ms;
+            c->probe_real[i] = 0;
         }
     }
     c->probe_n = (int)(cands.size() < 8 ? cands.size() : 8);
@@ -1525,11 +1537,11 @@ int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
     cur->pose_streams = c->sched.streams;
     cur->prepare = c->seq.on ? c->sched.prep : 0;
     if (probed)
-        *probed = c->sched_probed ? 1 : 0;
+        *probed = (c->seq.on && (c->seq.ab_phase == 1 || c->seq.ab_phase == 2)) ? 2 : c->sched_probed ? 1 : 0;
     return VO_OK;
 }
 
-int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands8, float *ms8, int *n)
+int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands8, float *ms8, int *real8, int *n)
 {
     if (!c || !n)
         return VO_ERR_ARG;
@@ -1539,6 +1551,8 @@ int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands8, float *ms8, int *n)
             cands8[i] = c->probe_cand[i];
         if (ms8)
             ms8[i] = c->probe_ms[i];
+        if (real8)
+            real8[i] = c->probe_real[i];
     }
     return VO_OK;
 }
@@ -1958,6 +1972,8 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
         ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (auto &e : q.ev_stage)
         ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : q.ev_ab)
+        ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         seq_free(c);
         return fail(c, VO_ERR_HIP, "vo_seq_configure: allocation failed");
@@ -2006,6 +2022,8 @@ int vo_seq_reset(vo_ctx *c, int seq)
         // slot 0, event slot 0, all max_steps trajectory rows available again (a long-lived context that recycles its
         // sequences never runs out of steps)
         q.step = 0;
+        if (q.ab_phase == 1 || q.ab_phase == 2)
+            q.ab_phase = 0; // an unfinished A/B is abandoned: the dry probe's pick stays
         q.begun = q.staged = q.broken = false;
         q.n_ing = 0;
         q.carry_pending = q.integ_pending = false;
@@ -2218,8 +2236,27 @@ int vo_seq_step(vo_ctx *c)
         int need = sched_resolve(c, stages);
         if (need < 0)
             rc = need;
-        else if (need)
+        else if (need) {
             rc = tune_schedule(c, stages, true, step_evs, /*dry*/ true);
+            if (rc == VO_OK && c->pin.prepare < 0) {
+                // The dry runs leave out the two kernels that advance the state, and with them some of what the prepare
+                // stream hides: measured against every pinned schedule (tools/schedule_sweep.py) their verdict on the
+                // prepare knob alone was wrong by 8-25 % at 1-32 sequences.  So that knob is settled over REAL steps:
+                // the pick runs for a while, then its prepare-flipped twin, end-of-step GPU timestamps decide.
+                double ms = 1.0;
+                for (int i = 0; i < c->probe_n; i++)
+                    if (c->probe_cand[i].pose_waves == c->sched.waves && c->probe_cand[i].pose_streams == c->sched.streams &&
+                        c->probe_cand[i].prepare == c->sched.prep)
+                        ms = c->probe_ms[i] > 0.02f ? c->probe_ms[i] : 0.02;
+                q.ab_n = (int)ceil(25.0 / ms);
+                q.ab_n = q.ab_n < 12 ? 12 : q.ab_n > 48 ? 48 : q.ab_n;
+                q.ab_phase = 1;
+                q.ab_left = 3 + q.ab_n;
+                c->ab_pick = c->sched;
+                memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
+                c->sched_probed = false; // "in progress" (vo_get_schedule reports 2)
+            }
+        }
     }
     if (rc == VO_OK)
         rc = run_stages(c, stages, true, step_evs);
@@ -2238,11 +2275,50 @@ int vo_seq_step(vo_ctx *c)
     }
     // end of the step = end of its last stream: the pose stream when a frame was processed; without a processed frame
     // the step's work is the ingest + pyramids (+ FAST) -- on the prepare stream when there is one
-    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], n_active > 0 && c->last_pose_stream ? c->last_pose_stream
-                                                  : c->sched.prep        ? q.copy
-                                                                         : c->stream));
+    hipStream_t end_stream = n_active > 0 && c->last_pose_stream ? c->last_pose_stream : c->sched.prep ? q.copy : c->stream;
+    VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], end_stream));
     q.step_pending[slot] = true;
     q.step++;
+    if ((q.ab_phase == 1 || q.ab_phase == 2) && n_active > 0 && 2 * n_active >= q.S) {
+        q.ab_left--;
+        if (q.ab_left == q.ab_n) { // ramp over: the clock starts at the end of this step
+            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[q.ab_phase == 1 ? 0 : 2], end_stream));
+        } else if (q.ab_left == 0) {
+            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[q.ab_phase == 1 ? 1 : 3], end_stream));
+            vo_ctx::Schedule twin = c->ab_pick;
+            twin.prep ^= 1;
+            if (q.ab_phase == 1) {
+                rc = set_sched(c, twin); // (drains every stream first)
+                if (rc != VO_OK)
+                    return rc;
+                q.ab_phase = 2;
+                q.ab_left = 3 + q.ab_n;
+            } else {
+                VO_HIP_TRY(c, hipEventSynchronize(q.ev_ab[3]));
+                float t1 = 0, t2 = 0;
+                VO_HIP_TRY(c, hipEventElapsedTime(&t1, q.ev_ab[0], q.ev_ab[1]));
+                VO_HIP_TRY(c, hipEventElapsedTime(&t2, q.ev_ab[2], q.ev_ab[3]));
+                const vo_ctx::Schedule best = t1 <= t2 ? c->ab_pick : twin;
+                rc = set_sched(c, best);
+                if (rc != VO_OK)
+                    return rc;
+                TuneKey key;
+                memcpy(key.k, c->ab_key, sizeof(key.k));
+                {
+                    std::lock_guard<std::mutex> lk(g_tune_mu);
+                    g_tuned[key] = best;
+                }
+                for (int i = 0; i < c->probe_n; i++) // the log shows what was measured over real steps
+                    if (c->probe_cand[i].pose_waves == best.waves && c->probe_cand[i].pose_streams == best.streams) {
+                        const bool first = c->probe_cand[i].prepare == c->ab_pick.prep;
+                        c->probe_ms[i] = (first ? t1 : t2) / q.ab_n;
+                        c->probe_real[i] = 1;
+                    }
+                q.ab_phase = 3;
+                c->sched_probed = true;
+            }
+        }
+    }
     return VO_OK;
 }
 
