@@ -1395,7 +1395,7 @@ static int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dr
 // STEADY-STATE milliseconds per run: n and n + K back-to-back runs are timed and the difference is divided by K, so that
 // what every measurement has once -- the ramp-up and the last run's pose chain, which nothing overlaps -- cancels (timing
 // one short burst instead favours the schedule with the shortest lone chain: the first version of this probe picked the
-// 512-register kernels for 256 sequences, 10 % below the 256-register ones in the real loop).  K >= 12 ms of work, 4 .. 24.
+// 512-register kernels for 256 sequences, 10 % below the 256-register ones in the real loop).  K >= 20 ms of work, 6 .. 24.
 static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, double *ms_per_run)
 {
     using clk = std::chrono::steady_clock;
@@ -1413,8 +1413,8 @@ static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, b
     int rc = burst(1, &warm);
     if (rc != VO_OK)
         return rc;
-    int K = warm > 0 ? (int)ceil(12.0 / warm) : 24;
-    K = K < 4 ? 4 : K > 24 ? 24 : K;
+    int K = warm > 0 ? (int)ceil(20.0 / warm) : 24;
+    K = K < 6 ? 6 : K > 24 ? 24 : K;
     rc = burst(3, &ta);
     if (rc == VO_OK)
         rc = burst(3 + K, &tb);
