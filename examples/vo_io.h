@@ -239,10 +239,14 @@ class ThreadPool {
     bool stop_ = false;
 };
 
-// The stereo pairs of frame `id` of several sequences, decoded by the pool; ok[s] = both images read at the expected size
+// The stereo pairs of frame `id` of several sequences, decoded by the pool; ok[s] = both images read at the expected size.
+// Each set counts its own outstanding jobs, so several sets can be in flight in one pool (look-ahead).
 struct FrameSet {
     std::vector<Image> left, right;
     std::vector<char> ok;
+    std::mutex mu;
+    std::condition_variable cv;
+    int outstanding = 0;
     void decode(ThreadPool &pool, const std::vector<std::string> &dirs, const std::vector<char> &live, int id, int w, int h)
     {
         const size_t S = dirs.size();
@@ -252,12 +256,26 @@ struct FrameSet {
         for (size_t s = 0; s < S; s++) {
             if (!live[s])
                 continue;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                outstanding++;
+            }
             pool.submit([this, &dirs, s, id, w, h] {
                 const bool a = read_frame(dirs[s], 0, id, left[s]) && (w == 0 || (left[s].w == w && left[s].h == h));
                 const bool b = a && read_frame(dirs[s], 1, id, right[s]) && right[s].w == left[s].w && right[s].h == left[s].h;
                 ok[s] = a && b;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    outstanding--;
+                }
+                cv.notify_all();
             });
         }
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return outstanding == 0; });
     }
 };
 

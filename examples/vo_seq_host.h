@@ -11,6 +11,7 @@
 #include "vo_hip.h"
 #include "vo_io.h"
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -74,15 +75,19 @@ inline WorkerResult run_worker(int device, const std::vector<std::string> &dirs,
     if ((rc = vo_batch_set_projection(ctx, P_l, P_r)) < 0)
         return fail("vo_batch_set_projection", rc);
 
+    // decoder pool with look-ahead: frames id + 1 .. id + depth are being read and decoded while frame id is pushed and
+    // runs; depth = as many frames as keep every decoder thread busy (one sequence: a frame is only two files)
     voio::ThreadPool pool(decode_threads);
-    voio::FrameSet sets[2];
+    const int depth = std::max(1, std::min(16, (decode_threads + 2 * S - 1) / (2 * S)));
+    std::vector<voio::FrameSet> sets((size_t)depth + 1);
     std::vector<char> live(S, 1);
     const auto t0 = std::chrono::steady_clock::now();
-    sets[0].decode(pool, dirs, live, 0, w, h);
+    for (int k = 0; k <= depth && k < max_frames; k++)
+        sets[k % (depth + 1)].decode(pool, dirs, live, k, w, h);
     for (int id = 0; id < max_frames; id++) {
-        voio::FrameSet &cur = sets[id & 1];
+        voio::FrameSet &cur = sets[id % (depth + 1)];
         const auto tw = std::chrono::steady_clock::now();
-        pool.wait(); // frame `id` of every live sequence is decoded
+        cur.wait(); // frame `id` of every live sequence is decoded
         out.decode_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         int pushed = 0;
         for (int s = 0; s < S; s++) {
@@ -96,14 +101,14 @@ inline WorkerResult run_worker(int device, const std::vector<std::string> &dirs,
         }
         if (!pushed)
             break;
-        if (id + 1 < max_frames) // the next frames are decoded while this step is pushed and runs
-            sets[(id + 1) & 1].decode(pool, dirs, live, id + 1, w, h);
         for (int s = 0; s < S; s++)
             if (live[s]) // pageable host memory: copied to the library's pinned staging now, moved to the GPU when the step runs
                 if ((rc = vo_seq_push_pair(ctx, s, cur.left[s].px.data(), cur.right[s].px.data(), w, /*host_pinned*/ 0)) < 0)
                     return fail("vo_seq_push_pair", rc);
         if ((rc = vo_seq_step(ctx)) < 0)
             return fail("vo_seq_step", rc);
+        if (id + depth + 1 < max_frames) // this slot is free again: the frame `depth + 1` ahead goes into it
+            cur.decode(pool, dirs, live, id + depth + 1, w, h);
     }
     pool.wait();
     if ((rc = vo_seq_sync(ctx)) < 0)

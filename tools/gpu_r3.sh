@@ -59,7 +59,7 @@ if has timeline; then
 fi
 if has ingest; then
     stamp "decode-inclusive ingest (C++ host + python front end, PNG / PGM, 1 and 8 sequences)"
-    timeout 900 python tools/ingest_bench.py 60 > "$OUT/ingest.json" 2> "$OUT/ingest.err"
+    timeout 900 python tools/ingest_bench.py 600 > "$OUT/ingest.json" 2> "$OUT/ingest.err"
     python -c "
 import json
 o=json.load(open('$OUT/ingest.json'))

@@ -2,8 +2,10 @@
 read + decode + upload + compute -- for 1 and 8 sequences, through the C++ host (examples/vo_seq_run.cpp: zlib-only PNG
 reader + decoder thread pool) and through the python front end (visual_odom_amd.run: PIL in a thread pool), PNG and PGM.
 
-A KITTI-00-shaped sequence is rendered (synth.py) and written once; 8 "sequences" are 8 links to it (the page cache then
-serves the files, as it would for a sequence that was just downloaded).  The rendered images carry sensor-like noise and
+A KITTI-00-shaped sequence is rendered (synth.py) and written once -- 40 distinct frames, continued to n frames by links
+that walk them forwards and backwards (consecutive files are always consecutive renders) -- and 8 "sequences" are 8 links
+to that directory: the page cache serves the files, as it would for a sequence that was just downloaded.  n defaults to
+600 so that the library's one-off schedule probe (~0.2 s at the start of a loop) does not dominate.  The rendered images carry sensor-like noise and
 compress to ~0.8 of their raw size, i.e. they are SLOWER to inflate than real KITTI PNGs (~0.55): a conservative number.
 
     python tools/ingest_bench.py [n_frames] > profiles/r03_ingest.json
@@ -24,13 +26,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+    n_distinct = min(n, 40)
     from PIL import Image
     from visual_odom_amd import synth
     import conftest
     exe = conftest._build_example("vo_seq_run")
     world = synth.StereoWorld(seed=20260925)
-    L, R, _, _ = world.render_sequence(n)
+    L, R, _, _ = world.render_sequence(n_distinct)
+
+    def tri(k):  # forwards, then backwards
+        m = k % (2 * (n_distinct - 1))
+        return m if m < n_distinct else 2 * (n_distinct - 1) - m
     tmp = tempfile.mkdtemp(prefix="vo_ingest_")
     sizes = {}
     for fmt in ("png", "pgm"):
@@ -44,6 +51,8 @@ def main():
                 else:
                     with open(path, "wb") as f:
                         f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+            for k in range(n_distinct, n):
+                os.symlink("%06d.%s" % (tri(k), fmt), os.path.join(d, "image_%d" % cam, "%06d.%s" % (k, fmt)))
         sizes[fmt] = os.path.getsize(os.path.join(d, "image_0", "000000." + fmt))
         for s in range(1, 8):
             os.symlink(d, os.path.join(tmp, fmt, "%02d" % s))

@@ -131,10 +131,13 @@ def main(argv=None):
 
     t_start = time.perf_counter()
     t_wait = 0.0
-    ahead = prefetch(1)
+    # look-ahead: as many frames as keep every decoder thread busy (one sequence: a frame is only two files)
+    depth = max(1, min(16, -(-max(args.decode_threads, 1) // (2 * S))))
+    from collections import deque
+    queue = deque(prefetch(k) for k in range(1, depth + 1))
     for frame_id in range(args.max_frames):
         pushed = 0
-        cur, ahead = ahead, {}
+        cur = queue.popleft() if frame_id > 0 and queue else {}
         pairs = {}
         for s, d in enumerate(dirs):
             if not live[s]:
@@ -147,8 +150,8 @@ def main(argv=None):
                 t_wait += time.perf_counter() - t0
             else:
                 pairs[s] = read_pair(d, frame_id)
-        if frame_id > 0:  # the next frame's files are decoded while this step is pushed and runs
-            ahead = prefetch(frame_id + 1)
+        if frame_id > 0:  # the frames ahead are decoded while this step is pushed and runs
+            queue.append(prefetch(frame_id + depth))
         for s, d in enumerate(dirs):
             if not live[s]:
                 continue
