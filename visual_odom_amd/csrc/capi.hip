@@ -11,12 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <map>
 #include <mutex>
-#include <thread>
 #include <string>
 #include <vector>
 
@@ -345,124 +342,6 @@ void release_streams(int device, const StreamSet &s)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_pool[device].push_back(s);
 }
-
-} // namespace
-
-// ---- staging copies on several host threads -------------------------------------------------------------------------
-// Host images arrive in pageable memory (a cv::Mat's buffer): they are repacked into the library's page-locked staging
-// area before the copy engine / the ingest kernel can take them.  Done on the calling thread that is 47 us per
-// 1241 x 376 image: 0.19 ms of vo_track_frame's 1.23 ms, and 24 ms per step for 256 sequences -- the limit of
-// `--ingest host` (32 k frames/s against 57 k from page-locked memory).  A small process-wide team of helper threads
-// (started on first use, never more than 8) splits every batch of copies into row bands; the caller works along and
-// returns when the batch is done, so the calls stay synchronous with respect to the caller's buffers.
-namespace {
-
-struct CopyJob {
-    uint8_t *dst;
-    const uint8_t *src;
-    size_t dst_pitch, src_stride, row_bytes;
-    int rows;
-};
-
-class StageTeam {
-  public:
-    static StageTeam &get()
-    {
-        static StageTeam *team = new StageTeam(); // never destroyed: its threads sleep until the process exits
-        return *team;
-    }
-    void run(std::vector<CopyJob> &jobs)
-    {
-        if (jobs.empty())
-            return;
-        // row bands of >= 96 rows: a pair of KITTI images becomes 8 pieces
-        std::vector<CopyJob> pieces;
-        for (const CopyJob &j : jobs)
-            for (int y = 0; y < j.rows; y += 96) {
-                CopyJob p = j;
-                p.dst += (size_t)y * j.dst_pitch;
-                p.src += (size_t)y * j.src_stride;
-                p.rows = j.rows - y < 96 ? j.rows - y : 96;
-                pieces.push_back(p);
-            }
-        if (workers_ == 0 || pieces.size() < 2) {
-            for (const CopyJob &p : pieces)
-                copy(p);
-            return;
-        }
-        std::lock_guard<std::mutex> one_batch(batch_mu_); // one batch at a time (contexts on several host threads)
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            pieces_ = &pieces;
-            next_ = 0;
-            left_ = (int)pieces.size();
-            generation_++;
-        }
-        cv_.notify_all();
-        work(); // the caller takes pieces too
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return left_ == 0; });
-        pieces_ = nullptr;
-    }
-
-  private:
-    StageTeam()
-    {
-        const unsigned hw = std::thread::hardware_concurrency();
-        workers_ = hw >= 16 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
-        for (int i = 0; i < workers_; i++)
-            std::thread([this] {
-                unsigned long long seen = 0;
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> lk(mu_);
-                        cv_.wait(lk, [&] { return generation_ != seen; });
-                        seen = generation_;
-                    }
-                    work();
-                }
-            }).detach();
-    }
-    static void copy(const CopyJob &p)
-    {
-        if (p.dst_pitch == p.row_bytes && p.src_stride == p.row_bytes)
-            memcpy(p.dst, p.src, p.row_bytes * (size_t)p.rows);
-        else
-            for (int y = 0; y < p.rows; y++)
-                memcpy(p.dst + (size_t)y * p.dst_pitch, p.src + (size_t)y * p.src_stride, p.row_bytes);
-    }
-    void work()
-    {
-        for (;;) {
-            CopyJob job;
-            {
-                // a piece is taken under the lock that also guards the batch pointer: the caller's vector outlives every
-                // piece that was handed out (left_ only reaches 0 after the last copy), and nothing else is ever read
-                std::lock_guard<std::mutex> lk(mu_);
-                if (!pieces_ || next_ >= pieces_->size())
-                    return;
-                job = (*pieces_)[next_++];
-            }
-            copy(job);
-            bool last;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                last = --left_ == 0;
-            }
-            if (last) {
-                done_.notify_all();
-                return;
-            }
-        }
-    }
-    int workers_ = 0;
-    std::mutex mu_, batch_mu_;
-    std::condition_variable cv_, done_;
-    const std::vector<CopyJob> *pieces_ = nullptr;
-    size_t next_ = 0;
-    int left_ = 0;
-    unsigned long long generation_ = 0;
-};
 
 } // namespace
 
@@ -834,8 +713,8 @@ static int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemc
             VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         uint8_t *slot = c->h_stage + c->stage_slot * (size_t)c->stage_next;
         c->stage_next = (c->stage_next + 1) % VO_STAGE_SLOTS;
-        std::vector<CopyJob> job{CopyJob{slot, (const uint8_t *)src, pitch, (size_t)stride, (size_t)c->w, c->h}};
-        StageTeam::get().run(job); // row bands on the helper threads (47 -> ~15 us per 1241 x 376 image)
+        for (int y = 0; y < c->h; y++)
+            memcpy(slot + (size_t)y * pitch, (const uint8_t *)src + (size_t)y * stride, (size_t)c->w);
         VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, pitch * (size_t)(c->h - 1) + (size_t)c->w, hipMemcpyHostToDevice,
                                      c->stream));
         return VO_OK;
@@ -2187,9 +2066,7 @@ static int seq_begin_step(vo_ctx *c)
 // A push only records where the pair is; vo_seq_step moves all pairs of the step with ONE kernel on the copy stream
 // (seq_ingest_kernel).  mode 0: pageable host memory, copied into the pinned staging area now so the caller's buffer
 // is free on return; 1: page-locked host memory, read by the GPU over PCIe when the step runs; 2: device memory.
-// defer (optional): staging copies are appended there instead of being done (vo_seq_push_pairs runs one batch per call)
-static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode,
-                    std::vector<CopyJob> *defer = nullptr)
+static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -2227,12 +2104,15 @@ static int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int
             q.stage_busy[g] = false;
         }
         uint8_t *sl = q.h_stage + (((size_t)g * q.S + seq) * 2) * img, *sr = sl + img;
-        std::vector<CopyJob> now;
-        std::vector<CopyJob> &jobs = defer ? *defer : now;
-        jobs.push_back(CopyJob{sl, (const uint8_t *)left, (size_t)c->w, (size_t)stride, (size_t)c->w, c->h});
-        jobs.push_back(CopyJob{sr, (const uint8_t *)right, (size_t)c->w, (size_t)stride, (size_t)c->w, c->h});
-        if (!defer)
-            StageTeam::get().run(now);
+        const uint8_t *srcs[2] = {(const uint8_t *)left, (const uint8_t *)right};
+        uint8_t *dsts[2] = {sl, sr};
+        for (int side = 0; side < 2; side++) {
+            if (stride == c->w)
+                memcpy(dsts[side], srcs[side], img);
+            else
+                for (int y = 0; y < c->h; y++)
+                    memcpy(dsts[side] + (size_t)y * c->w, srcs[side] + (size_t)y * stride, (size_t)c->w);
+        }
         e.left = sl;
         e.right = sr;
         e.stride = c->w;
@@ -2271,12 +2151,12 @@ int vo_seq_push_pairs(vo_ctx *c, int n, const int32_t *seq_ids, const void *cons
 {
     if (!c || n < 0 || (n > 0 && (!seq_ids || !left || !right)) || kind < 0 || kind > 2)
         return VO_ERR_ARG;
-    std::vector<CopyJob> jobs; // pageable sources: all staging copies of the call as ONE batch on the helper threads
-    int rc = VO_OK;
-    for (int i = 0; i < n && rc == VO_OK; i++)
-        rc = seq_push(c, seq_ids[i], left[i], right[i], stride, kind, kind == 0 ? &jobs : nullptr);
-    StageTeam::get().run(jobs); // (also after an error: the pairs accepted so far must be staged before the call returns)
-    return rc;
+    for (int i = 0; i < n; i++) {
+        int rc = seq_push(c, seq_ids[i], left[i], right[i], stride, kind);
+        if (rc != VO_OK)
+            return rc;
+    }
+    return VO_OK;
 }
 
 int vo_seq_step(vo_ctx *c)
