@@ -62,7 +62,7 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
     for (int first = 0, last = 1; first < p.levels; first = last, last = p.levels) {
         if (first == 1)
             for (int l = 0; l + 1 < p.levels; l++)
-                launch((p.lw[l + 1] + 63) / 64, (p.lh[l + 1] + 15) / 16, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
+                launch((p.lw[l + 1] + PN_TW - 1) / PN_TW, (p.lh[l + 1] + PN_TH - 1) / PN_TH, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
         const BorderBlocks bb = border_blocks(first, last, p.ls, p.lh);
         launch(bb.first[last], n_img, 1, 256, [&] { border_fill_kernel(d_imgs, last, bb); });
         const ScharrTiles st = scharr_tiles(first, last, p.lw, p.lh);

@@ -111,10 +111,91 @@ __global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// pyr_down WITHOUT LDS (round 3).  The tile kernel below keeps 9.5 KB of LDS per workgroup -- and the pose chain's
+// epnp_kernel fills the CUs' LDS completely while it runs (two 78 KB workgroups per CU), so next to a pose
+// chain its workgroups waited for LDS: 12 us stand-alone, 195 us on average and up to 0.7 ms in the benchmark's kernel
+// trace (profiles/r03.md), three launches per step.  Here a thread owns 4 adjacent output columns and walks DOWN the image:
+// per source row one 16-byte load, the horizontal [1 4 6 4 1] of its 4 outputs (the same v_alignbyte + v_dot4 forms, packed
+// two per register), a 5-row window of those in registers, and every second row the vertical filter + one 4-byte store.
+// No LDS, no barrier; neighbouring threads' loads overlap in the L1.  REFLECT_101 rows by index, the (at most two) columns
+// beyond the image edge by a per-byte gather in the two threads of a row that need them.  Bit-identical by construction
+// (same integer arithmetic, same order) and by the emulator / GPU pyramid tests.
+constexpr int PN_ROWS = 8;                 // output rows per thread
+constexpr int PN_TW = 64, PN_TH = 16 * PN_ROWS; // output tile of a 256-thread workgroup: 16 x 16 threads
+
+__device__ __forceinline__ uint2 pyr_hrow(const VO_GLOBAL uint8_t *__restrict__ row, int c0, int sw, bool edge)
+{
+    uint32_t w0, w1, w2, w3;
+    if (!edge) {
+        const U32x4 v = *(const VO_GLOBAL U32x4 *)(row + c0);
+        w0 = v.a;
+        w1 = v.b;
+        w2 = v.c;
+        w3 = v.d;
+    } else { // source columns c0 + 2 .. c0 + 12 through REFLECT_101 (the level's border is not read as data)
+        uint32_t b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            b[k] = (k >= 2 && k <= 12) ? (uint32_t)row[reflect101(c0 + k, sw)] : 0u;
+        w0 = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
+        w1 = b[4] | b[5] << 8 | b[6] << 16 | b[7] << 24;
+        w2 = b[8] | b[9] << 8 | b[10] << 16 | b[11] << 24;
+        w3 = b[12] | b[13] << 8 | b[14] << 16 | b[15] << 24;
+    }
+    (void)w0; // outputs x4 .. x4 + 3 read bytes 2 + 2k .. 6 + 2k of the 16 bytes at source column 2 x4 - 4
+    const uint32_t taps = 0x04060401u; // weights of bytes 0..3 of the aligned group; the fifth tap is the next byte
+    const uint32_t h0 = udot4(alignbyte(w1, w0, 2), taps, udot4(w1, 0x00010000u, 0));
+    const uint32_t h1 = udot4(w1, taps, udot4(w2, 0x00000001u, 0));
+    const uint32_t h2 = udot4(alignbyte(w2, w1, 2), taps, udot4(w2, 0x00010000u, 0));
+    const uint32_t h3 = udot4(w2, taps, udot4(w3, 0x00000001u, 0));
+    return make_uint2(h0 | h1 << 16, h2 | h3 << 16);
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restrict__ imgs, int level)
+{
+    const PyrImage &im = imgs[blockIdx.z];
+    const int sw = im.w[level], sh = im.h[level], sstride = im.stride[level];
+    const int dw = im.w[level + 1], dh = im.h[level + 1], dstride = im.stride[level + 1];
+    const VO_GLOBAL uint8_t *__restrict__ src = (const VO_GLOBAL uint8_t *)im.lvl[level];
+    VO_GLOBAL uint8_t *__restrict__ dst = (VO_GLOBAL uint8_t *)im.lvl[level + 1];
+    const int tid = threadIdx.x;
+    const int x4 = blockIdx.x * PN_TW + (tid & 15) * 4;              // first of this thread's 4 output columns
+    const int y0 = blockIdx.y * PN_TH + (tid >> 4) * PN_ROWS;        // first of its output rows
+    if (x4 >= dw || y0 >= dh)
+        return;
+    const int c0 = 2 * x4 - 4;                                       // source column of byte 0 of the 16-byte window
+    const bool edge = c0 + 2 < 0 || c0 + 12 >= sw;                   // a needed column lies outside the image
+    uint2 q0, q1, q2, q3, q4;
+    q0 = q1 = q2 = q3 = q4 = make_uint2(0, 0);
+    // source rows 2 y0 - 2 .. 2 (y0 + PN_ROWS - 1) + 2; output row y0 + j is complete after source row 2 j + 4 of the walk
+#pragma unroll
+    for (int r = 0; r < 2 * PN_ROWS + 3; r++) {
+        const int j = (r - 4) / 2; // output row this source row completes (r even, r >= 4)
+        if (r >= 5 && y0 + (r - 3) / 2 >= dh) // no further output row of this thread exists
+            break;
+        const int sy = reflect101(2 * y0 - 2 + r, sh);
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = q4;
+        q4 = pyr_hrow(src + (ptrdiff_t)sy * sstride, c0, sw, edge);
+        if (r >= 4 && (r & 1) == 0 && y0 + j < dh) {
+            // vertical 5-tap on two packed u16 pairs: 6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408 fits 16 bits, the result
+            // is its high byte.  Columns >= dw land in the right border (stride - VO_BX - dw >= VO_BY there) and are
+            // overwritten by border_fill_kernel afterwards
+            const uint32_t va = pk_mad_u16(q2.x, 6, pk_mad_u16(pk_add_u16(q1.x, q3.x), 4, pk_add_u16(pk_add_u16(q0.x, q4.x), 0x00800080u)));
+            const uint32_t vb = pk_mad_u16(q2.y, 6, pk_mad_u16(pk_add_u16(q1.y, q3.y), 4, pk_add_u16(pk_add_u16(q0.y, q4.y), 0x00800080u)));
+            *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(y0 + j) * dstride + x4) = perm_b32(vb, va, 0x07050301u);
+        }
+    }
+}
+
+#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL) // round 2's LDS tile kernel: the A/B partner (VO_PYR_LDS=1 in the developer build)
+// ---------------------------------------------------------------------------------------------------
 constexpr int PD_TW = 64, PD_TH = 16;             // output tile
 constexpr int PD_SW = 144, PD_SH = 2 * PD_TH + 3; // source tile (bytes x rows), x origin = 2*ox-4; LDS row stride = PD_SW
 
-__global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restrict__ imgs, int level)
+__global__ __launch_bounds__(256) void pyr_down_lds_kernel(const PyrImage *__restrict__ imgs, int level)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[PD_SH * PD_SW];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[PD_SH * PD_TW];
@@ -204,6 +285,8 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
         *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = perm_b32(vb, va, 0x07050301u);
     }
 }
+
+#endif // VO_DEV_VARIANTS || VO_HOST_EMUL
 
 // ---------------------------------------------------------------------------------------------------
 // all levels of all images in one launch: blockIdx.y = image, blockIdx.x = tile of 512 x 4 pixels numbered
@@ -312,7 +395,15 @@ void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, i
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)
 {
-    dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, n_images);
+#ifdef VO_DEV_VARIANTS
+    static const bool lds = [] { const char *e = getenv("VO_PYR_LDS"); return e && e[0] == '1'; }();
+    if (lds) {
+        dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, n_images);
+        hipLaunchKernelGGL(pyr_down_lds_kernel, grid, dim3(256), 0, stream, d_imgs, level);
+        return;
+    }
+#endif
+    dim3 grid((dw + PN_TW - 1) / PN_TW, (dh + PN_TH - 1) / PN_TH, n_images);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
 
