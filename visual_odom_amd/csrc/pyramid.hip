@@ -120,13 +120,22 @@ __global__ __launch_bounds__(256) void border_fill_kernel(const PyrImage *__rest
 // No LDS, no barrier; neighbouring threads' loads overlap in the L1.  REFLECT_101 rows by index, the (at most two) columns
 // beyond the image edge by a per-byte gather in the two threads of a row that need them.  Bit-identical by construction
 // (same integer arithmetic, same order) and by the emulator / GPU pyramid tests.
-constexpr int PN_ROWS = 8;                 // output rows per thread
+// Measured against the tile kernel (developer build, VO_PYR_LDS=1; gpurun_out/r3_14, pyramid stage ms | frames/s), 4 output
+// rows per thread: 256-frame batch at 340 points 1.26 -> 1.02 | 70.4 k -> 73.3 k, lock-step loop with 256 sequences
+// 1.56 -> 1.22 | 62.4 k -> 64.6 k, headline batch 1.33 -> 1.08 | 19.70 k -> 19.78 k; alone (no pose chain beside it) the tile
+// kernel is the faster one: `--stages lk` 0.70 -> 0.76, 1080p 1.60 -> 1.62.  8 / 16 / 32 rows per thread: 1.03 / 1.08 / 1.21 ms
+// at 340 points -- more threads beat fewer redundant rows.
+#ifndef VO_PN_ROWS
+#define VO_PN_ROWS 4
+#endif
+constexpr int PN_ROWS = VO_PN_ROWS;        // output rows per thread
 constexpr int PN_TW = 64, PN_TH = 16 * PN_ROWS; // output tile of a 256-thread workgroup: 16 x 16 threads
 
-__device__ __forceinline__ uint2 pyr_hrow(const VO_GLOBAL uint8_t *__restrict__ row, int c0, int sw, bool edge)
+template <bool EDGE>
+__device__ __forceinline__ uint2 pyr_hrow(const VO_GLOBAL uint8_t *__restrict__ row, int c0, int sw)
 {
     uint32_t w0, w1, w2, w3;
-    if (!edge) {
+    if (!EDGE) {
         const U32x4 v = *(const VO_GLOBAL U32x4 *)(row + c0);
         w0 = v.a;
         w1 = v.b;
@@ -142,13 +151,44 @@ __device__ __forceinline__ uint2 pyr_hrow(const VO_GLOBAL uint8_t *__restrict__ 
         w2 = b[8] | b[9] << 8 | b[10] << 16 | b[11] << 24;
         w3 = b[12] | b[13] << 8 | b[14] << 16 | b[15] << 24;
     }
-    (void)w0; // outputs x4 .. x4 + 3 read bytes 2 + 2k .. 6 + 2k of the 16 bytes at source column 2 x4 - 4
+    // outputs x4 .. x4 + 3 read bytes 2 + 2k .. 6 + 2k of the 16 bytes at source column 2 x4 - 4
     const uint32_t taps = 0x04060401u; // weights of bytes 0..3 of the aligned group; the fifth tap is the next byte
     const uint32_t h0 = udot4(alignbyte(w1, w0, 2), taps, udot4(w1, 0x00010000u, 0));
     const uint32_t h1 = udot4(w1, taps, udot4(w2, 0x00000001u, 0));
     const uint32_t h2 = udot4(alignbyte(w2, w1, 2), taps, udot4(w2, 0x00010000u, 0));
     const uint32_t h3 = udot4(w2, taps, udot4(w3, 0x00000001u, 0));
     return make_uint2(h0 | h1 << 16, h2 | h3 << 16);
+}
+
+// one thread's column: source rows 2 y0 - 2 .. 2 (y0 + PN_ROWS - 1) + 2; output row y0 + j is complete after row 2 j + 4
+template <bool EDGE>
+__device__ __forceinline__ void pyr_column(const VO_GLOBAL uint8_t *__restrict__ src, VO_GLOBAL uint8_t *__restrict__ dst,
+                                           int sw, int sh, int sstride, int dh, int dstride, int x4, int y0)
+{
+    const int c0 = 2 * x4 - 4; // source column of byte 0 of the 16-byte window
+    uint2 q0, q1, q2, q3, q4;
+    q0 = q1 = q2 = q3 = q4 = make_uint2(0, 0);
+    constexpr int UNROLL = EDGE ? 1 : 2 * PN_ROWS + 3; // the rare edge columns keep the loop (and its per-byte gathers) rolled
+#pragma unroll UNROLL
+    for (int r = 0; r < 2 * PN_ROWS + 3; r++) {
+        if (r >= 5 && y0 + (r - 3) / 2 >= dh) // no further output row of this thread exists
+            break;
+        const int sy = reflect101(2 * y0 - 2 + r, sh);
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = q4;
+        q4 = pyr_hrow<EDGE>(src + (ptrdiff_t)sy * sstride, c0, sw);
+        const int j = (r - 4) / 2; // output row this source row completes (r even, r >= 4)
+        if (r >= 4 && (r & 1) == 0 && y0 + j < dh) {
+            // vertical 5-tap on two packed u16 pairs: 6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408 fits 16 bits, the result
+            // is its high byte.  Columns >= dw land in the right border (stride - VO_BX - dw >= VO_BY there) and are
+            // overwritten by border_fill_kernel afterwards
+            const uint32_t va = pk_mad_u16(q2.x, 6, pk_mad_u16(pk_add_u16(q1.x, q3.x), 4, pk_add_u16(pk_add_u16(q0.x, q4.x), 0x00800080u)));
+            const uint32_t vb = pk_mad_u16(q2.y, 6, pk_mad_u16(pk_add_u16(q1.y, q3.y), 4, pk_add_u16(pk_add_u16(q0.y, q4.y), 0x00800080u)));
+            *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(y0 + j) * dstride + x4) = perm_b32(vb, va, 0x07050301u);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restrict__ imgs, int level)
@@ -163,31 +203,11 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
     const int y0 = blockIdx.y * PN_TH + (tid >> 4) * PN_ROWS;        // first of its output rows
     if (x4 >= dw || y0 >= dh)
         return;
-    const int c0 = 2 * x4 - 4;                                       // source column of byte 0 of the 16-byte window
-    const bool edge = c0 + 2 < 0 || c0 + 12 >= sw;                   // a needed column lies outside the image
-    uint2 q0, q1, q2, q3, q4;
-    q0 = q1 = q2 = q3 = q4 = make_uint2(0, 0);
-    // source rows 2 y0 - 2 .. 2 (y0 + PN_ROWS - 1) + 2; output row y0 + j is complete after source row 2 j + 4 of the walk
-#pragma unroll
-    for (int r = 0; r < 2 * PN_ROWS + 3; r++) {
-        const int j = (r - 4) / 2; // output row this source row completes (r even, r >= 4)
-        if (r >= 5 && y0 + (r - 3) / 2 >= dh) // no further output row of this thread exists
-            break;
-        const int sy = reflect101(2 * y0 - 2 + r, sh);
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
-        q3 = q4;
-        q4 = pyr_hrow(src + (ptrdiff_t)sy * sstride, c0, sw, edge);
-        if (r >= 4 && (r & 1) == 0 && y0 + j < dh) {
-            // vertical 5-tap on two packed u16 pairs: 6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408 fits 16 bits, the result
-            // is its high byte.  Columns >= dw land in the right border (stride - VO_BX - dw >= VO_BY there) and are
-            // overwritten by border_fill_kernel afterwards
-            const uint32_t va = pk_mad_u16(q2.x, 6, pk_mad_u16(pk_add_u16(q1.x, q3.x), 4, pk_add_u16(pk_add_u16(q0.x, q4.x), 0x00800080u)));
-            const uint32_t vb = pk_mad_u16(q2.y, 6, pk_mad_u16(pk_add_u16(q1.y, q3.y), 4, pk_add_u16(pk_add_u16(q0.y, q4.y), 0x00800080u)));
-            *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(y0 + j) * dstride + x4) = perm_b32(vb, va, 0x07050301u);
-        }
-    }
+    // a needed source column (2 x4 - 2 .. 2 x4 + 8) lies outside the image: the first thread of a row, and the last one or two
+    if (2 * x4 - 2 < 0 || 2 * x4 + 8 >= sw)
+        pyr_column<true>(src, dst, sw, sh, sstride, dh, dstride, x4, y0);
+    else
+        pyr_column<false>(src, dst, sw, sh, sstride, dh, dstride, x4, y0);
 }
 
 #if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL) // round 2's LDS tile kernel: the A/B partner (VO_PYR_LDS=1 in the developer build)
