@@ -54,6 +54,8 @@ void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
                 emu::run_block(threads, x, y, z, body);
 }
 
+int g_pyr_lds = 0; // ke_set_pyr_lds: which pyr_down kernel build_pyramids emulates
+
 // the PYRAMID stage of capi.hip's run_stages with the emulated kernels
 void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 {
@@ -62,7 +64,10 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
     for (int first = 0, last = 1; first < p.levels; first = last, last = p.levels) {
         if (first == 1)
             for (int l = 0; l + 1 < p.levels; l++)
-                launch((p.lw[l + 1] + PN_TW - 1) / PN_TW, (p.lh[l + 1] + PN_TH - 1) / PN_TH, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
+                if (g_pyr_lds) // both pyr_down kernels of the product are emulated (launch_pyr_down picks by image count)
+                    launch((p.lw[l + 1] + PD_TW - 1) / PD_TW, (p.lh[l + 1] + PD_TH - 1) / PD_TH, n_img, 256, [&] { pyr_down_lds_kernel(d_imgs, l); });
+                else
+                    launch((p.lw[l + 1] + PN_TW - 1) / PN_TW, (p.lh[l + 1] + PN_TH - 1) / PN_TH, n_img, 256, [&] { pyr_down_kernel(d_imgs, l); });
         const BorderBlocks bb = border_blocks(first, last, p.ls, p.lh);
         launch(bb.first[last], n_img, 1, 256, [&] { border_fill_kernel(d_imgs, last, bb); });
         const ScharrTiles st = scharr_tiles(first, last, p.lw, p.lh);
@@ -73,6 +78,7 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 } // namespace
 
 extern "C" {
+void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
 
 // the whole bordered allocation of one level of one image after the emulated pyramid build: rows -VO_BY .. h + VO_BY - 1,
 // `stride` bytes / dwords each starting at column -VO_BX (pixels poisoned with 0xA5 before the build, derivatives zero)

@@ -53,8 +53,16 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("shape", [(100, 200), (97, 131), (45, 53)])
-def test_emulated_pyramid_and_scharr_match_oracle(kemu, orc, shape):
+@pytest.fixture(params=[0, 1], ids=["column-walk", "lds-tile"])
+def pyr_kernel(kemu, request):
+    """both pyr_down kernels of the product library (launch_pyr_down picks by the number of images in the launch)"""
+    kemu.ke_set_pyr_lds(request.param)
+    yield request.param
+    kemu.ke_set_pyr_lds(0)
+
+
+@pytest.mark.parametrize("shape", [(100, 200), (97, 131), (45, 53), (150, 70)])
+def test_emulated_pyramid_and_scharr_match_oracle(kemu, orc, shape, pyr_kernel):
     rng = np.random.default_rng(shape[0])
     img = rng.integers(0, 256, shape, dtype=np.uint8)
     ref = orc.build_pyramid(img, 3)

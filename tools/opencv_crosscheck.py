@@ -8,7 +8,7 @@ boxes do not, so this tool is shipped unexecuted; it exits with code 2 and a mes
 
 Calls diffed (the reference's call sites): cv2.pyrDown (inside buildOpticalFlowPyramid), cv2.calcOpticalFlowPyrLK as
 feature.cpp:136-139 calls it (win 21, maxLevel 3, 30 / 0.01, minEig 1e-3), cv2.FAST(20, nonmax), cv2.triangulatePoints +
-convertPointsFromHomogeneous (main.cpp:170-171), cv2.solvePnPRansac + Rodrigues (visualOdometry.cpp:176,188) and
+convertPointsFromHomogeneous (main.cpp:170-171), cv2.solvePnPRansac + Rodrigues (visualOdometry.cpp:176,188; also with exactly 4 points = the P3P switch) and
 cv2.findEssentialMat + recoverPose (visualOdometry.cpp:152-153).  Expected against x86 OpenCV: pyramids and FAST
 bit-exact, LK positions within ~1e-3 px with identical status (OpenCV accumulates the 2x2 system in f32 SIMD lanes, the
 oracle exactly), triangulation 1e-5 relative, poses 1e-6 when the inlier sets match."""
@@ -62,6 +62,11 @@ def main():
     same = cv_pts.shape == my_pts.shape and np.array_equal(cv_pts, my_pts)
     report("FAST(20, nonmax) corners + order", 0.0 if same else 1.0, 0, "cv2 %d / oracle %d" % (len(cv_pts), len(my_pts)))
     golden["fast"] = cv_pts
+    kp0 = cv2.FastFeatureDetector_create(20, False, cv2.FAST_FEATURE_DETECTOR_TYPE_9_16).detect(L[0])
+    cv0 = np.array([k.pt for k in kp0], np.float32).reshape(-1, 2)
+    my0 = orc.fast_detect(L[0], 20, False, cap=1 << 20)
+    report("FAST(20, no nonmax) corners + order", 0.0 if cv0.shape == my0.shape and np.array_equal(cv0, my0) else 1.0, 0,
+           "cv2 %d / oracle %d" % (len(cv0), len(my0)))
     # ---- the four LK hops
     lk = dict(winSize=(21, 21), maxLevel=3, criteria=(cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, 30, 0.01), flags=0,
               minEigThreshold=0.001)
@@ -93,6 +98,24 @@ def main():
     report("solvePnPRansac rvec | tvec", float(max(np.abs(rvec.reshape(3) - rv).max(), np.abs(tvec.reshape(3) - tv).max())), 1e-6,
            "inlier sets %s" % ("identical" if same_inl else "DIFFER"))
     report("Rodrigues", float(np.abs(cv2.Rodrigues(rv.reshape(3, 1))[0] - orc.rodrigues(rv)).max()), 1e-12)
+    # ---- exactly four correspondences: OpenCV's `npoints == 4 -> SOLVEPNP_P3P` switch (oracle/orc_p3p.c, round 3).  The
+    # closed-form quartic loses digits near double roots, so several well-spread quadruples and a median
+    worst4, n4 = [], 0
+    rng = np.random.default_rng(args.seed)
+    for _ in range(50):
+        idx = rng.choice(len(xyz_my), 4, replace=False)
+        X4p, u4 = xyz_my[idx].astype(np.float32), l1[idx].astype(np.float32)
+        r0v, t0v = np.zeros((3, 1)), np.zeros((3, 1))
+        ok4, r4, t4, inl4 = cv2.solvePnPRansac(X4p.reshape(-1, 1, 3), u4.reshape(-1, 1, 2), K.astype(np.float32), np.zeros((4, 1)),
+                                               r0v, t0v, True, 500, 0.5, float(np.float32(0.999)), None, cv2.SOLVEPNP_ITERATIVE)
+        rc4, rv4, tv4, inl4_my, _ = orc.solve_pnp_ransac(X4p, u4, K)
+        if bool(ok4) != (rc4 == 1):
+            worst4.append(1.0)
+        elif ok4:
+            worst4.append(float(max(np.abs(r4.reshape(3) - rv4).max(), np.abs(t4.reshape(3) - tv4).max())))
+            n4 += 1
+    report("solvePnPRansac with 4 points (P3P), median", float(np.median(worst4)) if worst4 else 1.0, 1e-6,
+           "%d of 50 quadruples solved by cv2; 90 %% quantile %.3g" % (n4, float(np.percentile(worst4, 90)) if worst4 else 1.0))
     golden["rvec"], golden["tvec"] = rvec.reshape(3), tvec.reshape(3)
     # ---- essential matrix + recoverPose
     focal, pp = float(P_l[0, 0]), (float(P_l[0, 2]), float(P_l[1, 2]))

@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const PyrImage *__restric
         pyr_column<false>(src, dst, sw, sh, sstride, dh, dstride, x4, y0);
 }
 
-#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL) // round 2's LDS tile kernel: the A/B partner (VO_PYR_LDS=1 in the developer build)
+// Round 2's LDS tile kernel: still the one for SMALL launches (a single frame, a few sequences), where no pose chain of any
+// size runs beside it and latency is what counts -- 4 images: 3 x 4 us against 20 + 16 + 12 us for the column walk above
+// (profiles/r03_track_frame_timeline.txt vs gpurun_out/r3_15).
 // ---------------------------------------------------------------------------------------------------
 constexpr int PD_TW = 64, PD_TH = 16;             // output tile
 constexpr int PD_SW = 144, PD_SH = 2 * PD_TH + 3; // source tile (bytes x rows), x origin = 2*ox-4; LDS row stride = PD_SW
@@ -305,8 +307,6 @@ __global__ __launch_bounds__(256) void pyr_down_lds_kernel(const PyrImage *__res
         *(VO_GLOBAL uint32_t *)(dst + (ptrdiff_t)(oy + y) * dstride + ox + x4) = perm_b32(vb, va, 0x07050301u);
     }
 }
-
-#endif // VO_DEV_VARIANTS || VO_HOST_EMUL
 
 // ---------------------------------------------------------------------------------------------------
 // all levels of all images in one launch: blockIdx.y = image, blockIdx.x = tile of 512 x 4 pixels numbered
@@ -415,14 +415,20 @@ void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, i
 
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream)
 {
+    // Which kernel: the column walk needs no LDS and therefore starts next to a large pose chain (whose EPnP workgroups fill
+    // the CUs' LDS) -- that is what many frames per run look like; a few images have no such neighbour and want the tile
+    // kernel's latency.  128 images = 64 stereo pairs: a pose chain of 64 frames occupies a quarter of the chip's LDS.
+    bool lds = n_images < 128;
 #ifdef VO_DEV_VARIANTS
-    static const bool lds = [] { const char *e = getenv("VO_PYR_LDS"); return e && e[0] == '1'; }();
+    static const int forced = [] { const char *e = getenv("VO_PYR_LDS"); return e ? atoi(e) : -1; }();
+    if (forced >= 0)
+        lds = forced != 0;
+#endif
     if (lds) {
         dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, n_images);
         hipLaunchKernelGGL(pyr_down_lds_kernel, grid, dim3(256), 0, stream, d_imgs, level);
         return;
     }
-#endif
     dim3 grid((dw + PN_TW - 1) / PN_TW, (dh + PN_TH - 1) / PN_TH, n_images);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, stream, d_imgs, level);
 }
