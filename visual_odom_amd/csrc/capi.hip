@@ -1521,6 +1521,8 @@ int vo_set_schedule(vo_ctx *c, const vo_schedule *s)
         return rc;
     c->pin = p;
     c->sched_key[0] = -1; // resolved again at the next run
+    if (c->seq.ab_phase == 1 || c->seq.ab_phase == 2)
+        c->seq.ab_phase = 0; // a prepare-stream A/B in progress is abandoned: the caller has just said what they want
     if (c->seq.on) {      // the lock-step loop reads sched between steps: apply what is pinned now
         vo_ctx::Schedule sc = c->sched;
         apply_pins(c, &sc);
