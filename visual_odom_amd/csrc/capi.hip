@@ -2220,8 +2220,13 @@ int vo_seq_step(vo_ctx *c)
     }
     q.n_active = n_active;
     rc = seq_enqueue_inputs(c, /*dry*/ false);
-    if (rc != VO_OK)
+    if (rc != VO_OK) { // (the step's bookkeeping is already consumed: same treatment as a failure further down)
+        const std::string why = c->err;
+        (void)sync_all(c);
+        c->err = why;
+        q.broken = true;
         return rc;
+    }
     q.begun = false;
     c->pyr_first = r * q.S * 2;
     c->pyr_count = q.S * 2;
