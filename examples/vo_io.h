@@ -110,7 +110,7 @@ inline bool decode_png(const std::vector<uint8_t> &buf, Image &im)
         p += 12 + (size_t)len;
     }
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (w < 1 || h < 1 || depth != 8 || ch == 0 || interlace != 0 || z.empty())
+    if (w < 1 || h < 1 || w > 16384 || h > 16384 || depth != 8 || ch == 0 || interlace != 0 || z.empty())
         return false; // palette / 16-bit / interlaced files: convert them first (tools/kitti_to_pgm.py)
     const size_t row = (size_t)w * ch;
     std::vector<uint8_t> raw((row + 1) * (size_t)h);

@@ -77,9 +77,9 @@ inline WorkerResult run_worker(int device, const std::vector<std::string> &dirs,
 
     // decoder pool with look-ahead: frames id + 1 .. id + depth are being read and decoded while frame id is pushed and
     // runs; depth = as many frames as keep every decoder thread busy (one sequence: a frame is only two files)
-    voio::ThreadPool pool(decode_threads);
     const int depth = std::max(1, std::min(16, (decode_threads + 2 * S - 1) / (2 * S)));
     std::vector<voio::FrameSet> sets((size_t)depth + 1);
+    voio::ThreadPool pool(decode_threads); // declared after the sets: on an early return it drains its jobs before they go
     std::vector<char> live(S, 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k <= depth && k < max_frames; k++)
