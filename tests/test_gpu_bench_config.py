@@ -63,6 +63,31 @@ def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs)
         ctx.batch_sync()
         assert bench.validate_frames(ctx, (0, 21, 42, 63), lefts, rights, frame_pts, world, S, cache=cache) == 4
         assert all(t >= 0 for t in ctx.batch_slot_times(3))
+        # new images between two runs of a live batch (uploads queue behind the LK that still reads the old ones): the
+        # table shifted by one rendered pair, then survivors against the oracle
+        for j in range(B + 1):
+            ctx.batch_upload_image(2 * j, lefts[bench.tri(j + 1, S)])
+            ctx.batch_upload_image(2 * j + 1, rights[bench.tri(j + 1, S)])
+        shifted = [pts[bench.tri(b + 1, S)] for b in range(B)]
+        for b in range(B):
+            ctx.batch_set_points(b, shifted[b])
+        for _ in range(2):
+            ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        for b in (0, 1, 2, 3, 5, 62, 63):
+            a, c = bench.tri(b + 1, S), bench.tri(b + 2, S)
+            ref = orc.circular_matching(lefts[a], rights[a], lefts[c], rights[c], shifted[b])
+            assert np.array_equal(ctx.batch_get_filtered(b)["keep_idx_circ"], ref["keep_idx"]), b
+        # a sub-range rebuild (the streaming ring's way): only the re-uploaded pair's pyramids are built again
+        ctx.batch_upload_image(0, lefts[bench.tri(2, S)])
+        ctx.batch_upload_image(1, rights[bench.tri(2, S)])
+        ctx.batch_set_pyramid_range(0, 2)
+        ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        ref = orc.circular_matching(lefts[bench.tri(2, S)], rights[bench.tri(2, S)], lefts[bench.tri(2, S)],
+                                    rights[bench.tri(2, S)], shifted[0])
+        assert np.array_equal(ctx.batch_get_filtered(0)["keep_idx_circ"], ref["keep_idx"])
+        ctx.batch_set_pyramid_range(0, 2 * (B + 1))
     finally:
         ctx.close()
 
