@@ -7,6 +7,7 @@
 #include "../../visual_odom_amd/csrc/fast.hip"
 #include "../../visual_odom_amd/csrc/lk.hip"
 #include "../../visual_odom_amd/csrc/pyramid.hip"
+#include "../../visual_odom_amd/csrc/vo_svd_wide.h"
 
 #include <vector>
 
@@ -79,6 +80,34 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
+
+// EPnP's 12 x 12 SVD: the row-cooperative sweeps of vo_svd_wide.h (16 lanes per matrix, 16 matrices per 256-thread block, as
+// epnp_wide_kernel runs them) + jacobi12_finish on lane 0, next to the one-lane routine jacobi_svd<12, 12, false> the other
+// EPnP kernel uses.  mats: n x 144 (consumed); wide / serial: n x 144 sorted, normalised rows; returns the number of sweeps
+// the serial routine cannot report -- 0
+int ke_svd12_wide(const double *mats, int n, double *wide, double *serial)
+{
+    std::vector<double> w16((size_t)n * 192);
+    for (int q = 0; q < n; q++)
+        memcpy(wide + (size_t)q * 144, mats + (size_t)q * 144, 144 * sizeof(double));
+    launch((n + 15) / 16, 1, 1, 256, [&] {
+        const int q = (int)blockIdx.x * 16 + ((int)threadIdx.x >> 4), lane = (int)threadIdx.x & 15;
+        if (q >= n)
+            return; // (row-uniform)
+        vo::jacobi12_row_sweeps(wide + (size_t)q * 144, w16.data() + (size_t)q * 192, lane);
+        __syncthreads(); // (as in epnp_wide_kernel: the other lanes' last stores before lane 0 reads the matrix)
+        if (lane == 0) {
+            double W[12];
+            vo::jacobi12_finish(wide + (size_t)q * 144, W);
+        }
+    });
+    for (int q = 0; q < n; q++) {
+        double d12[12];
+        memcpy(serial + (size_t)q * 144, mats + (size_t)q * 144, 144 * sizeof(double));
+        vo::jacobi_svd<12, 12, false, 1>(serial + (size_t)q * 144, d12, nullptr);
+    }
+    return 0;
+}
 
 // the whole bordered allocation of one level of one image after the emulated pyramid build: rows -VO_BY .. h + VO_BY - 1,
 // `stride` bytes / dwords each starting at column -VO_BX (pixels poisoned with 0xA5 before the build, derivatives zero)

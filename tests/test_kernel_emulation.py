@@ -22,7 +22,8 @@ def kemu():
     so = os.path.join(out_dir, "libkernel_emu.so")
     csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
-    deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h")]
+    deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
+                                               "vo_linalg.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -310,3 +311,43 @@ def test_emulated_pyramid_extremes(kemu, orc, pattern):
     r = ke_run(kemu, [step], want_level=0)
     ix = (r["der"] & 0xffff).astype(np.uint16).view(np.int16)
     assert ix.max() == 16320
+
+
+def test_row_cooperative_svd12_is_bit_identical_to_the_one_lane_routine(kemu):
+    """vo_svd_wide.h (EPnP's 12 x 12 Jacobi sweeps over the 16 lanes of a DPP row, every sum in the serial order through
+    row broadcasts) + jacobi12_finish against jacobi_svd<12, 12, false>, the routine the one-hypothesis-per-lane kernel runs:
+    the sorted, normalised rows must agree BIT FOR BIT -- on M^T M of EPnP-shaped 10 x 12 matrices (rank 10: two singular values
+    at rounding level), on full-rank and on exactly singular matrices (zero rows: the pseudo-random fill of lapack.cpp)."""
+    rng = np.random.default_rng(7)
+    mats = []
+    for _ in range(37):  # M^T M with M's sparsity: rows (a fu, 0, a (uc - u)) / (0, a fv, a (vc - v)) per control point
+        M = np.zeros((10, 12))
+        al = rng.normal(0.25, 0.6, (5, 4))
+        uv = rng.uniform(0, 1241, (5, 2)) * [1, 0.3]
+        for p in range(5):
+            for q in range(4):
+                M[2 * p, 3 * q] = al[p, q] * 718.856
+                M[2 * p, 3 * q + 2] = al[p, q] * (607.19 - uv[p, 0])
+                M[2 * p + 1, 3 * q + 1] = al[p, q] * 718.856
+                M[2 * p + 1, 3 * q + 2] = al[p, q] * (185.2 - uv[p, 1])
+        mats.append(M.T @ M)
+    for _ in range(10):
+        A = rng.normal(size=(12, 12))
+        mats.append(A @ A.T)
+    Z = rng.normal(size=(12, 12))
+    Z[3] = 0
+    Z[:, 3] = 0
+    Z[7] = 0
+    Z[:, 7] = 0
+    mats += [(Z + Z.T) / 2 + 12 * np.diag((np.arange(12) % 4 != 3).astype(float)), np.zeros((12, 12)), np.eye(12)]
+    mats = np.ascontiguousarray(np.array(mats), np.float64)
+    n = len(mats)
+    wide, serial = np.zeros_like(mats), np.zeros_like(mats)
+    dp = C.POINTER(C.c_double)
+    kemu.ke_svd12_wide(mats.ctypes.data_as(dp), n, wide.ctypes.data_as(dp), serial.ctypes.data_as(dp))
+    assert np.isfinite(serial).all()
+    assert np.array_equal(wide.view(np.uint64), serial.view(np.uint64))
+    # and it is an SVD: rows orthonormal, the first EPnP matrix's last two rows span its null space
+    U = serial[0]
+    assert np.allclose(U @ U.T, np.eye(12), atol=1e-12)
+    assert np.abs(mats[0] @ U[10:].T).max() < 1e-6 * np.abs(mats[0]).max()

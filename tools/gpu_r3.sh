@@ -85,6 +85,24 @@ if has prof; then
     # the traces themselves are large: keep the stats and one trace per run for the register / LDS columns
     find "$OUT/prof_overlap" "$OUT/prof_seq" -name "*_kernel_trace.csv" -size +20M -delete 2>/dev/null
 fi
+if has wide; then
+    stamp "pose phases (developer build)"
+    VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 200 python tools/pose_phases.py 6 14 > "$OUT/pose_phases.txt" 2>&1
+    VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_EPNP_WIDE_MAX=0 timeout 200 python tools/pose_phases.py 6 14 > "$OUT/pose_phases_narrow.txt" 2>&1
+    cat "$OUT/pose_phases.txt" "$OUT/pose_phases_narrow.txt"
+    for WM in 0 16 64; do
+        for S in 1 8 16 32 64; do
+            VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_EPNP_WIDE_MAX=$WM timeout 300 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 60 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/wide_${WM}_seq_${S}.json" 2> "$OUT/wide_${WM}_seq_${S}.err"
+            python -c "import json; b=json.loads(open('$OUT/wide_${WM}_seq_${S}.json').read().strip().splitlines()[-1]); print('  wide_max=%-3d S=%-4d %.0f fps %.3f ms/step' % ($WM, $S, b['value'], b['ms_per_step']), {k: b['config']['schedule'][k] for k in ('pose_waves','pose_streams','prepare')})"
+        done
+    done
+    for WM in 0 16; do
+        for B in 8 16 32; do
+            VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_EPNP_WIDE_MAX=$WM timeout 300 python bench.py --workload kitti374 --frames $B --steps 30 --warmup 3 $LEAN > "$OUT/wide_${WM}_batch_${B}.json" 2> "$OUT/wide_${WM}_batch_${B}.err"
+            python -c "import json; b=json.loads(open('$OUT/wide_${WM}_batch_${B}.json').read().strip().splitlines()[-1]); print('  wide_max=%-3d batch B=%-4d %.0f fps %.3f ms/step' % ($WM, $B, b['value'], b['ms_per_step']))"
+        done
+    done
+fi
 if has pmc; then
     cd /tmp
     stamp "rocprofv3 pmc SQ pass (LK instruction counts)"

@@ -382,6 +382,12 @@ static void seq_free(vo_ctx *c)
     q = vo_ctx::Seq();
 }
 
+#ifdef VO_DEV_VARIANTS
+namespace vo {
+int pose_prof_read(long long *out64); // pnp.hip
+}
+#endif
+
 extern "C" {
 
 void vo_default_params(vo_params *p)
@@ -2723,4 +2729,13 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     return r.status == 1 ? VO_OK : VO_NO_MODEL;
 }
 
+#ifdef VO_DEV_VARIANTS
+// developer build only: the 100 MHz stamps the pose kernels left for frame 0 / hypothesis 0 (pnp.hip, tools/pose_phases.py)
+int vo_dev_pose_prof(vo_ctx *c, long long *out64)
+{
+    if (!c || !out64 || sync_all(c) != VO_OK)
+        return VO_ERR_ARG;
+    return vo::pose_prof_read(out64) == 0 ? VO_OK : VO_ERR_HIP;
+}
+#endif
 } // extern "C"

@@ -22,7 +22,24 @@
 //                              because rvec/tvec are shared buffers), inlier mask, the CvLevMarq
 //                              state machine with block-wide reductions of J^T J / J^T e, rvec -> R.
 #include "vo_kernels.h"
+#ifdef VO_DEV_VARIANTS
+// developer build: 100 MHz time stamps of one EPnP hypothesis / one refinement (tools/pose_phases.py)
+__device__ long long g_pose_prof[64];
+#ifdef __HIP_DEVICE_COMPILE__
+#define VO_EPNP_STAMP(i)                                                      \
+    do {                                                                      \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {         \
+            g_pose_prof[i] = (long long)wall_clock64();                       \
+        }                                                                     \
+    } while (0)
+#define VO_POSE_NOW() ((long long)wall_clock64())
+#endif
+#endif
+#ifndef VO_POSE_NOW
+#define VO_POSE_NOW() 0ll
+#endif
 #include "vo_epnp.h"
+#include "vo_svd_wide.h"
 #include "vo_p3p.h"
 #include "vo_seqtail.h"
 
@@ -245,6 +262,68 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
     m[5] = tv[2];
 }
 
+// The same solve for SMALL launches (a single frame, a lock-step step of a few sequences), where the pose chain is the latency
+// of the call and the GPU is otherwise idle: one hypothesis per DPP ROW instead of per lane.  Lane 0 of the row runs the
+// solver; for its 12 x 12 SVD -- 337 of the 466 us a hypothesis takes in the kernel above -- the row's 16 lanes join in
+// (vo_svd_wide.h: a lane per matrix column, every sum in the serial order through row broadcasts: bit-identical).
+// Matrices hypothesis-major in LDS (2.7 KB each with the per-lane norm copies).  ONE wavefront (4 hypotheses) per workgroup:
+// the solver is ~35 k instructions of mostly straight-line code, a wavefront streams it through the instruction cache, and
+// wavefronts of one CU that drift apart evict each other's loops -- with 16 hypotheses (4 wavefronts) per workgroup the
+// one-lane phases ran at half speed and the whole solve took as long as the kernel above (gpurun_out/r3_23, r3_24:
+// 465 vs 327 us per hypothesis).  The same effect bounds the launch size this kernel is good for (launch_pnp_ransac).
+// Costs ~7 x the VALU time of the kernel above per hypothesis (12 of 64 lanes do useful work in the sweeps, one in the rest).
+constexpr int EW_HYPS_DEFAULT = 4; // hypotheses (DPP rows) per workgroup
+
+template <int EW_HYPS>
+__global__ __launch_bounds__(16 * EW_HYPS, 1) void epnp_wide_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                           size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                           const int32_t *__restrict__ subsets, PnpParams prm,
+                                                           const RansacState *__restrict__ rstate, int h0, int hn,
+                                                           double *__restrict__ models /* [B][iters][6] */)
+{
+    // (146: the rows of the four hypotheses a wavefront holds start in different LDS banks -- 144 doubles put all four on the
+    // same one, and the one-lane phases, where lane 0 of each row walks its matrix, ran into 4-way conflicts)
+    __shared__ __attribute__((aligned(16))) double s_at[EW_HYPS][146];
+    __shared__ __attribute__((aligned(16))) double s_w16[EW_HYPS][192];
+    const int frame = blockIdx.y, row = threadIdx.x >> 4, lane = threadIdx.x & 15;
+    const int h = h0 + blockIdx.x * EW_HYPS + row;
+    const int count = n_pts[frame];
+    // (as in epnp_kernel: hypotheses beyond the iteration count the replay has settled on are never looked at)
+    const bool active = count >= 5 && h < h0 + hn && h < (count == 5 ? 1 : min(prm.iters, rstate[frame].niters));
+    Epnp5 e;
+    if (active && lane == 0) {
+        const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
+        float x5[15], u5[10];
+        for (int i = 0; i < 5; i++) {
+            const int k = idx[i];
+            const float *p = xyz + ((size_t)frame * cap + k) * 3;
+            x5[3 * i] = p[0];
+            x5[3 * i + 1] = p[1];
+            x5[3 * i + 2] = p[2];
+            const float2 q = uv[frame * uv_stride + k];
+            u5[2 * i] = q.x;
+            u5[2 * i + 1] = q.y;
+        }
+        epnp5_prepare<1>(x5, u5, prm.K, e, s_at[row]);
+    }
+    __syncthreads(); // (every thread of the workgroup reaches both barriers: no early return above)
+    if (active)
+        jacobi12_row_sweeps(s_at[row], s_w16[row], lane);
+    __syncthreads();
+    if (active && lane == 0) {
+        jacobi12_finish(s_at[row], s_w16[row]);
+        double rv[3], tv[3];
+        epnp5_finish<1>(e, s_at[row], rv, tv);
+        double *m = models + ((size_t)frame * prm.iters + h) * 6;
+        m[0] = rv[0];
+        m[1] = rv[1];
+        m[2] = rv[2];
+        m[3] = tv[0];
+        m[4] = tv[1];
+        m[5] = tv[2];
+    }
+}
+
 // squared reprojection error exactly as PnPRansacCallback::computeError: projection in f64,
 // stored as f32, difference and squared norm in f32
 __device__ __forceinline__ bool is_inlier(const double *R, const double *t, double fx, double fy, double cx,
@@ -355,6 +434,12 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int count = n_pts[frame];
     PnpResult &res = results[frame];
+#ifdef VO_DEV_VARIANTS
+    const bool prof = frame == 0 && tid == 0;
+    long long t_solve = 0, n_solve = 0;
+    if (prof)
+        g_pose_prof[16] = VO_POSE_NOW();
+#endif
     if (count < 5) {
         if (tid == 0 && count != 4) { // (exactly 4 points: p3p_kernel has already written this frame's record)
             res.status = -1;          // CV_Assert(npoints >= 4)
@@ -442,6 +527,10 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         }
     }
     const int n1 = s_ninl;
+#ifdef VO_DEV_VARIANTS
+    if (prof)
+        g_pose_prof[17] = VO_POSE_NOW();
+#endif
 
     // ---- CvLevMarq (cvFindExtrinsicCameraParams2, useExtrinsicGuess) from the LAST hypothesis ----
     enum { LM_DONE = 0, LM_STARTED = 1, LM_CALC_J = 2, LM_CHECK_ERR = 3 };
@@ -460,6 +549,9 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         if (tid == 0) {
             int want_J = 0, want_err = 0, proceed = 1;
             auto lm_step = [&]() {
+#ifdef VO_DEV_VARIANTS
+                const long long t_in = VO_POSE_NOW();
+#endif
                 const double lambda = exp(lambdaLg10 * log(10.));
                 double A[36], x[6];
                 for (int k = 0; k < 36; k++)
@@ -469,6 +561,10 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                 solve_svd<6, 6>(A, JtErr, x);
                 for (int k = 0; k < 6; k++)
                     s_param[k] = prevParam[k] - x[k];
+#ifdef VO_DEV_VARIANTS
+                t_solve += VO_POSE_NOW() - t_in;
+                n_solve++;
+#endif
             };
             if (state == LM_DONE) {
                 proceed = 0;
@@ -583,6 +679,14 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         res.best_iter = best;
         res.max_good = s_maxgood;
         res.lm_iters = iters;
+#ifdef VO_DEV_VARIANTS
+        if (prof) {
+            g_pose_prof[18] = t_solve;
+            g_pose_prof[19] = n_solve;
+            g_pose_prof[20] = VO_POSE_NOW();
+            g_pose_prof[21] = n1;
+        }
+#endif
     }
 }
 
@@ -697,10 +801,32 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
 #endif
         return want > need ? want : need;
     }();
+    // Small launches: one hypothesis per DPP row (epnp_wide_kernel).  Up to 4 frames x 128 hypotheses = 128 wavefronts, one
+    // per two CUs (= per instruction cache); measured in the lock-step loop (ms per step, this kernel | the one above):
+    // 1 sequence 0.545 | 0.601, 4 sequences 0.635 | 0.651, 8 sequences 0.820 | 0.639 (gpurun_out/r3_24).
+    int wide_max = 4;
+#ifdef VO_DEV_VARIANTS
+    static const int wide_env = [] { const char *e = getenv("VO_EPNP_WIDE_MAX"); return e ? atoi(e) : -1; }();
+    if (wide_env >= 0)
+        wide_max = wide_env;
+#endif
+    const bool wide = n_frames <= wide_max;
     for (int h0 = 0; h0 < prm.iters;) {
         const int hn = h0 == 0 ? min(RANSAC_CHUNK, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
         launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
+        if (wide) {
+#ifdef VO_DEV_VARIANTS
+            static const int ew = [] { const char *e = getenv("VO_EW_HYPS"); return e ? atoi(e) : EW_HYPS_DEFAULT; }();
+            if (ew == 16)
+                hipLaunchKernelGGL(epnp_wide_kernel<16>, dim3((hn + 15) / 16, n_frames), dim3(256), 0, stream, xyz, uv,
+                                   uv_stride, n_pts, cap, subsets, prm, state, h0, hn, models);
+            else
+#endif
+                hipLaunchKernelGGL(epnp_wide_kernel<EW_HYPS_DEFAULT>, dim3((hn + EW_HYPS_DEFAULT - 1) / EW_HYPS_DEFAULT, n_frames),
+                                   dim3(16 * EW_HYPS_DEFAULT), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                                   h0, hn, models);
+        } else
 #ifdef VO_DEV_VARIANTS // the 128-register instantiation: never the best one since round 2
         if (waves >= 4)
             hipLaunchKernelGGL(epnp_kernel<4>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
@@ -752,5 +878,12 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
+
+#ifdef VO_DEV_VARIANTS
+int pose_prof_read(long long *out64)
+{
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_pose_prof), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 } // namespace vo

@@ -13,6 +13,10 @@
 
 #include "vo_linalg.h"
 
+#ifndef VO_EPNP_STAMP
+#define VO_EPNP_STAMP(i)
+#endif
+
 namespace vo {
 
 struct Epnp5 {
@@ -222,13 +226,14 @@ VO_HD double epnp_compute_R_and_t(Epnp5 &e, const double *ut, const double *beta
 // that does not fit in registers next to everything else; the caller provides (144 + 12) * S doubles
 // for it, element idx at ut_mem[idx * S] (device: lane-interleaved LDS, S = workgroup size; host: a
 // private array, S = 1).
-template <int S>
-VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
-                                  double *tvec, double *ut)
-{
+// The solver in three pieces, so that the 12 x 12 SVD between the first two can also be run by a whole DPP row
+// (vo_svd_wide.h, epnp_wide_kernel): epnp5_prepare -- through M^T M in `ut`; the SVD; epnp5_finish -- the rest.
 #define VO_UT(idx) ut[(idx) * S]
+template <int S>
+VO_HD void epnp5_prepare(const float *xyz5, const float *uv5, const float *Kf, Epnp5 &e, double *ut)
+{
     const int n = 5;
-    Epnp5 e;
+    VO_EPNP_STAMP(0);
     e.fu = (double)Kf[0];
     e.fv = (double)Kf[4];
     e.uc = (double)Kf[2];
@@ -309,7 +314,7 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
     // M^T M is accumulated point by point (rows 2p and 2p+1 of M at a time): for every (i, j) the
     // partial sums are formed in the same order k = 0 .. 9 as the plain triple loop, so the result
     // is bit-identical, but M itself (120 doubles) never has to exist.
-    double d12[12];
+    VO_EPNP_STAMP(1);
     {
 #pragma unroll
         for (int i = 0; i < 12; i++)
@@ -346,8 +351,16 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
             for (int j = 0; j < i; j++)
                 VO_UT(i * 12 + j) = VO_UT(j * 12 + i);
     }
-    jacobi_svd<12, 12, false, S>(ut, d12, nullptr);
+    VO_EPNP_STAMP(2);
+}
 
+// rows 11, 10, 9, 8 of `ut` = the null-space basis (rows of U^T sorted by descending singular value)
+template <int S>
+VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
+{
+    const int n = 5;
+    (void)n;
+    VO_EPNP_STAMP(3);
     // ---- L_6x10, rho
     double L[60], rho[6];
     {
@@ -390,6 +403,7 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
         rho[5] = dist2(e.cws[2], e.cws[3]);
     }
 
+    VO_EPNP_STAMP(4);
     double Rs[3][9], ts[3][3], rep[3];
     // ---- approximation 1: betas10 columns [B11 B12 B13 B14]
     {
@@ -402,6 +416,7 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
             l[i * 4 + 3] = L[i * 10 + 6];
         }
         solve_svd<6, 4>(l, rho, b4);
+        VO_EPNP_STAMP(5);
         if (b4[0] < 0) {
             betas[0] = sqrt(-b4[0]);
             betas[1] = -b4[1] / betas[0];
@@ -414,7 +429,9 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
             betas[3] = b4[3] / betas[0];
         }
         epnp_gauss_newton(L, rho, betas);
+        VO_EPNP_STAMP(6);
         rep[0] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[0], ts[0]);
+        VO_EPNP_STAMP(7);
     }
     // ---- approximation 2: [B11 B12 B22]
     {
@@ -439,6 +456,7 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
         betas[3] = 0.0;
         epnp_gauss_newton(L, rho, betas);
         rep[1] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[1], ts[1]);
+        VO_EPNP_STAMP(8);
     }
     // ---- approximation 3: [B11 B12 B22 B13 B23]
     {
@@ -465,6 +483,7 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
         betas[3] = 0.0;
         epnp_gauss_newton(L, rho, betas);
         rep[2] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[2], ts[2]);
+        VO_EPNP_STAMP(9);
     }
     // best of the three by reprojection error (first strictly smaller wins); selected with
     // compile-time indices so Rs / ts stay in registers
@@ -479,10 +498,22 @@ VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const flo
     for (int k = 0; k < 3; k++)
         tb[k] = use2 ? ts[2][k] : use1 ? ts[1][k] : ts[0][k];
     rodrigues_m2v(Rb, rvec);
+    VO_EPNP_STAMP(10);
     tvec[0] = tb[0];
     tvec[1] = tb[1];
     tvec[2] = tb[2];
+}
 #undef VO_UT
+
+template <int S>
+VO_HD_NOINLINE void epnp5_solve_t(const float *xyz5, const float *uv5, const float *Kf, double *rvec,
+                                  double *tvec, double *ut)
+{
+    Epnp5 e;
+    double d12[12];
+    epnp5_prepare<S>(xyz5, uv5, Kf, e, ut);
+    jacobi_svd<12, 12, false, S>(ut, d12, nullptr);
+    epnp5_finish<S>(e, ut, rvec, tvec);
 }
 
 // private-array form (host unit tests, and any caller without a staging area)

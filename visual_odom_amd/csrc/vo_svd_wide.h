@@ -1,0 +1,224 @@
+// vo_svd_wide.h -- the Jacobi sweeps of EPnP's 12 x 12 SVD spread over the 16 lanes of a DPP row (round 3).
+//
+// Why: one hypothesis per lane (vo_epnp.h + jacobi_svd<12, 12, false, 64>) costs 466 us per solve, 337 us of them in
+// this SVD (developer-build time stamps, tools/pose_phases.py) -- one lane issuing ~380 dependent f64 instructions per
+// rotation while 63 lanes of the wavefront's issue slots are spent on other hypotheses that finish at the same time.
+// A single frame (vo_track_frame, a lock-step step of a few sequences) has 128 hypotheses and an otherwise idle GPU:
+// there the SVD is the latency of the call.  Here lane k < 12 of a row owns COLUMN k of the matrix (element k of every
+// row of At): the rotation of two rows and the products of a dot product become one instruction each, and what cannot
+// be spread -- the ORDER of every floating-point sum, which the result's last bits depend on -- is kept: a sum over k
+// is formed as s = ((0 + x_0) + x_1) + ... + x_11 by twelve row-broadcast + add steps (v_mov_b64_dpp row_newbcast:k
+// feeds lane k's term to the whole row), the rotation parameters are computed redundantly by every lane from those
+// sums.  Bit-identical to jacobi_svd<12, 12, false> by construction and by tests/test_kernel_emulation.py (CPU emulator:
+// this file against the serial routine on random and degenerate matrices) and the GPU parity tests of the pose solve.
+//
+// Layout: At[144] (row i at At + 12 i) followed by nothing -- the squared row norms live in a second array W16[12 * 16],
+// one copy per lane (W16[16 i + lane]): every lane computes the same values and reads back its own copy, so no lane
+// ever reads what another lane wrote (no ordering assumptions between lanes beyond the DPP instructions themselves).
+// After the sweeps the caller runs jacobi12_finish (final norms, descending selection sort, normalisation) on ONE lane.
+#pragma once
+
+#include "vo_linalg.h"
+
+namespace vo {
+
+#if defined(VO_HOST_EMUL)
+// CPU emulator (tests/host_check/hip_emu.h): lanes exchange through the emulator's per-block buffer
+static inline double row_bcast_f64(double v, int src_in_row)
+{
+    const int lane = emu::lane_id(), src = (lane & ~15) + src_in_row;
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    const uint32_t lo = emu::exchange((uint32_t)u, src, 0), hi = emu::exchange((uint32_t)(u >> 32), src, 0);
+    u = ((uint64_t)hi << 32) | lo;
+    memcpy(&v, &u, 8);
+    return v;
+}
+// s = ((0 + x_0) + x_1) + ... + x_11 over the first twelve lanes of the caller's row
+static inline double row_ordered_sum12(double x)
+{
+    double s = 0.0;
+    for (int k = 0; k < 12; k++)
+        s = s + row_bcast_f64(x, k);
+    return s;
+}
+static inline void row_ordered_sum12x2(double x, double y, double &sx, double &sy)
+{
+    sx = row_ordered_sum12(x);
+    sy = row_ordered_sum12(y);
+}
+#elif defined(__HIPCC__)
+#define VO_BC_ADD(K, S, X)                                                                   \
+    "v_mov_b64_dpp %[t], %[" X "] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"        \
+    "v_add_f64 %[" S "], %[" S "], %[t]\n\t"
+// (s_nop 1: a DPP instruction must not read a VGPR in the two slots after the VALU write that produced it -- the compiler
+// keeps that distance for its own instructions but does not look inside an asm block)
+__device__ __forceinline__ double row_ordered_sum12(double x)
+{
+    double s = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass of hipcc only needs the declaration)
+    double t;
+    asm volatile("s_nop 1\n\t" VO_BC_ADD(0, "s", "x") VO_BC_ADD(1, "s", "x") VO_BC_ADD(2, "s", "x") VO_BC_ADD(3, "s", "x")
+                     VO_BC_ADD(4, "s", "x") VO_BC_ADD(5, "s", "x") VO_BC_ADD(6, "s", "x") VO_BC_ADD(7, "s", "x")
+                         VO_BC_ADD(8, "s", "x") VO_BC_ADD(9, "s", "x") VO_BC_ADD(10, "s", "x") VO_BC_ADD(11, "s", "x")
+                 : [s] "+v"(s), [t] "=&v"(t)
+                 : [x] "v"(x));
+#else
+    s = x;
+#endif
+    return s;
+}
+// two independent sums in one block (their dependent adds interleave)
+__device__ __forceinline__ void row_ordered_sum12x2(double x, double y, double &sx, double &sy)
+{
+    double s = 0.0, r = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t;
+#define VO_BC_ADD2(K) VO_BC_ADD(K, "s", "x") VO_BC_ADD(K, "r", "y")
+    asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5) VO_BC_ADD2(6)
+                     VO_BC_ADD2(7) VO_BC_ADD2(8) VO_BC_ADD2(9) VO_BC_ADD2(10) VO_BC_ADD2(11)
+                 : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
+                 : [x] "v"(x), [y] "v"(y));
+#undef VO_BC_ADD2
+#else
+    s = x;
+    r = y;
+#endif
+    sx = s;
+    sy = r;
+}
+#undef VO_BC_ADD
+#endif
+
+#if defined(VO_HOST_EMUL) || defined(__HIPCC__)
+#if defined(VO_HOST_EMUL)
+#define VO_WIDE_FN static inline
+#else
+#define VO_WIDE_FN __device__ __forceinline__
+#endif
+
+// Squared row norms + the Jacobi sweeps of jacobi_svd<12, 12, false>.  Called by all 16 lanes of a row (`lane` = 0 .. 15;
+// lanes 12 .. 15 shadow lane 11); At: the 12 x 12 matrix (M^T M, symmetric: rows = columns), W16: 12 x 16 doubles.
+// Every branch below is uniform over the row: its conditions are functions of the broadcast sums only.
+VO_WIDE_FN void jacobi12_row_sweeps(double *At, double *W16, int lane)
+{
+    const int k = lane < 12 ? lane : 11;
+    const double eps = DBL_EPSILON * 10;
+    for (int i = 0; i < 12; i++) {
+        const double t = At[i * 12 + k];
+        W16[i * 16 + lane] = row_ordered_sum12(t * t);
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < 11; i++) {
+            // row i and its norm stay in registers over the inner loop; row j + 1 is fetched while pair (i, j) is worked on
+            double ai = At[i * 12 + k], a = W16[i * 16 + lane];
+            double aj_next = At[(i + 1) * 12 + k], b_next = W16[(i + 1) * 16 + lane];
+            for (int j = i + 1; j < 12; j++) {
+                const double aj = aj_next;
+                double b = b_next;
+                if (j + 1 < 12) {
+                    aj_next = At[(j + 1) * 12 + k];
+                    b_next = W16[(j + 1) * 16 + lane];
+                }
+                double p = row_ordered_sum12(ai * aj);
+                if (fabs(p) <= eps * sqrt(a * b))
+                    continue;
+                p *= 2;
+                const double beta = a - b, gamma = vo_hypot(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                const double t0 = c * ai + s * aj;
+                const double t1 = -s * ai + c * aj;
+                row_ordered_sum12x2(t0 * t0, t1 * t1, a, b);
+                ai = t0;
+                At[j * 12 + k] = t1;
+                W16[j * 16 + lane] = b;
+                changed = true;
+            }
+            At[i * 12 + k] = ai;
+            W16[i * 16 + lane] = a;
+        }
+        if (!changed)
+            break;
+    }
+}
+#undef VO_WIDE_FN
+#endif
+
+// What jacobi_svd<12, 12, false> does after its sweeps, for ONE lane on a matrix in memory: singular values = row norms,
+// descending selection sort (rows follow; OpenCV swaps row i with the FIRST index of the running maximum), normalised rows;
+// an exactly-zero singular value gets the deterministic pseudo-random vector OpenCV fills in (cv::RNG(0x12345678)).
+// W: 12 doubles of scratch.
+VO_HD void jacobi12_finish(double *At, double *W)
+{
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    for (int i = 0; i < 12; i++) {
+        double sd = 0;
+        for (int k = 0; k < 12; k++) {
+            const double t = At[i * 12 + k];
+            sd += t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < 11; i++) {
+        int j = i;
+        for (int k = i + 1; k < 12; k++)
+            if (W[j] < W[k])
+                j = k;
+        if (i != j) {
+            double t = W[i];
+            W[i] = W[j];
+            W[j] = t;
+            for (int k = 0; k < 12; k++) {
+                t = At[i * 12 + k];
+                At[i * 12 + k] = At[j * 12 + k];
+                At[j * 12 + k] = t;
+            }
+        }
+    }
+    uint64_t rng = 0x12345678;
+    for (int i = 0; i < 12; i++) {
+        double sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1. / 12;
+            for (int k = 0; k < 12; k++) {
+                rng = (uint64_t)(uint32_t)rng * 4164903690U + (uint32_t)(rng >> 32);
+                At[i * 12 + k] = ((uint32_t)rng & 256) != 0 ? val0 : -val0;
+            }
+            for (int iter = 0; iter < 2; iter++)
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < 12; k++)
+                        sd += At[i * 12 + k] * At[j * 12 + k];
+                    double asum = 0;
+                    for (int k = 0; k < 12; k++) {
+                        const double t = At[i * 12 + k] - sd * At[j * 12 + k];
+                        At[i * 12 + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < 12; k++)
+                        At[i * 12 + k] *= asum;
+                }
+            sd = 0;
+            for (int k = 0; k < 12; k++) {
+                const double t = At[i * 12 + k];
+                sd += t * t;
+            }
+            sd = sqrt(sd);
+        }
+        const double s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < 12; k++)
+            At[i * 12 + k] *= s;
+    }
+}
+
+} // namespace vo
