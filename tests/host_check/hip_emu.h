@@ -54,6 +54,7 @@ struct Block {
     std::vector<char> done;
     std::vector<uint64_t> xbuf;
     int cur = 0;
+    int bar_count = 0, bar_gen = 0; // emu::barrier()
     std::function<void()> body;
 };
 inline Block *&current()
@@ -81,6 +82,28 @@ inline void yield()
 {
     Block *b = current();
     swapcontext(&b->ctx[b->cur], &b->main);
+}
+
+// A real barrier over the work-items that are still running (yield() alone only works while every lane passes the same
+// number of yields -- not the case when DPP rows of one wavefront take different branches between two meeting points).
+inline void barrier()
+{
+    Block *b = current();
+    const int gen = b->bar_gen;
+    b->bar_count++;
+    for (;;) {
+        if (b->bar_gen != gen)
+            return;
+        int live = 0;
+        for (int i = 0; i < b->n; i++)
+            live += !b->done[i];
+        if (b->bar_count >= live) { // the last one in (or the last one left) opens it
+            b->bar_count = 0;
+            b->bar_gen++;
+            return;
+        }
+        yield();
+    }
 }
 
 inline void trampoline()

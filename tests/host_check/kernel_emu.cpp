@@ -81,25 +81,19 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
 
-// EPnP's 12 x 12 SVD: the row-cooperative sweeps of vo_svd_wide.h (16 lanes per matrix, 16 matrices per 256-thread block, as
-// epnp_wide_kernel runs them) + jacobi12_finish on lane 0, next to the one-lane routine jacobi_svd<12, 12, false> the other
-// EPnP kernel uses.  mats: n x 144 (consumed); wide / serial: n x 144 sorted, normalised rows; returns the number of sweeps
-// the serial routine cannot report -- 0
+// EPnP's 12 x 12 SVD: the wavefront-per-matrix sweeps of vo_svd_wide.h (four DPP rows = four independent pairs per step) +
+// jacobi12_finish on lane 0, as svd12_wave_kernel runs them, next to the one-lane routine jacobi_svd<12, 12, false> the
+// monolithic EPnP kernel uses.  mats: n x 144; wide / serial: n x 144 sorted, normalised rows
 int ke_svd12_wide(const double *mats, int n, double *wide, double *serial)
 {
-    std::vector<double> w16((size_t)n * 192);
+    std::vector<double> w((size_t)n * 12);
     for (int q = 0; q < n; q++)
         memcpy(wide + (size_t)q * 144, mats + (size_t)q * 144, 144 * sizeof(double));
-    launch((n + 15) / 16, 1, 1, 256, [&] {
-        const int q = (int)blockIdx.x * 16 + ((int)threadIdx.x >> 4), lane = (int)threadIdx.x & 15;
-        if (q >= n)
-            return; // (row-uniform)
-        vo::jacobi12_row_sweeps(wide + (size_t)q * 144, w16.data() + (size_t)q * 192, lane);
-        __syncthreads(); // (as in epnp_wide_kernel: the other lanes' last stores before lane 0 reads the matrix)
-        if (lane == 0) {
-            double W[12];
-            vo::jacobi12_finish(wide + (size_t)q * 144, W);
-        }
+    launch(n, 1, 1, 64, [&] {
+        const int q = (int)blockIdx.x, lane = (int)threadIdx.x;
+        vo::jacobi12_wave_sweeps(wide + (size_t)q * 144, w.data() + (size_t)q * 12, lane);
+        if (lane == 0)
+            vo::jacobi12_finish(wide + (size_t)q * 144, w.data() + (size_t)q * 12);
     });
     for (int q = 0; q < n; q++) {
         double d12[12];

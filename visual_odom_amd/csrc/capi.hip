@@ -84,6 +84,7 @@ struct vo_ctx {
         RansacState *rstate = nullptr;
         PnpResult *results = nullptr;
         EmResult *em_results = nullptr; // mono_rotation branch (allocated with the rest of `em` on first use)
+        double *epnp_ws = nullptr;      // workspace of the four-kernel EPnP (small launches, pnp.hip)
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         hipEvent_t em_done = nullptr; // essential-matrix chain done (mono_rotation)
         bool pending = false;                        // `done` has been recorded and not waited for
@@ -434,7 +435,7 @@ void vo_destroy(vo_ctx *c)
     seq_free(c);
     for (auto &b : c->pb) {
         void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results,
-                     b.em_results};
+                     b.em_results, b.epnp_ws};
         for (void *p : q)
             if (p)
                 (void)hipFree(p);
@@ -555,6 +556,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && dmalloc(&b.counts, B * c->ransac_cap) == hipSuccess;
         ok = ok && dmalloc(&b.results, B) == hipSuccess;
         ok = ok && dmalloc(&b.rstate, B) == hipSuccess;
+        ok = ok && dmalloc(&b.epnp_ws, (size_t)(c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES) *
+                                           VO_EPNP_WS_HYPS * VO_EPNP_WS_DOUBLES) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.tri_done, hipEventDisableTiming) == hipSuccess;
@@ -1168,7 +1171,8 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp_ransac(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
-                          pb.rstate, c->sched.waves, ps);
+                          pb.rstate, c->sched.waves, ps, pb.epnp_ws,
+                          c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
         SeqTail tail;
@@ -2546,7 +2550,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }

@@ -68,7 +68,7 @@ __device__ long long g_pose_prof[64];
 
 namespace vo {
 
-constexpr int RANSAC_CHUNK = 128;
+constexpr int RANSAC_CHUNK = VO_EPNP_WS_HYPS;
 
 // ---- random 5-subsets: RANSACPointSetRegistrator::getSubset with cv::RNG(-1) ----
 // cv::RNG is a multiply-with-carry generator whose raw 32-bit outputs do not depend on anything the caller passes: the
@@ -262,66 +262,142 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
     m[5] = tv[2];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
 // The same solve for SMALL launches (a single frame, a lock-step step of a few sequences), where the pose chain is the latency
-// of the call and the GPU is otherwise idle: one hypothesis per DPP ROW instead of per lane.  Lane 0 of the row runs the
-// solver; for its 12 x 12 SVD -- 337 of the 466 us a hypothesis takes in the kernel above -- the row's 16 lanes join in
-// (vo_svd_wide.h: a lane per matrix column, every sum in the serial order through row broadcasts: bit-identical).
-// Matrices hypothesis-major in LDS (2.7 KB each with the per-lane norm copies).  ONE wavefront (4 hypotheses) per workgroup:
-// the solver is ~35 k instructions of mostly straight-line code, a wavefront streams it through the instruction cache, and
-// wavefronts of one CU that drift apart evict each other's loops -- with 16 hypotheses (4 wavefronts) per workgroup the
-// one-lane phases ran at half speed and the whole solve took as long as the kernel above (gpurun_out/r3_23, r3_24:
-// 465 vs 327 us per hypothesis).  The same effect bounds the launch size this kernel is good for (launch_pnp_ransac).
-// Costs ~7 x the VALU time of the kernel above per hypothesis (12 of 64 lanes do useful work in the sweeps, one in the rest).
-constexpr int EW_HYPS_DEFAULT = 4; // hypotheses (DPP rows) per workgroup
+// of the call and the GPU is otherwise idle: FOUR kernels instead of one, each shaped for its part (round 3; developer-build
+// time stamps of the kernel above, tools/pose_phases.py: 16 us set-up, 337 us 12 x 12 SVD, 108 us the three approximations,
+// 6 us selection = 466 us per hypothesis, whatever the number of hypotheses):
+//   epnp_prepare_kernel  a lane per hypothesis as above: control points, barycentric coordinates, M^T M -> workspace
+//   svd12_wave_kernel    a WAVEFRONT per hypothesis (vo_svd_wide.h): a lane per matrix column, every sum in the serial order
+//                        through DPP row broadcasts, four independent pairs at a time on the four DPP rows -- bit-identical
+//   epnp_approx_kernel   a lane per (hypothesis, approximation): the three beta approximations + Gauss-Newton + R, t are
+//                        independent of each other; blockIdx.z picks the approximation, so a workgroup runs one code path
+//   epnp_select_kernel   a lane per hypothesis: best of three, R -> rvec, the model record
+// Why kernels and not phases of one kernel: the solver is ~35 k instructions of mostly straight-line code; a first version
+// with a DPP row per hypothesis inside ONE kernel (4 wavefronts per workgroup) ran its one-lane phases at HALF speed --
+// wavefronts of a CU that drift apart evict each other's loops from the instruction cache (465 us per hypothesis, no gain;
+// with one wavefront per workgroup 327 us, but only up to ~128 wavefronts per launch: gpurun_out/r3_23 ... r3_25).  Here the
+// wide part is a kernel of a few hundred instructions, and the long code runs in a few wavefronts as before.
+// Costs several times the VALU time of the kernel above per hypothesis (12 of 64 lanes do useful work in the sweeps):
+// launch_pnp_ransac uses it while that is free.
+constexpr int EPNP_WS = VO_EPNP_WS_DOUBLES; // doubles per hypothesis: Epnp5 (88) | At 144 | 12 spare | 3 x (rep, R[9], t[3]) | pad
+constexpr int EPNP_WS_AT = 88, EPNP_WS_RES = 244; // (232 .. 243 spare)
+static_assert(sizeof(Epnp5) == 88 * sizeof(double), "workspace layout");
 
-template <int EW_HYPS>
-__global__ __launch_bounds__(16 * EW_HYPS, 1) void epnp_wide_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
-                                                           size_t uv_stride, const int *__restrict__ n_pts, int cap,
-                                                           const int32_t *__restrict__ subsets, PnpParams prm,
-                                                           const RansacState *__restrict__ rstate, int h0, int hn,
-                                                           double *__restrict__ models /* [B][iters][6] */)
+// (as in epnp_kernel: hypotheses beyond the iteration count the replay has settled on are never looked at)
+__device__ __forceinline__ bool epnp_hyp_active(int count, int h, int h0, int hn, const PnpParams &prm, const RansacState *rs)
 {
-    // (146: the rows of the four hypotheses a wavefront holds start in different LDS banks -- 144 doubles put all four on the
-    // same one, and the one-lane phases, where lane 0 of each row walks its matrix, ran into 4-way conflicts)
-    __shared__ __attribute__((aligned(16))) double s_at[EW_HYPS][146];
-    __shared__ __attribute__((aligned(16))) double s_w16[EW_HYPS][192];
-    const int frame = blockIdx.y, row = threadIdx.x >> 4, lane = threadIdx.x & 15;
-    const int h = h0 + blockIdx.x * EW_HYPS + row;
-    const int count = n_pts[frame];
-    // (as in epnp_kernel: hypotheses beyond the iteration count the replay has settled on are never looked at)
-    const bool active = count >= 5 && h < h0 + hn && h < (count == 5 ? 1 : min(prm.iters, rstate[frame].niters));
+    return count >= 5 && h < h0 + hn && h < (count == 5 ? 1 : min(prm.iters, rs->niters));
+}
+
+__global__ __launch_bounds__(64, 1) void epnp_prepare_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                             size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                             const int32_t *__restrict__ subsets, PnpParams prm,
+                                                             const RansacState *__restrict__ rstate, int h0, int hn,
+                                                             double *__restrict__ ws /* [B][hn][EPNP_WS] */)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_ut[]; // 144 x 64, lane-interleaved as in epnp_kernel
+    const int frame = blockIdx.y, hl = blockIdx.x * 64 + threadIdx.x, h = h0 + hl;
+    if (!epnp_hyp_active(n_pts[frame], h, h0, hn, prm, rstate + frame))
+        return;
+    const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
+    float x5[15], u5[10];
+    for (int i = 0; i < 5; i++) {
+        const int k = idx[i];
+        const float *p = xyz + ((size_t)frame * cap + k) * 3;
+        x5[3 * i] = p[0];
+        x5[3 * i + 1] = p[1];
+        x5[3 * i + 2] = p[2];
+        const float2 q = uv[frame * uv_stride + k];
+        u5[2 * i] = q.x;
+        u5[2 * i + 1] = q.y;
+    }
+    double *w = ws + ((size_t)frame * hn + hl) * EPNP_WS;
     Epnp5 e;
-    if (active && lane == 0) {
-        const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
-        float x5[15], u5[10];
-        for (int i = 0; i < 5; i++) {
-            const int k = idx[i];
-            const float *p = xyz + ((size_t)frame * cap + k) * 3;
-            x5[3 * i] = p[0];
-            x5[3 * i + 1] = p[1];
-            x5[3 * i + 2] = p[2];
-            const float2 q = uv[frame * uv_stride + k];
-            u5[2 * i] = q.x;
-            u5[2 * i + 1] = q.y;
-        }
-        epnp5_prepare<1>(x5, u5, prm.K, e, s_at[row]);
-    }
-    __syncthreads(); // (every thread of the workgroup reaches both barriers: no early return above)
-    if (active)
-        jacobi12_row_sweeps(s_at[row], s_w16[row], lane);
+    epnp5_prepare<64>(x5, u5, prm.K, e, s_ut + threadIdx.x);
+    *(Epnp5 *)w = e;
+#pragma unroll 4
+    for (int i = 0; i < 144; i++)
+        w[EPNP_WS_AT + i] = s_ut[i * 64 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void svd12_wave_kernel(const int *__restrict__ n_pts, PnpParams prm,
+                                                        const RansacState *__restrict__ rstate, int h0, int hn,
+                                                        double *__restrict__ ws)
+{
+    __shared__ __attribute__((aligned(16))) double s_at[144];
+    __shared__ double s_w[12];
+    const int frame = blockIdx.y, hl = blockIdx.x, lane = threadIdx.x;
+    if (!epnp_hyp_active(n_pts[frame], h0 + hl, h0, hn, prm, rstate + frame)) // (uniform over the wavefront)
+        return;
+    double *w = ws + ((size_t)frame * hn + hl) * EPNP_WS + EPNP_WS_AT;
+    for (int i = lane; i < 144; i += 64)
+        s_at[i] = w[i];
     __syncthreads();
-    if (active && lane == 0) {
-        jacobi12_finish(s_at[row], s_w16[row]);
-        double rv[3], tv[3];
-        epnp5_finish<1>(e, s_at[row], rv, tv);
-        double *m = models + ((size_t)frame * prm.iters + h) * 6;
-        m[0] = rv[0];
-        m[1] = rv[1];
-        m[2] = rv[2];
-        m[3] = tv[0];
-        m[4] = tv[1];
-        m[5] = tv[2];
+    jacobi12_wave_sweeps(s_at, s_w, lane);
+    __syncthreads();
+    if (lane == 0)
+        jacobi12_finish(s_at, s_w);
+    __syncthreads();
+    for (int i = 96 + lane; i < 144; i += 64) // rows 8 .. 11: the null-space basis is all the rest of the solver reads
+        w[i] = s_at[i];
+}
+
+__global__ __launch_bounds__(64, 1) void epnp_approx_kernel(const int *__restrict__ n_pts, PnpParams prm,
+                                                            const RansacState *__restrict__ rstate, int h0, int hn,
+                                                            double *__restrict__ ws)
+{
+    const int frame = blockIdx.y, hl = blockIdx.x * 64 + threadIdx.x;
+    if (!epnp_hyp_active(n_pts[frame], h0 + hl, h0, hn, prm, rstate + frame))
+        return;
+    double *w = ws + ((size_t)frame * hn + hl) * EPNP_WS;
+    Epnp5 e = *(const Epnp5 *)w;
+    const double *ut = w + EPNP_WS_AT;
+    double L[60], rho[6], R[9], t[3], rep;
+    epnp5_L_rho<1>(e, ut, L, rho);
+    if (blockIdx.z == 0)
+        rep = epnp5_approx<1, 0>(e, ut, L, rho, R, t);
+    else if (blockIdx.z == 1)
+        rep = epnp5_approx<1, 1>(e, ut, L, rho, R, t);
+    else
+        rep = epnp5_approx<1, 2>(e, ut, L, rho, R, t);
+    double *o = w + EPNP_WS_RES + 13 * blockIdx.z;
+    o[0] = rep;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        o[1 + k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        o[10 + k] = t[k];
+}
+
+__global__ __launch_bounds__(64) void epnp_select_kernel(const int *__restrict__ n_pts, PnpParams prm,
+                                                         const RansacState *__restrict__ rstate, int h0, int hn,
+                                                         const double *__restrict__ ws, double *__restrict__ models)
+{
+    const int frame = blockIdx.y, hl = blockIdx.x * 64 + threadIdx.x, h = h0 + hl;
+    if (!epnp_hyp_active(n_pts[frame], h, h0, hn, prm, rstate + frame))
+        return;
+    const double *o = ws + ((size_t)frame * hn + hl) * EPNP_WS + EPNP_WS_RES;
+    double rep[3], R[3][9], t[3][3], rv[3], tv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        rep[a] = o[13 * a];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            R[a][k] = o[13 * a + 1 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            t[a][k] = o[13 * a + 10 + k];
     }
+    epnp5_select(rep, R[0], R[1], R[2], t[0], t[1], t[2], rv, tv);
+    double *m = models + ((size_t)frame * prm.iters + h) * 6;
+    m[0] = rv[0];
+    m[1] = rv[1];
+    m[2] = rv[2];
+    m[3] = tv[0];
+    m[4] = tv[1];
+    m[5] = tv[2];
 }
 
 // squared reprojection error exactly as PnPRansacCallback::computeError: projection in f64,
@@ -783,7 +859,8 @@ void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int h0, in
 // 128, i.e. 16 dependent launches per solve of which 12 found nothing to do.
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                       int waves /* 1 or 2 per SIMD: 512 / 256 registers */, hipStream_t stream)
+                       int waves /* 1 or 2 per SIMD: 512 / 256 registers */, hipStream_t stream,
+                       double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames)
 {
     if (n_frames <= 0)
         return;
@@ -801,31 +878,26 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
 #endif
         return want > need ? want : need;
     }();
-    // Small launches: one hypothesis per DPP row (epnp_wide_kernel).  Up to 4 frames x 128 hypotheses = 128 wavefronts, one
-    // per two CUs (= per instruction cache); measured in the lock-step loop (ms per step, this kernel | the one above):
-    // 1 sequence 0.545 | 0.601, 4 sequences 0.635 | 0.651, 8 sequences 0.820 | 0.639 (gpurun_out/r3_24).
-    int wide_max = 4;
+    // Small launches: the four-kernel form (epnp_prepare_kernel ...) for the first chunk; the rarely needed second chunk stays
+    // with the one kernel (four launches that mostly find nothing to do would cost more than they save).
+    int split_max = VO_EPNP_SPLIT_DEFAULT_FRAMES;
 #ifdef VO_DEV_VARIANTS
-    static const int wide_env = [] { const char *e = getenv("VO_EPNP_WIDE_MAX"); return e ? atoi(e) : -1; }();
-    if (wide_env >= 0)
-        wide_max = wide_env;
+    static const int split_env = [] { const char *e = getenv("VO_EPNP_SPLIT_MAX"); return e ? atoi(e) : -1; }();
+    if (split_env >= 0)
+        split_max = split_env;
 #endif
-    const bool wide = n_frames <= wide_max;
+    const bool split = epnp_ws && n_frames <= split_max && n_frames <= ws_frames;
     for (int h0 = 0; h0 < prm.iters;) {
         const int hn = h0 == 0 ? min(RANSAC_CHUNK, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
         launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
-        if (wide) {
-#ifdef VO_DEV_VARIANTS
-            static const int ew = [] { const char *e = getenv("VO_EW_HYPS"); return e ? atoi(e) : EW_HYPS_DEFAULT; }();
-            if (ew == 16)
-                hipLaunchKernelGGL(epnp_wide_kernel<16>, dim3((hn + 15) / 16, n_frames), dim3(256), 0, stream, xyz, uv,
-                                   uv_stride, n_pts, cap, subsets, prm, state, h0, hn, models);
-            else
-#endif
-                hipLaunchKernelGGL(epnp_wide_kernel<EW_HYPS_DEFAULT>, dim3((hn + EW_HYPS_DEFAULT - 1) / EW_HYPS_DEFAULT, n_frames),
-                                   dim3(16 * EW_HYPS_DEFAULT), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                                   h0, hn, models);
+        if (split && h0 == 0) {
+            hipLaunchKernelGGL(epnp_prepare_kernel, eg, dim3(64), 144 * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts,
+                               cap, subsets, prm, state, h0, hn, epnp_ws);
+            hipLaunchKernelGGL(svd12_wave_kernel, dim3(hn, n_frames), dim3(64), 0, stream, n_pts, prm, state, h0, hn, epnp_ws);
+            hipLaunchKernelGGL(epnp_approx_kernel, dim3(eg.x, n_frames, 3), dim3(64), 0, stream, n_pts, prm, state, h0, hn,
+                               epnp_ws);
+            hipLaunchKernelGGL(epnp_select_kernel, eg, dim3(64), 0, stream, n_pts, prm, state, h0, hn, epnp_ws, models);
         } else
 #ifdef VO_DEV_VARIANTS // the 128-register instantiation: never the best one since round 2
         if (waves >= 4)
@@ -873,9 +945,10 @@ void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, con
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream)
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames)
 {
-    launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream);
+    launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
+                      ws_frames);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

@@ -355,59 +355,58 @@ VO_HD void epnp5_prepare(const float *xyz5, const float *uv5, const float *Kf, E
 }
 
 // rows 11, 10, 9, 8 of `ut` = the null-space basis (rows of U^T sorted by descending singular value)
+// ---- L_6x10, rho
 template <int S>
-VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
+VO_HD void epnp5_L_rho(const Epnp5 &e, const double *ut, double *L /*60*/, double *rho /*6*/)
 {
-    const int n = 5;
-    (void)n;
-    VO_EPNP_STAMP(3);
-    // ---- L_6x10, rho
-    double L[60], rho[6];
-    {
-        double dv[4][6][3];
+    double dv[4][6][3];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int a = 0, b = 1;
+    for (int i = 0; i < 4; i++) {
+        int a = 0, b = 1;
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const int va = 12 * (11 - i) + 3 * a, vb = 12 * (11 - i) + 3 * b; // null vector i = row 11 - i
-                dv[i][j][0] = VO_UT(va) - VO_UT(vb);
-                dv[i][j][1] = VO_UT(va + 1) - VO_UT(vb + 1);
-                dv[i][j][2] = VO_UT(va + 2) - VO_UT(vb + 2);
-                b++;
-                if (b > 3) {
-                    a++;
-                    b = a + 1;
-                }
+        for (int j = 0; j < 6; j++) {
+            const int va = 12 * (11 - i) + 3 * a, vb = 12 * (11 - i) + 3 * b; // null vector i = row 11 - i
+            dv[i][j][0] = VO_UT(va) - VO_UT(vb);
+            dv[i][j][1] = VO_UT(va + 1) - VO_UT(vb + 1);
+            dv[i][j][2] = VO_UT(va + 2) - VO_UT(vb + 2);
+            b++;
+            if (b > 3) {
+                a++;
+                b = a + 1;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double *row = L + 10 * i;
-            row[0] = dot3(dv[0][i], dv[0][i]);
-            row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
-            row[2] = dot3(dv[1][i], dv[1][i]);
-            row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
-            row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
-            row[5] = dot3(dv[2][i], dv[2][i]);
-            row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
-            row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
-            row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
-            row[9] = dot3(dv[3][i], dv[3][i]);
-        }
-        rho[0] = dist2(e.cws[0], e.cws[1]);
-        rho[1] = dist2(e.cws[0], e.cws[2]);
-        rho[2] = dist2(e.cws[0], e.cws[3]);
-        rho[3] = dist2(e.cws[1], e.cws[2]);
-        rho[4] = dist2(e.cws[1], e.cws[3]);
-        rho[5] = dist2(e.cws[2], e.cws[3]);
     }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double *row = L + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+    rho[0] = dist2(e.cws[0], e.cws[1]);
+    rho[1] = dist2(e.cws[0], e.cws[2]);
+    rho[2] = dist2(e.cws[0], e.cws[3]);
+    rho[3] = dist2(e.cws[1], e.cws[2]);
+    rho[4] = dist2(e.cws[1], e.cws[3]);
+    rho[5] = dist2(e.cws[2], e.cws[3]);
+}
 
-    VO_EPNP_STAMP(4);
-    double Rs[3][9], ts[3][3], rep[3];
-    // ---- approximation 1: betas10 columns [B11 B12 B13 B14]
-    {
-        double l[24], b4[4], betas[4];
+// One of the three beta approximations (A = 0: [B11 B12 B13 B14], 1: [B11 B12 B22], 2: [B11 B12 B22 B13 B23]), its five
+// Gauss-Newton steps, R and t; returns the reprojection error.  The three are independent of each other (e.ccs / e.pcs are
+// scratch of epnp_compute_R_and_t): the monolithic solver runs them one after the other, epnp_approx_kernel side by side.
+template <int S, int A>
+VO_HD double epnp5_approx(Epnp5 &e, const double *ut, const double *L, const double *rho, double *R /*9*/, double *t /*3*/)
+{
+    double betas[4];
+    if (A == 0) {
+        double l[24], b4[4];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 4 + 0] = L[i * 10 + 0];
@@ -416,7 +415,6 @@ VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
             l[i * 4 + 3] = L[i * 10 + 6];
         }
         solve_svd<6, 4>(l, rho, b4);
-        VO_EPNP_STAMP(5);
         if (b4[0] < 0) {
             betas[0] = sqrt(-b4[0]);
             betas[1] = -b4[1] / betas[0];
@@ -428,14 +426,8 @@ VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
             betas[2] = b4[2] / betas[0];
             betas[3] = b4[3] / betas[0];
         }
-        epnp_gauss_newton(L, rho, betas);
-        VO_EPNP_STAMP(6);
-        rep[0] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[0], ts[0]);
-        VO_EPNP_STAMP(7);
-    }
-    // ---- approximation 2: [B11 B12 B22]
-    {
-        double l[18], b3[3], betas[4];
+    } else if (A == 1) {
+        double l[18], b3[3];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 3 + 0] = L[i * 10 + 0];
@@ -454,13 +446,8 @@ VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
             betas[0] = -betas[0];
         betas[2] = 0.0;
         betas[3] = 0.0;
-        epnp_gauss_newton(L, rho, betas);
-        rep[1] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[1], ts[1]);
-        VO_EPNP_STAMP(8);
-    }
-    // ---- approximation 3: [B11 B12 B22 B13 B23]
-    {
-        double l[30], b5[5], betas[4];
+    } else {
+        double l[30], b5[5];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             l[i * 5 + 0] = L[i * 10 + 0];
@@ -481,27 +468,48 @@ VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
             betas[0] = -betas[0];
         betas[2] = b5[3] / betas[0];
         betas[3] = 0.0;
-        epnp_gauss_newton(L, rho, betas);
-        rep[2] = epnp_compute_R_and_t<S>(e, ut, betas, Rs[2], ts[2]);
-        VO_EPNP_STAMP(9);
     }
-    // best of the three by reprojection error (first strictly smaller wins); selected with
-    // compile-time indices so Rs / ts stay in registers
+    epnp_gauss_newton(L, rho, betas);
+    return epnp_compute_R_and_t<S>(e, ut, betas, R, t);
+}
+
+// best of the three by reprojection error (first strictly smaller wins), R -> rvec; selected with compile-time indices so
+// that the candidates stay in registers
+VO_HD void epnp5_select(const double *rep, const double *R0, const double *R1, const double *R2, const double *t0,
+                        const double *t1, const double *t2, double *rvec, double *tvec)
+{
     const bool use1 = rep[1] < rep[0];
     const double rep01 = use1 ? rep[1] : rep[0];
     const bool use2 = rep[2] < rep01;
     double Rb[9], tb[3];
 #pragma unroll
     for (int k = 0; k < 9; k++)
-        Rb[k] = use2 ? Rs[2][k] : use1 ? Rs[1][k] : Rs[0][k];
+        Rb[k] = use2 ? R2[k] : use1 ? R1[k] : R0[k];
 #pragma unroll
     for (int k = 0; k < 3; k++)
-        tb[k] = use2 ? ts[2][k] : use1 ? ts[1][k] : ts[0][k];
+        tb[k] = use2 ? t2[k] : use1 ? t1[k] : t0[k];
     rodrigues_m2v(Rb, rvec);
-    VO_EPNP_STAMP(10);
     tvec[0] = tb[0];
     tvec[1] = tb[1];
     tvec[2] = tb[2];
+}
+
+template <int S>
+VO_HD void epnp5_finish(Epnp5 &e, const double *ut, double *rvec, double *tvec)
+{
+    VO_EPNP_STAMP(3);
+    double L[60], rho[6];
+    epnp5_L_rho<S>(e, ut, L, rho);
+    VO_EPNP_STAMP(4);
+    double Rs[3][9], ts[3][3], rep[3];
+    rep[0] = epnp5_approx<S, 0>(e, ut, L, rho, Rs[0], ts[0]);
+    VO_EPNP_STAMP(5);
+    rep[1] = epnp5_approx<S, 1>(e, ut, L, rho, Rs[1], ts[1]);
+    VO_EPNP_STAMP(6);
+    rep[2] = epnp5_approx<S, 2>(e, ut, L, rho, Rs[2], ts[2]);
+    VO_EPNP_STAMP(7);
+    epnp5_select(rep, Rs[0], Rs[1], Rs[2], ts[0], ts[1], ts[2], rvec, tvec);
+    VO_EPNP_STAMP(8);
 }
 #undef VO_UT
 

@@ -162,10 +162,14 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
                         hipStream_t stream);
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream);
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws = nullptr,
+                int ws_frames = 0);
+// epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip), VO_EPNP_WS_DOUBLES doubles per hypothesis of
+// the first RANSAC chunk (VO_EPNP_WS_HYPS hypotheses per frame) for ws_frames frames; null = always the one-kernel form
+constexpr int VO_EPNP_WS_DOUBLES = 288, VO_EPNP_WS_HYPS = 128, VO_EPNP_WS_MAX_FRAMES = 16, VO_EPNP_SPLIT_DEFAULT_FRAMES = 4;
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
-                       hipStream_t stream);
+                       hipStream_t stream, double *epnp_ws, int ws_frames);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);

@@ -1,21 +1,27 @@
-// vo_svd_wide.h -- the Jacobi sweeps of EPnP's 12 x 12 SVD spread over the 16 lanes of a DPP row (round 3).
+// vo_svd_wide.h -- the Jacobi sweeps of EPnP's 12 x 12 SVD run by a whole WAVEFRONT per matrix (round 3).
 //
 // Why: one hypothesis per lane (vo_epnp.h + jacobi_svd<12, 12, false, 64>) costs 466 us per solve, 337 us of them in
-// this SVD (developer-build time stamps, tools/pose_phases.py) -- one lane issuing ~380 dependent f64 instructions per
-// rotation while 63 lanes of the wavefront's issue slots are spent on other hypotheses that finish at the same time.
-// A single frame (vo_track_frame, a lock-step step of a few sequences) has 128 hypotheses and an otherwise idle GPU:
-// there the SVD is the latency of the call.  Here lane k < 12 of a row owns COLUMN k of the matrix (element k of every
-// row of At): the rotation of two rows and the products of a dot product become one instruction each, and what cannot
-// be spread -- the ORDER of every floating-point sum, which the result's last bits depend on -- is kept: a sum over k
-// is formed as s = ((0 + x_0) + x_1) + ... + x_11 by twelve row-broadcast + add steps (v_mov_b64_dpp row_newbcast:k
-// feeds lane k's term to the whole row), the rotation parameters are computed redundantly by every lane from those
-// sums.  Bit-identical to jacobi_svd<12, 12, false> by construction and by tests/test_kernel_emulation.py (CPU emulator:
-// this file against the serial routine on random and degenerate matrices) and the GPU parity tests of the pose solve.
+// this SVD (developer-build time stamps, tools/pose_phases.py): ~307 rotations + ~114 skipped pairs, each a chain of
+// dependent f64 instructions issued by one lane.  A single frame (vo_track_frame, a lock-step step of a few sequences)
+// has 128 hypotheses and an otherwise idle GPU: there the SVD is the latency of the call.  Two things are spread here,
+// neither of which changes a bit of the result:
+//   * inside a pair (i, j): lane k < 12 of a DPP row owns COLUMN k (element k of every row of At), so the rotation of
+//     the two rows and the products of a dot product are one instruction each.  What cannot be spread is the ORDER of a
+//     floating-point sum: s = ((0 + x_0) + x_1) + ... + x_11 is formed by twelve row-broadcast + add steps
+//     (v_mov_b64_dpp row_newbcast:k feeds lane k's term to the whole row); the rotation parameters are then computed
+//     redundantly by every lane of the row from those sums;
+//   * across pairs: the serial order (0,1), (0,2) ... (10,11) makes pair (i, j) wait for (i, j - 1) and (i - 1, j) only
+//     -- the last pairs before it that touch row i / row j -- so all pairs with the same i + j are independent and see
+//     exactly the rows they would see in the serial order.  The four DPP rows of the wavefront take up to four of them
+//     at a time: 26 steps per sweep instead of 66 (the table below).
+// Bit-identical to jacobi_svd<12, 12, false> by construction and by tests/test_kernel_emulation.py (CPU emulator: this
+// file against the serial routine on random, rank-deficient and degenerate matrices) and the GPU parity tests of the
+// pose solve.
 //
-// Layout: At[144] (row i at At + 12 i) followed by nothing -- the squared row norms live in a second array W16[12 * 16],
-// one copy per lane (W16[16 i + lane]): every lane computes the same values and reads back its own copy, so no lane
-// ever reads what another lane wrote (no ordering assumptions between lanes beyond the DPP instructions themselves).
-// After the sweeps the caller runs jacobi12_finish (final norms, descending selection sort, normalisation) on ONE lane.
+// Layout: At[144] (row i at At + 12 i) and W[12] (squared row norms) in LDS or any memory the wavefront shares; rows of
+// the matrix move between DPP rows through that memory, in program order of the one wavefront (VO_WAVE_SYNC keeps the
+// compiler from moving memory operations across a step boundary; the hardware executes a wavefront's LDS operations in
+// order).  After the sweeps ONE lane runs jacobi12_finish (final norms, descending selection sort, normalisation).
 #pragma once
 
 #include "vo_linalg.h"
@@ -93,60 +99,97 @@ __device__ __forceinline__ void row_ordered_sum12x2(double x, double y, double &
 #if defined(VO_HOST_EMUL) || defined(__HIPCC__)
 #if defined(VO_HOST_EMUL)
 #define VO_WIDE_FN static inline
+#define VO_WAVE_SYNC() emu::barrier()
+static inline bool wave_any(bool v) { return emu_ballot(v) != 0; }
 #else
 #define VO_WIDE_FN __device__ __forceinline__
+#define VO_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+__device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 #endif
 
-// Squared row norms + the Jacobi sweeps of jacobi_svd<12, 12, false>.  Called by all 16 lanes of a row (`lane` = 0 .. 15;
-// lanes 12 .. 15 shadow lane 11); At: the 12 x 12 matrix (M^T M, symmetric: rows = columns), W16: 12 x 16 doubles.
-// Every branch below is uniform over the row: its conditions are functions of the broadcast sums only.
-VO_WIDE_FN void jacobi12_row_sweeps(double *At, double *W16, int lane)
+// Pairs by anti-diagonal i + j = 1 .. 21, four per step: {i, j} of DPP row 0 .. 3, 255 = nothing to do in this step.
+struct Jacobi12Steps {
+    uint8_t ij[26][4][2];
+};
+constexpr Jacobi12Steps jacobi12_steps()
 {
-    const int k = lane < 12 ? lane : 11;
-    const double eps = DBL_EPSILON * 10;
-    for (int i = 0; i < 12; i++) {
-        const double t = At[i * 12 + k];
-        W16[i * 16 + lane] = row_ordered_sum12(t * t);
+    Jacobi12Steps t = {};
+    int step = 0;
+    for (int d = 1; d <= 21; d++) {
+        int n = 0;
+        for (int i = 0; i < 12; i++) {
+            const int j = d - i;
+            if (j <= i || j > 11)
+                continue;
+            if (n == 4) {
+                step++;
+                n = 0;
+            }
+            t.ij[step][n][0] = (uint8_t)i;
+            t.ij[step][n][1] = (uint8_t)j;
+            n++;
+        }
+        for (; n < 4; n++)
+            t.ij[step][n][0] = t.ij[step][n][1] = 255;
+        step++;
     }
+    return t;
+}
+#if defined(VO_HOST_EMUL)
+static const Jacobi12Steps JACOBI12_STEPS = jacobi12_steps();
+#else
+__device__ const Jacobi12Steps JACOBI12_STEPS = jacobi12_steps();
+#endif
+
+// Squared row norms + the Jacobi sweeps of jacobi_svd<12, 12, false>.  Called by all 64 lanes of ONE wavefront per matrix;
+// lanes 12 .. 15 of a DPP row shadow lane 11.  Every branch below is uniform over a DPP row: its conditions are functions
+// of the row's broadcast sums (or of the step table) only.
+VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
+{
+    const int row = (lane >> 4) & 3, l16 = lane & 15, k = l16 < 12 ? l16 : 11;
+    const double eps = DBL_EPSILON * 10;
+    for (int i = row; i < 12; i += 4) {
+        const double t = At[i * 12 + k];
+        const double sd = row_ordered_sum12(t * t);
+        if (l16 == 0)
+            W[i] = sd;
+    }
+    VO_WAVE_SYNC();
     for (int iter = 0; iter < 30; iter++) {
         bool changed = false;
-        for (int i = 0; i < 11; i++) {
-            // row i and its norm stay in registers over the inner loop; row j + 1 is fetched while pair (i, j) is worked on
-            double ai = At[i * 12 + k], a = W16[i * 16 + lane];
-            double aj_next = At[(i + 1) * 12 + k], b_next = W16[(i + 1) * 16 + lane];
-            for (int j = i + 1; j < 12; j++) {
-                const double aj = aj_next;
-                double b = b_next;
-                if (j + 1 < 12) {
-                    aj_next = At[(j + 1) * 12 + k];
-                    b_next = W16[(j + 1) * 16 + lane];
-                }
+        for (int step = 0; step < 26; step++) {
+            const int i = JACOBI12_STEPS.ij[step][row][0], j = JACOBI12_STEPS.ij[step][row][1];
+            if (i != 255) {
+                const double ai = At[i * 12 + k], aj = At[j * 12 + k];
+                double a = W[i], b = W[j];
                 double p = row_ordered_sum12(ai * aj);
-                if (fabs(p) <= eps * sqrt(a * b))
-                    continue;
-                p *= 2;
-                const double beta = a - b, gamma = vo_hypot(p, beta);
-                double c, s;
-                if (beta < 0) {
-                    const double delta = (gamma - beta) * 0.5;
-                    s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
-                } else {
-                    c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = vo_hypot(p, beta);
+                    double c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = sqrt(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = sqrt((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    const double t0 = c * ai + s * aj;
+                    const double t1 = -s * ai + c * aj;
+                    At[i * 12 + k] = t0;
+                    At[j * 12 + k] = t1;
+                    row_ordered_sum12x2(t0 * t0, t1 * t1, a, b);
+                    if (l16 == 0) {
+                        W[i] = a;
+                        W[j] = b;
+                    }
+                    changed = true;
                 }
-                const double t0 = c * ai + s * aj;
-                const double t1 = -s * ai + c * aj;
-                row_ordered_sum12x2(t0 * t0, t1 * t1, a, b);
-                ai = t0;
-                At[j * 12 + k] = t1;
-                W16[j * 16 + lane] = b;
-                changed = true;
             }
-            At[i * 12 + k] = ai;
-            W16[i * 16 + lane] = a;
+            VO_WAVE_SYNC();
         }
-        if (!changed)
+        if (!wave_any(changed))
             break;
     }
 }
