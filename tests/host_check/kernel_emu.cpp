@@ -81,6 +81,31 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
 
+// The Levenberg-Marquardt step's 6 x 6 solve as select_refine_kernel runs it -- wavefront sweeps with V, jacobi_finish and
+// svd_backsubst on lane 0 -- next to solve_svd<6, 6>.  A: n x 36 row-major, b: n x 6; x_wave / x_serial: n x 6
+int ke_solve6_wave(const double *A, const double *b, int n, double *x_wave, double *x_serial)
+{
+    std::vector<double> at((size_t)n * 36), vt((size_t)n * 36), w((size_t)n * 6);
+    launch(n, 1, 1, 64, [&] {
+        const int q = (int)blockIdx.x, lane = (int)threadIdx.x;
+        double *At = at.data() + (size_t)q * 36, *Vt = vt.data() + (size_t)q * 36, *W = w.data() + (size_t)q * 6;
+        if (lane == 0)
+            for (int i = 0; i < 6; i++)
+                for (int k = 0; k < 6; k++)
+                    At[i * 6 + k] = A[(size_t)q * 36 + k * 6 + i];
+        __syncthreads();
+        vo::jacobi6v_wave_sweeps(At, W, Vt, lane);
+        __syncthreads();
+        if (lane == 0) {
+            vo::jacobi_finish<6, true>(At, W, Vt);
+            vo::svd_backsubst<6>(At, W, Vt, b + (size_t)q * 6, x_wave + (size_t)q * 6);
+        }
+    });
+    for (int q = 0; q < n; q++)
+        vo::solve_svd<6, 6>(A + (size_t)q * 36, b + (size_t)q * 6, x_serial + (size_t)q * 6);
+    return 0;
+}
+
 // EPnP's 12 x 12 SVD: the wavefront-per-matrix sweeps of vo_svd_wide.h (four DPP rows = four independent pairs per step) +
 // jacobi12_finish on lane 0, as svd12_wave_kernel runs them, next to the one-lane routine jacobi_svd<12, 12, false> the
 // monolithic EPnP kernel uses.  mats: n x 144; wide / serial: n x 144 sorted, normalised rows

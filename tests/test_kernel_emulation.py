@@ -351,3 +351,28 @@ def test_row_cooperative_svd12_is_bit_identical_to_the_one_lane_routine(kemu):
     U = serial[0]
     assert np.allclose(U @ U.T, np.eye(12), atol=1e-12)
     assert np.abs(mats[0] @ U[10:].T).max() < 1e-6 * np.abs(mats[0]).max()
+
+
+def test_wavefront_6x6_solve_is_bit_identical_to_solve_svd(kemu):
+    """the Levenberg-Marquardt step of the pose refinement: (J^T J + lambda diag) x = J^T e through the SVD, its Jacobi
+    sweeps run by a wavefront (15 pairs in 9 steps, V accumulated) -- against solve_svd<6, 6> bit for bit, on normal
+    matrices of projection Jacobians, on an ill-conditioned and on a singular system"""
+    rng = np.random.default_rng(11)
+    As, bs = [], []
+    for _ in range(40):
+        J = rng.normal(size=(rng.integers(8, 400), 6)) * [300, 300, 300, 40, 40, 8]
+        A = J.T @ J
+        A[np.diag_indices(6)] *= 1 + 10.0 ** rng.integers(-8, 2)
+        As.append(A)
+        bs.append(J.T @ rng.normal(size=len(J)))
+    H = np.vander(np.linspace(1, 2, 6), 6)
+    As += [H.T @ H, np.diag([4.0, 3.0, 0.0, 2.0, 0.0, 1.0]), np.zeros((6, 6))]
+    bs += [np.ones(6), np.arange(6.0), np.ones(6)]
+    A = np.ascontiguousarray(np.array(As), np.float64)
+    b = np.ascontiguousarray(np.array(bs), np.float64)
+    xw, xs = np.zeros_like(b), np.zeros_like(b)
+    dp = C.POINTER(C.c_double)
+    kemu.ke_solve6_wave(A.ctypes.data_as(dp), b.ctypes.data_as(dp), len(A), xw.ctypes.data_as(dp), xs.ctypes.data_as(dp))
+    assert np.isfinite(xs).all()
+    assert np.array_equal(xw.view(np.uint64), xs.view(np.uint64))
+    assert np.allclose(A[0] @ xs[0], b[0], rtol=1e-8)

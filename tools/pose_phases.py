@@ -39,6 +39,10 @@ def main():
             acc += np.diff(t[:9])
             ref += [t[17] - t[16], buf[18] / 100.0, buf[19], t[20] - t[17], buf[21], 1]
     n = ref[5]
+    print("passes of the last call (us per pass): without J: rodrigues %.1f, points %.1f, reduction + barriers %.1f (%d passes); "
+          "with J: %.1f, %.1f, %.1f (%d passes)" % tuple(
+              [buf[22 + k] / 100.0 / max(buf[25], 1) for k in range(3)] + [buf[25]] +
+              [buf[26 + k] / 100.0 / max(buf[29], 1) for k in range(3)] + [buf[29]]))
     print("EPnP, hypothesis 0 of the frame (us, mean of %d calls, %d points per frame):" % (n, len(pts[0])))
     for i in range(8):
         print("  %-40s %7.1f" % (names[i], acc[i] / n))

@@ -483,14 +483,7 @@ __global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames
 }
 
 constexpr int LM_NRED = 28; // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, 64);
-    return v;
-}
+constexpr int LM_PITCH = 29; // row pitch of the per-thread partial sums in LDS
 
 // the work of one frame's workgroup (256 threads, all of them call it; every `return` below is block-uniform)
 __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xyz, const float2 *__restrict__ uv,
@@ -503,16 +496,18 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
     __shared__ int s_best, s_last, s_niters, s_maxgood, s_ninl;
     __shared__ int s_wave[4];
     __shared__ double s_param[6];
-    __shared__ double s_red[4][LM_NRED];
+    __shared__ double s_red[8][LM_NRED];
     __shared__ double s_sum[LM_NRED];
-    __shared__ int s_flags[2]; // [0] proceed & want_err, [1] want_J
+    __shared__ int s_flags[3]; // [0] proceed & want_err, [1] want_J, [2] a 6 x 6 solve is due
+    __shared__ __attribute__((aligned(16))) double s_acc[256 * LM_PITCH]; // per-thread partial sums of a pass
+    __shared__ double s_At[36], s_Vt[36], s_W6[6], s_b[6];             // the Levenberg-Marquardt step's linear system
 
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int count = n_pts[frame];
     PnpResult &res = results[frame];
 #ifdef VO_DEV_VARIANTS
     const bool prof = frame == 0 && tid == 0;
-    long long t_solve = 0, n_solve = 0;
+    long long t_solve = 0, n_solve = 0, t_pass[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (prof)
         g_pose_prof[16] = VO_POSE_NOW();
 #endif
@@ -609,6 +604,11 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
 #endif
 
     // ---- CvLevMarq (cvFindExtrinsicCameraParams2, useExtrinsicGuess) from the LAST hypothesis ----
+    // Thread 0 runs the solver's state machine; what it asks for is done by the workgroup:
+    //   * residuals (and Jacobians) of the inliers at s_param, summed over the workgroup (below);
+    //   * the step's 6 x 6 solve through the SVD (cv::solve(DECOMP_SVD)): its Jacobi sweeps by wavefront 0 (vo_svd_wide.h:
+    //     15 pairs in 9 steps on the four DPP rows, V accumulated, every sum in the serial order -- bit-identical to
+    //     solve_svd<6, 6>; one lane took 28 us per solve, four solves per frame: half of this kernel).
     enum { LM_DONE = 0, LM_STARTED = 1, LM_CALC_J = 2, LM_CHECK_ERR = 3 };
     // thread-0 private solver state
     double prevParam[6], JtJ[36], JtErr[6];
@@ -622,26 +622,11 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
     __syncthreads();
 
     for (;;) {
+#ifdef VO_DEV_VARIANTS
+        const long long t_in = VO_POSE_NOW();
+#endif
         if (tid == 0) {
-            int want_J = 0, want_err = 0, proceed = 1;
-            auto lm_step = [&]() {
-#ifdef VO_DEV_VARIANTS
-                const long long t_in = VO_POSE_NOW();
-#endif
-                const double lambda = exp(lambdaLg10 * log(10.));
-                double A[36], x[6];
-                for (int k = 0; k < 36; k++)
-                    A[k] = JtJ[k];
-                for (int k = 0; k < 6; k++)
-                    A[k * 6 + k] *= 1. + lambda;
-                solve_svd<6, 6>(A, JtErr, x);
-                for (int k = 0; k < 6; k++)
-                    s_param[k] = prevParam[k] - x[k];
-#ifdef VO_DEV_VARIANTS
-                t_solve += VO_POSE_NOW() - t_in;
-                n_solve++;
-#endif
-            };
+            int want_J = 0, want_err = 0, proceed = 1, need_solve = 0;
             if (state == LM_DONE) {
                 proceed = 0;
             } else if (state == LM_STARTED) {
@@ -659,7 +644,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                     JtErr[k] = s_sum[21 + k];
                     prevParam[k] = s_param[k];
                 }
-                lm_step();
+                need_solve = 1;
                 if (iters == 0)
                     prevErrNorm = sqrt(s_sum[27]);
                 want_err = 1;
@@ -669,7 +654,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                 bool handled = false;
                 if (errNorm > prevErrNorm) {
                     if (++lambdaLg10 <= 16) {
-                        lm_step();
+                        need_solve = 1;
                         want_err = 1;
                         state = LM_CHECK_ERR;
                         handled = true;
@@ -692,32 +677,85 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                     }
                 }
             }
+            if (need_solve) { // CvLevMarq::step: (J^T J with its diagonal scaled by 1 + lambda) x = J^T e; At = A^T as solve_svd
+                const double lambda = exp(lambdaLg10 * log(10.));
+                for (int i = 0; i < 6; i++)
+                    for (int k = 0; k < 6; k++)
+                        s_At[i * 6 + k] = k == i ? JtJ[k * 6 + i] * (1. + lambda) : JtJ[k * 6 + i];
+                for (int k = 0; k < 6; k++)
+                    s_b[k] = JtErr[k];
+            }
             s_flags[0] = proceed && want_err;
             s_flags[1] = want_J;
+            s_flags[2] = need_solve;
         }
         __syncthreads();
+        if (s_flags[2]) { // (uniform over the workgroup)
+            if (wv == 0)
+                jacobi6v_wave_sweeps(s_At, s_W6, s_Vt, lane);
+            __syncthreads();
+            if (tid == 0) {
+                double x[6];
+                jacobi_finish<6, true>(s_At, s_W6, s_Vt);
+                svd_backsubst<6>(s_At, s_W6, s_Vt, s_b, x);
+                for (int k = 0; k < 6; k++)
+                    s_param[k] = prevParam[k] - x[k];
+            }
+            __syncthreads();
+#ifdef VO_DEV_VARIANTS
+            t_solve += VO_POSE_NOW() - t_in;
+            n_solve++;
+#endif
+        }
         if (!s_flags[0])
             break;
         const bool want_J = s_flags[1] != 0;
 
-        // ---- residuals (and Jacobian) of every inlier at s_param; block-wide reduction ----
+        // ---- residuals (and Jacobian) of every inlier at s_param ----
         double acc[LM_NRED];
 #pragma unroll
         for (int k = 0; k < LM_NRED; k++)
             acc[k] = 0;
+#ifdef VO_DEV_VARIANTS
+        const long long tp0 = VO_POSE_NOW();
+        long long tp1 = 0, tp2 = 0;
+#endif
         {
             double R[9], dRdr[27];
             const double rv[3] = {s_param[0], s_param[1], s_param[2]};
             const double t[3] = {s_param[3], s_param[4], s_param[5]};
             rodrigues_v2m(rv, R, want_J ? dRdr : nullptr);
-            for (int k = tid; k < n1; k += 256) {
+#ifdef VO_DEV_VARIANTS
+            tp1 = VO_POSE_NOW();
+#endif
+            // (the point of the NEXT round is fetched -- index, then coordinates: two dependent loads -- while this one's
+            // projection is computed: the loop was bound by that latency, 1.3 us per point)
+            int k = tid;
+            float px = 0, py = 0, pz = 0;
+            float2 q = make_float2(0, 0);
+            if (k < n1) {
                 const int i = inl[k];
                 const float *p = X + (size_t)i * 3;
-                const float2 q = U[i];
+                px = p[0];
+                py = p[1];
+                pz = p[2];
+                q = U[i];
+            }
+            for (; k < n1; k += 256) {
+                const float cx_ = px, cy_ = py, cz_ = pz;
+                const float2 cq = q;
+                if (k + 256 < n1) {
+                    const int i = inl[k + 256];
+                    const float *p = X + (size_t)i * 3;
+                    px = p[0];
+                    py = p[1];
+                    pz = p[2];
+                    q = U[i];
+                }
                 double uvd[2], Ju[6], Jv[6];
-                project_point(R, t, dRdr, fx, fy, cx, cy, (double)p[0], (double)p[1], (double)p[2], uvd,
-                              want_J ? Ju : nullptr, want_J ? Jv : nullptr);
-                const double eu = uvd[0] - (double)q.x, ev = uvd[1] - (double)q.y;
+                project_point(R, t, dRdr, fx, fy, cx, cy, (double)cx_, (double)cy_, (double)cz_, uvd, want_J ? Ju : nullptr,
+                              want_J ? Jv : nullptr);
+                const double eu = uvd[0] - (double)cq.x, ev = uvd[1] - (double)cq.y;
                 acc[27] += eu * eu + ev * ev;
                 if (want_J) {
                     int qq = 0;
@@ -731,16 +769,46 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                 }
             }
         }
+#ifdef VO_DEV_VARIANTS
+        tp2 = VO_POSE_NOW();
+#endif
+        // ---- sum over the workgroup, in a fixed order: thread-major partial sums in LDS (row pitch 29: neighbouring threads
+        // land in different banks), 8 x 28 threads add 32 of them each, 28 threads the 8 results.  (Butterfly sums through
+        // ds_bpermute -- 12 per value and level set, 28 values -- took 6 us per pass, eight passes per frame.)
+        if (want_J) {
 #pragma unroll
-        for (int k = 0; k < LM_NRED; k++) {
-            const double s = wave_sum_f64(acc[k]);
-            if (lane == 0)
-                s_red[wv][k] = s;
+            for (int k = 0; k < LM_NRED; k++)
+                s_acc[tid * LM_PITCH + k] = acc[k];
+        } else {
+            s_acc[tid * LM_PITCH + 27] = acc[27];
         }
         __syncthreads();
-        if (tid < LM_NRED)
-            s_sum[tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+        {
+            const int part = tid / LM_NRED, k = tid - part * LM_NRED;
+            if (part < 8 && (want_J || k == 27)) {
+                double sum = 0;
+                for (int i = 0; i < 32; i++)
+                    sum += s_acc[(part * 32 + i) * LM_PITCH + k];
+                s_red[part][k] = sum;
+            }
+        }
         __syncthreads();
+        if (tid < LM_NRED && (want_J || tid == 27)) {
+            double sum = 0;
+            for (int part = 0; part < 8; part++)
+                sum += s_red[part][tid];
+            s_sum[tid] = sum;
+        }
+        __syncthreads();
+#ifdef VO_DEV_VARIANTS
+        if (prof) { // [22 + 4 j ..]: rodrigues, point loop, reduction, count -- j = 1 for passes with the Jacobian
+            const int o = want_J ? 4 : 0;
+            t_pass[o] += tp1 - tp0;
+            t_pass[o + 1] += tp2 - tp1;
+            t_pass[o + 2] += VO_POSE_NOW() - tp2;
+            t_pass[o + 3] += 1;
+        }
+#endif
     }
 
     if (tid == 0) {
@@ -761,6 +829,8 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
             g_pose_prof[19] = n_solve;
             g_pose_prof[20] = VO_POSE_NOW();
             g_pose_prof[21] = n1;
+            for (int k = 0; k < 8; k++)
+                g_pose_prof[22 + k] = t_pass[k];
         }
 #endif
     }

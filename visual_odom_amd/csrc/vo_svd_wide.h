@@ -40,52 +40,63 @@ static inline double row_bcast_f64(double v, int src_in_row)
     memcpy(&v, &u, 8);
     return v;
 }
-// s = ((0 + x_0) + x_1) + ... + x_11 over the first twelve lanes of the caller's row
-static inline double row_ordered_sum12(double x)
+// s = ((0 + x_0) + x_1) + ... + x_{N-1} over the first N lanes of the caller's DPP row
+template <int N>
+static inline double row_ordered_sum(double x)
 {
     double s = 0.0;
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < N; k++)
         s = s + row_bcast_f64(x, k);
     return s;
 }
-static inline void row_ordered_sum12x2(double x, double y, double &sx, double &sy)
+template <int N>
+static inline void row_ordered_sum_x2(double x, double y, double &sx, double &sy)
 {
-    sx = row_ordered_sum12(x);
-    sy = row_ordered_sum12(y);
+    sx = row_ordered_sum<N>(x);
+    sy = row_ordered_sum<N>(y);
 }
 #elif defined(__HIPCC__)
 #define VO_BC_ADD(K, S, X)                                                                   \
     "v_mov_b64_dpp %[t], %[" X "] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"        \
     "v_add_f64 %[" S "], %[" S "], %[t]\n\t"
+#define VO_BC_ADD6(S, X) VO_BC_ADD(0, S, X) VO_BC_ADD(1, S, X) VO_BC_ADD(2, S, X) VO_BC_ADD(3, S, X) VO_BC_ADD(4, S, X) VO_BC_ADD(5, S, X)
+#define VO_BC_ADD6B(S, X) VO_BC_ADD(6, S, X) VO_BC_ADD(7, S, X) VO_BC_ADD(8, S, X) VO_BC_ADD(9, S, X) VO_BC_ADD(10, S, X) VO_BC_ADD(11, S, X)
+#define VO_BC_ADD2(K) VO_BC_ADD(K, "s", "x") VO_BC_ADD(K, "r", "y")
 // (s_nop 1: a DPP instruction must not read a VGPR in the two slots after the VALU write that produced it -- the compiler
 // keeps that distance for its own instructions but does not look inside an asm block)
-__device__ __forceinline__ double row_ordered_sum12(double x)
+template <int N>
+__device__ __forceinline__ double row_ordered_sum(double x)
 {
+    static_assert(N == 6 || N == 12, "chain lengths built below");
     double s = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass of hipcc only needs the declaration)
     double t;
-    asm volatile("s_nop 1\n\t" VO_BC_ADD(0, "s", "x") VO_BC_ADD(1, "s", "x") VO_BC_ADD(2, "s", "x") VO_BC_ADD(3, "s", "x")
-                     VO_BC_ADD(4, "s", "x") VO_BC_ADD(5, "s", "x") VO_BC_ADD(6, "s", "x") VO_BC_ADD(7, "s", "x")
-                         VO_BC_ADD(8, "s", "x") VO_BC_ADD(9, "s", "x") VO_BC_ADD(10, "s", "x") VO_BC_ADD(11, "s", "x")
-                 : [s] "+v"(s), [t] "=&v"(t)
-                 : [x] "v"(x));
+    if (N == 6)
+        asm volatile("s_nop 1\n\t" VO_BC_ADD6("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
+    else
+        asm volatile("s_nop 1\n\t" VO_BC_ADD6("s", "x") VO_BC_ADD6B("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
 #else
     s = x;
 #endif
     return s;
 }
 // two independent sums in one block (their dependent adds interleave)
-__device__ __forceinline__ void row_ordered_sum12x2(double x, double y, double &sx, double &sy)
+template <int N>
+__device__ __forceinline__ void row_ordered_sum_x2(double x, double y, double &sx, double &sy)
 {
+    static_assert(N == 6 || N == 12, "chain lengths built below");
     double s = 0.0, r = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
     double t;
-#define VO_BC_ADD2(K) VO_BC_ADD(K, "s", "x") VO_BC_ADD(K, "r", "y")
-    asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5) VO_BC_ADD2(6)
-                     VO_BC_ADD2(7) VO_BC_ADD2(8) VO_BC_ADD2(9) VO_BC_ADD2(10) VO_BC_ADD2(11)
-                 : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
-                 : [x] "v"(x), [y] "v"(y));
-#undef VO_BC_ADD2
+    if (N == 6)
+        asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5)
+                     : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
+                     : [x] "v"(x), [y] "v"(y));
+    else
+        asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5) VO_BC_ADD2(6)
+                         VO_BC_ADD2(7) VO_BC_ADD2(8) VO_BC_ADD2(9) VO_BC_ADD2(10) VO_BC_ADD2(11)
+                     : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
+                     : [x] "v"(x), [y] "v"(y));
 #else
     s = x;
     r = y;
@@ -93,6 +104,9 @@ __device__ __forceinline__ void row_ordered_sum12x2(double x, double y, double &
     sx = s;
     sy = r;
 }
+#undef VO_BC_ADD2
+#undef VO_BC_ADD6B
+#undef VO_BC_ADD6
 #undef VO_BC_ADD
 #endif
 
@@ -107,19 +121,23 @@ static inline bool wave_any(bool v) { return emu_ballot(v) != 0; }
 __device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 #endif
 
-// Pairs by anti-diagonal i + j = 1 .. 21, four per step: {i, j} of DPP row 0 .. 3, 255 = nothing to do in this step.
-struct Jacobi12Steps {
-    uint8_t ij[26][4][2];
+// Pairs (i, j), i < j < N, by anti-diagonal i + j, four per step: {i, j} of DPP row 0 .. 3, 255 = nothing to do in this
+// step.  N = 12: 26 steps for 66 pairs, N = 6: 9 steps for 15.
+template <int N>
+struct JacobiSteps {
+    uint8_t ij[N * (N - 1) / 2][4][2];
+    int n;
 };
-constexpr Jacobi12Steps jacobi12_steps()
+template <int N>
+constexpr JacobiSteps<N> jacobi_steps()
 {
-    Jacobi12Steps t = {};
+    JacobiSteps<N> t = {};
     int step = 0;
-    for (int d = 1; d <= 21; d++) {
+    for (int d = 1; d <= 2 * N - 3; d++) {
         int n = 0;
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < N; i++) {
             const int j = d - i;
-            if (j <= i || j > 11)
+            if (j <= i || j > N - 1)
                 continue;
             if (n == 4) {
                 step++;
@@ -133,36 +151,43 @@ constexpr Jacobi12Steps jacobi12_steps()
             t.ij[step][n][0] = t.ij[step][n][1] = 255;
         step++;
     }
+    t.n = step;
     return t;
 }
 #if defined(VO_HOST_EMUL)
-static const Jacobi12Steps JACOBI12_STEPS = jacobi12_steps();
+static const JacobiSteps<12> JACOBI_STEPS_12 = jacobi_steps<12>();
+static const JacobiSteps<6> JACOBI_STEPS_6 = jacobi_steps<6>();
 #else
-__device__ const Jacobi12Steps JACOBI12_STEPS = jacobi12_steps();
+__device__ const JacobiSteps<12> JACOBI_STEPS_12 = jacobi_steps<12>();
+__device__ const JacobiSteps<6> JACOBI_STEPS_6 = jacobi_steps<6>();
 #endif
-
-// Squared row norms + the Jacobi sweeps of jacobi_svd<12, 12, false>.  Called by all 64 lanes of ONE wavefront per matrix;
-// lanes 12 .. 15 of a DPP row shadow lane 11.  Every branch below is uniform over a DPP row: its conditions are functions
-// of the row's broadcast sums (or of the step table) only.
-VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
+// Squared row norms (+ Vt = I) and the Jacobi sweeps of jacobi_svd<N, N, WANT_V>.  Called by all 64 lanes of ONE wavefront per
+// matrix; lanes N .. 15 of a DPP row shadow lane N - 1.  Every branch below is uniform over a DPP row: its conditions are
+// functions of the row's broadcast sums (or of the step table) only.  At, Vt: N x N row-major, W: N.
+template <int N, bool WANT_V>
+VO_WIDE_FN void jacobi_wave_sweeps(const JacobiSteps<N> &tab, double *At, double *W, double *Vt, int lane)
 {
-    const int row = (lane >> 4) & 3, l16 = lane & 15, k = l16 < 12 ? l16 : 11;
+    const int row = (lane >> 4) & 3, l16 = lane & 15, k = l16 < N ? l16 : N - 1;
+    const bool owner = l16 < N; // lanes N .. 15 follow the row's control flow and feed nothing: they never store
     const double eps = DBL_EPSILON * 10;
-    for (int i = row; i < 12; i += 4) {
-        const double t = At[i * 12 + k];
-        const double sd = row_ordered_sum12(t * t);
+    for (int i = row; i < N; i += 4) {
+        const double t = At[i * N + k];
+        const double sd = row_ordered_sum<N>(t * t);
         if (l16 == 0)
             W[i] = sd;
+        if (WANT_V && owner)
+            Vt[i * N + k] = i == k ? 1.0 : 0.0;
     }
     VO_WAVE_SYNC();
-    for (int iter = 0; iter < 30; iter++) {
+    const int max_iter = N > 30 ? N : 30;
+    for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
-        for (int step = 0; step < 26; step++) {
-            const int i = JACOBI12_STEPS.ij[step][row][0], j = JACOBI12_STEPS.ij[step][row][1];
+        for (int step = 0; step < tab.n; step++) {
+            const int i = tab.ij[step][row][0], j = tab.ij[step][row][1];
             if (i != 255) {
-                const double ai = At[i * 12 + k], aj = At[j * 12 + k];
+                const double ai = At[i * N + k], aj = At[j * N + k];
                 double a = W[i], b = W[j];
-                double p = row_ordered_sum12(ai * aj);
+                double p = row_ordered_sum<N>(ai * aj);
                 if (!(fabs(p) <= eps * sqrt(a * b))) {
                     p *= 2;
                     const double beta = a - b, gamma = vo_hypot(p, beta);
@@ -177,12 +202,19 @@ VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
                     }
                     const double t0 = c * ai + s * aj;
                     const double t1 = -s * ai + c * aj;
-                    At[i * 12 + k] = t0;
-                    At[j * 12 + k] = t1;
-                    row_ordered_sum12x2(t0 * t0, t1 * t1, a, b);
+                    if (owner) {
+                        At[i * N + k] = t0;
+                        At[j * N + k] = t1;
+                    }
+                    row_ordered_sum_x2<N>(t0 * t0, t1 * t1, a, b);
                     if (l16 == 0) {
                         W[i] = a;
                         W[j] = b;
+                    }
+                    if (WANT_V && owner) {
+                        const double vi = Vt[i * N + k], vj = Vt[j * N + k];
+                        Vt[i * N + k] = c * vi + s * vj;
+                        Vt[j * N + k] = -s * vi + c * vj;
                     }
                     changed = true;
                 }
@@ -193,74 +225,114 @@ VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
             break;
     }
 }
+VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
+{
+    jacobi_wave_sweeps<12, false>(JACOBI_STEPS_12, At, W, nullptr, lane);
+}
+VO_WIDE_FN void jacobi6v_wave_sweeps(double *At, double *W, double *Vt, int lane)
+{
+    jacobi_wave_sweeps<6, true>(JACOBI_STEPS_6, At, W, Vt, lane);
+}
 #undef VO_WIDE_FN
 #endif
 
-// What jacobi_svd<12, 12, false> does after its sweeps, for ONE lane on a matrix in memory: singular values = row norms,
-// descending selection sort (rows follow; OpenCV swaps row i with the FIRST index of the running maximum), normalised rows;
-// an exactly-zero singular value gets the deterministic pseudo-random vector OpenCV fills in (cv::RNG(0x12345678)).
-// W: 12 doubles of scratch.
-VO_HD void jacobi12_finish(double *At, double *W)
+// What jacobi_svd<N, N, WANT_V> does after its sweeps, for ONE lane on matrices in memory: singular values = row norms,
+// descending selection sort (rows of At and Vt follow; OpenCV swaps row i with the FIRST index of the running maximum),
+// normalised rows of At; an exactly-zero singular value gets the deterministic pseudo-random vector OpenCV fills in
+// (cv::RNG(0x12345678)).  W: N doubles, on return the singular values.
+template <int N, bool WANT_V>
+VO_HD void jacobi_finish(double *At, double *W, double *Vt)
 {
     const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < N; i++) {
         double sd = 0;
-        for (int k = 0; k < 12; k++) {
-            const double t = At[i * 12 + k];
+        for (int k = 0; k < N; k++) {
+            const double t = At[i * N + k];
             sd += t * t;
         }
         W[i] = sqrt(sd);
     }
-    for (int i = 0; i < 11; i++) {
+    for (int i = 0; i < N - 1; i++) {
         int j = i;
-        for (int k = i + 1; k < 12; k++)
+        for (int k = i + 1; k < N; k++)
             if (W[j] < W[k])
                 j = k;
         if (i != j) {
             double t = W[i];
             W[i] = W[j];
             W[j] = t;
-            for (int k = 0; k < 12; k++) {
-                t = At[i * 12 + k];
-                At[i * 12 + k] = At[j * 12 + k];
-                At[j * 12 + k] = t;
+            for (int k = 0; k < N; k++) {
+                t = At[i * N + k];
+                At[i * N + k] = At[j * N + k];
+                At[j * N + k] = t;
             }
+            if (WANT_V)
+                for (int k = 0; k < N; k++) {
+                    t = Vt[i * N + k];
+                    Vt[i * N + k] = Vt[j * N + k];
+                    Vt[j * N + k] = t;
+                }
         }
     }
     uint64_t rng = 0x12345678;
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < N; i++) {
         double sd = W[i];
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const double val0 = 1. / 12;
-            for (int k = 0; k < 12; k++) {
+            const double val0 = 1. / N;
+            for (int k = 0; k < N; k++) {
                 rng = (uint64_t)(uint32_t)rng * 4164903690U + (uint32_t)(rng >> 32);
-                At[i * 12 + k] = ((uint32_t)rng & 256) != 0 ? val0 : -val0;
+                At[i * N + k] = ((uint32_t)rng & 256) != 0 ? val0 : -val0;
             }
             for (int iter = 0; iter < 2; iter++)
                 for (int j = 0; j < i; j++) {
                     sd = 0;
-                    for (int k = 0; k < 12; k++)
-                        sd += At[i * 12 + k] * At[j * 12 + k];
+                    for (int k = 0; k < N; k++)
+                        sd += At[i * N + k] * At[j * N + k];
                     double asum = 0;
-                    for (int k = 0; k < 12; k++) {
-                        const double t = At[i * 12 + k] - sd * At[j * 12 + k];
-                        At[i * 12 + k] = t;
+                    for (int k = 0; k < N; k++) {
+                        const double t = At[i * N + k] - sd * At[j * N + k];
+                        At[i * N + k] = t;
                         asum += fabs(t);
                     }
                     asum = asum > eps * 100 ? 1 / asum : 0;
-                    for (int k = 0; k < 12; k++)
-                        At[i * 12 + k] *= asum;
+                    for (int k = 0; k < N; k++)
+                        At[i * N + k] *= asum;
                 }
             sd = 0;
-            for (int k = 0; k < 12; k++) {
-                const double t = At[i * 12 + k];
+            for (int k = 0; k < N; k++) {
+                const double t = At[i * N + k];
                 sd += t * t;
             }
             sd = sqrt(sd);
         }
         const double s = sd > minval ? 1 / sd : 0.;
-        for (int k = 0; k < 12; k++)
-            At[i * 12 + k] *= s;
+        for (int k = 0; k < N; k++)
+            At[i * N + k] *= s;
+    }
+}
+VO_HD void jacobi12_finish(double *At, double *W) { jacobi_finish<12, false>(At, W, nullptr); }
+
+// x = pinv(A) b as solve_svd<N, N> forms it, from the factors jacobi_finish left: At rows = U^T, W, Vt
+template <int N>
+VO_HD void svd_backsubst(const double *At, const double *W, const double *Vt, const double *b, double *x)
+{
+    double threshold = 0;
+    for (int i = 0; i < N; i++)
+        x[i] = 0;
+    for (int i = 0; i < N; i++)
+        threshold += W[i];
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < N; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold)
+            continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < N; j++)
+            s += At[i * N + j] * b[j];
+        s *= wi;
+        for (int j = 0; j < N; j++)
+            x[j] = x[j] + s * Vt[i * N + j];
     }
 }
 
