@@ -92,6 +92,36 @@ def test_bench_configuration_parity_crowded_overlapped(volib, orc, bench_inputs)
         ctx.close()
 
 
+def test_large_batch_first_ransac_chunk(volib, orc, bench_inputs):
+    """from 128 frames on the first RANSAC chunk is 64 hypotheses and the second one takes over for the frames whose adaptive
+    iteration count reaches further (pnp.hip, launch_pnp_ransac).  A 128-frame batch with a reprojection threshold of
+    0.4 px (fewer inliers -> more iterations, so both kinds of frame occur): RANSAC control flow, inlier sets and poses
+    against the oracle at the same threshold"""
+    bench, S, world, lefts, rights, pts = bench_inputs
+    B = 128
+    ctx = volib.Context(0, world.w, world.h, 8192, B)
+    try:
+        ctx.set_params(ransac_reproj_error=0.4)
+        frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
+        for _ in range(2):
+            ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        P_l, P_r = world.proj_matrices()
+        K = world.K()
+        seen = []
+        for b in (0, 1, 2, 3, 5, 64, 126, 127):
+            got, pose = ctx.batch_get_filtered(b), ctx.batch_get_pose(b)
+            xyz = orc.triangulate(P_l, P_r, got["l0"], got["r0"])
+            rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(xyz, got["l1"], K, reproj=0.4)
+            assert pose["status"] == rc and np.array_equal(pose["inliers"], inl), b
+            assert (pose["niters"], pose["best_iter"], pose["max_good"]) == tuple(int(x) for x in dbg[:3]), b
+            assert np.abs(pose["rvec"] - rv).max() <= 1e-6 and np.abs(pose["tvec"] - tv).max() <= 1e-6, b
+            seen.append(pose["niters"])
+        assert min(seen) <= 64 < max(seen), seen  # both sides of the first chunk
+    finally:
+        ctx.close()
+
+
 def test_bench_configuration_detect_and_lk_only(volib, orc, bench_inputs):
     """the other two stage sets bench.py offers (config 2 `--stages lk`, and `--stages detect+full`) on a 16-frame batch:
     two XCD groups, DETECT output feeding LK on the device"""

@@ -957,8 +957,20 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
         split_max = split_env;
 #endif
     const bool split = epnp_ws && n_frames <= split_max && n_frames <= ws_frames;
+    // First chunk: 128 hypotheses cover what OpenCV's adaptive count asks for down to ~55 % inliers in ONE round of dependent
+    // launches -- right where the chain's latency counts.  From 128 frames on the chain is hidden behind the next run's
+    // tracking kernels and what counts is how much of the chip the EPnP workgroups hold while they are resident (78 KB of
+    // LDS and half a SIMD's registers each): 64 first, the rest only for the frames that ask for more (measured, 256-frame
+    // batch, ms per step with 128 | 64 | 32: 12.84 | 12.55 | 13.83 at ~2000 points, 3.57 | 3.18 | 3.64 at 340; lock-step loop
+    // 256 sequences 4.03 | 4.04 | 4.23, 64 sequences 1.25 | 1.39 | 1.41 -- gpurun_out/r3_28).
+    int first_chunk = n_frames >= 128 ? 64 : RANSAC_CHUNK;
+#ifdef VO_DEV_VARIANTS
+    static const int chunk_env = [] { const char *e = getenv("VO_RANSAC_CHUNK"); return e ? atoi(e) : 0; }();
+    if (chunk_env > 0 && chunk_env <= RANSAC_CHUNK && !split)
+        first_chunk = chunk_env;
+#endif
     for (int h0 = 0; h0 < prm.iters;) {
-        const int hn = h0 == 0 ? min(RANSAC_CHUNK, prm.iters) : prm.iters - h0;
+        const int hn = h0 == 0 ? min(first_chunk, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
         launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
         if (split && h0 == 0) {
