@@ -130,7 +130,8 @@ struct vo_ctx {
     long long sched_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0}; // key `sched` was resolved for
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
-    Schedule ab_pick;                // lock-step loop: what the dry probe picked, while the prepare A/B is running
+    bool sync_call = false;          // the run being scheduled is a synchronous drop-in call (its own probe key: latency)
+    Schedule ab_list[4];             // lock-step loop: the candidates being timed over real steps (vo_seq_step)
     long long ab_key[8] = {};
     // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
     int probe_n = 0;
@@ -201,9 +202,11 @@ struct vo_ctx {
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
         int n_ing = 0, n_active = 0;    // pairs pushed for / sequences active in the pending step
         // A/B of the prepare stream over REAL steps (vo_seq_step): 1 = timing the dry probe's pick, 2 = timing its
-        // prepare-flipped twin, 3 = decided; ab_left counts down the phase's steps (3 untimed ramp steps + ab_n timed)
-        int ab_phase = 0, ab_left = 0, ab_n = 0;
-        hipEvent_t ev_ab[4] = {};
+        // prepare-flipped twin, ... (ab_cnt candidates), ab_cnt + 1 = decided; ab_left counts down the phase's steps (3 untimed
+        // ramp steps + ab_n timed)
+        int ab_phase = 0, ab_left = 0, ab_n = 0, ab_cnt = 0;
+        hipEvent_t ev_ab[8] = {};
+        bool ab_running() const { return ab_phase >= 1 && ab_phase <= ab_cnt; }
 
         bool begun = false, staged = false;
     } seq;
@@ -1176,11 +1179,14 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
         SeqTail tail;
+        // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it -- only the refinement kernels of
+        // consecutive chains are ordered, their RANSAC parts overlap.  (A dry run of the schedule probe keeps the ORDER without
+        // the integration: with two pose streams its refinements otherwise overlap as no real step's can, and the probe saw
+        // 0.34 ms per step where the loop then ran at 0.49 -- one sequence, profiles/r03_schedule_sweep.jsonl of r3_30.)
+        if (sq.on && sq.integ_pending)
+            VO_HIP_TRY(c, hipStreamWaitEvent(ps, sq.ev_integ, 0));
         if (sq.on && !dry) { // euler gates + integrateOdometryStereo of every sequence, one trajectory row each: inside
                              // select_refine_kernel (vo_seqtail.h)
-            if (sq.integ_pending) // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it --
-                                  // only the refinement kernels of consecutive chains are ordered, their RANSAC parts overlap
-                VO_HIP_TRY(c, hipStreamWaitEvent(ps, sq.ev_integ, 0));
             tail.active = seq_active;
             tail.em = c->prm.mono_rotation ? pb.em_results : nullptr;
             tail.pose = sq.d_pose;
@@ -1191,7 +1197,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
         launch_pnp_refine(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.models, pb.rstate, pb.inliers,
                           pb.results, c->sched.waves, tail, ps);
-        if (sq.on && !dry) {
+        if (sq.on) {
             VO_HIP_TRY(c, hipEventRecord(sq.ev_integ, ps));
             sq.integ_pending = true;
         }
@@ -1263,7 +1269,7 @@ TuneKey tune_key(const vo_ctx *c, int stages)
     key.k[4] = c->levels;
     key.k[5] = c->n_frames;
     key.k[6] = pts_bucket(pts);
-    key.k[7] = (c->prm.mono_rotation ? 1 : 0) | ((stages & VO_STAGE_DETECT) ? 2 : 0);
+    key.k[7] = (c->prm.mono_rotation ? 1 : 0) | ((stages & VO_STAGE_DETECT) ? 2 : 0) | (c->sync_call && !c->seq.on ? 16 : 0);
     return key;
 }
 
@@ -1406,9 +1412,26 @@ static int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dr
 // what every measurement has once -- the ramp-up and the last run's pose chain, which nothing overlaps -- cancels (timing
 // one short burst instead favours the schedule with the shortest lone chain: the first version of this probe picked the
 // 512-register kernels for 256 sequences, 10 % below the 256-register ones in the real loop).  K >= 20 ms of work, 6 .. 24.
-static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, double *ms_per_run)
+// latency (the synchronous drop-in calls: one run, then the caller waits for it): the mean of K runs each followed by a
+// synchronisation -- what such a caller sees; the steady-state figure hides exactly the chain latency it is waiting for.
+static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency, double *ms_per_run)
 {
     using clk = std::chrono::steady_clock;
+    if (latency) {
+        int rc = sync_all(c);
+        double total = 0;
+        const int K = 8;
+        for (int i = 0; i < K + 2 && rc == VO_OK; i++) {
+            const auto t0 = clk::now();
+            rc = probe_run(c, stages, timed, evs, dry);
+            if (rc == VO_OK)
+                rc = sync_all(c);
+            if (i >= 2)
+                total += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        }
+        *ms_per_run = total / K;
+        return rc;
+    }
     auto burst = [&](int n, double *ms) {
         int rc = sync_all(c);
         const auto t0 = clk::now();
@@ -1436,7 +1459,7 @@ static int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, b
 
 // Probe every candidate the pins leave open on the data the caller is about to process, keep the fastest.
 // Batch mode: plain runs (a batch run is idempotent).  Lock-step loop: dry runs of the pending step.
-static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
+static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency = false)
 {
     const TuneKey key = tune_key(c, stages);
     std::vector<vo_ctx::Schedule> cands;
@@ -1467,7 +1490,7 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
         rc = set_sched(c, cands[i]);
         double ms = 0;
         if (rc == VO_OK)
-            rc = cands.size() > 1 ? probe_candidate(c, stages, timed, evs, dry, &ms) : VO_OK;
+            rc = cands.size() > 1 ? probe_candidate(c, stages, timed, evs, dry, latency, &ms) : VO_OK;
         if (rc == VO_OK && (i == 0 || ms < best_ms)) {
             best = (int)i;
             best_ms = ms;
@@ -1495,14 +1518,17 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
 }
 
 // run_stages for the batch entry points: settles the schedule first (cached, pinned or probed) when the run has a pose chain
-static int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr)
+// sync_call: a drop-in call that returns results -- the caller waits for every run, so candidates are compared by latency
+static int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool sync_call = false)
 {
+    if (!c->tuning)
+        c->sync_call = sync_call;
     if ((stages & VO_STAGE_PNP) && !c->tuning && c->n_images > 0 && c->have_P) {
         int need = sched_resolve(c, stages);
         if (need < 0)
             return need;
         if (need) {
-            int rc = tune_schedule(c, stages, timed, evs, false);
+            int rc = tune_schedule(c, stages, timed, evs, false, sync_call);
             if (rc != VO_OK)
                 return rc;
         }
@@ -1531,8 +1557,8 @@ int vo_set_schedule(vo_ctx *c, const vo_schedule *s)
         return rc;
     c->pin = p;
     c->sched_key[0] = -1; // resolved again at the next run
-    if (c->seq.ab_phase == 1 || c->seq.ab_phase == 2)
-        c->seq.ab_phase = 0; // a prepare-stream A/B in progress is abandoned: the caller has just said what they want
+    if (c->seq.ab_running())
+        c->seq.ab_phase = 0; // a comparison over real steps in progress is abandoned: the caller has just said what they want
     if (c->seq.on) {      // the lock-step loop reads sched between steps: apply what is pinned now
         vo_ctx::Schedule sc = c->sched;
         apply_pins(c, &sc);
@@ -1549,7 +1575,7 @@ int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
     cur->pose_streams = c->sched.streams;
     cur->prepare = c->seq.on ? c->sched.prep : 0;
     if (probed)
-        *probed = (c->seq.on && (c->seq.ab_phase == 1 || c->seq.ab_phase == 2)) ? 2 : c->sched_probed ? 1 : 0;
+        *probed = (c->seq.on && c->seq.ab_running()) ? 2 : c->sched_probed ? 1 : 0;
     return VO_OK;
 }
 
@@ -2034,8 +2060,8 @@ int vo_seq_reset(vo_ctx *c, int seq)
         // slot 0, event slot 0, all max_steps trajectory rows available again (a long-lived context that recycles its
         // sequences never runs out of steps)
         q.step = 0;
-        if (q.ab_phase == 1 || q.ab_phase == 2)
-            q.ab_phase = 0; // an unfinished A/B is abandoned: the dry probe's pick stays
+        if (q.ab_running())
+            q.ab_phase = 0; // an unfinished comparison is abandoned: the dry probe's pick stays
         q.begun = q.staged = q.broken = false;
         q.n_ing = 0;
         q.carry_pending = q.integ_pending = false;
@@ -2255,23 +2281,55 @@ int vo_seq_step(vo_ctx *c)
             rc = need;
         else if (need) {
             rc = tune_schedule(c, stages, true, step_evs, /*dry*/ true);
-            if (rc == VO_OK && c->pin.prepare < 0) {
-                // The dry runs leave out the two kernels that advance the state, and with them some of what the prepare
-                // stream hides: measured against every pinned schedule (tools/schedule_sweep.py) their verdict on the
-                // prepare knob alone was wrong by 8-25 % at 1-32 sequences.  So that knob is settled over REAL steps:
-                // the pick runs for a while, then its prepare-flipped twin, end-of-step GPU timestamps decide.
-                double ms = 1.0;
-                for (int i = 0; i < c->probe_n; i++)
-                    if (c->probe_cand[i].pose_waves == c->sched.waves && c->probe_cand[i].pose_streams == c->sched.streams &&
-                        c->probe_cand[i].prepare == c->sched.prep)
-                        ms = c->probe_ms[i] > 0.02f ? c->probe_ms[i] : 0.02;
-                q.ab_n = (int)ceil(25.0 / ms);
-                q.ab_n = q.ab_n < 12 ? 12 : q.ab_n > 48 ? 48 : q.ab_n;
-                q.ab_phase = 1;
-                q.ab_left = 3 + q.ab_n;
-                c->ab_pick = c->sched;
-                memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
-                c->sched_probed = false; // "in progress" (vo_get_schedule reports 2)
+            if (rc == VO_OK && c->probe_n > 1) {
+                // The dry runs leave out the two kernels that advance the state, and with them some of what the streams
+                // hide: measured against every pinned schedule (tools/schedule_sweep.py) their verdict on the prepare knob was
+                // wrong by 8-25 % at 1-32 sequences, and once the pose chain got shorter (round 3) they ranked the other two
+                // knobs wrongly by 5-8 % in five of sixteen loops (two pose streams look better dry than real with one
+                // sequence, one stream with 128).  So the dry probe only NOMINATES: its pick, the pick's prepare-flipped twin,
+                // the best candidate with another (waves, streams) pair and that one's twin run for a while each over REAL
+                // steps; end-of-step GPU timestamps decide.
+                auto dry_ms = [&](const vo_ctx::Schedule &x) {
+                    for (int i = 0; i < c->probe_n; i++)
+                        if (c->probe_cand[i].pose_waves == x.waves && c->probe_cand[i].pose_streams == x.streams &&
+                            c->probe_cand[i].prepare == x.prep)
+                            return (double)c->probe_ms[i];
+                    return -1.0;
+                };
+                int n = 0;
+                c->ab_list[n++] = c->sched;
+                vo_ctx::Schedule other = c->sched;
+                double other_ms = -1;
+                for (int i = 0; i < c->probe_n; i++) {
+                    const vo_schedule &pc = c->probe_cand[i];
+                    if ((pc.pose_waves != c->sched.waves || pc.pose_streams != c->sched.streams) &&
+                        (other_ms < 0 || c->probe_ms[i] < other_ms)) {
+                        other_ms = c->probe_ms[i];
+                        other.waves = pc.pose_waves;
+                        other.streams = pc.pose_streams;
+                        other.prep = pc.prepare;
+                    }
+                }
+                if (other_ms >= 0)
+                    c->ab_list[n++] = other;
+                const int base = n;
+                for (int i = 0; i < base && c->pin.prepare < 0; i++) { // twins that the dry probe was able to run
+                    vo_ctx::Schedule t = c->ab_list[i];
+                    t.prep ^= 1;
+                    if (dry_ms(t) >= 0)
+                        c->ab_list[n++] = t;
+                }
+                if (n > 1) {
+                    double ms = dry_ms(c->sched);
+                    ms = ms > 0.02 ? ms : 0.02;
+                    q.ab_n = (int)ceil(25.0 / ms);
+                    q.ab_n = q.ab_n < 12 ? 12 : q.ab_n > 48 ? 48 : q.ab_n;
+                    q.ab_cnt = n;
+                    q.ab_phase = 1;
+                    q.ab_left = 3 + q.ab_n;
+                    memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
+                    c->sched_probed = false; // "in progress" (vo_get_schedule reports 2)
+                }
             }
         }
     }
@@ -2296,42 +2354,45 @@ int vo_seq_step(vo_ctx *c)
     VO_HIP_TRY(c, hipEventRecord(q.ev_step[slot], end_stream));
     q.step_pending[slot] = true;
     q.step++;
-    if ((q.ab_phase == 1 || q.ab_phase == 2) && n_active > 0 && 2 * n_active >= q.S) {
+    if (q.ab_running() && n_active > 0 && 2 * n_active >= q.S) {
+        const int ph = q.ab_phase - 1;
         q.ab_left--;
         if (q.ab_left == q.ab_n) { // ramp over: the clock starts at the end of this step
-            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[q.ab_phase == 1 ? 0 : 2], end_stream));
+            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[2 * ph], end_stream));
         } else if (q.ab_left == 0) {
-            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[q.ab_phase == 1 ? 1 : 3], end_stream));
-            vo_ctx::Schedule twin = c->ab_pick;
-            twin.prep ^= 1;
-            if (q.ab_phase == 1) {
-                rc = set_sched(c, twin); // (drains every stream first)
+            VO_HIP_TRY(c, hipEventRecord(q.ev_ab[2 * ph + 1], end_stream));
+            if (q.ab_phase < q.ab_cnt) {
+                rc = set_sched(c, c->ab_list[q.ab_phase]); // (drains every stream first when the prepare knob changes)
                 if (rc != VO_OK)
                     return rc;
-                q.ab_phase = 2;
+                q.ab_phase++;
                 q.ab_left = 3 + q.ab_n;
             } else {
-                VO_HIP_TRY(c, hipEventSynchronize(q.ev_ab[3]));
-                float t1 = 0, t2 = 0;
-                VO_HIP_TRY(c, hipEventElapsedTime(&t1, q.ev_ab[0], q.ev_ab[1]));
-                VO_HIP_TRY(c, hipEventElapsedTime(&t2, q.ev_ab[2], q.ev_ab[3]));
-                const vo_ctx::Schedule best = t1 <= t2 ? c->ab_pick : twin;
-                rc = set_sched(c, best);
+                VO_HIP_TRY(c, hipEventSynchronize(q.ev_ab[2 * ph + 1]));
+                int best = 0;
+                float t[4] = {0, 0, 0, 0};
+                for (int i = 0; i < q.ab_cnt; i++) {
+                    VO_HIP_TRY(c, hipEventElapsedTime(&t[i], q.ev_ab[2 * i], q.ev_ab[2 * i + 1]));
+                    if (t[i] < t[best])
+                        best = i;
+                }
+                rc = set_sched(c, c->ab_list[best]);
                 if (rc != VO_OK)
                     return rc;
                 TuneKey key;
                 memcpy(key.k, c->ab_key, sizeof(key.k));
                 {
                     std::lock_guard<std::mutex> lk(g_tune_mu);
-                    g_tuned[key] = best;
+                    g_tuned[key] = c->ab_list[best];
                 }
-                for (int i = 0; i < c->probe_n; i++) // the log shows what was measured over real steps
-                    if (c->probe_cand[i].pose_waves == best.waves && c->probe_cand[i].pose_streams == best.streams) {
-                        const bool first = c->probe_cand[i].prepare == c->ab_pick.prep;
-                        c->probe_ms[i] = (first ? t1 : t2) / q.ab_n;
-                        c->probe_real[i] = 1;
-                    }
-                q.ab_phase = 3;
+                for (int k = 0; k < q.ab_cnt; k++) // the log shows what was measured over real steps
+                    for (int i = 0; i < c->probe_n; i++)
+                        if (c->probe_cand[i].pose_waves == c->ab_list[k].waves && c->probe_cand[i].pose_streams == c->ab_list[k].streams &&
+                            c->probe_cand[i].prepare == c->ab_list[k].prep) {
+                            c->probe_ms[i] = t[k] / q.ab_n;
+                            c->probe_real[i] = 1;
+                        }
+                q.ab_phase = q.ab_cnt + 1;
                 c->sched_probed = true;
             }
         }
@@ -2657,7 +2718,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     rc = vo_batch_set_projection(c, P_l, P_r);
     if (rc != VO_OK)
         return rc;
-    rc = run_stages_auto(c, VO_STAGE_ALL, false);
+    rc = run_stages_auto(c, VO_STAGE_ALL, false, nullptr, /*sync_call*/ true);
     if (rc != VO_OK)
         return rc;
     // Results: one kernel behind the pose solve gathers the counts, the PnpResult and every output array into one

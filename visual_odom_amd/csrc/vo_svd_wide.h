@@ -188,6 +188,8 @@ VO_WIDE_FN void jacobi_wave_sweeps(const JacobiSteps<N> &tab, double *At, double
                 const double ai = At[i * N + k], aj = At[j * N + k];
                 double a = W[i], b = W[j];
                 double p = row_ordered_sum<N>(ai * aj);
+                // (forming the rotation's hypot before this branch, next to the skip test's sqrt -- two independent chains of
+                // ~20 dependent f64 instructions -- was measured and gains nothing: 127.7 vs 127.9 us, gpurun_out/r3_31)
                 if (!(fabs(p) <= eps * sqrt(a * b))) {
                     p *= 2;
                     const double beta = a - b, gamma = vo_hypot(p, beta);
