@@ -2286,9 +2286,8 @@ int vo_seq_step(vo_ctx *c)
                 // hide: measured against every pinned schedule (tools/schedule_sweep.py) their verdict on the prepare knob was
                 // wrong by 8-25 % at 1-32 sequences, and once the pose chain got shorter (round 3) they ranked the other two
                 // knobs wrongly by 5-8 % in five of sixteen loops (two pose streams look better dry than real with one
-                // sequence, one stream with 128).  So the dry probe only NOMINATES: its pick, the pick's prepare-flipped twin,
-                // the best candidate with another (waves, streams) pair and that one's twin run for a while each over REAL
-                // steps; end-of-step GPU timestamps decide.
+                // sequence, one stream with 128).  So the dry probe only NOMINATES; up to four candidates then run for a while
+                // each over REAL steps and end-of-step GPU timestamps decide.
                 auto dry_ms = [&](const vo_ctx::Schedule &x) {
                     for (int i = 0; i < c->probe_n; i++)
                         if (c->probe_cand[i].pose_waves == x.waves && c->probe_cand[i].pose_streams == x.streams &&
@@ -2296,29 +2295,26 @@ int vo_seq_step(vo_ctx *c)
                             return (double)c->probe_ms[i];
                     return -1.0;
                 };
+                // one candidate per (pose_streams, prepare) -- the two knobs the dry runs misjudge -- each with the register
+                // budget the dry runs prefer for it; the dry pick first (it stays if the loop ends before the comparison does)
                 int n = 0;
                 c->ab_list[n++] = c->sched;
-                vo_ctx::Schedule other = c->sched;
-                double other_ms = -1;
-                for (int i = 0; i < c->probe_n; i++) {
-                    const vo_schedule &pc = c->probe_cand[i];
-                    if ((pc.pose_waves != c->sched.waves || pc.pose_streams != c->sched.streams) &&
-                        (other_ms < 0 || c->probe_ms[i] < other_ms)) {
-                        other_ms = c->probe_ms[i];
-                        other.waves = pc.pose_waves;
-                        other.streams = pc.pose_streams;
-                        other.prep = pc.prepare;
+                for (int st = 1; st <= 2; st++)
+                    for (int pr = 1; pr >= 0; pr--) {
+                        if (st == c->sched.streams && pr == c->sched.prep)
+                            continue;
+                        int bi = -1;
+                        for (int i = 0; i < c->probe_n; i++)
+                            if (c->probe_cand[i].pose_streams == st && c->probe_cand[i].prepare == pr &&
+                                (bi < 0 || c->probe_ms[i] < c->probe_ms[bi]))
+                                bi = i;
+                        if (bi >= 0 && n < 4) {
+                            c->ab_list[n].waves = c->probe_cand[bi].pose_waves;
+                            c->ab_list[n].streams = st;
+                            c->ab_list[n].prep = pr;
+                            n++;
+                        }
                     }
-                }
-                if (other_ms >= 0)
-                    c->ab_list[n++] = other;
-                const int base = n;
-                for (int i = 0; i < base && c->pin.prepare < 0; i++) { // twins that the dry probe was able to run
-                    vo_ctx::Schedule t = c->ab_list[i];
-                    t.prep ^= 1;
-                    if (dry_ms(t) >= 0)
-                        c->ab_list[n++] = t;
-                }
                 if (n > 1) {
                     double ms = dry_ms(c->sched);
                     ms = ms > 0.02 ? ms : 0.02;
