@@ -93,9 +93,9 @@ int ke_solve6_wave(const double *A, const double *b, int n, double *x_wave, doub
             for (int i = 0; i < 6; i++)
                 for (int k = 0; k < 6; k++)
                     At[i * 6 + k] = A[(size_t)q * 36 + k * 6 + i];
-        __syncthreads();
+        emu::barrier();
         vo::jacobi6v_wave_sweeps(At, W, Vt, lane);
-        __syncthreads();
+        emu::barrier();
         if (lane == 0) {
             vo::jacobi_finish<6, true>(At, W, Vt);
             vo::svd_backsubst<6>(At, W, Vt, b + (size_t)q * 6, x_wave + (size_t)q * 6);
@@ -114,10 +114,11 @@ int ke_svd12_wide(const double *mats, int n, double *wide, double *serial)
     std::vector<double> w((size_t)n * 12);
     for (int q = 0; q < n; q++)
         memcpy(wide + (size_t)q * 144, mats + (size_t)q * 144, 144 * sizeof(double));
-    launch(n, 1, 1, 64, [&] {
-        const int q = (int)blockIdx.x, lane = (int)threadIdx.x;
-        vo::jacobi12_wave_sweeps(wide + (size_t)q * 144, w.data() + (size_t)q * 12, lane);
-        if (lane == 0)
+    std::vector<int> flags((size_t)n);
+    launch(n, 1, 1, 128, [&] {
+        const int q = (int)blockIdx.x, tid = (int)threadIdx.x;
+        vo::jacobi12_pipe_sweeps(wide + (size_t)q * 144, w.data() + (size_t)q * 12, flags.data() + q, tid);
+        if (tid == 0)
             vo::jacobi12_finish(wide + (size_t)q * 144, w.data() + (size_t)q * 12);
     });
     for (int q = 0; q < n; q++) {

@@ -268,8 +268,9 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
 // time stamps of the kernel above, tools/pose_phases.py: 16 us set-up, 337 us 12 x 12 SVD, 108 us the three approximations,
 // 6 us selection = 466 us per hypothesis, whatever the number of hypotheses):
 //   epnp_prepare_kernel  a lane per hypothesis as above: control points, barycentric coordinates, M^T M -> workspace
-//   svd12_wave_kernel    a WAVEFRONT per hypothesis (vo_svd_wide.h): a lane per matrix column, every sum in the serial order
-//                        through DPP row broadcasts, four independent pairs at a time on the four DPP rows -- bit-identical
+//   svd12_wave_kernel    TWO WAVEFRONTS per hypothesis (vo_svd_wide.h): a lane per matrix column, every sum in the serial
+//                        order through DPP row broadcasts, up to six independent pairs per time slot on the eight DPP rows,
+//                        the next sweep started while this one finishes -- bit-identical
 //   epnp_approx_kernel   a lane per (hypothesis, approximation): the three beta approximations + Gauss-Newton + R, t are
 //                        independent of each other; blockIdx.z picks the approximation, so a workgroup runs one code path
 //   epnp_select_kernel   a lane per hypothesis: best of three, R -> rvec, the model record
@@ -321,26 +322,27 @@ __global__ __launch_bounds__(64, 1) void epnp_prepare_kernel(const float *__rest
         w[EPNP_WS_AT + i] = s_ut[i * 64 + threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void svd12_wave_kernel(const int *__restrict__ n_pts, PnpParams prm,
-                                                        const RansacState *__restrict__ rstate, int h0, int hn,
-                                                        double *__restrict__ ws)
+__global__ __launch_bounds__(128) void svd12_wave_kernel(const int *__restrict__ n_pts, PnpParams prm,
+                                                         const RansacState *__restrict__ rstate, int h0, int hn,
+                                                         double *__restrict__ ws)
 {
     __shared__ __attribute__((aligned(16))) double s_at[144];
     __shared__ double s_w[12];
-    const int frame = blockIdx.y, hl = blockIdx.x, lane = threadIdx.x;
-    if (!epnp_hyp_active(n_pts[frame], h0 + hl, h0, hn, prm, rstate + frame)) // (uniform over the wavefront)
+    __shared__ int s_flag;
+    const int frame = blockIdx.y, hl = blockIdx.x, tid = threadIdx.x;
+    if (!epnp_hyp_active(n_pts[frame], h0 + hl, h0, hn, prm, rstate + frame)) // (uniform over the workgroup)
         return;
     double *w = ws + ((size_t)frame * hn + hl) * EPNP_WS + EPNP_WS_AT;
-    for (int i = lane; i < 144; i += 64)
+    for (int i = tid; i < 144; i += 128)
         s_at[i] = w[i];
     __syncthreads();
-    jacobi12_wave_sweeps(s_at, s_w, lane);
+    jacobi12_pipe_sweeps(s_at, s_w, &s_flag, tid); // two wavefronts: up to six independent pairs per time slot
     __syncthreads();
-    if (lane == 0)
+    if (tid == 0)
         jacobi12_finish(s_at, s_w);
     __syncthreads();
-    for (int i = 96 + lane; i < 144; i += 64) // rows 8 .. 11: the null-space basis is all the rest of the solver reads
-        w[i] = s_at[i];
+    if (tid < 48) // rows 8 .. 11: the null-space basis is all the rest of the solver reads
+        w[96 + tid] = s_at[96 + tid];
 }
 
 __global__ __launch_bounds__(64, 1) void epnp_approx_kernel(const int *__restrict__ n_pts, PnpParams prm,
@@ -976,7 +978,7 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
         if (split && h0 == 0) {
             hipLaunchKernelGGL(epnp_prepare_kernel, eg, dim3(64), 144 * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts,
                                cap, subsets, prm, state, h0, hn, epnp_ws);
-            hipLaunchKernelGGL(svd12_wave_kernel, dim3(hn, n_frames), dim3(64), 0, stream, n_pts, prm, state, h0, hn, epnp_ws);
+            hipLaunchKernelGGL(svd12_wave_kernel, dim3(hn, n_frames), dim3(128), 0, stream, n_pts, prm, state, h0, hn, epnp_ws);
             hipLaunchKernelGGL(epnp_approx_kernel, dim3(eg.x, n_frames, 3), dim3(64), 0, stream, n_pts, prm, state, h0, hn,
                                epnp_ws);
             hipLaunchKernelGGL(epnp_select_kernel, eg, dim3(64), 0, stream, n_pts, prm, state, h0, hn, epnp_ws, models);

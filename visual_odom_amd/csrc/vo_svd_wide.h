@@ -1,4 +1,5 @@
-// vo_svd_wide.h -- the Jacobi sweeps of EPnP's 12 x 12 SVD run by a whole WAVEFRONT per matrix (round 3).
+// vo_svd_wide.h -- the Jacobi sweeps of EPnP's 12 x 12 SVD (and of the refinement's 6 x 6 solve) run by one or two
+// WAVEFRONTS per matrix (round 3).
 //
 // Why: one hypothesis per lane (vo_epnp.h + jacobi_svd<12, 12, false, 64>) costs 466 us per solve, 337 us of them in
 // this SVD (developer-build time stamps, tools/pose_phases.py): ~307 rotations + ~114 skipped pairs, each a chain of
@@ -12,8 +13,9 @@
 //     redundantly by every lane of the row from those sums;
 //   * across pairs: the serial order (0,1), (0,2) ... (10,11) makes pair (i, j) wait for (i, j - 1) and (i - 1, j) only
 //     -- the last pairs before it that touch row i / row j -- so all pairs with the same i + j are independent and see
-//     exactly the rows they would see in the serial order.  The four DPP rows of the wavefront take up to four of them
-//     at a time: 26 steps per sweep instead of 66 (the table below).
+//     exactly the rows they would see in the serial order -- and the next sweep's early pairs do not have to wait for this
+//     sweep's late ones either (JacobiPipe below): 12 time slots per sweep instead of 66 pairs, each slot up to six pairs
+//     on the DPP rows of two wavefronts.
 // Bit-identical to jacobi_svd<12, 12, false> by construction and by tests/test_kernel_emulation.py (CPU emulator: this
 // file against the serial routine on random, rank-deficient and degenerate matrices) and the GPU parity tests of the
 // pose solve.
@@ -113,64 +115,95 @@ __device__ __forceinline__ void row_ordered_sum_x2(double x, double y, double &s
 #if defined(VO_HOST_EMUL) || defined(__HIPCC__)
 #if defined(VO_HOST_EMUL)
 #define VO_WIDE_FN static inline
-#define VO_WAVE_SYNC() emu::barrier()
+static inline void wide_sync(bool one_wave)
+{
+    (void)one_wave;
+    emu::barrier();
+}
 static inline bool wave_any(bool v) { return emu_ballot(v) != 0; }
 #else
 #define VO_WIDE_FN __device__ __forceinline__
-#define VO_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+// one wavefront: its LDS operations execute in order, the fences keep the compiler from moving memory operations across
+// the step boundary; several wavefronts: a workgroup barrier
+__device__ __forceinline__ void wide_sync(bool one_wave)
+{
+    if (one_wave) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
 __device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 #endif
 
-// Pairs (i, j), i < j < N, by anti-diagonal i + j, four per step: {i, j} of DPP row 0 .. 3, 255 = nothing to do in this
-// step.  N = 12: 26 steps for 66 pairs, N = 6: 9 steps for 15.
-template <int N>
-struct JacobiSteps {
-    uint8_t ij[N * (N - 1) / 2][4][2];
-    int n;
+// The schedule.  Serial order: sweep after sweep, in a sweep the pairs (0,1), (0,2) ... (N-2,N-1).  Pair (i, j) reads and
+// writes rows i and j only, so it has to wait for the LAST earlier pair that touched row i and for the last one that touched
+// row j -- nothing else:
+//   * inside a sweep those are (i, j - 1) and (i - 1, j): all pairs on an anti-diagonal d = i + j are independent and may
+//     run side by side, d = 1 .. D = 2N - 3 one after the other;
+//   * across sweeps row r is last touched by (r, N-1) on diagonal r + N - 1 (row N-1 by (N-2, N-1) on D), so pair (i, j) of
+//     the NEXT sweep may run P = N diagonals after the same pair of this one: diagonal d of sweep s + 1 together with
+//     diagonal d + P of sweep s.  The two never share a row (rows <= d against rows >= d + 1), and every pair sees exactly
+//     the rows the serial order would show it.
+// A sweep that rotates nothing ends the algorithm; the next sweep has by then started speculatively -- and, reading the very
+// rows the idle sweep left untouched, has skipped every pair as well: nothing to undo.
+// One time slot per P diagonals-of-the-newest-sweep: up to ROWS pairs, one per DPP row (N = 12: at most 6 -> two
+// wavefronts, 12 slots per sweep instead of the serial 66 pairs; N = 6: at most 3 -> one wavefront, 6 slots instead of 15).
+template <int N, int ROWS>
+struct JacobiPipe {
+    static constexpr int P = N, D = 2 * N - 3;
+    uint8_t e[P][ROWS][3]; // slot phi = 1 .. P: {i, j, 1 = pair of the OLDER sweep}; i = 255: nothing to do
 };
-template <int N>
-constexpr JacobiSteps<N> jacobi_steps()
+template <int N, int ROWS>
+constexpr JacobiPipe<N, ROWS> jacobi_pipe()
 {
-    JacobiSteps<N> t = {};
-    int step = 0;
-    for (int d = 1; d <= 2 * N - 3; d++) {
+    JacobiPipe<N, ROWS> t = {};
+    for (int phi = 1; phi <= N; phi++) {
         int n = 0;
-        for (int i = 0; i < N; i++) {
-            const int j = d - i;
-            if (j <= i || j > N - 1)
+        for (int old = 0; old < 2; old++) {
+            const int d = phi + old * N;
+            if (d > 2 * N - 3)
                 continue;
-            if (n == 4) {
-                step++;
-                n = 0;
+            for (int i = 0; i < N; i++) {
+                const int j = d - i;
+                if (j <= i || j > N - 1)
+                    continue;
+                t.e[phi - 1][n][0] = (uint8_t)i; // (n < ROWS: an index past the array stops the constant evaluation)
+                t.e[phi - 1][n][1] = (uint8_t)j;
+                t.e[phi - 1][n][2] = (uint8_t)old;
+                n++;
             }
-            t.ij[step][n][0] = (uint8_t)i;
-            t.ij[step][n][1] = (uint8_t)j;
-            n++;
         }
-        for (; n < 4; n++)
-            t.ij[step][n][0] = t.ij[step][n][1] = 255;
-        step++;
+        for (; n < ROWS; n++)
+            t.e[phi - 1][n][0] = t.e[phi - 1][n][1] = 255;
     }
-    t.n = step;
     return t;
 }
 #if defined(VO_HOST_EMUL)
-static const JacobiSteps<12> JACOBI_STEPS_12 = jacobi_steps<12>();
-static const JacobiSteps<6> JACOBI_STEPS_6 = jacobi_steps<6>();
+static const JacobiPipe<12, 8> JACOBI_PIPE_12 = jacobi_pipe<12, 8>();
+static const JacobiPipe<6, 4> JACOBI_PIPE_6 = jacobi_pipe<6, 4>();
 #else
-__device__ const JacobiSteps<12> JACOBI_STEPS_12 = jacobi_steps<12>();
-__device__ const JacobiSteps<6> JACOBI_STEPS_6 = jacobi_steps<6>();
+__device__ const JacobiPipe<12, 8> JACOBI_PIPE_12 = jacobi_pipe<12, 8>();
+__device__ const JacobiPipe<6, 4> JACOBI_PIPE_6 = jacobi_pipe<6, 4>();
 #endif
-// Squared row norms (+ Vt = I) and the Jacobi sweeps of jacobi_svd<N, N, WANT_V>.  Called by all 64 lanes of ONE wavefront per
-// matrix; lanes N .. 15 of a DPP row shadow lane N - 1.  Every branch below is uniform over a DPP row: its conditions are
-// functions of the row's broadcast sums (or of the step table) only.  At, Vt: N x N row-major, W: N.
-template <int N, bool WANT_V>
-VO_WIDE_FN void jacobi_wave_sweeps(const JacobiSteps<N> &tab, double *At, double *W, double *Vt, int lane)
+
+// Squared row norms (+ Vt = I) and the Jacobi sweeps of jacobi_svd<N, N, WANT_V>.  Called by all 16 * ROWS threads that work
+// on ONE matrix (ROWS = 4: a wavefront, possibly one of several in its workgroup -- no workgroup barrier is used; ROWS = 8:
+// a 128-thread workgroup); `tid` = 0 .. 16 ROWS - 1; lanes N .. 15 of a DPP row follow their row and never store.  Every
+// branch below is uniform over a DPP row: its conditions are functions of the row's broadcast sums or of the table.
+// At, Vt: N x N row-major, W: N, flag: one int the threads share (ROWS = 8 only).
+template <int N, bool WANT_V, int ROWS>
+VO_WIDE_FN void jacobi_pipe_sweeps(const JacobiPipe<N, ROWS> &tab, double *At, double *W, double *Vt, int *flag, int tid)
 {
-    const int row = (lane >> 4) & 3, l16 = lane & 15, k = l16 < N ? l16 : N - 1;
-    const bool owner = l16 < N; // lanes N .. 15 follow the row's control flow and feed nothing: they never store
+    constexpr int P = JacobiPipe<N, ROWS>::P, D = JacobiPipe<N, ROWS>::D;
+    constexpr bool ONE_WAVE = ROWS <= 4;
+    const int row = tid >> 4, l16 = tid & 15, k = l16 < N ? l16 : N - 1;
+    const bool owner = l16 < N;
     const double eps = DBL_EPSILON * 10;
-    for (int i = row; i < N; i += 4) {
+    const int max_iter = N > 30 ? N : 30;
+    for (int i = row; i < N; i += ROWS) {
         const double t = At[i * N + k];
         const double sd = row_ordered_sum<N>(t * t);
         if (l16 == 0)
@@ -178,13 +211,14 @@ VO_WIDE_FN void jacobi_wave_sweeps(const JacobiSteps<N> &tab, double *At, double
         if (WANT_V && owner)
             Vt[i * N + k] = i == k ? 1.0 : 0.0;
     }
-    VO_WAVE_SYNC();
-    const int max_iter = N > 30 ? N : 30;
-    for (int iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-        for (int step = 0; step < tab.n; step++) {
-            const int i = tab.ij[step][row][0], j = tab.ij[step][row][1];
-            if (i != 255) {
+    wide_sync(ONE_WAVE);
+    bool chg_old = false, chg_new = false; // this thread's row rotated something in the older / the newest sweep
+    for (int sweep = 0;; sweep++) {         // `sweep` = index of the newest sweep in flight
+        const bool new_on = sweep < max_iter;
+        for (int phi = 1; phi <= P; phi++) {
+            const int i = tab.e[phi - 1][row][0], j = tab.e[phi - 1][row][1];
+            const bool old = tab.e[phi - 1][row][2] != 0;
+            if (i != 255 && (old ? sweep >= 1 : new_on)) {
                 const double ai = At[i * N + k], aj = At[j * N + k];
                 double a = W[i], b = W[j];
                 double p = row_ordered_sum<N>(ai * aj);
@@ -218,22 +252,42 @@ VO_WIDE_FN void jacobi_wave_sweeps(const JacobiSteps<N> &tab, double *At, double
                         Vt[i * N + k] = c * vi + s * vj;
                         Vt[j * N + k] = -s * vi + c * vj;
                     }
-                    changed = true;
+                    if (old)
+                        chg_old = true;
+                    else
+                        chg_new = true;
                 }
             }
-            VO_WAVE_SYNC();
+            wide_sync(ONE_WAVE);
+            if (phi == D - P && sweep >= 1) { // the older sweep has just run its last diagonal: did it rotate anything?
+                bool any;
+                if (ONE_WAVE) {
+                    any = wave_any(chg_old);
+                } else {
+                    if (tid == 0)
+                        *flag = 0;
+                    wide_sync(false);
+                    if (chg_old)
+                        *flag = 1;
+                    wide_sync(false);
+                    any = *flag != 0;
+                    wide_sync(false);
+                }
+                if (!any || !new_on)
+                    return;
+            }
         }
-        if (!wave_any(changed))
-            break;
+        chg_old = chg_new;
+        chg_new = false;
     }
 }
-VO_WIDE_FN void jacobi12_wave_sweeps(double *At, double *W, int lane)
+VO_WIDE_FN void jacobi12_pipe_sweeps(double *At, double *W, int *flag, int tid /* 0 .. 127 */)
 {
-    jacobi_wave_sweeps<12, false>(JACOBI_STEPS_12, At, W, nullptr, lane);
+    jacobi_pipe_sweeps<12, false, 8>(JACOBI_PIPE_12, At, W, nullptr, flag, tid);
 }
-VO_WIDE_FN void jacobi6v_wave_sweeps(double *At, double *W, double *Vt, int lane)
+VO_WIDE_FN void jacobi6v_wave_sweeps(double *At, double *W, double *Vt, int lane /* 0 .. 63 */)
 {
-    jacobi_wave_sweeps<6, true>(JACOBI_STEPS_6, At, W, Vt, lane);
+    jacobi_pipe_sweeps<6, true, 4>(JACOBI_PIPE_6, At, W, Vt, nullptr, lane);
 }
 #undef VO_WIDE_FN
 #endif
