@@ -1095,9 +1095,12 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
     // Run k writes buffer set k % 2; its filter first waits for the pose solve of run k - 2 (same set).
     // The tracking stream only waits -- before its next DETECT / LK, i.e. after a whole pyramid stage --
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
-    hipStream_t fs = c->serial_pose ? c->stream : c->stream_filter;
-    const bool two_pose_streams = !c->serial_pose && !c->prm.mono_rotation && c->sched.streams == 2;
-    hipStream_t ps = c->serial_pose ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
+    // A synchronous drop-in call (vo_track_frame) has nothing to overlap with: everything on the tracking stream saves the
+    // three cross-stream hand-offs of the chain (~12 us each in the kernel timeline of one call).
+    const bool serial = c->serial_pose || (c->sync_call && !sq.on);
+    hipStream_t fs = serial ? c->stream : c->stream_filter;
+    const bool two_pose_streams = !serial && !c->prm.mono_rotation && c->sched.streams == 2;
+    hipStream_t ps = serial ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
     if (touches_pose) {
         VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
         VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
@@ -1167,7 +1170,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
             ep.max_iters = EM_MAX_ITERS;
             // its own stream: the two chains only share their inputs, and together they would outlast the LK
             // launch they hide behind
-            hipStream_t es = c->serial_pose ? c->stream : c->stream_em;
+            hipStream_t es = serial ? c->stream : c->stream_em;
             VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
             launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
                              /*crowded*/ crowded, es);
@@ -1464,7 +1467,7 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
     const TuneKey key = tune_key(c, stages);
     std::vector<vo_ctx::Schedule> cands;
     for (int waves = 1; waves <= 2; waves++)
-        for (int streams = 1; streams <= 2; streams++)
+        for (int streams = 1; streams <= (c->sync_call && !c->seq.on ? 1 : 2); streams++) // (a synchronous call runs on one stream)
             for (int prep = 1; prep >= 0; prep--) {
                 vo_ctx::Schedule s, t;
                 s.waves = waves;
