@@ -64,8 +64,9 @@ static inline void row_ordered_sum_x2(double x, double y, double &sx, double &sy
 #define VO_BC_ADD6(S, X) VO_BC_ADD(0, S, X) VO_BC_ADD(1, S, X) VO_BC_ADD(2, S, X) VO_BC_ADD(3, S, X) VO_BC_ADD(4, S, X) VO_BC_ADD(5, S, X)
 #define VO_BC_ADD6B(S, X) VO_BC_ADD(6, S, X) VO_BC_ADD(7, S, X) VO_BC_ADD(8, S, X) VO_BC_ADD(9, S, X) VO_BC_ADD(10, S, X) VO_BC_ADD(11, S, X)
 #define VO_BC_ADD2(K) VO_BC_ADD(K, "s", "x") VO_BC_ADD(K, "r", "y")
-// (s_nop 1: a DPP instruction must not read a VGPR in the two slots after the VALU write that produced it -- the compiler
-// keeps that distance for its own instructions but does not look inside an asm block)
+// (s_nop 4: a DPP instruction must not read a VGPR in the two slots after the VALU write that produced it, nor follow a
+// VALU write of EXEC by fewer than five -- the compiler keeps those distances for its own instructions but does not look
+// inside an asm block; five idle cycles per chain of 24 to 48 instructions)
 template <int N>
 __device__ __forceinline__ double row_ordered_sum(double x)
 {
@@ -74,9 +75,9 @@ __device__ __forceinline__ double row_ordered_sum(double x)
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass of hipcc only needs the declaration)
     double t;
     if (N == 6)
-        asm volatile("s_nop 1\n\t" VO_BC_ADD6("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
+        asm volatile("s_nop 4\n\t" VO_BC_ADD6("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
     else
-        asm volatile("s_nop 1\n\t" VO_BC_ADD6("s", "x") VO_BC_ADD6B("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
+        asm volatile("s_nop 4\n\t" VO_BC_ADD6("s", "x") VO_BC_ADD6B("s", "x") : [s] "+v"(s), [t] "=&v"(t) : [x] "v"(x));
 #else
     s = x;
 #endif
@@ -91,11 +92,11 @@ __device__ __forceinline__ void row_ordered_sum_x2(double x, double y, double &s
 #if defined(__HIP_DEVICE_COMPILE__)
     double t;
     if (N == 6)
-        asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5)
+        asm volatile("s_nop 4\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5)
                      : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
                      : [x] "v"(x), [y] "v"(y));
     else
-        asm volatile("s_nop 1\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5) VO_BC_ADD2(6)
+        asm volatile("s_nop 4\n\t" VO_BC_ADD2(0) VO_BC_ADD2(1) VO_BC_ADD2(2) VO_BC_ADD2(3) VO_BC_ADD2(4) VO_BC_ADD2(5) VO_BC_ADD2(6)
                          VO_BC_ADD2(7) VO_BC_ADD2(8) VO_BC_ADD2(9) VO_BC_ADD2(10) VO_BC_ADD2(11)
                      : [s] "+v"(s), [r] "+v"(r), [t] "=&v"(t)
                      : [x] "v"(x), [y] "v"(y));
