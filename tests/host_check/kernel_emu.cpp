@@ -8,6 +8,7 @@
 #include "../../visual_odom_amd/csrc/lk.hip"
 #include "../../visual_odom_amd/csrc/pyramid.hip"
 #include "../../visual_odom_amd/csrc/vo_svd_wide.h"
+#include "../../visual_odom_amd/csrc/vo_epnp.h"
 
 #include <vector>
 
@@ -80,6 +81,32 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
+
+// The four-kernel EPnP of pnp.hip on the CPU: epnp5_prepare (one lane) -> the 12 x 12 SVD by a 128-thread workgroup
+// (emulated) + jacobi12_finish -> the three approximations taken separately -> epnp5_select, next to the one-piece solver
+// epnp5_solve the one-kernel form runs.  xyz5: n x 15, uv5: n x 10 (f32), K: 3 x 3 f32; rt_split / rt_mono: n x 6 (rvec, tvec)
+int ke_epnp_split(const float *xyz5, const float *uv5, const float *K, int n, double *rt_split, double *rt_mono)
+{
+    for (int q = 0; q < n; q++) {
+        vo::Epnp5 e;
+        std::vector<double> ut(144), w(12);
+        int flag = 0;
+        vo::epnp5_prepare<1>(xyz5 + 15 * q, uv5 + 10 * q, K, e, ut.data());
+        launch(1, 1, 1, 128, [&] { vo::jacobi12_pipe_sweeps(ut.data(), w.data(), &flag, (int)threadIdx.x); });
+        vo::jacobi12_finish(ut.data(), w.data());
+        double L[60], rho[6], rep[3], R[3][9], t[3][3];
+        for (int a = 0; a < 3; a++) { // (each approximation starts from the state the kernel loads from the workspace)
+            vo::Epnp5 ea = e;
+            vo::epnp5_L_rho<1>(ea, ut.data(), L, rho);
+            rep[a] = a == 0   ? vo::epnp5_approx<1, 0>(ea, ut.data(), L, rho, R[0], t[0])
+                     : a == 1 ? vo::epnp5_approx<1, 1>(ea, ut.data(), L, rho, R[1], t[1])
+                              : vo::epnp5_approx<1, 2>(ea, ut.data(), L, rho, R[2], t[2]);
+        }
+        vo::epnp5_select(rep, R[0], R[1], R[2], t[0], t[1], t[2], rt_split + 6 * q, rt_split + 6 * q + 3);
+        vo::epnp5_solve(xyz5 + 15 * q, uv5 + 10 * q, K, rt_mono + 6 * q, rt_mono + 6 * q + 3);
+    }
+    return 0;
+}
 
 // The Levenberg-Marquardt step's 6 x 6 solve as select_refine_kernel runs it -- wavefront sweeps with V, jacobi_finish and
 // svd_backsubst on lane 0 -- next to solve_svd<6, 6>.  A: n x 36 row-major, b: n x 6; x_wave / x_serial: n x 6

@@ -23,7 +23,7 @@ def kemu():
     csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
     deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
-                                               "vo_linalg.h")]
+                                               "vo_linalg.h", "vo_epnp.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -376,3 +376,30 @@ def test_wavefront_6x6_solve_is_bit_identical_to_solve_svd(kemu):
     assert np.isfinite(xs).all()
     assert np.array_equal(xw.view(np.uint64), xs.view(np.uint64))
     assert np.allclose(A[0] @ xs[0], b[0], rtol=1e-8)
+
+
+def test_four_kernel_epnp_composition_is_bit_identical_to_the_one_piece_solver(kemu, orc):
+    """pnp.hip's small-launch EPnP on the CPU: set-up, the 12 x 12 SVD by an (emulated) 128-thread workgroup, each of the
+    three approximations from the state the workspace holds, selection -- rvec and tvec BIT FOR BIT those of epnp5_solve (the
+    one-kernel form, itself bit-identical to the oracle's EPnP: test_device_math_on_host.py), on noisy, exact, far and
+    near-planar 5-point sets"""
+    rng = np.random.default_rng(21)
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], np.float32)
+    X, U = [], []
+    for case in range(120):
+        lo, hi = ([-8, -2, 4], [8, 2, 40]) if case % 4 else ([-30, -6, 60], [30, 6, 200])
+        xyz = rng.uniform(lo, hi, (5, 3)).astype(np.float32)
+        if case % 7 == 3:
+            xyz[:, 2] = xyz[0, 2] + rng.normal(0, 0.01, 5).astype(np.float32)  # almost fronto-parallel plane
+        rv, tv = rng.normal(0, 0.02, 3), rng.normal(0, 0.5, 3)
+        uv = orc.project_points(xyz, rv, tv, K) + (rng.normal(0, 0.4, (5, 2)) if case % 3 else 0)
+        X.append(xyz)
+        U.append(uv.astype(np.float32))
+    X = np.ascontiguousarray(np.array(X, np.float32))
+    U = np.ascontiguousarray(np.array(U, np.float32))
+    split, mono = np.zeros((len(X), 6)), np.zeros((len(X), 6))
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    kemu.ke_epnp_split(X.ctypes.data_as(fp), U.ctypes.data_as(fp), K.ctypes.data_as(fp), len(X), split.ctypes.data_as(dp),
+                       mono.ctypes.data_as(dp))
+    assert np.isfinite(mono).all()
+    assert np.array_equal(split.view(np.uint64), mono.view(np.uint64))
