@@ -55,6 +55,7 @@ struct Block {
     std::vector<uint64_t> xbuf;
     int cur = 0;
     int bar_count = 0, bar_gen = 0; // emu::barrier()
+    int wbar_count[16] = {}, wbar_gen[16] = {}; // emu::wave_barrier(), per wavefront (blocks of up to 1024 threads)
     std::function<void()> body;
 };
 inline Block *&current()
@@ -76,6 +77,13 @@ inline EmuIdx &bdim()
 {
     static EmuIdx t{1, 1, 1};
     return t;
+}
+
+// dynamic LDS of the block being run (set by the harness before the launch)
+inline void *&dyn_shared()
+{
+    static void *p = nullptr;
+    return p;
 }
 
 inline void yield()
@@ -100,6 +108,28 @@ inline void barrier()
         if (b->bar_count >= live) { // the last one in (or the last one left) opens it
             b->bar_count = 0;
             b->bar_gen++;
+            return;
+        }
+        yield();
+    }
+}
+
+// the same for the 64 lanes of the caller's wavefront only (code that one wavefront of a block runs on its own)
+inline void wave_barrier()
+{
+    Block *b = current();
+    const int w = b->cur >> 6, lo = w * 64, hi = lo + 64 < b->n ? lo + 64 : b->n;
+    const int gen = b->wbar_gen[w];
+    b->wbar_count[w]++;
+    for (;;) {
+        if (b->wbar_gen[w] != gen)
+            return;
+        int live = 0;
+        for (int i = lo; i < hi; i++)
+            live += !b->done[i];
+        if (b->wbar_count[w] >= live) {
+            b->wbar_count[w] = 0;
+            b->wbar_gen[w]++;
             return;
         }
         yield();
@@ -189,7 +219,7 @@ inline int dpp_source(int lane, int ctrl)
 #define blockIdx (emu::bidx())
 #define blockDim (emu::bdim())
 
-static inline void __syncthreads() { emu::yield(); }
+static inline void __syncthreads() { emu::barrier(); } // a real barrier: wavefronts of a block may pass different numbers of yields
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
 static inline int __float_as_int(float v)
 {
@@ -254,6 +284,34 @@ static inline unsigned long long emu_ballot(bool pred)
     emu::yield();
     return m;
 }
+static inline bool __any(bool pred) { return emu_ballot(pred) != 0; }
+static inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+// __shfl family (width 64) for 4- and 8-byte types: lane `src` of the caller's wavefront, own value if out of range
+template <typename T>
+static inline T emu_shfl_abs(T v, int src_lane)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte types");
+    const int lane = emu::lane_id(), wave0 = lane & ~63;
+    const int src = (src_lane >= 0 && src_lane < 64) ? wave0 + src_lane : lane;
+    uint64_t u = 0;
+    memcpy(&u, &v, sizeof(T));
+    const uint32_t lo = emu::exchange((uint32_t)u, src, 0);
+    uint32_t hi = 0;
+    if (sizeof(T) == 8)
+        hi = emu::exchange((uint32_t)(u >> 32), src, 0);
+    u = ((uint64_t)hi << 32) | lo;
+    T r;
+    memcpy(&r, &u, sizeof(T));
+    return r;
+}
+template <typename T>
+static inline T __shfl(T v, int src_lane, int = 64) { return emu_shfl_abs(v, src_lane); }
+template <typename T>
+static inline T __shfl_up(T v, unsigned delta, int = 64) { return emu_shfl_abs(v, (emu::lane_id() & 63) - (int)delta); }
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl_abs(v, (emu::lane_id() & 63) ^ mask); }
 // lanes run one at a time between yields, so plain read-modify-write is atomic here
 static inline int atomicAdd(int *p, int v)
 {

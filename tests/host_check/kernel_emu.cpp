@@ -7,8 +7,7 @@
 #include "../../visual_odom_amd/csrc/fast.hip"
 #include "../../visual_odom_amd/csrc/lk.hip"
 #include "../../visual_odom_amd/csrc/pyramid.hip"
-#include "../../visual_odom_amd/csrc/vo_svd_wide.h"
-#include "../../visual_odom_amd/csrc/vo_epnp.h"
+#include "../../visual_odom_amd/csrc/pnp.hip" // (brings vo_epnp.h, vo_svd_wide.h, vo_p3p.h; host launch code is compiled out)
 
 #include <vector>
 
@@ -81,6 +80,67 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
+
+// The whole pose solve of ONE frame on the CPU emulator, kernel by kernel in launch_pnp's order: raw RNG table -> per chunk
+// (subsets -> EPnP -> votes -> control-flow replay) -> P3P -> winner / inlier mask / Levenberg-Marquardt refinement.
+// split = 1: the first chunk's EPnP as the four kernels small launches use (epnp_prepare / svd12_wave / epnp_approx /
+// epnp_select), 0: epnp_kernel<1>.  first_chunk: 128 or 64 (big launches).  Returns the PnpResult fields and the inliers.
+int ke_pnp_ransac(const float *xyz, const float *uv, int n, const float *K9, int iters, float reproj, double confidence,
+                  int split, int first_chunk, double *rvec, double *tvec, int32_t *inliers, int *n_inliers, int *dbg4)
+{
+    using namespace vo;
+    const int cap = n > 8 ? n : 8;
+    PnpParams prm;
+    prm.iters = iters;
+    prm.reproj = reproj;
+    prm.confidence = confidence;
+    memcpy(prm.K, K9, sizeof(prm.K));
+    std::vector<uint32_t> raw(RNG_TABLE);
+    launch(1, 1, 1, 1, [&] { rng_table_kernel(raw.data(), RNG_TABLE); });
+    std::vector<float> X(xyz, xyz + (size_t)3 * n);
+    X.resize((size_t)3 * cap);
+    std::vector<float2> U((size_t)cap);
+    for (int i = 0; i < n; i++)
+        U[i] = make_float2(uv[2 * i], uv[2 * i + 1]);
+    std::vector<int32_t> subsets((size_t)iters * 5), inl((size_t)cap);
+    std::vector<double> models((size_t)iters * 6), ws((size_t)VO_EPNP_WS_HYPS * VO_EPNP_WS_DOUBLES);
+    std::vector<int> counts((size_t)iters);
+    std::vector<double> lds((size_t)(144 + 12) * 64);
+    RansacState st;
+    PnpResult res;
+    memset(&res, 0, sizeof(res));
+    int n_pts = n;
+    emu::dyn_shared() = lds.data();
+    for (int h0 = 0; h0 < iters;) {
+        const int hn = h0 == 0 ? std::min(first_chunk, iters) : iters - h0;
+        const unsigned eg = (unsigned)(hn + 63) / 64;
+        launch(1, 1, 1, 64, [&] { ransac_subsets_kernel(&n_pts, 1, iters, h0, hn, raw.data(), RNG_TABLE, subsets.data(), &st); });
+        if (split && h0 == 0) {
+            launch(eg, 1, 1, 64, [&] { epnp_prepare_kernel(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, ws.data()); });
+            launch((unsigned)hn, 1, 1, 128, [&] { svd12_wave_kernel(&n_pts, prm, &st, h0, hn, ws.data()); });
+            launch(eg, 1, 3, 64, [&] { epnp_approx_kernel(&n_pts, prm, &st, h0, hn, ws.data()); });
+            launch(eg, 1, 1, 64, [&] { epnp_select_kernel(&n_pts, prm, &st, h0, hn, ws.data(), models.data()); });
+        } else {
+            launch(eg, 1, 1, 64, [&] { epnp_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data()); });
+        }
+        launch((unsigned)hn, 1, 1, 64, [&] { vote_kernel(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, h0, counts.data()); });
+        launch(1, 1, 1, 64, [&] { ransac_replay_kernel(&n_pts, 1, prm, h0 + hn, counts.data(), &st); });
+        h0 += hn;
+    }
+    launch(1, 1, 1, 64, [&] { p3p_kernel(X.data(), U.data(), 0, &n_pts, cap, 1, prm, inl.data(), &res); });
+    launch(1, 1, 1, 256, [&] { select_refine_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, inl.data(), &res, SeqTail()); });
+    emu::dyn_shared() = nullptr;
+    memcpy(rvec, res.rvec, sizeof(res.rvec));
+    memcpy(tvec, res.tvec, sizeof(res.tvec));
+    *n_inliers = res.n_inliers;
+    for (int i = 0; i < res.n_inliers && i < n; i++)
+        inliers[i] = inl[i];
+    dbg4[0] = res.niters;
+    dbg4[1] = res.best_iter;
+    dbg4[2] = res.max_good;
+    dbg4[3] = res.lm_iters;
+    return res.status;
+}
 
 // The four-kernel EPnP of pnp.hip on the CPU: epnp5_prepare (one lane) -> the 12 x 12 SVD by a 128-thread workgroup
 // (emulated) + jacobi12_finish -> the three approximations taken separately -> epnp5_select, next to the one-piece solver

@@ -68,6 +68,14 @@ __device__ long long g_pose_prof[64];
 
 namespace vo {
 
+// dynamic LDS of the workgroup (tests/host_check/kernel_emu.cpp runs these kernels on the CPU emulator, which hands the
+// block's buffer over through emu::dyn_shared())
+#ifdef VO_HOST_EMUL
+#define VO_DYN_LDS(type, name) type *name = (type *)emu::dyn_shared()
+#else
+#define VO_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+
 constexpr int RANSAC_CHUNK = VO_EPNP_WS_HYPS;
 
 // ---- random 5-subsets: RANSACPointSetRegistrator::getSubset with cv::RNG(-1) ----
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
     // s_ut[idx * 64 + l] -> consecutive lanes hit consecutive 8-byte words (conflict-free ds_*_b64)
     // (dynamic LDS, (144 + 12) * 64 doubles: with a static array the compiler derives one wave per SIMD
     // from the LDS footprint and spends all 512 registers, ignoring the launch bound above)
-    extern __shared__ __attribute__((aligned(16))) double s_ut[];
+    VO_DYN_LDS(double, s_ut);
     const int frame = blockIdx.y, h = h0 + blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
     if (count < 5 || h >= h0 + hn)
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(64, 1) void epnp_prepare_kernel(const float *__rest
                                                              const RansacState *__restrict__ rstate, int h0, int hn,
                                                              double *__restrict__ ws /* [B][hn][EPNP_WS] */)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_ut[]; // 144 x 64, lane-interleaved as in epnp_kernel
+    VO_DYN_LDS(double, s_ut); // 144 x 64, lane-interleaved as in epnp_kernel
     const int frame = blockIdx.y, hl = blockIdx.x * 64 + threadIdx.x, h = h0 + hl;
     if (!epnp_hyp_active(n_pts[frame], h, h0, hn, prm, rstate + frame))
         return;
@@ -896,6 +904,7 @@ __global__ void p3p_kernel(const float *__restrict__ xyz, const float2 *__restri
             inliers[(size_t)frame * cap + i] = i;
 }
 
+#ifndef VO_HOST_EMUL // ---- host side: launches ----
 // the raw cv::RNG(-1) stream of the device the calling thread has selected (created on first use)
 static const uint32_t *rng_table(hipStream_t stream)
 {
@@ -1035,6 +1044,8 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
                       ws_frames);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
+
+#endif // VO_HOST_EMUL
 
 #ifdef VO_DEV_VARIANTS
 int pose_prof_read(long long *out64)

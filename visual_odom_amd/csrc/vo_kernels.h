@@ -94,6 +94,10 @@ struct SeqIngest {
 #define VO_SEQ_F_GAP 16
 #endif
 
+// workspace of the four-kernel EPnP used for small launches (pnp.hip): VO_EPNP_WS_DOUBLES doubles per hypothesis of the first
+// RANSAC chunk (VO_EPNP_WS_HYPS hypotheses per frame), allocated for up to VO_EPNP_WS_MAX_FRAMES frames
+constexpr int VO_EPNP_WS_DOUBLES = 288, VO_EPNP_WS_HYPS = 128, VO_EPNP_WS_MAX_FRAMES = 16, VO_EPNP_SPLIT_DEFAULT_FRAMES = 4;
+
 #ifndef VO_HOST_EMUL
 struct EmBufs {
     double2 *q0 = nullptr, *q1 = nullptr; // [B][cap] normalised points
@@ -164,9 +168,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws = nullptr,
                 int ws_frames = 0);
-// epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip), VO_EPNP_WS_DOUBLES doubles per hypothesis of
-// the first RANSAC chunk (VO_EPNP_WS_HYPS hypotheses per frame) for ws_frames frames; null = always the one-kernel form
-constexpr int VO_EPNP_WS_DOUBLES = 288, VO_EPNP_WS_HYPS = 128, VO_EPNP_WS_MAX_FRAMES = 16, VO_EPNP_SPLIT_DEFAULT_FRAMES = 4;
+// epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
                        hipStream_t stream, double *epnp_ws, int ws_frames);

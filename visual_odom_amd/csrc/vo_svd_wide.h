@@ -118,8 +118,10 @@ __device__ __forceinline__ void row_ordered_sum_x2(double x, double y, double &s
 #define VO_WIDE_FN static inline
 static inline void wide_sync(bool one_wave)
 {
-    (void)one_wave;
-    emu::barrier();
+    if (one_wave)
+        emu::wave_barrier();
+    else
+        emu::barrier();
 }
 static inline bool wave_any(bool v) { return emu_ballot(v) != 0; }
 #else
