@@ -7,6 +7,7 @@
 #include "../../visual_odom_amd/csrc/fast.hip"
 #include "../../visual_odom_amd/csrc/lk.hip"
 #include "../../visual_odom_amd/csrc/pyramid.hip"
+#include "../../visual_odom_amd/csrc/post.hip"
 #include "../../visual_odom_amd/csrc/pnp.hip" // (brings vo_epnp.h, vo_svd_wide.h, vo_p3p.h; host launch code is compiled out)
 
 #include <vector>
@@ -80,6 +81,24 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
+
+// post.hip on the emulator: deleteUnmatchFeaturesCircle (stage A) + checkValidMatch / removeInvalidPoints (stage B) of one
+// frame's four tracking hops, then triangulation of the stage-B left / right points.
+// pts: n x 2, trk: 4 x n x 2 (r0, r1, l1, l0_ret), status: 4 x n; outA: 5 x n x 2, outB: 4 x n x 2, xyz: n x 3
+int ke_post(const float *pts, const float *trk, const uint8_t *status, int n, int threshold, const float *P_l, const float *P_r,
+            float *outA, int32_t *idxA, int *nA, float *outB, int32_t *idxB, int *nB, float *xyz)
+{
+    const int cap = n > 1 ? n : 1;
+    int n_pts = n;
+    launch(1, 1, 1, 256, [&] {
+        vo::compact_kernel((const float2 *)pts, (const float2 *)trk, status, &n_pts, cap, threshold, (float2 *)outA, idxA, nA,
+                           (float2 *)outB, idxB, nB);
+    });
+    launch((unsigned)(cap + 255) / 256, 1, 1, 256, [&] {
+        vo::triangulate_kernel(P_l, P_r, (const float2 *)outB, (const float2 *)outB + cap, (size_t)4 * cap, nB, cap, xyz);
+    });
+    return 0;
+}
 
 // The whole pose solve of ONE frame on the CPU emulator, kernel by kernel in launch_pnp's order: raw RNG table -> per chunk
 // (subsets -> EPnP -> votes -> control-flow replay) -> P3P -> winner / inlier mask / Levenberg-Marquardt refinement.

@@ -24,7 +24,7 @@ def kemu():
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
     deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
                                                "vo_linalg.h", "vo_epnp.h", "pnp.hip", "vo_p3p.h",
-                                               "vo_seqtail.h", "vo_integrate.h")]
+                                               "vo_seqtail.h", "vo_integrate.h", "post.hip", "vo_tri.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -467,3 +467,48 @@ def test_emulated_pose_chain_four_kernel_epnp_and_edge_cases(kemu, orc):
     assert grc == rc and np.array_equal(ginl, inl)
     if rc == 1:
         assert np.abs(grv - rv).max() <= 1e-9 and np.abs(gtv - tv).max() <= 1e-9
+
+
+def ke_post(lib, pts, trk, status, P_l, P_r, threshold=0):
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = len(pts)
+    trk = np.ascontiguousarray(trk, np.float32).reshape(4, n, 2)
+    status = np.ascontiguousarray(status, np.uint8).reshape(4, n)
+    P_l, P_r = np.ascontiguousarray(P_l, np.float32), np.ascontiguousarray(P_r, np.float32)
+    outA, outB = np.zeros((5, max(n, 1), 2), np.float32), np.zeros((4, max(n, 1), 2), np.float32)
+    idxA, idxB = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    nA, nB = C.c_int(0), C.c_int(0)
+    xyz = np.zeros((max(n, 1), 3), np.float32)
+    lib.ke_post(vp(pts), vp(trk), vp(status), n, threshold, vp(P_l), vp(P_r), vp(outA), vp(idxA), C.byref(nA), vp(outB),
+                vp(idxB), C.byref(nB), vp(xyz))
+    a, b = nA.value, nB.value
+    return dict(A=outA[:, :a], idxA=idxA[:a], B=outB[:, :b], idxB=idxB[:b], xyz=xyz[:b])
+
+
+def test_whole_hot_path_on_the_cpu_emulator(kemu, orc, small_world, small_seq):
+    """circularMatching -> filters -> triangulation -> solvePnPRansac with nothing but the product's kernel sources, run on
+    the CPU emulator launch by launch (pyramid.hip, lk.hip, post.hip, pnp.hip), against the oracle: survivors and tracks bit
+    for bit, triangulation identical, inlier set / RANSAC control flow / Levenberg-Marquardt iterations identical, pose
+    <= 1e-6.  What the GPU parity tests assert of the library, asserted of its kernel code without a GPU."""
+    s = small_seq
+    imgs = [s["L"][0], s["R"][0], s["L"][1], s["R"][1]]
+    pts = s["pts"][0].astype(np.float32)
+    r = ke_run(kemu, imgs, pts, full_chain=0)                      # the product's default: a feature retires at its first bad hop
+    P_l, P_r = small_world.proj_matrices()
+    post = ke_post(kemu, pts, r["trk"], r["status"], P_l, P_r)
+    ref = orc.circular_matching(*imgs, pts)
+    assert np.array_equal(post["idxA"], ref["keep_idx"]) and len(ref["keep_idx"]) > 100
+    for row, name in enumerate(("l0", "r0", "r1", "l1", "l0_ret")):
+        assert np.array_equal(bits(post["A"][row]), bits(ref[name])), name
+    (l0, r0, l1, r1), valid = orc.check_valid_and_remove(ref["l0"], ref["r0"], ref["l1"], ref["r1"], ref["l0_ret"])
+    assert np.array_equal(post["idxB"], ref["keep_idx"][valid])
+    for row, a in enumerate((l0, r0, l1, r1)):
+        assert np.array_equal(bits(post["B"][row]), bits(a)), row
+    xyz = orc.triangulate(P_l, P_r, l0, r0)
+    assert np.array_equal(post["xyz"], xyz)
+    K = small_world.K()
+    rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(xyz, l1, K)
+    grc, grv, gtv, ginl, gdbg = ke_pnp(kemu, post["xyz"], post["B"][2], K)
+    assert grc == rc == 1 and np.array_equal(ginl, inl)
+    assert tuple(gdbg[:4]) == tuple(int(x) for x in dbg[:4])
+    assert np.abs(grv - rv).max() <= 1e-6 and np.abs(gtv - tv).max() <= 1e-6

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float *__restric
     o[2] = out[2];
 }
 
+#ifndef VO_HOST_EMUL // (the CPU emulator of tests/host_check runs the two kernels above)
 // see FrameGather (vo_kernels.h); `out` is page-locked host memory mapped into the device's address space
 __global__ __launch_bounds__(256) void frame_gather_kernel(FrameGather g, uint8_t *__restrict__ out)
 {
@@ -184,5 +185,6 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
     hipLaunchKernelGGL(triangulate_kernel, dim3((max_pts + 255) / 256, n_frames), dim3(256), 0, stream, Pl, Pr,
                        pl, pr, frame_stride, n_pts, cap, xyz);
 }
+#endif // VO_HOST_EMUL
 
 } // namespace vo
