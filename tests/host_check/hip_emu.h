@@ -31,6 +31,10 @@ struct float2 {
     float x, y;
 };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct double2 {
+    double x, y;
+};
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 struct uint4 {
     uint32_t x, y, z, w;
 };

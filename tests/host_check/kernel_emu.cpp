@@ -9,6 +9,7 @@
 #include "../../visual_odom_amd/csrc/pyramid.hip"
 #include "../../visual_odom_amd/csrc/post.hip"
 #include "../../visual_odom_amd/csrc/pnp.hip" // (brings vo_epnp.h, vo_svd_wide.h, vo_p3p.h; host launch code is compiled out)
+#include "../../visual_odom_amd/csrc/essential.hip"
 
 #include <vector>
 
@@ -81,6 +82,58 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
+
+// essential.hip on the emulator, launch by launch as launch_essential does: findEssentialMat(RANSAC) + recoverPose of one frame.
+// p0, p1: n x 2 pixels.  Returns EmResult::status; E, R: 9, t: 3, mask: n, dbg: {n_inliers, n_good, niters, best}
+int ke_essential(const float *p0, const float *p1, int n, double focal, double ppx, double ppy, double prob, double threshold,
+                 int max_iters, double *E, double *R, double *t, uint8_t *mask, int *dbg4)
+{
+    using namespace vo;
+    const int cap = n > 8 ? n : 8, iters = max_iters;
+    EmParams prm;
+    prm.focal = focal;
+    prm.ppx = ppx;
+    prm.ppy = ppy;
+    prm.prob = prob;
+    prm.threshold = threshold;
+    prm.max_iters = max_iters;
+    std::vector<uint32_t> raw(RNG_TABLE);
+    launch(1, 1, 1, 1, [&] { rng_table_kernel(raw.data(), RNG_TABLE); });
+    std::vector<float2> a((size_t)cap), b((size_t)cap);
+    for (int i = 0; i < n; i++) {
+        a[i] = make_float2(p0[2 * i], p0[2 * i + 1]);
+        b[i] = make_float2(p1[2 * i], p1[2 * i + 1]);
+    }
+    std::vector<double2> q0((size_t)cap), q1((size_t)cap);
+    std::vector<int32_t> subsets((size_t)iters * 5);
+    std::vector<double> models((size_t)EM_CHUNK * EM_MAX_MODELS * 9), bestE(9);
+    std::vector<int> nmodels((size_t)EM_CHUNK), counts((size_t)EM_CHUNK * EM_MAX_MODELS);
+    std::vector<uint8_t> m((size_t)cap);
+    RansacState st;
+    EmResult res;
+    memset(&res, 0, sizeof(res));
+    int n_pts = n;
+    const double thr = prm.threshold / ((prm.focal + prm.focal) / 2);
+    const float thr2 = (float)(thr * thr);
+    launch((unsigned)(cap + 255) / 256, 1, 1, 256, [&] { em_normalise_kernel(a.data(), b.data(), 0, &n_pts, cap, prm, q0.data(), q1.data()); });
+    const int n_chunks = (iters + EM_CHUNK - 1) / EM_CHUNK;
+    for (int chunk = 0; chunk < n_chunks; chunk++) {
+        launch(1, 1, 1, 64, [&] { ransac_subsets_kernel(&n_pts, 1, iters, chunk * EM_CHUNK, EM_CHUNK, raw.data(), RNG_TABLE, subsets.data(), &st); });
+        launch(EM_CHUNK / 64, 1, 1, 64, [&] { em_solve_kernel<1>(q0.data(), q1.data(), &n_pts, cap, iters, chunk, subsets.data(), &st, models.data(), nmodels.data()); });
+        launch(EM_CHUNK * EM_MAX_MODELS, 1, 1, 64, [&] { em_vote_kernel(q0.data(), q1.data(), &n_pts, cap, iters, chunk, thr2, &st, models.data(), nmodels.data(), counts.data()); });
+        launch(1, 1, 1, 64, [&] { em_replay_kernel(&n_pts, 1, iters, prm.prob, chunk, models.data(), nmodels.data(), counts.data(), &st, bestE.data()); });
+    }
+    launch(1, 1, 1, 256, [&] { em_finish_kernel(q0.data(), q1.data(), &n_pts, cap, thr2, &st, bestE.data(), m.data(), &res); });
+    memcpy(E, res.E, sizeof(res.E));
+    memcpy(R, res.R, sizeof(res.R));
+    memcpy(t, res.t, sizeof(res.t));
+    memcpy(mask, m.data(), (size_t)n);
+    dbg4[0] = res.n_inliers;
+    dbg4[1] = res.n_good;
+    dbg4[2] = res.niters;
+    dbg4[3] = res.best;
+    return res.status;
+}
 
 // post.hip on the emulator: deleteUnmatchFeaturesCircle (stage A) + checkValidMatch / removeInvalidPoints (stage B) of one
 // frame's four tracking hops, then triangulation of the stage-B left / right points.

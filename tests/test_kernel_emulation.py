@@ -24,7 +24,8 @@ def kemu():
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
     deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
                                                "vo_linalg.h", "vo_epnp.h", "pnp.hip", "vo_p3p.h",
-                                               "vo_seqtail.h", "vo_integrate.h", "post.hip", "vo_tri.h")]
+                                               "vo_seqtail.h", "vo_integrate.h", "post.hip", "vo_tri.h",
+                                               "essential.hip", "vo_fivept.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -512,3 +513,36 @@ def test_whole_hot_path_on_the_cpu_emulator(kemu, orc, small_world, small_seq):
     assert grc == rc == 1 and np.array_equal(ginl, inl)
     assert tuple(gdbg[:4]) == tuple(int(x) for x in dbg[:4])
     assert np.abs(grv - rv).max() <= 1e-6 and np.abs(gtv - tv).max() <= 1e-6
+
+
+def ke_essential(lib, p0, p1, focal, pp, prob=0.999, threshold=1.0, max_iters=1000):
+    p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    n = len(p0)
+    E, R, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+    mask = np.zeros(max(n, 1), np.uint8)
+    dbg = (C.c_int * 4)()
+    lib.ke_essential.restype = C.c_int
+    rc = lib.ke_essential(vp(p0), vp(p1), n, C.c_double(focal), C.c_double(pp[0]), C.c_double(pp[1]), C.c_double(prob),
+                          C.c_double(threshold), max_iters, vp(E), vp(R), vp(t), vp(mask), dbg)
+    return rc, E, R, t, mask[:n].copy(), list(dbg)
+
+
+@pytest.mark.parametrize("n,outliers,seed", [(300, 0.0, 1), (400, 0.3, 2), (60, 0.5, 3), (5, 0.0, 5), (6, 0.0, 6)])
+def test_emulated_essential_chain_matches_oracle(kemu, orc, n, outliers, seed):
+    """essential.hip launch by launch on the CPU emulator (`mono_rotation`, SURVEY 8 row f4: five-point samples from the
+    wavefront subset kernel, Sampson votes, control-flow replay over the 128-sample chunks, mask + cheirality + selection)
+    against the oracle's findEssentialMat + recoverPose: E <= 1e-9, identical masks and cheirality counts, R / t <= 1e-9"""
+    from test_gpu_parity import _em_scene
+    p1, p2, R, t, F, PP = _em_scene(seed, n, outliers)
+    rc, E, Rg, tg, mask, dbg = ke_essential(kemu, p1, p2, F, PP)
+    ok, Eo, mo, odbg = orc.find_essential_mat(p1, p2, F, PP)
+    assert (rc == 1) == bool(ok)
+    if not ok:
+        return
+    assert np.abs(E - Eo).max() <= 1e-9
+    go, Ro, to, m2 = orc.recover_pose(Eo, p1, p2, F, PP, mo)
+    assert dbg[1] == go and np.array_equal(mask, m2)
+    assert np.abs(Rg - Ro).max() <= 1e-9 and np.abs(tg - to).max() <= 1e-9
+    if n >= 60:
+        assert np.abs(Rg - R).max() < 5e-3  # and it is the planted rotation

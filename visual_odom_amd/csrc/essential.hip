@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void em_finish_kernel(const double2 *__restric
     }
 }
 
+#ifndef VO_HOST_EMUL // (the CPU emulator of tests/host_check launches the kernels above itself)
 void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const int *n_pts, int cap, int n_frames,
                       const EmParams &prm, const EmBufs &eb, EmResult *results, bool crowded, hipStream_t stream)
 {
@@ -285,5 +286,6 @@ void launch_essential(const float2 *p0, const float2 *p1, size_t stride, const i
     hipLaunchKernelGGL(em_finish_kernel, dim3(n_frames), dim3(256), 0, stream, eb.q0, eb.q1, n_pts, cap, thr2,
                        eb.rstate, eb.bestE, eb.mask, results);
 }
+#endif // VO_HOST_EMUL
 
 } // namespace vo
