@@ -10,6 +10,7 @@
 #include "../../visual_odom_amd/csrc/post.hip"
 #include "../../visual_odom_amd/csrc/pnp.hip" // (brings vo_epnp.h, vo_svd_wide.h, vo_p3p.h; host launch code is compiled out)
 #include "../../visual_odom_amd/csrc/essential.hip"
+#include "../../visual_odom_amd/csrc/seq.hip"
 
 #include <vector>
 
@@ -157,8 +158,9 @@ int ke_post(const float *pts, const float *trk, const uint8_t *status, int n, in
 // (subsets -> EPnP -> votes -> control-flow replay) -> P3P -> winner / inlier mask / Levenberg-Marquardt refinement.
 // split = 1: the first chunk's EPnP as the four kernels small launches use (epnp_prepare / svd12_wave / epnp_approx /
 // epnp_select), 0: epnp_kernel<1>.  first_chunk: 128 or 64 (big launches).  Returns the PnpResult fields and the inliers.
-int ke_pnp_ransac(const float *xyz, const float *uv, int n, const float *K9, int iters, float reproj, double confidence,
-                  int split, int first_chunk, double *rvec, double *tvec, int32_t *inliers, int *n_inliers, int *dbg4)
+static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const float *K9, int iters, float reproj,
+                               double confidence, int split, int first_chunk, double *rvec, double *tvec, int32_t *inliers,
+                               int *n_inliers, int *dbg4, const vo::SeqTail &tail)
 {
     using namespace vo;
     const int cap = n > 8 ? n : 8;
@@ -200,7 +202,7 @@ int ke_pnp_ransac(const float *xyz, const float *uv, int n, const float *K9, int
         h0 += hn;
     }
     launch(1, 1, 1, 64, [&] { p3p_kernel(X.data(), U.data(), 0, &n_pts, cap, 1, prm, inl.data(), &res); });
-    launch(1, 1, 1, 256, [&] { select_refine_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, inl.data(), &res, SeqTail()); });
+    launch(1, 1, 1, 256, [&] { select_refine_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, inl.data(), &res, tail); });
     emu::dyn_shared() = nullptr;
     memcpy(rvec, res.rvec, sizeof(res.rvec));
     memcpy(tvec, res.tvec, sizeof(res.tvec));
@@ -212,6 +214,51 @@ int ke_pnp_ransac(const float *xyz, const float *uv, int n, const float *K9, int
     dbg4[2] = res.max_good;
     dbg4[3] = res.lm_iters;
     return res.status;
+}
+
+int ke_pnp_ransac(const float *xyz, const float *uv, int n, const float *K9, int iters, float reproj, double confidence,
+                  int split, int first_chunk, double *rvec, double *tvec, int32_t *inliers, int *n_inliers, int *dbg4)
+{
+    return pnp_ransac_emulated(xyz, uv, n, K9, iters, reproj, confidence, split, first_chunk, rvec, tvec, inliers, n_inliers,
+                               dbg4, vo::SeqTail());
+}
+
+// the same with the lock-step loop's tail: thread 0 of the refinement kernel goes on with the Euler gates +
+// integrateOdometryStereo + one trajectory row (vo_seqtail.h).  pose16: frame_pose in / out; rows27: the sequence's
+// trajectory rows so far (n_rows of them) + room for one more; info8 of the new row out
+int ke_pnp_ransac_tail(const float *xyz, const float *uv, int n, const float *K9, int split, double *pose16, double *rows27,
+                       int *n_rows, int max_steps, int *info8, int *dbg4)
+{
+    std::vector<vo::SeqFrameInfo> info((size_t)max_steps);
+    int active = 1;
+    vo::SeqTail tail;
+    tail.active = &active;
+    tail.pose = pose16;
+    tail.traj = rows27;
+    tail.info = info.data();
+    tail.n_rows = n_rows;
+    tail.max_steps = max_steps;
+    double rv[3], tv[3];
+    std::vector<int32_t> inl((size_t)(n > 1 ? n : 1));
+    int ninl = 0;
+    const int row = *n_rows;
+    const int rc = pnp_ransac_emulated(xyz, uv, n, K9, 500, 0.5f, (double)0.999f, split, 128, rv, tv, inl.data(), &ninl, dbg4, tail);
+    if (row < max_steps)
+        memcpy(info8, &info[row], sizeof(vo::SeqFrameInfo));
+    return rc;
+}
+
+// currentVOFeatures of the sequence after a frame (seq_carry_kernel): stage-B pointsLeft_t1 + the erase-compacted ages
+int ke_seq_carry(const float *outB, int nB, const int32_t *idxA, int nA, const int32_t *ages, int n_bucketed, int cap, int fcap,
+                 float *feat, int32_t *fages, int *n_tracked, int *n_ages)
+{
+    int active = 1, overflow = 0, n_rows_carry = 0;
+    std::vector<vo::SeqFrameInfo> info(1);
+    launch(1, 1, 1, 256, [&] {
+        vo::seq_carry_kernel(&active, (const float2 *)outB, &nB, idxA, &nA, ages, &n_bucketed, cap, fcap, (float2 *)feat, fages,
+                             n_tracked, &overflow, &n_rows_carry, n_ages, info.data(), 1);
+    });
+    return 0;
 }
 
 // The four-kernel EPnP of pnp.hip on the CPU: epnp5_prepare (one lane) -> the 12 x 12 SVD by a 128-thread workgroup

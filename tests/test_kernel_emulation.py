@@ -25,7 +25,7 @@ def kemu():
     deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
                                                "vo_linalg.h", "vo_epnp.h", "pnp.hip", "vo_p3p.h",
                                                "vo_seqtail.h", "vo_integrate.h", "post.hip", "vo_tri.h",
-                                               "essential.hip", "vo_fivept.h")]
+                                               "essential.hip", "vo_fivept.h", "seq.hip")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
@@ -546,3 +546,77 @@ def test_emulated_essential_chain_matches_oracle(kemu, orc, n, outliers, seed):
     assert np.abs(Rg - Ro).max() <= 1e-9 and np.abs(tg - to).max() <= 1e-9
     if n >= 60:
         assert np.abs(Rg - R).max() < 5e-3  # and it is the planted rotation
+
+
+def test_emulated_frame_loop_matches_the_oracle_chain(kemu, orc, small_world):
+    """The reference's frame loop (main.cpp:123-224: appendNewFeatures when fewer than 2000 features are carried, bucketing,
+    circularMatching, filters, the feature carry with its ages, triangulation, solvePnPRansac, Euler gates +
+    integrateOdometryStereo) for one sequence, every device-side step run from the product's kernel sources on the CPU
+    emulator in the order vo_seq_step launches them -- fast.hip, pyramid.hip, lk.hip, post.hip, seq.hip (carry), pnp.hip with
+    the integration tail of vo_seqtail.h -- against the oracle's functions chained the same way: carried features and ages
+    bit for bit after every frame, counts identical, frame_pose <= 1e-6."""
+    kemu.ke_set_fast_big(0)
+    n = 3
+    L, R, poses, _ = small_world.render_sequence(n)
+    P_l, P_r = small_world.proj_matrices()
+    K = np.ascontiguousarray(small_world.K(), np.float32)
+    h, w = L[0].shape
+    fpb, max_steps = 1, 8
+    feat, fages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)          # emulated currentVOFeatures
+    pose = np.eye(4).ravel().copy()
+    rows = np.zeros((max_steps, 27))
+    n_rows = C.c_int(0)
+    o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)        # the oracle's
+    o_pose, o_t = np.eye(4), np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    for k in range(1, n):
+        imgs = [L[k - 1], R[k - 1], L[k], R[k]]
+        # ---- emulated kernels
+        bp, ba = ke_detect(kemu, imgs[0], feat, fages, detect=int(len(feat) < 2000), bucket_size=h // 10, fpb=fpb)
+        r = ke_run(kemu, imgs, bp, full_chain=0)
+        post = ke_post(kemu, bp, r["trk"], r["status"], P_l, P_r)
+        cap = max(len(bp), 1)
+        outB = np.zeros((4, cap, 2), np.float32)
+        outB[:, :post["B"].shape[1]] = post["B"]
+        idxA = np.zeros(cap, np.int32)
+        idxA[:len(post["idxA"])] = post["idxA"]
+        ages_b = np.zeros(cap, np.int32)
+        ages_b[:len(ba)] = ba
+        fcap = 4096
+        feat_o, fages_o = np.zeros((fcap, 2), np.float32), np.zeros(fcap, np.int32)
+        ntr, nag = C.c_int(0), C.c_int(0)
+        kemu.ke_seq_carry(vp(outB), len(post["idxB"]), vp(idxA), len(post["idxA"]), vp(ages_b), len(bp), cap, fcap, vp(feat_o),
+                          vp(fages_o), C.byref(ntr), C.byref(nag))
+        feat, fages = feat_o[:ntr.value].copy(), fages_o[:nag.value].copy()
+        info = (C.c_int * 8)()
+        dbg = (C.c_int * 4)()
+        xyz = np.ascontiguousarray(post["xyz"], np.float32)
+        l1 = np.ascontiguousarray(post["B"][2], np.float32)
+        kemu.ke_pnp_ransac_tail.restype = C.c_int
+        # (the one-kernel EPnP: the four-kernel form gives the same bits -- test above -- and takes minutes to emulate)
+        rc_e = kemu.ke_pnp_ransac_tail(vp(xyz), vp(l1), len(xyz), vp(K), 0, pose.ctypes.data_as(dp), rows.ctypes.data_as(dp),
+                                       C.byref(n_rows), max_steps, info, dbg)
+        # ---- the oracle's chain (tests/test_gpu_sequences.py holds the GPU loop to the same one)
+        if len(o_pts) < 2000:
+            fast = orc.fast_detect(imgs[0], 20, True)
+            o_pts = np.vstack([o_pts, fast])
+            o_ages = np.concatenate([o_ages, np.zeros(len(fast), np.int32)])
+        obp, oba = orc.bucketing_features(h, w, o_pts, o_ages, h // 10, fpb)
+        cm = orc.circular_matching(*imgs, obp, ages=oba)
+        (pl0, pr0, pl1, pr1), _ = orc.check_valid_and_remove(cm["l0"], cm["r0"], cm["l1"], cm["r1"], cm["l0_ret"])
+        o_pts, o_ages = pl1, cm["ages"]
+        oxyz = orc.triangulate(P_l, P_r, pl0, pr0)
+        rc, rv, tv, inl, odbg = orc.solve_pnp_ransac(oxyz, pl1, K, tvec=o_t)
+        o_t = tv
+        Rm = orc.rodrigues(rv)
+        e = orc.rotation_matrix_to_euler(Rm)
+        if abs(e[1]) < 0.1 and abs(e[0]) < 0.1 and abs(e[2]) < 0.1:
+            o_pose, _ = orc.integrate_odometry_stereo(o_pose, Rm, tv)
+        # ---- compare
+        assert np.array_equal(bits(bp), bits(obp)) and np.array_equal(ba, oba), k
+        assert np.array_equal(bits(feat), bits(o_pts)) and np.array_equal(fages, o_ages), k
+        assert rc_e == rc and info[3] == len(inl) and info[6] == int(odbg[0]), k
+        assert np.abs(pose.reshape(4, 4) - o_pose).max() <= 1e-6, k
+        assert len(o_pts) > 100
+    assert n_rows.value == n - 1
+    assert np.abs(rows[n - 2, :12] - o_pose[:3].ravel()).max() <= 1e-6

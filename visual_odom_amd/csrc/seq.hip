@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void seq_ingest_kernel(const SeqIngest *__rest
     }
 }
 
+#ifndef VO_HOST_EMUL // (the CPU emulator of tests/host_check launches the kernels above itself)
 void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
                        hipStream_t stream)
 {
@@ -137,5 +138,7 @@ void launch_seq_carry(const int *active, const float2 *outB, const int *nB, cons
     hipLaunchKernelGGL(seq_carry_kernel, dim3(n_seq), dim3(256), 0, stream, active, outB, nB, idxA, nA, ages,
                        n_bucketed, cap, fcap, feat, fages, n_tracked, overflow, n_rows_carry, n_ages, info, max_steps);
 }
+
+#endif // VO_HOST_EMUL
 
 } // namespace vo
