@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
 // Why kernels and not phases of one kernel: the solver is ~35 k instructions of mostly straight-line code; a first version
 // with a DPP row per hypothesis inside ONE kernel (4 wavefronts per workgroup) ran its one-lane phases at HALF speed --
 // wavefronts of a CU that drift apart evict each other's loops from the instruction cache (465 us per hypothesis, no gain;
-// with one wavefront per workgroup 327 us, but only up to ~128 wavefronts per launch: gpurun_out/r3_23 ... r3_25).  Here the
+// with one wavefront per workgroup 327 us, but only up to ~128 wavefronts per launch: profiles/r03_pose_chain_experiments.md).  Here the
 // wide part is a kernel of a few hundred instructions, and the long code runs in a few wavefronts as before.
 // Costs several times the VALU time of the kernel above per hypothesis (12 of 64 lanes do useful work in the sweeps):
 // launch_pnp_ransac uses it while that is free.
@@ -973,7 +973,7 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
     // tracking kernels and what counts is how much of the chip the EPnP workgroups hold while they are resident (78 KB of
     // LDS and half a SIMD's registers each): 64 first, the rest only for the frames that ask for more (measured, 256-frame
     // batch, ms per step with 128 | 64 | 32: 12.84 | 12.55 | 13.83 at ~2000 points, 3.57 | 3.18 | 3.64 at 340; lock-step loop
-    // 256 sequences 4.03 | 4.04 | 4.23, 64 sequences 1.25 | 1.39 | 1.41 -- gpurun_out/r3_28).
+    // 256 sequences 4.03 | 4.04 | 4.23, 64 sequences 1.25 | 1.39 | 1.41 -- profiles/r03_pose_chain_experiments.md).
     int first_chunk = n_frames >= 128 ? 64 : RANSAC_CHUNK;
 #ifdef VO_DEV_VARIANTS
     static const int chunk_env = [] { const char *e = getenv("VO_RANSAC_CHUNK"); return e ? atoi(e) : 0; }();
