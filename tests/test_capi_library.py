@@ -142,3 +142,14 @@ def test_product_library_reads_no_environment_variable():
     # kernel symbols are mangled: epnp_kernel<4> / select_refine_kernel<4> = ...ILi4EE...
     assert b"epnp_kernelILi4EE" not in blob and b"select_refine_kernelILi4EE" not in blob
     assert b"epnp_kernelILi2EE" in blob and b"epnp_kernelILi1EE" in blob
+
+
+def test_product_library_exports_only_the_header():
+    """the developer build adds entry points of its own (vo_dev_*: time stamps of the pose kernels); the product library's
+    vo_* exports are exactly the functions include/vo_hip.h declares"""
+    import subprocess
+    from visual_odom_amd import build
+    so = build.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("vo_")}
+    assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
