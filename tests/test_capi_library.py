@@ -142,6 +142,9 @@ def test_product_library_reads_no_environment_variable():
     # kernel symbols are mangled: epnp_kernel<4> / select_refine_kernel<4> = ...ILi4EE...
     assert b"epnp_kernelILi4EE" not in blob and b"select_refine_kernelILi4EE" not in blob
     assert b"epnp_kernelILi2EE" in blob and b"epnp_kernelILi1EE" in blob
+    # the small-launch form of the pose solve is part of the product (pnp.hip, vo_svd_wide.h)
+    for name in (b"epnp_prepare_kernel", b"svd12_wave_kernel", b"epnp_approx_kernel", b"epnp_select_kernel"):
+        assert name in blob, name
 
 
 def test_product_library_exports_only_the_header():
