@@ -289,7 +289,7 @@ def main(argv=None):
     replay_leg = args.mode == "batch" and not args.no_replay_leg and args.workload.startswith("kitti") and \
         not args.mono_rotation and args.frames >= 256
     config_legs = default_run and not args.no_configs and world_size == 1
-    kept = [] if (replay_leg or config_legs) else None
+    kept = [] if (replay_leg or config_legs or (world_size > 1 and default_run and not args.no_configs)) else None
     if args.mode == "sequences":
         out = run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas)
     else:
@@ -331,6 +331,8 @@ def main(argv=None):
 
         leg("config2_lk_only", 2, kept[0], stages="lk")
         leg("reference_default_374", 3, kept[0], workload="kitti374", steps=20)
+        if rank == 0:
+            legs.append(latency_leg(kept[0]))
         kept[0].close()
         kept[0] = None
         from visual_odom_amd import _lib
@@ -349,6 +351,24 @@ def main(argv=None):
                              "points_per_frame": er["points_per_frame"], "validated_frames": er["validated_frames"],
                              "schedule": er["schedule"], "stage_ms": er["stage_ms"], "roofline": er["roofline"]})
             out["configs"] = legs
+    if world_size > 1 and default_run and not args.no_configs:
+        # BASELINE config 5 as written -- one sequence per GPU, exact replay of the reference's frame loop -- next to the
+        # weak-scaled batch headline: every rank runs ONE sequence of its own through the lock-step loop (`--mode sequences
+        # --seqs 1`), per-GPU frames/s gathered, aggregate = frames of all ranks / max-over-ranks time
+        import copy
+        a5 = copy.copy(args)
+        a5.mode, a5.seqs, a5.ring, a5.ingest, a5.no_cpu_baseline, a5.workload = "sequences", 1, 3, "device", True, "kitti374"
+        a5.steps, a5.warmup, a5.validate = 200, 10, min(args.validate, 2)
+        r5 = run_sequences(a5, rank, world_size, local_dev, dev, dist, barrier, torch, replicas,
+                           ctx=kept[0] if kept else None, per_rank=True)
+        if rank == 0 and out is not None and r5 is not None:
+            out.setdefault("configs", []).append({
+                "name": "config5_one_sequence_per_gpu", "baseline_config": 5, "workload": r5["config"]["workload"],
+                "mode": r5["config"]["mode"], "stages": "detect+full", "value": r5["value"], "unit": r5["unit"],
+                "per_gpu_value": r5["per_rank_value"], "n_gpus": N_GPUS, "ranks": world_size, "sequences_per_gpu": 1,
+                "ms_per_step": r5["ms_per_step"], "steps": r5["steps"], "warmup": r5["warmup"],
+                "points_per_frame": r5["config"]["points_per_frame"], "validated_frames": r5["validated_frames"],
+                "schedule": r5["config"]["schedule"], "stage_ms": r5["config"]["stage_ms"], "roofline": r5["roofline"]})
     if kept and kept[0] is not None:
         kept[0].close()
     if rank == 0:
@@ -456,7 +476,14 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": measured_traffic(args.workload, B) if profiled_config else None,
-                         # profile-derived, IMPORTED from the committed PMC pass of this same command, not measured in this run
+                         "traffic_source": ("profiles/lk_traffic.json: rocprofv3 --pmc passes of this command, imported, not "
+                                            "measured in this run") if profiled_config and measured_traffic(args.workload, B)
+                         else "not profiled for this configuration",
+                         # what binds the kernel: VALU issue.  valu_issue_frac = issue-cost bound / measured = (the launch's VALU
+                         # instructions -- SQ_INSTS_VALU of the imported PMC pass, per feature x this launch's features -- x the
+                         # 4.05 SIMD-cycles per wave64 instruction its opcode mix costs by the micro-benchmark table) / (1024
+                         # SIMDs x 2.4 GHz x THIS run's launch time); 1.0 = every SIMD issues a VALU instruction whenever it can
+                         "valu_issue_frac": valu_issue_frac(args.workload, B, pts_per_launch, lk_ms) if profiled_config else None,
                          "valu_issue_imported": measured_issue(args.workload, B) if profiled_config else None,
                          "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
                          "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1),
@@ -472,7 +499,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     return out
 
 
-def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=None):
+def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=None, per_rank=False):
     """exact replay: S sequences x 1 frame per step, feature state carried on the device"""
     from visual_odom_amd import _lib
     S, Q = args.seqs, args.quads
@@ -531,6 +558,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     ctx.seq_sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_fps = replicas.gather_values(dist, S * K / elapsed, dev) if per_rank else None
     elapsed, frames_total = replicas.aggregate(dist, elapsed, S * K, dev)
     if dist is not None:
         dist.barrier()
@@ -555,7 +583,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": N_GPUS, "ranks": world_size, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 LK (f32 2x2 solve), f64 pose solve", "data": "synthetic",
-            "validated_frames": validated,
+            "validated_frames": validated, "per_rank_value": rank_fps,
             "config": {"workload": WORKLOADS[args.workload][4],
                        "mode": "sequences (exact replay of the reference frame loop: FAST + bucketing from the carried "
                                "features, state on the device, %d sequences x 1 frame per step, ring %d)" % (S, args.ring),
@@ -571,7 +599,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                        "model_bytes_per_frame": frame_bytes},
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
+                         "traffic_source": "not profiled for this configuration", "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
                          "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1)},
         }
         if not args.no_cpu_baseline and world_size == 1:
@@ -579,6 +607,66 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                                                per_bucket=per_bucket)
     if own_ctx:
         ctx.close()
+    return out
+
+
+def latency_leg(ctx, n_calls=100, n_steps=400):
+    """LATENCY MODE of the drop-in boundary, measured by the driver's own run: the reference's real use is
+    one sequence, one synchronous call per frame (main.cpp:123-224).  HOST images in, host results out, one frame in flight --
+    PCIe-inclusive, never `value`: (a) vo_track_frame per call at the ~2000-point and the reference-default load; (b) the whole
+    frame loop for ONE sequence through the lock-step API (push pair -> step, nothing read back until the end: the pose solve
+    of frame k runs under detection + tracking of frame k + 1)."""
+    from visual_odom_amd import synth
+    world, lefts, rights, pts6, _ = build_inputs("kitti2000", 8, 20260925)
+    _, _, _, pts1, _ = build_inputs("kitti374", 8, 20260925)
+    P_l, P_r = world.proj_matrices()
+    w, h = world.w, world.h
+    ctx.set_params(lk_max_level=3, mono_rotation=0)
+    ctx.set_schedule()
+    out = {"name": "latency_drop_in", "baseline_config": 3, "workload": WORKLOADS["kitti2000"][4],
+           "inputs": "pageable host images in, host results out, one frame in flight (PCIe-inclusive; never `value`)",
+           "unit": "ms per vo_track_frame call"}
+    order = [0, 1, 2, 3, 4, 3, 2, 1]
+    for tag, pts in (("2000", pts6), ("374", pts1)):
+        def call(i):
+            k = i % 4
+            return ctx.track_frame(lefts[k], rights[k], lefts[k + 1], rights[k + 1], pts[k], P_l, P_r)
+        for i in range(12):  # (the first call of a shape probes the schedule)
+            call(i)
+        t = []
+        for i in range(n_calls):
+            t0 = time.perf_counter()
+            r = call(i)
+            t.append(time.perf_counter() - t0)
+        t = np.array(t) * 1e3
+        out["track_frame_ms_%s" % tag] = {"median": float(np.median(t)), "mean": float(t.mean()), "p95": float(np.percentile(t, 95)),
+                                          "points": int(len(pts[0])), "calls": n_calls, "inliers_last": int(len(r["inliers"]))}
+    for tag, fpb in (("2000", 6), ("374", 1)):
+        ctx.batch_set_detect_params(features_per_bucket=fpb)
+        ctx.seq_configure(1, w, h, 3, n_steps + 64)
+        ctx.batch_set_projection(P_l, P_r)
+        for i in range(24):
+            ctx.seq_push_pair(0, lefts[order[i % 8]], rights[order[i % 8]])
+            ctx.seq_step()
+        extra = 0
+        while ctx.get_schedule()["settling"] and extra < 280:
+            ctx.seq_push_pair(0, lefts[order[(24 + extra) % 8]], rights[order[(24 + extra) % 8]])
+            ctx.seq_step()
+            extra += 1
+        ctx.seq_sync()
+        ctx.seq_reset(-1)
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            ctx.seq_push_pair(0, lefts[order[i % 8]], rights[order[i % 8]])
+            ctx.seq_step()
+        ctx.seq_sync()
+        dt = time.perf_counter() - t0
+        rows, info = ctx.seq_get_trajectory(0)
+        out["one_sequence_pipelined_%s" % tag] = {"frames_per_s": n_steps / dt, "ms_per_frame": 1e3 * dt / n_steps,
+                                                   "frames": int(len(rows)), "points_per_frame": float(np.mean(info[:, 0])),
+                                                   "schedule": ctx.get_schedule()}
+    ctx.batch_set_detect_params()
+    out["value"] = out["track_frame_ms_2000"]["median"]
     return out
 
 
@@ -636,6 +724,24 @@ def measured_issue(workload, frames):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def valu_issue_frac(workload, frames, points_per_launch, launch_ms):
+    """measured / issue-bound: VALU instructions per feature and SIMD-cycles per instruction come from the committed PMC pass
+    (profiles/lk_issue.json), the launch time from THIS run's HIP events; None without a matching pass"""
+    rec = measured_issue(workload, frames)
+    if not rec or launch_ms <= 0:
+        return None
+    try:
+        per_feature = float(rec["valu_instructions_per_feature"])
+        # the issue COST of the kernel's instruction mix from the micro-benchmark table (profiles/r02_valu_issue_cost.txt via
+        # tools/isa_histogram.py), not the cycles the same PMC pass measured -- that ratio would be 1 by construction
+        cyc = float(rec["issue_cost_bound_cycles_per_valu_instruction"])
+        clock_hz = float(rec.get("shader_clock_mhz", 2400.0)) * 1e6
+    except (KeyError, TypeError, ValueError):
+        return None
+    issue_s = per_feature * points_per_launch * cyc / (1024.0 * clock_hz)
+    return issue_s / (launch_ms * 1e-3)
 
 
 def measured_traffic(workload, frames):
@@ -704,7 +810,29 @@ def cpu_baseline(lefts, rights, pts, world, n_frames, stages, per_bucket=1):
     best_t = min(med, key=med.get)
     best = timed(best_t, n_frames, 10.0)
     single = timed(1, min(n_frames, 2), 6.0)
-    return {"value": best, "unit": "frames/s", "cores": best_t, "kind": "port",
+    # the same port built the way a tuned CPU build would be (-O3 -march=native) with OpenCV's x86 accumulation order in the LK
+    # sums (accum_mode 2, oracle/vo_oracle.h) -- still the scalar restatement, but neither -O2 nor exact-integer sums handicap it
+    native = None
+    try:
+        nat = orc.native_variant()
+        if nat is not None:
+            def one_native(k, threads):
+                r = nat.circular_matching(lefts[k], rights[k], lefts[k + 1], rights[k + 1], pts[k], nthreads=threads, accum_mode=2)
+                (l0, r0, l1, r1), _ = orc.check_valid_and_remove(r["l0"], r["r0"], r["l1"], r["r1"], r["l0_ret"])
+                if stages != "lk" and len(l0) >= 5:
+                    nat.solve_pnp_ransac(nat.triangulate(P_l, P_r, l0, r0), l1, K)
+            one_native(0, best_t)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 6.0:
+                for k in range(n_frames):
+                    one_native(k, best_t)
+                n += n_frames
+            native = {"value": n / (time.perf_counter() - t0), "unit": "frames/s", "cores": best_t, "kind": "port",
+                      "build": "-O3 -march=native, LK sums in OpenCV's x86 SIMD accumulation order (accum_mode 2)"}
+    except Exception as e:  # the baseline never fails the benchmark
+        native = {"error": str(e)[:200]}
+    return {"value": best, "unit": "frames/s", "cores": best_t, "kind": "port", "native_build": native,
             "single_thread": {"value": single, "unit": "frames/s", "cores": 1},
             "width_sweep_s_per_frame": {str(t): med[t] for t in widths},
             "sample": "passes over %d frame quadruples of the same workload for ~10 s (best width) and ~6 s (1 thread); "

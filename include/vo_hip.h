@@ -114,9 +114,11 @@ int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
  * never depend on any of it).  The synchronous drop-in call vo_track_frame compares its candidates by the latency of
  * a run, everything else by steady-state throughput. */
 int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
-/* what the last probe run by this context measured: *n (<= 8) candidates and their steady-state milliseconds per run;
- * real8[i] (optional) = 1 where the figure was re-measured over real steps of the lock-step loop */
-int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands8, float *ms8, int *real8, int *n);
+/* what the last probe run by this context measured: *n (<= VO_PROBE_LOG_MAX) candidates and their steady-state
+ * milliseconds per run (the arrays hold VO_PROBE_LOG_MAX entries); real[i] (optional) = 1 where the figure was re-measured
+ * over real steps of the lock-step loop */
+#define VO_PROBE_LOG_MAX 12
+int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands, float *ms, int *real, int *n);
 int vo_get_params(const vo_ctx *ctx, vo_params *p);
 
 /* ------------------------------------------------------------------------------------------
@@ -253,6 +255,9 @@ int vo_batch_get_tracks(vo_ctx *ctx, int frame, float *r0, float *r1, float *l1,
                         uint8_t *status4, int n);
 int vo_batch_get_filtered(vo_ctx *ctx, int frame, float *l0, float *r0, float *l1, float *r1, float *xyz,
                           int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ);
+/* rvec / tvec / R are pure outputs here (a batch frame has no caller-side pose): a four-point frame whose P3P has no
+ * solution (status 0, lm_iters -1) returns rvec = tvec = 0 and R = identity -- the reference's zeroed rvec,
+ * visualOdometry.cpp:162 -- whereas the drop-in calls vo_pnp_ransac / vo_track_frame leave their rvec_io / tvec_io untouched */
 int vo_batch_get_pose(vo_ctx *ctx, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
                       int *n_inliers, int *status, int32_t *dbg4 /* niters, best, max_good, lm_iters */);
 /* with vo_params.mono_rotation the R of vo_batch_get_pose / vo_track_frame is recoverPose's rotation (left
@@ -300,7 +305,9 @@ int vo_seq_configure(vo_ctx *ctx, int n_seq, int w, int h, int ring, int max_ste
  * seq < 0 also rewinds the loop's step counter (all max_steps rows of every sequence are available again) and clears
  * the "a step failed half-way" state after which every vo_seq_push_pair / vo_seq_step returns VO_ERR_STATE.
  * vo_seq_step refuses (VO_ERR_STATE, the pairs pushed for that step are dropped) when an active sequence has used up
- * its max_steps rows; vo_seq_reset(seq) gives them back. */
+ * its max_steps rows; vo_seq_reset(seq) gives them back and the SAME pairs can be pushed again.  A caller that goes on with
+ * later pairs instead has paused every sequence of the dropped step: its next pair restarts the image pair and the frame
+ * after it carries VO_SEQ_F_GAP (it is never matched against the pair from two pushes ago). */
 int vo_seq_reset(vo_ctx *ctx, int seq);
 /* the next stereo pair of sequence `seq` (8-bit gray, byte stride).  host_pinned = 0: pageable memory, staged
  * through the library's pinned buffers (the call returns when the images have been copied out of the caller's
@@ -327,7 +334,7 @@ int vo_seq_get_trajectory(vo_ctx *ctx, int seq, int first, int count, double *ro
 /* HIP-event duration of the last `n` steps' stages is available through vo_batch_slot_times: step k records
  * ring slot k % VO_EVENT_SLOTS */
 
-/* one pyramid level of one image back to the host (tests): out must hold w_l*h_l bytes */
+/* one pyramid level of one image back to the host (tests): out must hold w_l*h_l bytes (NULL: only the size is returned) */
 int vo_batch_get_pyramid_level(vo_ctx *ctx, int image_idx, int level, uint8_t *out, int *w_l, int *h_l);
 
 /* algorithmic HBM bytes of one frame at the current configuration:

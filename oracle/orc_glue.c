@@ -13,6 +13,12 @@
 #include <math.h>
 #include <string.h>
 
+/* accumulation order of the LK sums inside orc_circular_matching (vo_oracle.h: 0 exact, the checker's default; 2 / 3 OpenCV's
+ * x86 order -- bench.py's native CPU baseline times mode 2) */
+static int g_glue_accum_mode = 0;
+void orc_set_circular_matching_accum_mode(int mode) { g_glue_accum_mode = mode < 0 || mode > 3 ? 0 : mode; }
+
+
 /* feature.cpp:118-148 */
 int orc_circular_matching(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
                           const uint8_t *r1, int w, int h, float *p0, int n, float *p1, float *p2,
@@ -35,13 +41,13 @@ int orc_circular_matching_lvl(const uint8_t *l0, const uint8_t *r0, const uint8_
     uint8_t *s0 = st, *s1 = st + n, *s2 = st + 2 * n, *s3 = st + 3 * n;
     long long it = 0;
     /* feature.cpp:136-139: win 21, maxLevel 3, COUNT+EPS(30, 0.01), flags 0, minEig 0.001 */
-    orc_calc_optical_flow_pyr_lk(l0, r0, w, h, p0, n, p1, s0, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(l0, r0, w, h, p0, n, p1, s0, err, 21, max_level, 30, 0.01, 0.001, g_glue_accum_mode, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(r0, r1, w, h, p1, n, p2, s1, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(r0, r1, w, h, p1, n, p2, s1, err, 21, max_level, 30, 0.01, 0.001, g_glue_accum_mode, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(r1, l1, w, h, p2, n, p3, s2, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(r1, l1, w, h, p2, n, p3, s2, err, 21, max_level, 30, 0.01, 0.001, g_glue_accum_mode, nthreads);
     it += orc_lk_last_iteration_count();
-    orc_calc_optical_flow_pyr_lk(l1, l0, w, h, p3, n, p0r, s3, err, 21, max_level, 30, 0.01, 0.001, 0, nthreads);
+    orc_calc_optical_flow_pyr_lk(l1, l0, w, h, p3, n, p0r, s3, err, 21, max_level, 30, 0.01, 0.001, g_glue_accum_mode, nthreads);
     it += orc_lk_last_iteration_count();
     (void)it;
     if (status4)

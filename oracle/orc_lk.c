@@ -258,6 +258,9 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
         const int stepI = I->stride, stepJ = J->stride;
         long long iA11 = 0, iA12 = 0, iA22 = 0;
         float fA11 = 0, fA12 = 0, fA22 = 0;
+        /* accum_mode 2 / 3: the four f32 lanes of OpenCV's v_float32x4 accumulators qA11 / qA12 / qA22 (see the header) */
+        float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0};
+        const int simd_cols = accum_mode >= 2 ? (win / 8) * 8 : 0; /* columns the 8-pixel SIMD loop covers (16 of 21) */
         for (int y = 0; y < win; y++) {
             const uint8_t *src = I->img + (ptrdiff_t)(y + ipy) * stepI + ipx;
             const int16_t *dsrc = deriv0 + (ptrdiff_t)(y + ipy) * dstride + ipx * 2;
@@ -279,12 +282,32 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
                     iA11 += (long long)ixval * ixval;
                     iA12 += (long long)ixval * iyval;
                     iA22 += (long long)iyval * iyval;
+                } else if (x < simd_cols) {
+                    /* lane = x mod 4; fx, fy = v_cvt_f32 of the int16 values; qA = v_muladd(f, f, qA): multiply and add
+                     * rounded separately (mode 2, SSE2 / SSE3 baseline) or fused (mode 3, a CV_FMA3 baseline) */
+                    const float fx = (float)ixval, fy = (float)iyval;
+                    const int l = x & 3;
+                    if (accum_mode == 3) {
+                        qA22[l] = fmaf(fy, fy, qA22[l]);
+                        qA12[l] = fmaf(fx, fy, qA12[l]);
+                        qA11[l] = fmaf(fx, fx, qA11[l]);
+                    } else {
+                        volatile float p22 = fy * fy, p12 = fx * fy, p11 = fx * fx; /* (rounded products) */
+                        qA22[l] += p22;
+                        qA12[l] += p12;
+                        qA11[l] += p11;
+                    }
                 } else {
                     fA11 += (float)(ixval * ixval);
                     fA12 += (float)(ixval * iyval);
                     fA22 += (float)(iyval * iyval);
                 }
             }
+        }
+        if (accum_mode >= 2) { /* iA += v_reduce_sum(qA): (q0 + q2) + (q1 + q3) */
+            fA11 += (qA11[0] + qA11[2]) + (qA11[1] + qA11[3]);
+            fA12 += (qA12[0] + qA12[2]) + (qA12[1] + qA12[3]);
+            fA22 += (qA22[0] + qA22[2]) + (qA22[1] + qA22[3]);
         }
         float A11, A12, A22;
         if (accum_mode == 0) {
@@ -329,9 +352,12 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             long long ib1 = 0, ib2 = 0;
             float fb1 = 0, fb2 = 0;
+            /* accum_mode 2 / 3: lanes 0 / 2 (x part) and 1 / 3 (y part) of qb0 and qb1 */
+            float qb0x[2] = {0, 0}, qb0y[2] = {0, 0}, qb1x[2] = {0, 0}, qb1y[2] = {0, 0};
             for (int y = 0; y < win; y++) {
                 const uint8_t *Jptr = J->img + (ptrdiff_t)(y + iny) * stepJ + inx;
                 const int16_t *Iptr = IWin + y * win, *dIptr = dIWin + y * win * 2;
+                int dblk[8]; /* the eight residuals of an 8-pixel SIMD block */
                 for (int x = 0; x < win; x++, dIptr += 2) {
                     int diff = DESCALE(Jptr[x] * iw00 + Jptr[x + 1] * iw01 + Jptr[x + stepJ] * iw10 +
                                            Jptr[x + stepJ + 1] * iw11,
@@ -340,11 +366,32 @@ static void lk_level(const OrcLevel *I, const OrcLevel *J, const int16_t *derivB
                     if (accum_mode == 0) {
                         ib1 += (long long)diff * dIptr[0];
                         ib2 += (long long)diff * dIptr[1];
+                    } else if (x < simd_cols) {
+                        /* v_pack saturates the residual to int16 before the products; then pixels (k, k + 4) of the block
+                         * are paired by v_dotprod (_mm_madd_epi16: exact int32 pair sum), converted to f32 and added:
+                         * qb0 lanes <- pairs (0, 4) and (1, 5), qb1 lanes <- pairs (2, 6) and (3, 7) */
+                        diff = diff > 32767 ? 32767 : diff < -32768 ? -32768 : diff;
+                        dblk[x & 7] = diff;
+                        if ((x & 7) == 7) {
+                            const int16_t *dI = dIptr - 14; /* (Ix, Iy) of pixel 0 of the block */
+                            for (int k = 0; k < 4; k++) {
+                                const int sx = dblk[k] * dI[2 * k] + dblk[k + 4] * dI[2 * (k + 4)];
+                                const int sy = dblk[k] * dI[2 * k + 1] + dblk[k + 4] * dI[2 * (k + 4) + 1];
+                                float *qx = k < 2 ? &qb0x[k] : &qb1x[k - 2], *qy = k < 2 ? &qb0y[k] : &qb1y[k - 2];
+                                *qx += (float)sx;
+                                *qy += (float)sy;
+                            }
+                        }
                     } else {
                         fb1 += (float)(diff * dIptr[0]);
                         fb2 += (float)(diff * dIptr[1]);
                     }
                 }
+            }
+            if (accum_mode >= 2) {
+                /* v_recombine(v_interleave_pairs(qb0 + qb1), 0, qf0, qf1); ib1 += v_reduce_sum(qf0) = (s0 + 0) + (s2 + 0) */
+                fb1 += (qb0x[0] + qb1x[0]) + (qb0x[1] + qb1x[1]);
+                fb2 += (qb0y[0] + qb1y[0]) + (qb0y[1] + qb1y[1]);
             }
             float b1, b2;
             if (accum_mode == 0) {

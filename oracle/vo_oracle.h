@@ -38,8 +38,20 @@ void orc_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst);
 void orc_scharr(const uint8_t *src, int w, int h, int16_t *dst);
 
 /* ---------- cv::calcOpticalFlowPyrLK (feature.cpp:136-139 call sites) ---------------- */
-/* accum_mode: 0 = exact int64 accumulators (determinism recipe, default);
- *             1 = float accumulators in scalar pixel order (x86 non-SIMD OpenCV build) */
+/* accum_mode: how the 441 products of A11 / A12 / A22 and of b1 / b2 are summed (everything else is identical):
+ *   0 = exact int64 accumulators, rounded to f32 once (determinism recipe, default: what the HIP kernel computes; OpenCV's
+ *       NEON builds also accumulate in integers)
+ *   1 = f32 accumulators in scalar pixel order (an x86 build without SIMD, e.g. -DCV_ENABLE_INTRINSICS=OFF)
+ *   2 = OpenCV 4.5.x's universal-intrinsics path on x86 (lkpyramid.cpp `#if CV_SIMD128 && !CV_NEON`, v_int16x8 /
+ *       v_float32x4 -- 128 bits wide in EVERY x86 build, the file has no AVX2 dispatch) [upstream-memory]: per window row the
+ *       first 16 columns go through two 8-pixel blocks -- A: lane (x mod 4) of three v_float32x4 accumulators gets
+ *       v_muladd(f, f, q) with f = (float)int16; b: the int16-saturated residuals of pixels (k, k + 4) of a block are paired
+ *       by v_dotprod (exact int32), converted to f32 and added to lanes of qb0 (k = 0, 1) / qb1 (k = 2, 3) -- and columns
+ *       16 .. 20 through the scalar tail into an f32 scalar; at the end scalar += v_reduce_sum(q) = (q0 + q2) + (q1 + q3).
+ *       v_muladd WITHOUT fused multiply-add: the default x86-64 baseline (SSE3) of the distro packages the reference's CI
+ *       installs (.github/workflows/cmake.yml:20,25)
+ *   3 = the same with v_muladd = _mm_fmadd_ps: a build whose CPU_BASELINE includes FMA3 / AVX2 (only the A sums differ)
+ * tools/opencv_crosscheck.py reports which mode a real cv2 matches bit for bit. */
 int orc_calc_optical_flow_pyr_lk(const uint8_t *prev, const uint8_t *next, int w, int h,
                                  const float *prev_pts, int n, float *next_pts,
                                  uint8_t *status, float *err,
@@ -50,6 +62,8 @@ long long orc_lk_last_iteration_count(void);
 /* hist101[k] = (point, level) solves that ran k inner iterations since the last reset */
 void orc_lk_iteration_histogram(long long *hist101, int reset);
 
+/* accum_mode of the four LK calls inside orc_circular_matching* (default 0) */
+void orc_set_circular_matching_accum_mode(int mode);
 /* ---------- feature.cpp:76-148 : circularMatching + deleteUnmatchFeaturesCircle ------- */
 /* pts_l0 [n*2] in; outputs sized n*2 floats each; ages [n_ages] in/out (ages += 1, then
  * compacted together with the points, feature.cpp:83-86,111).  Returns survivors M.

@@ -67,7 +67,7 @@ def host_check():
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhost_check.so")
-    deps = [src] + [os.path.join(ROOT, "visual_odom_amd", "csrc", f) for f in ("vo_linalg.h", "vo_epnp.h", "vo_tri.h", "vo_lkmath.h", "vo_fivept.h", "vo_p3p.h")]
+    deps = [src] + [os.path.join(ROOT, "visual_odom_amd", "csrc", f) for f in ("vo_linalg.h", "vo_epnp.h", "vo_tri.h", "vo_lkmath.h", "vo_fivept.h", "vo_p3p.h", "vo_math.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     return ctypes.CDLL(so)

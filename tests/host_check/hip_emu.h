@@ -223,6 +223,7 @@ inline int dpp_source(int lane, int ctrl)
 #define blockIdx (emu::bidx())
 #define blockDim (emu::bdim())
 
+static inline void __threadfence() {} // (one host thread runs every work item: stores are visible at once)
 static inline void __syncthreads() { emu::barrier(); } // a real barrier: wavefronts of a block may pass different numbers of yields
 static inline int __float2int_rn(float v) { return (int)lrintf(v); }
 static inline int __float_as_int(float v)

@@ -22,6 +22,13 @@ int hc_p3p4(const float *xyz4, const float *uv4, const float *K, double *rvec, d
     return vo::p3p4_solve(xyz4, uv4, K, rvec, tvec);
 }
 int hc_p3p_deg4(double a, double b, double c, double d, double e, double *x) { return vo::p3p_deg4(a, b, c, d, e, x); }
+// vo_math.h: what == 0 cbrt, 1 acos, 2 cos, 3 sin, 4 the Levenberg-Marquardt lambda table over n values
+void hc_math(int what, const double *x, int n, double *y)
+{
+    for (int i = 0; i < n; i++)
+        y[i] = what == 0 ? vo::vo_cbrt(x[i]) : what == 1 ? vo::vo_acos(x[i]) : what == 2 ? vo::vo_cos(x[i])
+               : what == 3 ? vo::vo_sin(x[i]) : vo::vo_lm_lambda((int)x[i]);
+}
 void hc_rodrigues_v2m(const double *r, double *R, double *J) { vo::rodrigues_v2m(r, R, J); }
 void hc_rodrigues_m2v(const double *R, double *r) { vo::rodrigues_m2v(R, r); }
 void hc_triangulate(const float *Pl, const float *Pr, const float *pl, const float *pr, int n, float *xyz)

@@ -58,13 +58,19 @@ void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
                 emu::run_block(threads, x, y, z, body);
 }
 
-int g_pyr_lds = 0; // ke_set_pyr_lds: which pyr_down kernel build_pyramids emulates
+int g_pyr_lds = 0; // ke_set_pyr_lds: which pyramid chain build_pyramids emulates (0 / 1: three kernels with the column-walk / LDS pyr_down; 2: fused passes)
 
 // the PYRAMID stage of capi.hip's run_stages with the emulated kernels
 void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 {
     using namespace vo;
-    // the order of capi.hip: level 0's border + Scharr image, the pyr_down chain, then the other levels
+    if (g_pyr_lds == 2) { // the fused passes (round 4; what launch_pyramid_fused enqueues): one launch per level
+        const PassPlan pp = pass_plan(p.levels, p.lw, p.lh, p.ls);
+        for (int l = 0; l < p.levels; l++)
+            launch((unsigned)(pp.n_items[l] + 255) / 256, n_img, 1, 256, [&] { pyr_pass_kernel(d_imgs, l, p.levels, pp); });
+        return;
+    }
+    // the three-kernel chain: level 0's border + Scharr image, the pyr_down chain, then the other levels
     for (int first = 0, last = 1; first < p.levels; first = last, last = p.levels) {
         if (first == 1)
             for (int l = 0; l + 1 < p.levels; l++)
@@ -179,7 +185,7 @@ static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const f
     std::vector<int32_t> subsets((size_t)iters * 5), inl((size_t)cap);
     std::vector<double> models((size_t)iters * 6), ws((size_t)VO_EPNP_WS_HYPS * VO_EPNP_WS_DOUBLES);
     std::vector<int> counts((size_t)iters);
-    std::vector<double> lds((size_t)(144 + 12) * 64);
+    std::vector<double> lds((size_t)(144 + 12) * 64), gws((size_t)VO_EPNP_GWS_BLOCKS * VO_EPNP_UT_DOUBLES * 64);
     RansacState st;
     PnpResult res;
     memset(&res, 0, sizeof(res));
@@ -189,13 +195,17 @@ static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const f
         const int hn = h0 == 0 ? std::min(first_chunk, iters) : iters - h0;
         const unsigned eg = (unsigned)(hn + 63) / 64;
         launch(1, 1, 1, 64, [&] { ransac_subsets_kernel(&n_pts, 1, iters, h0, hn, raw.data(), RNG_TABLE, subsets.data(), &st); });
-        if (split && h0 == 0) {
+        if (split == 1 && h0 == 0) {
             launch(eg, 1, 1, 64, [&] { epnp_prepare_kernel(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, ws.data()); });
             launch((unsigned)hn, 1, 1, 128, [&] { svd12_wave_kernel(&n_pts, prm, &st, h0, hn, ws.data()); });
             launch(eg, 1, 3, 64, [&] { epnp_approx_kernel(&n_pts, prm, &st, h0, hn, ws.data()); });
             launch(eg, 1, 1, 64, [&] { epnp_select_kernel(&n_pts, prm, &st, h0, hn, ws.data(), models.data()); });
         } else {
-            launch(eg, 1, 1, 64, [&] { epnp_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data()); });
+            // split == 2: the slim form's first chunk -- the 12 x 12 matrices in the global workspace instead of LDS
+            if (split == 2 && h0 == 0 && eg <= (unsigned)VO_EPNP_GWS_BLOCKS)
+                launch(eg, 1, 1, 64, [&] { epnp_kernel<1, true>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data(), gws.data()); });
+            else
+                launch(eg, 1, 1, 64, [&] { epnp_kernel<1, false>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data(), nullptr); });
         }
         launch((unsigned)hn, 1, 1, 64, [&] { vote_kernel(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, h0, counts.data()); });
         launch(1, 1, 1, 64, [&] { ransac_replay_kernel(&n_pts, 1, prm, h0 + hn, counts.data(), &st); });

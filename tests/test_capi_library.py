@@ -140,8 +140,9 @@ def test_product_library_reads_no_environment_variable():
         assert name not in blob, name
     assert b"lk_circular_kernel" in blob and b"p3p_kernel" in blob
     # kernel symbols are mangled: epnp_kernel<4> / select_refine_kernel<4> = ...ILi4EE...
-    assert b"epnp_kernelILi4EE" not in blob and b"select_refine_kernelILi4EE" not in blob
-    assert b"epnp_kernelILi2EE" in blob and b"epnp_kernelILi1EE" in blob
+    # (epnp_kernel<WAVES, GWS>: GWS = true is the slim form of the round-4 experiment, developer build only)
+    assert b"epnp_kernelILi4E" not in blob and b"select_refine_kernelILi4EE" not in blob and b"Lb1EE" not in blob
+    assert b"epnp_kernelILi2ELb0EE" in blob and b"epnp_kernelILi1ELb0EE" in blob
     # the small-launch form of the pose solve is part of the product (pnp.hip, vo_svd_wide.h)
     for name in (b"epnp_prepare_kernel", b"svd12_wave_kernel", b"epnp_approx_kernel", b"epnp_select_kernel"):
         assert name in blob, name

@@ -1,6 +1,9 @@
 """The VO_HD headers the kernels are built from (vo_linalg.h / vo_epnp.h / vo_tri.h), compiled by
 g++ (tests/host_check) and compared with the oracle: same operation order + no FMA contraction =>
-bit-identical on the CPU.  This is a unit test of device code, not a product path."""
+bit-identical on the CPU -- except where the CPU path calls libm: since round 4 the headers take sin / cos / acos (Rodrigues)
+from csrc/vo_math.h (IEEE operations only, so that gfx950 and this host build compute the SAME bits; the GPU suite holds the
+device to this build bit for bit), while the oracle calls glibc's like OpenCV does: both are within one ulp of the exact
+value, so those outputs agree to a few ulp instead of to the bit.  This is a unit test of device code, not a product path."""
 import ctypes as C
 
 import numpy as np
@@ -10,7 +13,7 @@ from conftest import vp
 K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], np.float32)
 
 
-def test_epnp5_bit_identical(orc, host_check):
+def test_epnp5_matches_oracle(orc, host_check):
     rng = np.random.default_rng(0)
     for _ in range(300):
         xyz = rng.uniform([-8, -2, 4], [8, 2, 40], (5, 3)).astype(np.float32)
@@ -20,7 +23,8 @@ def test_epnp5_bit_identical(orc, host_check):
         r0 = orc.rodrigues(R)
         r1, t1 = np.zeros(3), np.zeros(3)
         host_check.hc_epnp5(vp(xyz), vp(uv), vp(K), vp(r1), vp(t1))
-        assert np.array_equal(r0, r1) and np.array_equal(t, t1)
+        assert np.array_equal(t, t1)                   # no libm on the way to t
+        assert np.abs(r0 - r1).max() <= 4e-16          # rvec = Rodrigues(R): one acos (vo_math.h vs glibc, a few ulp of <= pi)
 
 
 def test_triangulate_bit_identical(orc, host_check, kitti_world):
@@ -37,17 +41,19 @@ def test_triangulate_bit_identical(orc, host_check, kitti_world):
     assert np.array_equal(a, b)
 
 
-def test_rodrigues_bit_identical(orc, host_check):
+def test_rodrigues_matches_oracle_to_a_few_ulp(orc, host_check):
     rng = np.random.default_rng(2)
     for _ in range(100):
         r = rng.normal(0, 0.5, 3)
         R0, J0 = orc.rodrigues_jac(r)
         R1, J1 = np.zeros((3, 3)), np.zeros((3, 9))
         host_check.hc_rodrigues_v2m(vp(r), vp(R1), vp(J1))
-        assert np.array_equal(R0, R1) and np.array_equal(J0, J1)
+        # sin / cos / acos: vo_math.h here, glibc in the oracle -- a few ulp of values <= 1 (R), <= ~2 (J), <= pi (rvec)
+        assert np.abs(R0 - R1).max() <= 4e-16 and np.abs(J0 - J1).max() <= 2e-15
         back = np.zeros(3)
         host_check.hc_rodrigues_m2v(vp(R1), vp(back))
-        assert np.array_equal(back, orc.rodrigues(R0))
+        assert np.abs(back - orc.rodrigues(R0)).max() <= 2e-15
+        assert np.abs(back - r).max() <= 1e-14         # and the round trip returns the vector
 
 
 # ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ def kemu():
     csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
     deps = [os.path.join(src_dir, f) for f in ("kernel_emu.cpp", "hip_emu.h")]
     deps += [os.path.join(csrc, f) for f in ("lk.hip", "pyramid.hip", "fast.hip", "vo_dev.h", "vo_kernels.h", "vo_lkmath.h", "vo_svd_wide.h",
-                                               "vo_linalg.h", "vo_epnp.h", "pnp.hip", "vo_p3p.h",
+                                               "vo_linalg.h", "vo_epnp.h", "pnp.hip", "vo_p3p.h", "vo_math.h",
                                                "vo_seqtail.h", "vo_integrate.h", "post.hip", "vo_tri.h",
                                                "essential.hip", "vo_fivept.h", "seq.hip")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
@@ -56,9 +56,10 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.fixture(params=[0, 1], ids=["column-walk", "lds-tile"])
+@pytest.fixture(params=[2, 0, 1], ids=["fused-pass", "column-walk", "lds-tile"])
 def pyr_kernel(kemu, request):
-    """both pyr_down kernels of the product library (launch_pyr_down picks by the number of images in the launch)"""
+    """the product's pyramid chain (round 4: the fused passes, pyr_pass_kernel level by level) and the three-kernel chain it
+    replaced with either of its pyr_down kernels"""
     kemu.ke_set_pyr_lds(request.param)
     yield request.param
     kemu.ke_set_pyr_lds(0)
@@ -83,7 +84,7 @@ def test_emulated_pyramid_and_scharr_match_oracle(kemu, orc, shape, pyr_kernel):
 
 
 @pytest.mark.parametrize("shape", [(100, 203), (61, 96), (48, 45)])
-def test_emulated_borders(kemu, orc, shape):
+def test_emulated_borders(kemu, orc, shape, pyr_kernel):
     """every pixel of the bordered allocation that a kernel may read: REFLECT_101 of the level around it (VO_BY rows above /
     below, VO_BX columns left, at least VO_BY right -- the fill runs to the end of the row), derivatives zero outside the
     image (calcSharrDeriv's constant border of the derivative image, which LK reads for off-image windows)"""
@@ -291,7 +292,7 @@ def test_fast_compass_pretest_is_necessary_exhaustive(kemu):
 
 
 @pytest.mark.parametrize("pattern", ["white", "black", "columns", "rows", "checker"])
-def test_emulated_pyramid_extremes(kemu, orc, pattern):
+def test_emulated_pyramid_extremes(kemu, orc, pattern, pyr_kernel):
     """the packed 16-bit arithmetic of pyr_down_kernel (6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408) and scharr_kernel
     (|4 Ix|, |4 Iy| <= 16320) at the ends of their ranges"""
     h, w = 90, 150
@@ -452,8 +453,10 @@ def test_emulated_pose_chain_four_kernel_epnp_and_edge_cases(kemu, orc):
     rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(X, uv, K_KITTI, iterations=40)  # (40 hypotheses: the emulated SVD is slow)
     a = ke_pnp(kemu, X, uv, K_KITTI, iters=40, split=1)
     b = ke_pnp(kemu, X, uv, K_KITTI, iters=40, split=0)
-    assert a[0] == b[0] == rc and np.array_equal(a[3], inl) and np.array_equal(b[3], inl)
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]   # the two forms: bit for bit
+    s = ke_pnp(kemu, X, uv, K_KITTI, iters=40, split=2)  # the slim form (round 4): matrices in the global workspace
+    assert a[0] == b[0] == s[0] == rc and np.array_equal(a[3], inl) and np.array_equal(b[3], inl) and np.array_equal(s[3], inl)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]   # the forms: bit for bit
+    assert np.array_equal(s[1], b[1]) and np.array_equal(s[2], b[2]) and s[4] == b[4]
     assert np.abs(a[1] - rv).max() <= 1e-6 and np.abs(a[2] - tv).max() <= 1e-6
     rng = np.random.default_rng(9)
     Xr = rng.uniform([-10, -2, 4], [10, 2, 50], (60, 3)).astype(np.float32)

@@ -1,0 +1,103 @@
+#!/bin/bash
+# Round-4 GPU session driver.  Usage (from the authoring container):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh <tag> <part> [<part> ...]'
+# parts: tests slimab slimdev seqab bench prof pmc latency
+TAG=${1:-r4}
+shift
+PARTS="$*"
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT" || exit 1
+export TMPDIR=/tmp
+t0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a "$OUT/timeline.log"; }
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+LEAN="--no-cpu-baseline --sustain 0 --no-replay-leg --no-configs"
+line() { python -c "import json,sys; b=json.loads(open('$1').read().strip().splitlines()[-1]); print('  $2 %.0f fps %.3f ms/step lk %.3f' % (b['value'], b['ms_per_step'], b['roofline']['launch_ms']), {k: round(v,2) for k,v in b['config'].get('stage_ms',{}).items()}, b['config'].get('schedule'), 'val', b.get('validated_frames'))" 2>&1 | tee -a "$OUT/summary.txt"; }
+
+if has tests; then
+    stamp "pytest -m gpu $PYTEST_K"
+    timeout 1500 python -m pytest tests -m gpu -q --durations=10 ${PYTEST_K:+-k "$PYTEST_K"} > "$OUT/pytest.log" 2>&1
+    stamp "pytest rc=$?"
+    tail -15 "$OUT/pytest.log"
+fi
+if has slimab; then   # pinned schedules, product library: the slim pose chain (pose_waves 4) against the round-3 ones
+    for WL in kitti2000 kitti374; do
+        for SCHED in 2,1,0 2,2,0 4,1,0 4,2,0; do
+            stamp "bench $WL --schedule $SCHED"
+            timeout 300 python bench.py --workload $WL --steps 20 --warmup 3 $LEAN --validate 2 --schedule $SCHED > "$OUT/ab_${WL}_${SCHED}.json" 2> "$OUT/ab_${WL}_${SCHED}.err"
+            line "$OUT/ab_${WL}_${SCHED}.json" "$WL $SCHED"
+        done
+    done
+fi
+if has slimdev; then  # register budget of the slim EPnP (developer build)
+    export VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so
+    for WL in kitti2000 kitti374; do
+        for SW in 4 5 7; do
+            stamp "dev: VO_SLIM_WAVES=$SW bench $WL --schedule 4,1,0"
+            VO_SLIM_WAVES=$SW timeout 300 python bench.py --workload $WL --steps 20 --warmup 3 $LEAN --validate 0 --schedule 4,1,0 > "$OUT/dev_${WL}_sw${SW}.json" 2> "$OUT/dev_${WL}_sw${SW}.err"
+            line "$OUT/dev_${WL}_sw${SW}.json" "$WL slim_waves=$SW"
+        done
+        for CH in 128; do
+            stamp "dev: VO_RANSAC_CHUNK=$CH bench $WL --schedule 4,1,0"
+            VO_RANSAC_CHUNK=$CH timeout 300 python bench.py --workload $WL --steps 20 --warmup 3 $LEAN --validate 0 --schedule 4,1,0 > "$OUT/dev_${WL}_ch${CH}.json" 2> "$OUT/dev_${WL}_ch${CH}.err"
+            line "$OUT/dev_${WL}_ch${CH}.json" "$WL chunk=$CH"
+        done
+    done
+    unset VO_HIP_LIB
+fi
+if has seqab; then    # lock-step loop, 256 sequences: does the prepare stream pay once the pose chain is slim?
+    for WL in kitti374 kitti2000; do
+        for SCHED in 2,2,0 2,2,1 4,2,0 4,2,1 4,1,1; do
+            stamp "bench --mode sequences $WL --seqs 256 --schedule $SCHED"
+            timeout 300 python bench.py --mode sequences --workload $WL --seqs 256 --steps 40 --warmup 4 --no-cpu-baseline --validate 2 --schedule $SCHED > "$OUT/seq_${WL}_${SCHED}.json" 2> "$OUT/seq_${WL}_${SCHED}.err"
+            python -c "import json; b=json.loads(open('$OUT/seq_${WL}_${SCHED}.json').read().strip().splitlines()[-1]); print('  seq256 $WL $SCHED %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']), b.get('validated_frames'))" 2>&1 | tee -a "$OUT/summary.txt"
+        done
+    done
+fi
+if has pyrab; then    # fused pyramid passes against the three-kernel chain (developer build), rows per work item
+    for WL in kitti2000 kitti374; do
+        for V in "dev 0" "dev 1" "pf4 1" "pf16 1"; do
+            set -- $V
+            stamp "lib=$1 VO_PYR_FUSED=$2 bench $WL --schedule 2,1,0"
+            VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_$1.so VO_PYR_FUSED=$2 timeout 300 python bench.py --workload $WL --steps 20 --warmup 3 $LEAN --validate 2 --schedule 2,1,0 > "$OUT/pyr_${WL}_$1_$2.json" 2> "$OUT/pyr_${WL}_$1_$2.err"
+            line "$OUT/pyr_${WL}_$1_$2.json" "$WL lib=$1 fused=$2"
+        done
+    done
+    for V in "dev 0" "dev 1"; do
+        set -- $V
+        stamp "lib=$1 VO_PYR_FUSED=$2 bench --stages lk"
+        VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_$1.so VO_PYR_FUSED=$2 timeout 300 python bench.py --stages lk --steps 20 --warmup 3 $LEAN --validate 2 > "$OUT/pyr_lk_$1_$2.json" 2> "$OUT/pyr_lk_$1_$2.err"
+        line "$OUT/pyr_lk_$1_$2.json" "stages=lk lib=$1 fused=$2"
+        stamp "lib=$1 VO_PYR_FUSED=$2 latency mode"
+        VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_$1.so VO_PYR_FUSED=$2 timeout 300 python tools/latency_mode.py 200 > "$OUT/latency_$1_$2.log" 2>&1
+        grep -i "track_frame\|ms" "$OUT/latency_$1_$2.log" | head -12
+    done
+fi
+if has bench; then
+    stamp "bench (default: headline + exact replay + configs)"
+    timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    tail -c 600 "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+fi
+if has prof; then
+    stamp "rocprofv3 --kernel-trace --stats of the default headline (lean)"
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$ROOT/bench.py" --steps 20 --warmup 3 $LEAN --validate 0 > "$OUT/prof.log" 2>&1)
+    find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_batch.csv"
+    find "$OUT/prof" -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_trace_batch.csv"
+    rm -rf "$OUT/prof"
+    head -12 "$OUT/kernel_stats_batch.csv" | cut -c1-200
+fi
+if has latency; then
+    stamp "latency mode of the drop-in boundary"
+    timeout 300 python tools/latency_mode.py 200 > "$OUT/latency.log" 2>&1
+    cat "$OUT/latency.log"
+fi
+if has pyrprof; then  # kernel-level split of the pyramid stage (developer build; VO_PYR_FUSED from the environment)
+    stamp "rocprofv3 kernel stats, dev lib, VO_PYR_FUSED=${VO_PYR_FUSED:-default}"
+    (cd /tmp && VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pyrprof" -- python "$ROOT/bench.py" --workload kitti374 --steps 20 --warmup 3 $LEAN --validate 0 --schedule 2,1,0 > "$OUT/pyrprof.log" 2>&1)
+    find "$OUT/pyrprof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_pyr.csv"
+    rm -rf "$OUT/pyrprof"
+    head -14 "$OUT/kernel_stats_pyr.csv" | cut -c1-60,100-
+fi
+stamp "done"

@@ -72,6 +72,11 @@ def main():
               minEigThreshold=0.001)
     chain = [(L[0], R[0]), (R[0], R[1]), (R[1], L[1]), (L[1], L[0])]
     p_cv = p_my = pts
+    # oracle accum_mode (oracle/vo_oracle.h): 0 exact integer sums (the HIP kernel), 1 sequential f32, 2 OpenCV's 128-bit
+    # universal-intrinsics order without FMA (default x86-64 baseline), 3 the same with fused v_muladd -- which one is THIS cv2?
+    MODES = {0: "exact integer sums", 1: "sequential f32", 2: "x86 SIMD128 order, no FMA", 3: "x86 SIMD128 order, FMA"}
+    identical = {m: 0 for m in MODES}
+    total = 0
     for hop, (a, b) in enumerate(chain):
         q_cv, st_cv, _ = cv2.calcOpticalFlowPyrLK(a, b, p_cv.reshape(-1, 1, 2), None, **lk)
         q_cv, st_cv = q_cv.reshape(-1, 2), st_cv.reshape(-1)
@@ -79,8 +84,20 @@ def main():
         both = (st_cv == 1) & (st_my == 1)
         report("calcOpticalFlowPyrLK hop %d positions" % hop, float(np.abs(q_cv[both] - q_my[both]).max()), 1e-3,
                "status differs at %d of %d" % (int((st_cv != st_my).sum()), len(st_cv)))
+        # every accumulation mode from cv2's OWN input points of this hop: bit-identical tracks per mode
+        for m in MODES:
+            q_m, st_m, _ = orc.calc_optical_flow_pyr_lk(a, b, p_cv, accum_mode=m)
+            ok = (st_cv == 1) & (st_m == 1)
+            identical[m] += int((np.ascontiguousarray(q_m[ok]).view(np.uint32) == np.ascontiguousarray(q_cv[ok]).view(np.uint32)).all(1).sum())
+        total += int((st_cv == 1).sum())
         golden["lk_hop%d" % hop], golden["lk_status%d" % hop] = q_cv, st_cv
         p_cv, p_my = q_cv, q_my
+    best = max(MODES, key=lambda m: identical[m])
+    print("LK accumulation order of this cv2 build: " + "; ".join("mode %d (%s) %d of %d tracks bit-identical" % (m, MODES[m], identical[m], total)
+                                                                   for m in MODES))
+    print("  -> matches accum_mode %d%s" % (best, " BIT FOR BIT on every track" if identical[best] == total else " best (not exactly: the "
+          "restatement of the accumulation order, [upstream-memory] in oracle/vo_oracle.h, needs another look for this version)"))
+    golden["lk_accum_mode"] = np.array([best, identical[best], total])
     # ---- triangulation
     ref = orc.circular_matching(L[0], R[0], L[1], R[1], pts)
     (l0, r0, l1, r1), _ = orc.check_valid_and_remove(ref["l0"], ref["r0"], ref["l1"], ref["r1"], ref["l0_ret"])

@@ -92,6 +92,17 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _imgs(*arrays):
+    """8-bit gray images as the ABI takes them: a base pointer + one byte stride for all of them.  Row-contiguous views (a
+    padded buffer, an ROI of a bigger image: strides (stride, 1)) are passed AS THEY ARE with their stride -- no copy --
+    when they all share it; anything else is made contiguous (stride = width)."""
+    arrs = [np.asarray(a) for a in arrays]
+    ok = all(a.dtype == np.uint8 and a.ndim == 2 and a.strides[1] == 1 and a.strides[0] >= a.shape[1] for a in arrs)
+    if not ok or len({a.strides[0] for a in arrs}) != 1 or len({a.shape for a in arrs}) != 1:
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in arrs]
+    return arrs, int(arrs[0].strides[0])
+
+
 def _f32(a, shape=None):
     a = np.ascontiguousarray(a, np.float32)
     return a if shape is None else a.reshape(shape)
@@ -166,14 +177,14 @@ class Context:
 
     def get_probe_log(self):
         """{"w,s,p": steady-state ms per run} as measured by the last schedule probe of this context ({} if none ran)"""
-        cands, ms, real, n = (VoSchedule * 8)(), (C.c_float * 8)(), (C.c_int * 8)(), C.c_int(0)
+        cands, ms, real, n = (VoSchedule * 12)(), (C.c_float * 12)(), (C.c_int * 12)(), C.c_int(0)
         self._chk(self.lib.vo_get_probe_log(self.h, cands, ms, real, C.byref(n)))
         return {"%d,%d,%d%s" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare, " (real steps)" if real[i] else ""):
                 float(ms[i]) for i in range(n.value)}
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):
-        imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
+        imgs, stride = _imgs(l0, r0, l1, r1)
         h, w = imgs[0].shape
         pts = _f32(pts_l0, (-1, 2))
         n = pts.shape[0]
@@ -183,7 +194,7 @@ class Context:
         n_out = C.c_int(0)
         st_flat = np.zeros(4 * max(n, 1), np.uint8)
         self._chk(self.lib.vo_circular_match(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
-                                             w, h, w, _p(pts), n, _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                                             w, h, stride, _p(pts), n, _p(outs[0]), _p(outs[1]), _p(outs[2]),
                                              _p(outs[3]), _p(outs[4]), _p(st_flat), _p(keep),
                                              C.byref(n_out), int(apply_consistency)))
         m = n_out.value
@@ -237,11 +248,11 @@ class Context:
 
     def fast_detect(self, img, threshold=20, nonmax=True, cap=65536):
         """featureDetectionFast (feature.cpp:39-47): corners in row-major order, (n, 2) float32"""
-        img = np.ascontiguousarray(img, np.uint8)
+        (img,), stride = _imgs(img)
         h, w = img.shape
         pts = np.zeros((cap, 2), np.float32)
         n = C.c_int(0)
-        self._chk(self.lib.vo_fast_detect(self.h, _p(img), w, h, w, int(threshold), int(bool(nonmax)), _p(pts), cap,
+        self._chk(self.lib.vo_fast_detect(self.h, _p(img), w, h, stride, int(threshold), int(bool(nonmax)), _p(pts), cap,
                                           C.byref(n)))
         if n.value > cap:
             raise VoError(VO_ERR_ARG, "fast_detect: %d corners exceed cap %d" % (n.value, cap))
@@ -250,7 +261,7 @@ class Context:
     def detect_bucket(self, img, pts, ages, **detect_kw):
         """appendNewFeatures (if fewer than redetect_below points) + bucketingFeatures
         (visualOdometry.cpp:95-108); returns (points, ages) of the bucketed set"""
-        img = np.ascontiguousarray(img, np.uint8)
+        (img,), stride = _imgs(img)
         h, w = img.shape
         pts = _f32(pts, (-1, 2))
         ages = np.ascontiguousarray(ages, np.int32).reshape(-1)
@@ -261,12 +272,12 @@ class Context:
         a_io[:len(ages)] = ages
         n_pts, n_ages = C.c_int(len(pts)), C.c_int(len(ages))
         dp = self.detect_params(**detect_kw)
-        self._chk(self.lib.vo_detect_bucket(self.h, _p(img), w, h, w, C.byref(dp), _p(p_io), C.byref(n_pts), _p(a_io),
+        self._chk(self.lib.vo_detect_bucket(self.h, _p(img), w, h, stride, C.byref(dp), _p(p_io), C.byref(n_pts), _p(a_io),
                                             C.byref(n_ages), cap))
         return p_io[:n_pts.value].copy(), a_io[:n_ages.value].copy()
 
     def track_frame(self, l0, r0, l1, r1, pts_l0, P_l, P_r, rvec=None, tvec=None):
-        imgs = [np.ascontiguousarray(a, np.uint8) for a in (l0, r0, l1, r1)]
+        imgs, stride = _imgs(l0, r0, l1, r1)
         h, w = imgs[0].shape
         pts = _f32(pts_l0, (-1, 2))
         n = pts.shape[0]
@@ -279,7 +290,7 @@ class Context:
         tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3).copy()
         R = np.zeros((3, 3))
         rc = self._chk(self.lib.vo_track_frame(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
-                                               w, h, w, _p(pts), n, _p(P_l), _p(P_r), _p(o[0]), _p(o[1]),
+                                               w, h, stride, _p(pts), n, _p(P_l), _p(P_r), _p(o[0]), _p(o[1]),
                                                _p(o[2]), _p(o[3]), _p(xyz), _p(keep), C.byref(n_out),
                                                _p(keepc), C.byref(n_circ), _p(rv), _p(tv), _p(R), _p(inl),
                                                C.byref(ninl)), allow=(VO_NO_MODEL, VO_NO_ESSENTIAL, VO_ERR_TOO_FEW))
@@ -294,8 +305,8 @@ class Context:
         self.n_frames = n_frames
 
     def batch_upload_image(self, idx, img):
-        img = np.ascontiguousarray(img, np.uint8)
-        self._chk(self.lib.vo_batch_upload_image(self.h, idx, _p(img), img.shape[1]))
+        (img,), stride = _imgs(img)
+        self._chk(self.lib.vo_batch_upload_image(self.h, idx, _p(img), stride))
 
     def batch_upload_image_dev(self, idx, dev_ptr, stride):
         self._chk(self.lib.vo_batch_upload_image_dev(self.h, idx, C.c_void_p(dev_ptr), stride))
@@ -398,9 +409,8 @@ class Context:
     def seq_push_pair(self, seq, left, right, pinned=False):
         """left / right: uint8 (h, w) numpy arrays (pinned=True: views of page-locked memory that stay untouched
         until the step has run)"""
-        left = np.ascontiguousarray(left, np.uint8)
-        right = np.ascontiguousarray(right, np.uint8)
-        self._chk(self.lib.vo_seq_push_pair(self.h, seq, _p(left), _p(right), left.shape[1], int(bool(pinned))))
+        (left, right), stride = _imgs(left, right)
+        self._chk(self.lib.vo_seq_push_pair(self.h, seq, _p(left), _p(right), stride, int(bool(pinned))))
 
     def seq_push_pair_dev(self, seq, left_ptr, right_ptr, stride):
         self._chk(self.lib.vo_seq_push_pair_dev(self.h, seq, C.c_void_p(left_ptr), C.c_void_p(right_ptr), stride))

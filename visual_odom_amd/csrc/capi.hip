@@ -85,6 +85,7 @@ struct vo_ctx {
         PnpResult *results = nullptr;
         EmResult *em_results = nullptr; // mono_rotation branch (allocated with the rest of `em` on first use)
         double *epnp_ws = nullptr;      // workspace of the four-kernel EPnP (small launches, pnp.hip)
+        double *epnp_gws = nullptr;     // developer build: the slim chain's 12 x 12 matrices [max_frames][VO_EPNP_GWS_BLOCKS][156][64]
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         hipEvent_t em_done = nullptr; // essential-matrix chain done (mono_rotation)
         bool pending = false;                        // `done` has been recorded and not waited for
@@ -135,9 +136,9 @@ struct vo_ctx {
     long long ab_key[8] = {};
     // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
     int probe_n = 0;
-    vo_schedule probe_cand[8] = {};
-    float probe_ms[8] = {};
-    int probe_real[8] = {};          // 1: probe_ms[i] was (re)measured over real steps of the lock-step loop
+    vo_schedule probe_cand[VO_PROBE_LOG_MAX] = {};
+    float probe_ms[VO_PROBE_LOG_MAX] = {};
+    int probe_real[VO_PROBE_LOG_MAX] = {};          // 1: probe_ms[i] was (re)measured over real steps of the lock-step loop
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
@@ -438,7 +439,7 @@ void vo_destroy(vo_ctx *c)
     seq_free(c);
     for (auto &b : c->pb) {
         void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results,
-                     b.em_results, b.epnp_ws};
+                     b.em_results, b.epnp_ws, b.epnp_gws};
         for (void *p : q)
             if (p)
                 (void)hipFree(p);
@@ -561,6 +562,9 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && dmalloc(&b.rstate, B) == hipSuccess;
         ok = ok && dmalloc(&b.epnp_ws, (size_t)(c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES) *
                                            VO_EPNP_WS_HYPS * VO_EPNP_WS_DOUBLES) == hipSuccess;
+#ifdef VO_DEV_VARIANTS
+        ok = ok && dmalloc(&b.epnp_gws, B * VO_EPNP_GWS_BLOCKS * VO_EPNP_UT_DOUBLES * 64) == hipSuccess;
+#endif
         ok = ok && hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&b.tri_done, hipEventDisableTiming) == hipSuccess;
@@ -956,15 +960,21 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
-            // Level 0 first, with the two kernels that use no LDS: in steady state the pose solve of the previous run starts
-            // on the pose stream at about this moment, and two of its EPnP workgroups fill a CU's LDS (pnp.hip, launch_pnp)
-            // -- an LDS-using kernel launched now would wait ~0.6 ms for them, these two do not.
-            launch_border_fill(tab, ni, 0, 1, c->lstride, c->lh, pyrs);
-            launch_scharr(tab, ni, 0, 1, c->lw, c->lh, pyrs);
-            for (int l = 0; l + 1 < c->levels; l++)
-                launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], pyrs); // reflects on its own: needs no border
-            launch_border_fill(tab, ni, 1, c->levels, c->lstride, c->lh, pyrs);
-            launch_scharr(tab, ni, 1, c->levels, c->lw, c->lh, pyrs);
+            // Two launches, no LDS (round 4): level 0 is read once and gives its Scharr image, level 1 and its own border; the
+            // small levels follow in one launch, a workgroup per image (pyramid.hip).  (Round 3: eight launches of three
+            // kernels that each fetched the level again.)
+#ifdef VO_DEV_VARIANTS
+            static const bool fused = [] { const char *e = getenv("VO_PYR_FUSED"); return !(e && e[0] == '0'); }();
+            if (!fused) {
+                launch_border_fill(tab, ni, 0, 1, c->lstride, c->lh, pyrs);
+                launch_scharr(tab, ni, 0, 1, c->lw, c->lh, pyrs);
+                for (int l = 0; l + 1 < c->levels; l++)
+                    launch_pyr_down(tab, ni, l, c->lw[l + 1], c->lh[l + 1], pyrs);
+                launch_border_fill(tab, ni, 1, c->levels, c->lstride, c->lh, pyrs);
+                launch_scharr(tab, ni, 1, c->levels, c->lw, c->lh, pyrs);
+            } else
+#endif
+                launch_pyramid_fused(tab, ni, c->levels, c->lw, c->lh, c->lstride, pyrs);
             std::fill(c->img_stale.begin() + c->pyr_first, c->img_stale.begin() + c->pyr_first + ni, (uint8_t)0);
         }
     }
@@ -1178,7 +1188,7 @@ static int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullp
         }
         launch_pnp_ransac(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                           pb.rstate, c->sched.waves, ps, pb.epnp_ws,
-                          c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES);
+                          c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES, pb.epnp_gws);
         if (c->prm.mono_rotation)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
         SeqTail tail;
@@ -1271,7 +1281,9 @@ TuneKey tune_key(const vo_ctx *c, int stages)
     key.k[3] = c->h;
     key.k[4] = c->levels;
     key.k[5] = c->n_frames;
-    key.k[6] = pts_bucket(pts);
+    // (the synchronous drop-in call is keyed on the image shape only: a live sequence whose feature count drifts across a
+    // bucket boundary must not pay a probe -- ~20 frame times -- in the middle of real-time use)
+    key.k[6] = (c->sync_call && !c->seq.on) ? 0 : pts_bucket(pts);
     key.k[7] = (c->prm.mono_rotation ? 1 : 0) | ((stages & VO_STAGE_DETECT) ? 2 : 0) | (c->sync_call && !c->seq.on ? 16 : 0);
     return key;
 }
@@ -1498,13 +1510,13 @@ static int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, boo
             best = (int)i;
             best_ms = ms;
         }
-        if (i < 8) {
+        if (i < VO_PROBE_LOG_MAX) {
             c->probe_cand[i] = vo_schedule{cands[i].waves, cands[i].streams, cands[i].prep};
             c->probe_ms[i] = (float)ms;
             c->probe_real[i] = 0;
         }
     }
-    c->probe_n = (int)(cands.size() < 8 ? cands.size() : 8);
+    c->probe_n = (int)(cands.size() < VO_PROBE_LOG_MAX ? cands.size() : VO_PROBE_LOG_MAX);
     c->tuning = false;
     if (rc != VO_OK)
         return rc;
@@ -1548,7 +1560,7 @@ int vo_set_schedule(vo_ctx *c, const vo_schedule *s)
         p = *s;
     const int max_waves =
 #ifdef VO_DEV_VARIANTS
-        4;
+        4; // the slim pose chain (pnp.hip): measured slower everywhere, kept for the record in the developer build
 #else
         2;
 #endif
@@ -1582,18 +1594,18 @@ int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
     return VO_OK;
 }
 
-int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands8, float *ms8, int *real8, int *n)
+int vo_get_probe_log(const vo_ctx *c, vo_schedule *cands, float *ms, int *real, int *n)
 {
     if (!c || !n)
         return VO_ERR_ARG;
     *n = c->probe_n;
     for (int i = 0; i < c->probe_n; i++) {
-        if (cands8)
-            cands8[i] = c->probe_cand[i];
-        if (ms8)
-            ms8[i] = c->probe_ms[i];
-        if (real8)
-            real8[i] = c->probe_real[i];
+        if (cands)
+            cands[i] = c->probe_cand[i];
+        if (ms)
+            ms[i] = c->probe_ms[i];
+        if (real)
+            real[i] = c->probe_real[i];
     }
     return VO_OK;
 }
@@ -1737,7 +1749,7 @@ static int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, fl
 // pnp_rotation: R = Rodrigues(rvec) even under mono_rotation (vo_pnp_ransac).  em_status (optional): status of the
 // essential-matrix side of the frame under mono_rotation (1 ok, 0 no model, -1 too few points), 1 otherwise.
 static int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
-                         int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status)
+                         int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status, bool io_pose = true)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -1750,9 +1762,12 @@ static int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, doubl
     PnpResult r;
     VO_HIP_TRY(c, hipMemcpyAsync(&r, pb.results + frame, sizeof(r), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (r.status == 0 && r.lm_iters < 0) {
+    if (r.status == 0 && r.lm_iters < 0 && io_pose) {
         // four points, P3P without a solution: solvePnP returned false and never wrote rvec / tvec -- the caller's
-        // buffers stay as they are; the reference then still runs Rodrigues(rvec, rotation) on what rvec holds
+        // buffers stay as they are; the reference then still runs Rodrigues(rvec, rotation) on what rvec holds.
+        // (io_pose = false, vo_batch_get_pose: its rvec / tvec / R are pure OUTPUTS -- a batch frame has no caller pose -- and
+        // receive what the kernel left: rvec = 0 like the reference's `cv::Mat::zeros` at visualOdometry.cpp:162, tvec = 0,
+        // R = identity, never a Rodrigues of uninitialised memory)
         if (R && rvec && (pnp_rotation || !c->prm.mono_rotation))
             rodrigues_v2m(rvec, R, nullptr);
     } else if (r.status >= 0) {
@@ -1794,7 +1809,7 @@ static int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, doubl
 int vo_batch_get_pose(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,
                       int *n_inliers, int *status, int32_t *dbg4)
 {
-    return get_pose_impl(c, frame, rvec, tvec, R, inliers, n_inliers, status, dbg4, false, nullptr);
+    return get_pose_impl(c, frame, rvec, tvec, R, inliers, n_inliers, status, dbg4, false, nullptr, /*io_pose*/ false);
 }
 
 int vo_batch_get_essential(vo_ctx *c, int frame, double *E, double *R, double *t, uint8_t *mask, int n,
@@ -2224,12 +2239,20 @@ int vo_seq_step(vo_ctx *c)
         if (q.pushed[s] && q.had_prev[s] && q.h_rows[s] >= q.max_steps) {
             // refuse the step and drop its pending pairs: the loop stays usable (trajectories can be read,
             // vo_seq_reset(s) gives the sequence its rows back)
-            for (int k = 0; k < q.S; k++)
+            // Dropping a pair is a PAUSE of its sequence: if the caller moves on instead of re-pushing the same
+            // pairs after vo_seq_reset(s), the next pair of such a sequence restarts its image pair (it is NOT matched against
+            // the pair from two pushes ago) and the frame after that carries VO_SEQ_F_GAP, exactly like a resumed sequence.
+            for (int k = 0; k < q.S; k++) {
+                if (q.pushed[k])
+                    q.had_prev[k] = 0;
                 q.pushed[k] = 0;
+            }
             q.begun = false;
             q.n_ing = 0;
+            q.staged = false; // (the staging area holds only the dropped pairs: nothing was enqueued that reads it)
             return fail(c, VO_ERR_STATE, "vo_seq_step: a sequence's trajectory capacity (max_steps of vo_seq_configure) is "
-                                         "exhausted; the pairs pushed for this step were dropped");
+                                         "exhausted; the pairs pushed for this step were dropped (re-push them after "
+                                         "vo_seq_reset(seq), or go on: the affected sequences resume as after a pause)");
         }
     VO_HIP_TRY(c, hipSetDevice(c->device));
     int rc = seq_begin_step(c);
@@ -2610,7 +2633,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1, pb.epnp_gws);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }
@@ -2667,7 +2690,7 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
 int vo_detect_bucket(vo_ctx *c, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
                      float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap)
 {
-    if (!c || !n_pts || !n_ages || !pts_io || !ages_io || cap < 1)
+    if (!c || !n_pts || !n_ages || !pts_io || !ages_io || cap < 1 || *n_pts > cap || *n_ages > cap) // (the arrays hold cap entries)
         return VO_ERR_ARG;
     int rc = single_image_setup(c, img, w, h, stride);
     if (rc != VO_OK)

@@ -77,6 +77,8 @@ namespace vo {
 #endif
 
 constexpr int RANSAC_CHUNK = VO_EPNP_WS_HYPS;
+constexpr int EPNP_UT_DOUBLES = VO_EPNP_UT_DOUBLES; // M^T M + its 12 column norms, per hypothesis
+#define VO_SLIM_WAVES 6 // register budget of the slim pose kernels as waves per SIMD (6: 80 registers)
 
 // ---- random 5-subsets: RANSACPointSetRegistrator::getSubset with cv::RNG(-1) ----
 // cv::RNG is a multiply-with-carry generator whose raw 32-bit outputs do not depend on anything the caller passes: the
@@ -226,19 +228,24 @@ __global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restric
         rstate[frame] = st;
 }
 
-template <int WAVES>
+// GWS = true ("slim", round 4): the same lane-interleaved matrix in a GLOBAL workspace (one 156 x 64 block of doubles per
+// workgroup, L2 / Infinity-Cache resident while the wave runs) instead of LDS, and a small register budget -- a wave that
+// needs neither LDS nor half a SIMD's registers starts in the slot any retiring LK wave leaves (see launch_pnp_ransac).
+template <int WAVES, bool GWS>
 __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
                                                   size_t uv_stride, const int *__restrict__ n_pts, int cap,
                                                   const int32_t *__restrict__ subsets, PnpParams prm,
                                                   const RansacState *__restrict__ rstate, int h0, int hn,
-                                                  double *__restrict__ models /* [B][iters][6] */)
+                                                  double *__restrict__ models /* [B][iters][6] */,
+                                                  double *__restrict__ gws /* [frames][VO_EPNP_GWS_BLOCKS][156][64] or null */)
 {
     // M^T M (12 x 12) + its column norms of every lane, lane-interleaved: element idx of lane l at
     // s_ut[idx * 64 + l] -> consecutive lanes hit consecutive 8-byte words (conflict-free ds_*_b64)
     // (dynamic LDS, (144 + 12) * 64 doubles: with a static array the compiler derives one wave per SIMD
     // from the LDS footprint and spends all 512 registers, ignoring the launch bound above)
-    VO_DYN_LDS(double, s_ut);
+    VO_DYN_LDS(double, s_lds);
+    double *s_ut = GWS ? gws + ((size_t)blockIdx.y * VO_EPNP_GWS_BLOCKS + blockIdx.x) * (EPNP_UT_DOUBLES * 64) : s_lds;
     const int frame = blockIdx.y, h = h0 + blockIdx.x * 64 + threadIdx.x;
     const int count = n_pts[frame];
     if (count < 5 || h >= h0 + hn)
@@ -688,7 +695,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                 }
             }
             if (need_solve) { // CvLevMarq::step: (J^T J with its diagonal scaled by 1 + lambda) x = J^T e; At = A^T as solve_svd
-                const double lambda = exp(lambdaLg10 * log(10.));
+                const double lambda = vo_lm_lambda(lambdaLg10); // exp(lambdaLg10 * log(10.)), glibc's bits (vo_math.h)
                 for (int i = 0; i < 6; i++)
                     for (int k = 0; k < 6; k++)
                         s_At[i * 6 + k] = k == i ? JtJ[k * 6 + i] * (1. + lambda) : JtJ[k * 6 + i];
@@ -930,8 +937,11 @@ int pnp_init_device(hipStream_t stream) { return rng_table(stream) ? 0 : -1; }
 void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int h0, int hn, int32_t *subsets,
                            RansacState *rstate, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ransac_subsets_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, iters, h0, hn,
-                       rng_table(stream), RNG_TABLE, subsets, rstate);
+    // (no table -- hipMalloc failed, or a device ordinal beyond the cache: n_raw = 0 sends every frame to the kernel's exact
+    // serial generator instead of dereferencing a null table)
+    const uint32_t *tab = rng_table(stream);
+    hipLaunchKernelGGL(ransac_subsets_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, iters, h0, hn, tab,
+                       tab ? RNG_TABLE : 0, subsets, rstate);
 }
 
 // RANSAC hypotheses + votes + control-flow replay, everything up to the choice of the winner.  Two chunks: the first
@@ -940,8 +950,9 @@ void launch_ransac_subsets(const int *n_pts, int n_frames, int iters, int h0, in
 // 128, i.e. 16 dependent launches per solve of which 12 found nothing to do.
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                       int waves /* 1 or 2 per SIMD: 512 / 256 registers */, hipStream_t stream,
-                       double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames)
+                       int waves /* 1 or 2 per SIMD: 512 / 256 registers; 4: the slim form (needs gws) */, hipStream_t stream,
+                       double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames,
+                       double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */)
 {
     if (n_frames <= 0)
         return;
@@ -992,18 +1003,34 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                                epnp_ws);
             hipLaunchKernelGGL(epnp_select_kernel, eg, dim3(64), 0, stream, n_pts, prm, state, h0, hn, epnp_ws, models);
         } else
-#ifdef VO_DEV_VARIANTS // the 128-register instantiation: never the best one since round 2
-        if (waves >= 4)
-            hipLaunchKernelGGL(epnp_kernel<4>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               h0, hn, models);
-        else
+#ifdef VO_DEV_VARIANTS
+        if (waves >= 4 && gws && (int)eg.x <= VO_EPNP_GWS_BLOCKS) {
+            // SLIM (round-4 experiment, developer build only): 12 x 12 matrices in a global workspace, VO_SLIM_WAVES waves per
+            // SIMD worth of registers, no LDS -- such a wave starts wherever ONE LK wave has retired instead of waiting for half
+            // an empty SIMD and 78 KB of LDS.  Bit-identical, and SLOWER in every configuration measured
+            // (profiles/r04_experiments.md: headline step 12.45 -> 12.68 ms, 340-point step 3.15 -> 3.32 ... 3.72, lock-step loop
+            // 3.71 -> 4.10): the scratch-resident solver takes 2 x as long and costs LK more than the fat one does.
+            static const int sw = [] { const char *e = getenv("VO_SLIM_WAVES"); return e ? atoi(e) : VO_SLIM_WAVES; }();
+            if (sw == 4)
+                hipLaunchKernelGGL((epnp_kernel<4, true>), eg, dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
+                                   state, h0, hn, models, gws);
+            else if (sw == 5)
+                hipLaunchKernelGGL((epnp_kernel<5, true>), eg, dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
+                                   state, h0, hn, models, gws);
+            else if (sw == 7)
+                hipLaunchKernelGGL((epnp_kernel<7, true>), eg, dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm,
+                                   state, h0, hn, models, gws);
+            else
+                hipLaunchKernelGGL((epnp_kernel<VO_SLIM_WAVES, true>), eg, dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
+                                   subsets, prm, state, h0, hn, models, gws);
+        } else
 #endif
         if (waves >= 2)
-            hipLaunchKernelGGL(epnp_kernel<2>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               h0, hn, models);
+            hipLaunchKernelGGL((epnp_kernel<2, false>), eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               h0, hn, models, (double *)nullptr);
         else
-            hipLaunchKernelGGL(epnp_kernel<1>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               h0, hn, models);
+            hipLaunchKernelGGL((epnp_kernel<1, false>), eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               h0, hn, models, (double *)nullptr);
         hipLaunchKernelGGL(vote_kernel, dim3(hn, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, prm, models,
                            state, h0, counts);
         hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, prm,
@@ -1023,7 +1050,7 @@ void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, con
     hipLaunchKernelGGL(p3p_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
                        n_frames, prm, inliers, results);
 #ifdef VO_DEV_VARIANTS
-    if (waves >= 4)
+    if (waves >= 4) // slim: 128 registers
         hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
                            cap, prm, models, state, inliers, results, tail);
     else
@@ -1038,10 +1065,10 @@ void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, con
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames)
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames, double *gws)
 {
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
-                      ws_frames);
+                      ws_frames, gws);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

@@ -39,6 +39,9 @@ struct __attribute__((packed, aligned(4))) U32x4 {
     uint32_t a, b, c, d;
 };
 
+#if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL)
+// ROUND-3 CHAIN (developer build and CPU emulator only: the A/B partner of the fused passes below, VO_PYR_FUSED=0):
+// border_fill_kernel -> scharr -> pyr_down x (L - 1) -> border_fill_kernel -> scharr, eight launches per pyramid build.
 // ---------------------------------------------------------------------------------------------------
 // Border words of one level.  Work items: first the 2 * VO_BY rows above / below the image (stride / 4 words each), then,
 // per image row, the VO_BX / 4 words left of the image and the words from the one holding pixel w - 1 (or starting at w)
@@ -402,7 +405,268 @@ __global__ __launch_bounds__(256) void scharr_nt_kernel(const PyrImage *__restri
     scharr_body<true>(imgs, n_levels, st);
 }
 
+
+#endif // round-3 chain
+
+// ---------------------------------------------------------------------------------------------------
+// FUSED PYRAMID PASS (round 4).  One pass over a level reads it ONCE and emits everything that depends on it: its Scharr
+// image, the next level (pyrDown) and its own REFLECT_101 border -- the three kernels above each fetched level 0 from memory
+// (8 launches per pyramid build, FETCH_SIZE 1.6-3.1 x the algorithmic bytes in pyr_down).  No LDS, no
+// barrier in the pass: a work item is 4 adjacent columns x PF_ROWS rows; the thread walks DOWN its rows with one 8-byte load
+// per source row (columns x4 - 2 .. x4 + 5: the 6 columns of the 3 x 3 Scharr stencil and the 7 of the 5-tap pyrDown
+// window of its 2 next-level outputs), keeps a 3-row window of lifted u16 pairs for Scharr and a 5-row window of horizontal
+// pyrDown sums in registers, and stores 16 bytes of (4 Ix | 4 Iy << 16) per row plus 2 next-level pixels every second row.
+// Rows / columns outside the image are fetched through REFLECT_101 BY INDEX (edge items gather their 7 bytes), never from
+// the level's border: the border is written by the same launch (border items appended to the grid -- the body of
+// border_fill_kernel), and the next level's border by the next pass.  Arithmetic = scharr_body / pyr_hrow / pyr_column above,
+// so the results are bit-identical to the three-kernel chain (emulator + GPU pyramid tests).
+//   pyr_pass_kernel      one level of all images: blockIdx.y = image, blockIdx.x = 256 work items (main items, then border);
+//                        one launch per level (L instead of 2 L + 2 launches)
+#ifndef VO_PF_ROWS
+#define VO_PF_ROWS 8
+#endif
+constexpr int PF_ROWS = VO_PF_ROWS; // rows per work item (even)
+static_assert(PF_ROWS % 2 == 0 && PF_ROWS <= 16, "a work item starts on an even row; one REFLECT_101 step covers its halo (levels have >= 22 rows)");
+
+struct PassPlan {
+    int ng[VO_MAX_LEVELS];       // 4-column groups of a level
+    int ni[VO_MAX_LEVELS];       // of which interior: groups 1 .. ni read columns 4 g - 2 .. 4 g + 4 inside the image
+    int n_main[VO_MAX_LEVELS];   // main work items (column groups x row blocks)
+    int n_items[VO_MAX_LEVELS];  // main + border work items
+};
+struct __attribute__((packed, aligned(2))) LkU2x { // an 8-byte row window at an even column
+    uint32_t lo, hi;
+};
+
+inline int border_items(int h, int w, int stride)
+{
+    const int cpr = stride >> 4, xr0 = w & ~15;
+    return 2 * VO_BY * cpr + h * (VO_BX / 16 + ((stride - VO_BX - xr0) >> 4));
+}
+
+inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int *lstride)
+{
+    PassPlan pp = {};
+    for (int l = 0; l < n_levels; l++) {
+        pp.ng[l] = (lw[l] + 3) / 4;
+        pp.ni[l] = lw[l] >= 9 ? (lw[l] - 5) >> 2 : 0; // 4 g + 4 <= w - 1
+        pp.n_main[l] = pp.ng[l] * ((lh[l] + PF_ROWS - 1) / PF_ROWS);
+        pp.n_items[l] = pp.n_main[l] + border_items(lh[l], lw[l], lstride[l]);
+    }
+    return pp;
+}
+
+// one 16-byte chunk of a level's REFLECT_101 border (the work item of border_fill_kernel)
+__device__ __forceinline__ void border_item(const PyrImage &im, int level, int item)
+{
+    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
+    VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
+    const int cpr = stride >> 4;
+    const int xr0 = w & ~15;
+    const int nb = VO_BX / 16 + ((stride - VO_BX - xr0) >> 4);
+    const int n_out = 2 * VO_BY * cpr;
+    int y, x0;
+    if (item < n_out) {
+        const int r = item / cpr;
+        y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
+        x0 = 16 * (item - r * cpr) - VO_BX;
+    } else {
+        item -= n_out;
+        const int r = item / nb, k = item - r * nb;
+        if (r >= h)
+            return;
+        y = r;
+        x0 = k < VO_BX / 16 ? 16 * k - VO_BX : xr0 + 16 * (k - VO_BX / 16);
+    }
+    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
+    uint32_t v[4];
+    if (x0 >= 0 && x0 + 15 < w) {
+        const U32x4 t = *(const VO_GLOBAL U32x4 *)(src + x0);
+        v[0] = t.a;
+        v[1] = t.b;
+        v[2] = t.c;
+        v[3] = t.d;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = x0 + 4 * q;
+            v[q] = (uint32_t)src[reflect101(x, w)] | (uint32_t)src[reflect101(x + 1, w)] << 8 |
+                   (uint32_t)src[reflect101(x + 2, w)] << 16 | (uint32_t)src[reflect101(x + 3, w)] << 24;
+        }
+    }
+    *(VO_GLOBAL uint4 *)(p + (ptrdiff_t)y * stride + x0) = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// main work item: column group g (columns 4 g .. 4 g + 3), row block b (rows PF_ROWS b ..)
+//
+// Why FOUR columns per lane: the Scharr image is 80 % of the stage's bytes and goes out with non-temporal stores.  A lane that
+// owns 8 pixels writes 32 bytes per row as two 16-byte stores, i.e. every store instruction of the wavefront covers 64 x 16
+// bytes at a 32-byte stride -- and that pattern runs at 2.4 TB/s on the MI355X, whatever the kernel around it
+// (tools/ubench/store_rate.hip: 2.44 TB/s, against 6.26 TB/s for the same non-temporal stores when the 64 lanes of an
+// instruction write one contiguous KB; round 3's scharr_nt_kernel and the first fused pass both sat at that rate).  With 4
+// pixels per lane each store instruction is one contiguous KB.
+template <bool HAS_NEXT, bool EDGE>
+__device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, int b)
+{
+    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
+    const VO_GLOBAL uint8_t *__restrict__ src = (const VO_GLOBAL uint8_t *)im.lvl[level];
+    VO_GLOBAL uint32_t *__restrict__ der = (VO_GLOBAL uint32_t *)im.der[level];
+    const int x4 = 4 * g, y0 = PF_ROWS * b, c0 = x4 - 2; // c0: column of byte 0 of the 8-byte window (bytes 0 .. 6 are used:
+                                                         // columns x4 - 2 .. x4 + 4; an EDGE item gathers them by REFLECT_101)
+    int dw = 0, dh = 0, dstride = 0;
+    VO_GLOBAL uint8_t *__restrict__ dst = nullptr;
+    if (HAS_NEXT) {
+        dw = im.w[level + 1];
+        dh = im.h[level + 1];
+        dstride = im.stride[level + 1];
+        dst = (VO_GLOBAL uint8_t *)im.lvl[level + 1];
+    }
+    const int x2 = x4 >> 1, oy0 = y0 >> 1;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0; // pyrDown: horizontal sums (two u16) of the last five source rows
+    uint32_t A[3], B[3], C[3];                      // Scharr: lifted column pairs (j, j + 1), j = 0, 2, 4 of the last three rows
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        A[k] = B[k] = C[k] = 0;
+    // ALL source rows of the item are requested before the first one is used (interior items): with the load inside the row
+    // loop the compiler waited for every row before touching it -- one exposed memory latency per row, ~11 per item, and the
+    // level-0 pass sat at 0.48 ms whatever the store pattern (gpurun_out/r4_06; the ISA had `s_waitcnt vmcnt(0)` behind each
+    // of the loads).  2 registers per row.  (Rows past the last one an output of this item depends on -- the last row block of
+    // a level -- are loaded too: REFLECT_101 keeps the address inside the image.)
+    uint32_t W0[PF_ROWS + 3], W1[PF_ROWS + 3];
+    if (!EDGE) {
+#pragma unroll
+        for (int r = 0; r < PF_ROWS + 3; r++) {
+            // (one reflection is enough: -2 <= row < h + PF_ROWS + 1 and every level is taller than PF_ROWS + 2 -- a level
+            // is at least 22 rows, buildOpticalFlowPyramid's stop rule; reflect101's general loop costs ~30 instructions)
+            // 32-bit unsigned offset from the (wavefront-uniform) level base: one multiply-add per row instead of a 64-bit one
+            const int p = y0 - 2 + r, sy = p < 0 ? -p : p >= h ? 2 * h - 2 - p : p;
+            const LkU2x v = *(const VO_GLOBAL LkU2x *)(src + ((uint32_t)sy * (uint32_t)stride + (uint32_t)c0));
+            W0[r] = v.lo;
+            W1[r] = v.hi;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PF_ROWS + 3; r++) {
+        // source row y0 - 2 + r: Scharr row y0 + j reads r = j + 1 .. j + 3, next-level row oy0 + j reads r = 2 j .. 2 j + 4
+        uint32_t w0, w1;
+        if (!EDGE) {
+            w0 = W0[r];
+            w1 = W1[r];
+        } else {
+            if (r >= 5 && !(y0 + r - 3 < h) && !(HAS_NEXT && oy0 + (r - 3) / 2 < dh))
+                break; // (the last row block of a level: nothing of this item depends on the remaining rows)
+            const VO_GLOBAL uint8_t *__restrict__ row = src + (ptrdiff_t)reflect101(y0 - 2 + r, h) * stride;
+            uint32_t bt[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                bt[k] = k <= 6 ? (uint32_t)row[reflect101(c0 + k, w)] : 0u;
+            w0 = bt[0] | bt[1] << 8 | bt[2] << 16 | bt[3] << 24;
+            w1 = bt[4] | bt[5] << 8 | bt[6] << 16 | bt[7] << 24;
+        }
+        if (HAS_NEXT) { // horizontal [1 4 6 4 1] of the 2 next-level outputs: bytes 0 .. 4 and 2 .. 6
+            const uint32_t taps = 0x04060401u;
+            const uint32_t h0 = udot4(w0, taps, udot4(w1, 0x00000001u, 0));
+            const uint32_t h1 = udot4(alignbyte(w1, w0, 2), taps, udot4(w1, 0x00010000u, 0));
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = q4;
+            q4 = h0 | h1 << 16;
+            if (r >= 4 && (r & 1) == 0) { // source row 2 (oy0 + j) + 2 has arrived: output row oy0 + j, j = (r - 4) / 2
+                const int oy = oy0 + (r - 4) / 2;
+                if (oy < dh && x2 < dw) {
+                    // 6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408 fits 16 bits; the result is its high byte.  A second column
+                    // >= dw lands in the right border, which the next level's pass rewrites
+                    const uint32_t v = pk_mad_u16(q2, 6, pk_mad_u16(pk_add_u16(q1, q3), 4, pk_add_u16(pk_add_u16(q0, q4), 0x00800080u)));
+                    *(VO_GLOBAL uint16_t *)(dst + ((uint32_t)oy * (uint32_t)dstride + (uint32_t)x2)) = (uint16_t)perm_b32(0, v, 0x0c0c0301u);
+                }
+            }
+        }
+        // Scharr window: bytes 1 .. 6 of the 8 = columns x4 - 1 .. x4 + 4
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            A[k] = B[k];
+            B[k] = C[k];
+        }
+        C[0] = perm_b32(w1, w0, 0x0c020c01u);
+        C[1] = perm_b32(w1, w0, 0x0c040c03u);
+        C[2] = perm_b32(w1, w0, 0x0c060c05u);
+        if (r >= 3) { // rows y - 1, y, y + 1 of Scharr row y = y0 + r - 3 are in A, B, C
+            const int y = y0 + r - 3;
+            if (y < h) {
+                uint32_t T[3], U[3]; // T = 4 t0 = 12 (above + below) + 40 row (<= 16320), U = t1 = below - above (scharr_body)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    T[k] = pk_mad_u16(B[k], 40, pk_mad_u16(pk_add_u16(A[k], C[k]), 12, 0));
+                    U[k] = pk_sub_i16(C[k], A[k]);
+                }
+                uint32_t out[4];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t ix = pk_sub_i16(T[k + 1], T[k]);
+                    const uint32_t mid = alignbyte(U[k + 1], U[k], 2);
+                    const uint32_t iy = pk_mad_u16(mid, 40, pk_mad_u16(pk_add_u16(U[k], U[k + 1]), 12, 0));
+                    out[2 * k] = perm_b32(iy, ix, VO_SEL_LO16);
+                    out[2 * k + 1] = perm_b32(iy, ix, VO_SEL_HI16);
+                }
+                if (EDGE && x4 + 4 > w) { // pixels >= w of the last group (always an edge group) fall into the (zero) right border
+#pragma unroll
+                    for (int k = 1; k < 4; k++)
+                        if (x4 + k >= w)
+                            out[k] = 0;
+                }
+                VO_GLOBAL uint4 *o = (VO_GLOBAL uint4 *)(der + ((uint32_t)y * (uint32_t)stride + (uint32_t)x4));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 oa = {out[0], out[1], out[2], out[3]};
+                __builtin_nontemporal_store(oa, (VO_GLOBAL u32x4 *)o);
+#else
+                o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+#endif
+            }
+        }
+    }
+}
+
+// Work items of a level in launch order: the INTERIOR column groups of every row block, then the EDGE groups (the first
+// group and the one or two at the right end that need a column outside the image) of every row block, then the border
+// chunks.  Edge items gather single bytes through REFLECT_101 (7 loads per row instead of one) -- numbered row block by row
+// block they sat in 4 of every 10 wavefronts and the whole wavefront waited for them (gpurun_out/r4_03: level-0 pass 0.46
+// ms); grouped at the end they fill one or two wavefronts per image.
+__device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int n_levels, const PassPlan &pp, int item)
+{
+    if (item >= pp.n_items[level])
+        return;
+    if (item >= pp.n_main[level]) {
+        border_item(im, level, item - pp.n_main[level]);
+        return;
+    }
+    const int ng = pp.ng[level], ni = pp.ni[level], nb = pp.n_main[level] / ng, n_int = nb * ni;
+    const bool has_next = level + 1 < n_levels;
+    if (item < n_int) {
+        const int b = item / ni, g = 1 + item - b * ni;
+        if (has_next)
+            pass_item<true, false>(im, level, g, b);
+        else
+            pass_item<false, false>(im, level, g, b);
+        return;
+    }
+    const int ne = ng - ni, e = item - n_int;
+    const int b = e / ne, k = e - b * ne;
+    const int g = k == 0 ? 0 : ni + k; // group 0, then groups ni + 1 .. ng - 1
+    if (has_next)
+        pass_item<true, true>(im, level, g, b);
+    else
+        pass_item<false, true>(im, level, g, b);
+}
+
+__global__ __launch_bounds__(256) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+{
+    pass_dispatch(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+
 #ifndef VO_HOST_EMUL
+#ifdef VO_DEV_VARIANTS
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lstride,
                         const int *lh, hipStream_t stream)
 {
@@ -451,6 +715,22 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
     }
 #endif
     hipLaunchKernelGGL(scharr_nt_kernel, grid, dim3(256), 0, stream, d_imgs, n_levels, st);
+}
+#endif // VO_DEV_VARIANTS
+
+// the whole pyramid build of a range of images: level 0's pass, then levels 1 .. L-1 in one launch (two launches instead of
+// eight; a one-level pyramid is one launch)
+void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh, const int *lstride,
+                          hipStream_t stream)
+{
+    if (n_images <= 0 || n_levels <= 0)
+        return;
+    const PassPlan pp = pass_plan(n_levels, lw, lh, lstride);
+    // one launch per level.  (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel,
+    // pass / fence + barrier / pass -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms
+    // for level 0, gpurun_out/r4_04: a few hundred workgroups of serial phases do not fill the chip.)
+    for (int l = 0; l < n_levels; l++)
+        hipLaunchKernelGGL(pyr_pass_kernel, dim3((pp.n_items[l] + 255) / 256, n_images), dim3(256), 0, stream, d_imgs, l, n_levels, pp);
 }
 
 #endif // VO_HOST_EMUL

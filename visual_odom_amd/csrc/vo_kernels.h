@@ -38,7 +38,7 @@ struct RansacState {
     int niters;    // current adaptive iteration bound
     int max_good;  // best inlier count
     int best;      // index of the hypothesis that achieved it (-1: none)
-    uint64_t rng;  // cv::RNG state after the subsets drawn so far
+    uint64_t rng;  // POSITION in the raw cv::RNG(-1) stream after the subsets drawn so far (ransac_subsets_kernel)
 };
 
 // findEssentialMat(points0, points1, focal, pp, RANSAC, prob, threshold) + recoverPose (visualOdometry.cpp:152-153)
@@ -96,6 +96,9 @@ struct SeqIngest {
 
 // workspace of the four-kernel EPnP used for small launches (pnp.hip): VO_EPNP_WS_DOUBLES doubles per hypothesis of the first
 // RANSAC chunk (VO_EPNP_WS_HYPS hypotheses per frame), allocated for up to VO_EPNP_WS_MAX_FRAMES frames
+// slim pose chain (waves = 4): the 12 x 12 M^T M (+ 12 column norms) of every hypothesis of the FIRST RANSAC chunk in a global
+// workspace, lane-interleaved per 64-hypothesis block: [frames][VO_EPNP_GWS_BLOCKS][VO_EPNP_UT_DOUBLES][64] doubles
+constexpr int VO_EPNP_UT_DOUBLES = 144 + 12, VO_EPNP_GWS_BLOCKS = 2;
 constexpr int VO_EPNP_WS_DOUBLES = 288, VO_EPNP_WS_HYPS = 128, VO_EPNP_WS_MAX_FRAMES = 16, VO_EPNP_SPLIT_DEFAULT_FRAMES = 4;
 
 #ifndef VO_HOST_EMUL
@@ -110,11 +113,15 @@ struct EmBufs {
     uint8_t *mask = nullptr;              // [B][cap]
 };
 
+#ifdef VO_DEV_VARIANTS // the round-3 three-kernel pyramid chain (A/B partner of launch_pyramid_fused, VO_PYR_FUSED=0)
 void launch_border_fill(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lstride,
                         const int *lh, hipStream_t stream);
 void launch_pyr_down(const PyrImage *d_imgs, int n_images, int level, int dw, int dh, hipStream_t stream);
 void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_levels, const int *lw, const int *lh,
                    hipStream_t stream);
+#endif
+void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh, const int *lstride,
+                          hipStream_t stream);
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
@@ -167,11 +174,11 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws = nullptr,
-                int ws_frames = 0);
+                int ws_frames = 0, double *gws = nullptr);
 // epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
-                       hipStream_t stream, double *epnp_ws, int ws_frames);
+                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);

@@ -12,20 +12,7 @@
 // (Apache-2.0) -- see NOTICE.  Written for this repository; no OpenCV source is included.
 #pragma once
 
-#include <float.h>
-#include <math.h>
-#include <stdint.h>
-
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
-#define VO_HD __host__ __device__ __forceinline__
-// NB: a real (non-inlined) device call of the EPnP solver hangs on gfx950 when built at -O3 with
-// ROCm 7.2 (tools/bisect/epnp_bisect.hip reproduces it; -O1 or inlining is fine) -> always inline.
-#define VO_HD_NOINLINE __host__ __device__ __forceinline__
-#else
-#define VO_HD inline
-#define VO_HD_NOINLINE
-#endif
+#include "vo_math.h" // VO_HD, and the sin / cos / acos Rodrigues uses: IEEE operations only, the same bits on gfx950 and g++
 
 namespace vo {
 
@@ -297,7 +284,7 @@ VO_HD void rodrigues_v2m(const double *rv, double *R, double *J)
         }
         return;
     }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c;
+    double c = vo_cos(theta), s = vo_sin(theta), c1 = 1. - c;
     double itheta = theta ? 1. / theta : 0.;
     rx *= itheta;
     ry *= itheta;
@@ -346,7 +333,7 @@ VO_HD void rodrigues_m2v(const double *Rin, double *rv)
     double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1. ? 1. : c < -1. ? -1. : c;
-    double theta = acos(c);
+    double theta = vo_acos(c);
     if (s < 1e-5) {
         if (c > 0)
             rx = ry = rz = 0;

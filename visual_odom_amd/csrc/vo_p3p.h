@@ -12,8 +12,9 @@
 // closed form through the resolvent cubic, Horn's quaternion alignment through a cyclic Jacobi of a symmetric 4 x 4),
 // ranked by the fourth point's error in normalised coordinates, then re-ranked by the squared pixel error of all four
 // points after Rodrigues + projectPoints; the first one is the answer.  Operation order follows the library so that
-// the result tracks the CPU path to rounding; pow / acos / cos of the cubic are the platform's, so "to rounding" is
-// what the parity test states (1e-9 relative on well-conditioned quadruples).
+// the result tracks the CPU path to rounding.  The cubic's pow(x, 1/3.) / acos / cos are vo_math.h's (IEEE +, -, *, /, sqrt
+// only): the device computes the same bits as the host build of this header (tested bit for bit on the MI355X), and the
+// host build is held to the CPU checker -- which calls glibc's, as OpenCV does -- on the CPU (tests/test_p3p.py).
 // Attribution: follows the operation order of OpenCV's calib3d p3p.cpp / polynom_solver.cpp (Apache-2.0) -- see NOTICE.
 // Written for this repository; no OpenCV source is included.
 #pragma once
@@ -63,18 +64,18 @@ VO_HD int p3p_deg3(double a, double b, double c, double d, double &x0, double &x
             x0 = x1 = x2 = -b_a_3;
             return 3;
         }
-        x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+        x0 = vo_cbrt(2 * R) - b_a_3; // (library text: pow(2 * R, 1 / 3.0))
         return 1;
     }
     if (D <= 0) { // three real roots
-        const double theta = acos(R / sqrt(-Q3));
+        const double theta = vo_acos(R / sqrt(-Q3));
         const double sqrt_Q = sqrt(-Q);
-        x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
-        x1 = 2 * sqrt_Q * cos((theta + 2 * PI) / 3.0) - b_a_3;
-        x2 = 2 * sqrt_Q * cos((theta + 4 * PI) / 3.0) - b_a_3;
+        x0 = 2 * sqrt_Q * vo_cos(theta / 3.0) - b_a_3;
+        x1 = 2 * sqrt_Q * vo_cos((theta + 2 * PI) / 3.0) - b_a_3;
+        x2 = 2 * sqrt_Q * vo_cos((theta + 4 * PI) / 3.0) - b_a_3;
         return 3;
     }
-    const double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    const double AD = vo_cbrt(fabs(R) + sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0)); // (pow(.., 1.0 / 3.0))
     const double BD = (AD == 0) ? 0 : -Q / AD;
     x0 = AD + BD - b_a_3;
     return 1;

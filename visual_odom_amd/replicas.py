@@ -45,3 +45,16 @@ def aggregate(dist, elapsed_s, frames_done, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(t.item()), int(f.item())
+
+
+def gather_values(dist, value, device=None):
+    """[value of rank 0, value of rank 1, ...] on every rank (per-GPU frames/s next to the aggregate: BASELINE config 5)"""
+    if dist is None:
+        return [float(value)]
+    import torch
+    if dist.get_backend() == "gloo":
+        device = None
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
