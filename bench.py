@@ -289,7 +289,10 @@ def main(argv=None):
     replay_leg = args.mode == "batch" and not args.no_replay_leg and args.workload.startswith("kitti") and \
         not args.mono_rotation and args.frames >= 256
     config_legs = default_run and not args.no_configs and world_size == 1
-    kept = [] if (replay_leg or config_legs or (world_size > 1 and default_run and not args.no_configs)) else None
+    # N > 1: BASELINE config 5 (one sequence per GPU, exact replay) beside the weak-scaled batch headline
+    config5_leg = world_size > 1 and args.mode == "batch" and args.stages == "full" and args.workload == "kitti2000" and \
+        not args.mono_rotation and not args.no_configs
+    kept = [] if (replay_leg or config_legs or config5_leg) else None
     if args.mode == "sequences":
         out = run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, replicas)
     else:
@@ -351,7 +354,7 @@ def main(argv=None):
                              "points_per_frame": er["points_per_frame"], "validated_frames": er["validated_frames"],
                              "schedule": er["schedule"], "stage_ms": er["stage_ms"], "roofline": er["roofline"]})
             out["configs"] = legs
-    if world_size > 1 and default_run and not args.no_configs:
+    if config5_leg:
         # BASELINE config 5 as written -- one sequence per GPU, exact replay of the reference's frame loop -- next to the
         # weak-scaled batch headline: every rank runs ONE sequence of its own through the lock-step loop (`--mode sequences
         # --seqs 1`), per-GPU frames/s gathered, aggregate = frames of all ranks / max-over-ranks time
@@ -428,10 +431,11 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     # the results of the LAST timed step, held to the oracle outside the timer: the first and last frame of the
     # batch (first / last XCD group of the LK grid) and one from the middle
     validated = 0
-    if args.validate > 0 and rank == 0:
+    if args.validate > 0:  # EVERY rank holds frames of its own last step to the oracle; the line reports the smallest count
         picks = sorted({int(round(x)) for x in np.linspace(0, B - 1, max(args.validate, 2))})
         validated = validate_frames(ctx, picks, lefts, rights, frame_pts, world, S, full=args.stages != "lk",
                                     max_level=max_level)
+        validated = int(min(replicas.gather_values(dist, validated, dev)))
     sustained = None
     if args.sustain > 0:
         n_sus = max(K, int(np.ceil(args.sustain / max(elapsed / K, 1e-6))))
@@ -466,7 +470,8 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                        "frames_per_step_per_gpu": B, "pyramids_per_step_per_gpu": n_images,
                        "points_per_frame": float(np.mean([len(p) for p in frame_pts])),
                        "parallelism": "replicas x%d (one sequence per GPU, no collective)" % world_size,
-                       "schedule": dict(ctx.get_schedule(), probe_ms=ctx.get_probe_log()),
+                       # (an LK-only run has no pose chain: nothing to schedule, and the context's last probe was another leg's)
+                       "schedule": dict(ctx.get_schedule(), probe_ms=ctx.get_probe_log()) if args.stages != "lk" else None,
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
                        "model_bytes_per_frame": frame_bytes,
                        "hbm_roof_fps_per_gpu": PEAK_HBM_GBS * 1e9 / frame_bytes},
@@ -569,8 +574,9 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     n_bucketed = np.array([i[-K:, 0] for i in info])          # [S][K]
     integrated = np.mean([(i[-K:, 5] & _lib.SEQ_F_INTEGRATED) != 0 for i in info])
     validated = 0
-    if args.validate > 0 and rank == 0:
+    if args.validate > 0:
         validated = validate_sequences(ctx, sorted({0, S - 1}), feed, lefts, rights, world, args.validate, per_bucket)
+        validated = int(min(replicas.gather_values(dist, validated, dev)))
     pts_per_launch = float(n_bucketed.sum(0).mean())
     lk_bytes = float(ctx.model_bytes(w, h, 1)[1]) * pts_per_launch
     frame_bytes = float(ctx.model_bytes(w, h, int(round(pts_per_launch / S))).sum())
@@ -685,7 +691,8 @@ def pyramid_roofline(ctx, w, h, n_images, stage_ms):
         if lv == max_level or nw <= 21 or nh <= 21:
             break
         cw, ch, lv = nw, nh, lv + 1
-    moved = algo + (px * 1.0 + px * 4.0) * n_images                  # + Scharr pass: read every level, write 4 B per pixel
+    moved = algo + px * 4.0 * n_images   # + the 4-byte Scharr pixel per pyramid pixel (the fused pass reads a level ONCE: round
+                                         # 3's separate Scharr kernel read every level a second time, + px per image)
     return {"pyramid": {"bound": "hbm", "stage_ms": ms, "algorithmic_bytes": algo, "designed_bytes": moved,
                         "achieved": algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                         "achieved_designed": moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,

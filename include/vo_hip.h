@@ -119,6 +119,20 @@ int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
  * over real steps of the lock-step loop */
 #define VO_PROBE_LOG_MAX 12
 int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands, float *ms, int *real, int *n);
+/* The process-wide table of settled schedules, out and in: a service exports it once (after a warm-up run of every shape it
+ * uses) and imports it at start-up, so that no context of the new process probes -- the first run of a probed key otherwise
+ * costs 25-100 runs' time (0.03 s for one 1241 x 376 frame, ~0.6 s for a 256-frame batch at 2000 points, ~1.2 s for 256
+ * sequences; an upper bound: ~100 runs of the caller's own shape) and, in the lock-step loop, up to three pipeline drains
+ * within its first ~200 steps.  key = (device, mode, width, height, pyramid levels, frames per run, point-load bucket, flags);
+ * records are valid for the same library build and device model.  Neither call needs a context.
+ *   vo_export_schedule: writes min(*n, cap) records, *n = records in the table (recs may be NULL with cap = 0 to ask)
+ *   vo_import_schedule: all records are validated first (VO_ERR_ARG leaves the table untouched); existing keys are replaced */
+typedef struct vo_schedule_record {
+    int64_t key[8];
+    vo_schedule schedule;
+} vo_schedule_record;
+int vo_export_schedule(vo_schedule_record *recs, int cap, int *n);
+int vo_import_schedule(const vo_schedule_record *recs, int n);
 int vo_get_params(const vo_ctx *ctx, vo_params *p);
 
 /* ------------------------------------------------------------------------------------------

@@ -99,6 +99,22 @@ def main():
     expect("vo_get_schedule", ARG, ctx, NULL, NULL)
     expect("vo_get_probe_log", ARG, NULL, NULL, NULL, NULL, C.byref(n_out))
     expect("vo_get_probe_log", ARG, ctx, NULL, NULL, NULL, NULL)
+    rec = _lib.VoScheduleRecord()
+    expect("vo_export_schedule", ARG, NULL, 0, NULL)
+    expect("vo_export_schedule", ARG, NULL, 4, C.byref(n_out))
+    expect("vo_export_schedule", ARG, C.byref(rec), -1, C.byref(n_out))
+    expect("vo_export_schedule", OK, NULL, 0, C.byref(n_out))
+    expect("vo_import_schedule", ARG, NULL, 1)
+    expect("vo_import_schedule", ARG, C.byref(rec), -1)
+    for key, sc in (((0, 0, 640, 480, 4, 1, 20, 0), (3, 1, 0)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 0, 0)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 1, 2)),
+                    ((-1, 0, 640, 480, 4, 1, 20, 0), (1, 1, 0)), ((0, 0, 8, 480, 4, 1, 20, 0), (1, 1, 0)), ((0, 0, 640, 480, 9, 1, 20, 0), (1, 1, 0)),
+                    ((0, 0, 640, 480, 4, 0, 20, 0), (1, 1, 0))):
+        r2 = _lib.VoScheduleRecord()
+        for i in range(8):
+            r2.key[i] = key[i]
+        r2.schedule = _lib.VoSchedule(*sc)
+        expect("vo_import_schedule", ARG, C.byref(r2), 1)
+    expect("vo_import_schedule", OK, NULL, 0)
     expect("vo_batch_set_detect_params", ARG, NULL, C.byref(dprm))
     for field, val in (("features_per_bucket", 0), ("features_per_bucket", 9), ("bucket_size", -1)):
         d2 = _lib.VoDetectParams()

@@ -191,3 +191,97 @@ def test_argument_sweep_over_every_export():
     assert rep["failures"] == [], "\n".join(rep["failures"])
     assert rep["not_covered"] == []
     assert rep["checked"] >= 250
+
+
+def test_two_ranks_of_bench_share_gpu_zero():
+    """the N > 1 path of bench.py with REAL GPU work in both ranks (tests/test_replicas_gloo.py only
+    fabricates timings): the driver's launch line with two ranks, both on GPU 0 (VO_ALLOW_SHARED_GPU=1, gloo for the barrier
+    and the reductions since RCCL refuses duplicate devices).  The line must say ranks = 2 on ONE GPU, sum the frames of both
+    ranks over the max-over-ranks time, have both ranks' frames validated against the oracle, and carry BASELINE config 5
+    (one sequence per GPU, exact replay) with a per-GPU figure for each rank."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VO_ALLOW_SHARED_GPU="1", VO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "16", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--sustain", "0", "--no-replay-leg", "--validate", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0
+    b = json.loads(lines[0])
+    assert b["ranks"] == 2 and b["n_gpus"] == 1 and b["scaling"] == "weak"
+    assert b["validated_frames"] == 2                 # the smaller of the two ranks' counts: both validated
+    frames = b["value"] * b["ms_per_step"] * 1e-3 * b["steps"]
+    assert abs(frames - 2 * 16 * 3) < 1e-6 * frames   # frames of both ranks / max-over-ranks time
+    c5 = [c for c in b["configs"] if c["name"] == "config5_one_sequence_per_gpu"]
+    assert len(c5) == 1 and c5[0]["baseline_config"] == 5 and c5[0]["ranks"] == 2 and c5[0]["sequences_per_gpu"] == 1
+    assert len(c5[0]["per_gpu_value"]) == 2 and all(v > 0 for v in c5[0]["per_gpu_value"])
+    assert c5[0]["value"] <= sum(c5[0]["per_gpu_value"]) * 1.0001 and c5[0]["validated_frames"] >= 1
+    print("two ranks on GPU 0: batch %.0f frames/s; config 5: %.0f frames/s aggregate, per rank %s"
+          % (b["value"], c5[0]["value"], ["%.0f" % v for v in c5[0]["per_gpu_value"]]))
+
+
+def test_schedule_export_import_skips_the_probe(volib, small_world, small_seq):
+    """vo_export_schedule / vo_import_schedule: a settled schedule leaves the process as plain records
+    and comes back in; a context whose key is in the table does not probe -- its first run takes one run's time -- and
+    reports the imported schedule with probed = 1.  Here: probe an 8-frame batch, export, re-key the record to a 6-frame
+    batch with the OTHER pose_streams value (a schedule no probe of this process produced), import, run 6 frames."""
+    import time
+    from visual_odom_amd import synth
+    lefts, rights = small_seq["L"], small_seq["R"]
+    h, w = lefts[0].shape
+    P_l, P_r = small_world.proj_matrices()
+    pts = synth.select_keypoints(lefts[0], bucket=h // 10, per_bucket=4)
+
+    def batch(B):
+        ctx = volib.Context(0, w, h, 4096, B)
+        ctx.batch_configure(4, w, h, B)
+        for i, a in enumerate((lefts[0], rights[0], lefts[1], rights[1])):
+            ctx.batch_upload_image(i, a)
+        ctx.batch_set_quads([[0, 1, 2, 3]] * B)
+        for b in range(B):
+            ctx.batch_set_points(b, pts)
+        ctx.batch_set_projection(P_l, P_r)
+        return ctx
+
+    ctx = batch(8)
+    try:
+        ctx.batch_run(volib.STAGE_ALL)   # probes
+        ctx.batch_sync()
+        s8 = ctx.get_schedule()
+        assert s8["probed"]
+        ref_pose = ctx.batch_get_pose(0)
+    finally:
+        ctx.close()
+    table = volib.export_schedules()
+    mine = [r for r in table if r["key"][2] == w and r["key"][3] == h and r["key"][5] == 8 and r["key"][1] == 0]
+    assert len(mine) == 1 and (mine[0]["pose_waves"], mine[0]["pose_streams"]) == (s8["pose_waves"], s8["pose_streams"])
+    rec = dict(mine[0], key=list(mine[0]["key"]))
+    rec["key"][5] = 6
+    rec["pose_streams"] = 3 - s8["pose_streams"]
+    rec["pose_waves"] = 3 - s8["pose_waves"]
+    volib.import_schedules([rec])
+    assert rec in volib.export_schedules()
+    ctx = batch(6)
+    try:
+        t0 = time.perf_counter()
+        ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        first = time.perf_counter() - t0
+        s6 = ctx.get_schedule()
+        assert (s6["pose_waves"], s6["pose_streams"], s6["probed"]) == (rec["pose_waves"], rec["pose_streams"], True)
+        assert ctx.get_probe_log() == {} or len(ctx.get_probe_log()) == 0   # no probe ran in this context
+        t0 = time.perf_counter()
+        ctx.batch_run(volib.STAGE_ALL)
+        ctx.batch_sync()
+        second = time.perf_counter() - t0
+        assert first < 5 * second + 2e-3, (first, second)                   # one run's time, not a probe's 25-100
+        p = ctx.batch_get_pose(0)
+        assert np.array_equal(p["rvec"], ref_pose["rvec"]) and np.array_equal(p["inliers"], ref_pose["inliers"])
+    finally:
+        ctx.close()
+    with pytest.raises(volib.VoError):
+        volib.import_schedules([dict(rec, pose_waves=3)])

@@ -93,6 +93,31 @@ if has latency; then
     timeout 300 python tools/latency_mode.py 200 > "$OUT/latency.log" 2>&1
     cat "$OUT/latency.log"
 fi
+if has seqinline; then  # (round-4 experiment, removed from the code: filter + carry on the tracking stream -- no gain at 1 sequence, -1..-10 % at 8 / 64; profiles/r04_experiments.md)
+    export VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so
+    for INL in 0 1; do
+        for S in 1 8 64 256; do
+            for WL in kitti374 kitti2000; do
+                stamp "VO_SEQ_INLINE_FILTER=$INL bench --mode sequences $WL --seqs $S"
+                VO_SEQ_INLINE_FILTER=$INL timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps $([ $S -le 8 ] && echo 300 || echo 60) --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/inl${INL}_${WL}_${S}.json" 2> "$OUT/inl${INL}_${WL}_${S}.err"
+                python -c "import json; b=json.loads(open('$OUT/inl${INL}_${WL}_${S}.json').read().strip().splitlines()[-1]); print('  inline=$INL $WL S=%-4d %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']), {k: b['config']['schedule'][k] for k in ('pose_waves','pose_streams','prepare')})" 2>&1 | tee -a "$OUT/summary.txt"
+            done
+        done
+    done
+    unset VO_HIP_LIB
+fi
+if has timeline; then
+    stamp "kernel timeline of vo_track_frame"
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tf" -- python "$ROOT/tools/latency_mode.py" trackonly 6 60 > "$OUT/tf.log" 2>&1)
+    python tools/kernel_timeline.py "$OUT/tf" 52 > "$OUT/timeline.txt" 2>&1
+    rm -rf "$OUT/tf"
+    tail -40 "$OUT/timeline.txt"
+    stamp "kernel timeline of the one-sequence lock-step loop"
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/sq" -- python "$ROOT/tools/latency_mode.py" pipelined 6 30 > "$OUT/sq.log" 2>&1)
+    python tools/kernel_timeline.py "$OUT/sq" 120 > "$OUT/timeline_seq.txt" 2>&1
+    rm -rf "$OUT/sq"
+    tail -60 "$OUT/timeline_seq.txt"
+fi
 if has pyrprof; then  # kernel-level split of the pyramid stage (developer build; VO_PYR_FUSED from the environment)
     stamp "rocprofv3 kernel stats, dev lib, VO_PYR_FUSED=${VO_PYR_FUSED:-default}"
     (cd /tmp && VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pyrprof" -- python "$ROOT/bench.py" --workload kitti374 --steps 20 --warmup 3 $LEAN --validate 0 --schedule 2,1,0 > "$OUT/pyrprof.log" 2>&1)

@@ -35,6 +35,7 @@ EXPORTS = (
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
     "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_push_pairs", "vo_seq_step", "vo_seq_sync",
     "vo_seq_get_state", "vo_seq_get_trajectory", "vo_set_schedule", "vo_get_schedule", "vo_get_probe_log",
+    "vo_export_schedule", "vo_import_schedule",
 )
 
 
@@ -86,6 +87,39 @@ def load():
     lib.vo_default_detect_params.restype = None
     _lib = lib
     return lib
+
+
+class VoScheduleRecord(C.Structure):
+    """vo_schedule_record: the key a schedule was settled for + the schedule"""
+    _fields_ = [("key", C.c_int64 * 8), ("schedule", VoSchedule)]
+
+
+def export_schedules():
+    """the process-wide table of settled schedules as a list of dicts (JSON-able): vo_export_schedule"""
+    lib = load()
+    n = C.c_int(0)
+    rc = lib.vo_export_schedule(None, 0, C.byref(n))
+    if rc != VO_OK:
+        raise VoError(rc, "vo_export_schedule")
+    recs = (VoScheduleRecord * max(n.value, 1))()
+    rc = lib.vo_export_schedule(recs, n.value, C.byref(n))
+    if rc != VO_OK:
+        raise VoError(rc, "vo_export_schedule")
+    return [dict(key=[int(v) for v in r.key], pose_waves=r.schedule.pose_waves, pose_streams=r.schedule.pose_streams,
+                 prepare=r.schedule.prepare) for r in recs[:n.value]]
+
+
+def import_schedules(records):
+    """vo_import_schedule: records as export_schedules() returned them (e.g. read back from a JSON file)"""
+    lib = load()
+    recs = (VoScheduleRecord * max(len(records), 1))()
+    for r, d in zip(recs, records):
+        for i in range(8):
+            r.key[i] = int(d["key"][i])
+        r.schedule = VoSchedule(int(d["pose_waves"]), int(d["pose_streams"]), int(d["prepare"]))
+    rc = lib.vo_import_schedule(recs, len(records))
+    if rc != VO_OK:
+        raise VoError(rc, "vo_import_schedule: bad record")
 
 
 def _p(a):

@@ -20,7 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 SO = os.path.join(HERE, "libvo_hip.so")
-SOURCES = ["pyramid.hip", "fast.hip", "lk.hip", "post.hip", "pnp.hip", "essential.hip", "seq.hip", "capi.hip"]
+SOURCES = ["pyramid.hip", "fast.hip", "lk.hip", "post.hip", "pnp.hip", "essential.hip", "seq.hip", "capi.hip", "capi_run.hip",
+           "capi_sched.hip", "capi_seq.hip", "capi_dropin.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

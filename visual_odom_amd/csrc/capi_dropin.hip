@@ -1,0 +1,359 @@
+// capi_dropin.hip -- the synchronous drop-in calls (host buffers in, host buffers out): vo_circular_match, vo_triangulate,
+// vo_pnp_ransac, vo_fast_detect, vo_detect_bucket, vo_integrate_odometry, vo_track_frame.
+#include "capi_internal.h"
+
+namespace vo_capi {
+
+/* ---------------------------------- drop-in calls ---------------------------------------- */
+
+int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
+                              const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
+{
+    if (!l0 || !r0 || !l1 || !r1 || n < 0 || (n > 0 && !pts))
+        return fail(c, VO_ERR_ARG, "null image / points");
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    int rc = vo_batch_configure(c, 4, w, h, 1);
+    if (rc != VO_OK)
+        return rc;
+    const uint8_t *imgs[4] = {l0, r0, l1, r1};
+    for (int i = 0; i < 4; i++) {
+        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice);
+        if (rc != VO_OK)
+            return rc;
+    }
+    const int32_t quad[4] = {0, 1, 2, 3};
+    rc = vo_batch_set_quads(c, quad, 1);
+    if (rc != VO_OK)
+        return rc;
+    return vo_batch_set_points(c, 0, pts, n);
+}
+
+} // namespace vo_capi
+
+extern "C" {
+
+int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1,
+                      int w, int h, int stride, const float *pts, int n, float *out_l0, float *out_r0,
+                      float *out_r1, float *out_l1, float *out_l0_ret, uint8_t *status4, int32_t *keep_idx,
+                      int *n_out, int apply_consistency)
+{
+    if (!c || !n_out)
+        return VO_ERR_ARG;
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    if (rc != VO_OK)
+        return rc;
+    rc = run_stages(c, VO_STAGE_PYRAMID | VO_STAGE_LK | VO_STAGE_FILTER, false);
+    if (rc != VO_OK)
+        return rc;
+    if (status4) {
+        rc = vo_batch_get_tracks(c, 0, nullptr, nullptr, nullptr, nullptr, status4, n);
+        if (rc != VO_OK)
+            return rc;
+    }
+    if (!apply_consistency)
+        return get_stage_a(c, 0, out_l0, out_r0, out_r1, out_l1, out_l0_ret, keep_idx, n_out);
+    // stage B drops l0_ret (removeInvalidPoints is not applied to it); fill it from stage A by index
+    int K = 0;
+    rc = vo_batch_get_filtered(c, 0, out_l0, out_r0, out_l1, out_r1, nullptr, keep_idx, &K, nullptr, nullptr);
+    if (rc != VO_OK)
+        return rc;
+    if (out_l0_ret && K > 0) {
+        std::vector<int32_t> idx((size_t)K);
+        std::vector<float> ret((size_t)2 * (n > 0 ? n : 1));
+        VO_HIP_TRY(c, hipMemcpy(idx.data(), c->pb[c->last].idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+        VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk2[c->trk_last] + (size_t)3 * c->cap, sizeof(float2) * n,
+                                hipMemcpyDeviceToHost));
+        for (int i = 0; i < K; i++) {
+            out_l0_ret[2 * i] = ret[2 * idx[i]];
+            out_l0_ret[2 * i + 1] = ret[2 * idx[i] + 1];
+        }
+    }
+    *n_out = K;
+    return VO_OK;
+}
+
+int vo_triangulate(vo_ctx *c, const float *P_l, const float *P_r, const float *pl, const float *pr, int n,
+                   float *xyz_out)
+{
+    if (!c || !P_l || !P_r || n < 0 || (n > 0 && (!pl || !pr || !xyz_out)))
+        return VO_ERR_ARG;
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    if (n == 0)
+        return VO_OK;
+    int rc = vo_batch_set_projection(c, P_l, P_r);
+    if (rc != VO_OK)
+        return rc;
+    rc = sync_all(c);
+    if (rc != VO_OK)
+        return rc;
+    // frame 0, stage-B rows 0 (left) and 1 (right)
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB, pl, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + c->cap, pr, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + c->cap, (size_t)4 * c->cap, pb.nB, c->cap, n, 1,
+                       pb.xyz, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    VO_HIP_TRY(c, hipMemcpyAsync(xyz_out, pb.xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+} // extern "C"
+
+namespace vo_capi {
+
+int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
+                      int *n_inliers, bool pnp_rotation)
+{
+    int status = 0, ninl = 0, em_status = 1;
+    int rc = get_pose_impl(c, 0, rvec_io, tvec_io, R_out, inliers, &ninl, &status, nullptr, pnp_rotation, &em_status);
+    if (rc != VO_OK)
+        return rc;
+    if (n_inliers)
+        *n_inliers = ninl;
+    if (status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
+    if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
+        return VO_NO_ESSENTIAL;
+    return status == 1 ? VO_OK : VO_NO_MODEL;
+}
+
+} // namespace vo_capi
+
+extern "C" {
+
+int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
+                  double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers)
+{
+    if (!c || !K || n < 0 || (n > 0 && (!xyz || !uv)))
+        return VO_ERR_ARG;
+    if (n > c->cap)
+        return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    int rcs = sync_all(c);
+    if (rcs != VO_OK)
+        return rcs;
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    PnpParams pp;
+    pp.iters = c->prm.ransac_iterations;
+    pp.reproj = c->prm.ransac_reproj_error;
+    pp.confidence = c->prm.ransac_confidence;
+    memcpy(pp.K, K, sizeof(pp.K));
+    if (n > 0) {
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + 2 * (size_t)c->cap, uv, sizeof(float2) * n, hipMemcpyHostToDevice,
+                                     c->stream));
+    }
+    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (c->n_frames < 1)
+        c->n_frames = 1;
+    launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1, pb.epnp_gws);
+    VO_HIP_TRY(c, hipGetLastError());
+    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
+}
+
+} // extern "C"
+
+namespace vo_capi {
+
+// one image as a 1-frame batch whose quad points at image 0 four times
+int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
+{
+    if (!img)
+        return fail(c, VO_ERR_ARG, "null image");
+    int rc = vo_batch_configure(c, 4, w, h, 1);
+    if (rc != VO_OK)
+        return rc;
+    rc = upload_image(c, 0, img, stride, hipMemcpyHostToDevice);
+    if (rc != VO_OK)
+        return rc;
+    const int32_t quad[4] = {0, 0, 0, 0};
+    return vo_batch_set_quads(c, quad, 1);
+}
+
+} // namespace vo_capi
+
+extern "C" {
+
+int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int threshold, int nonmax,
+                   float *pts_out, int cap, int *n_out)
+{
+    if (!c || !n_out || cap < 0 || (cap > 0 && !pts_out))
+        return VO_ERR_ARG;
+    if (w > 4096)
+        return fail(c, VO_ERR_ARG, "vo_fast_detect: images up to 4096 pixels wide");
+    int rc = single_image_setup(c, img, w, h, stride);
+    if (rc != VO_OK)
+        return rc;
+    const int one = 1, zero = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_ntracked, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->h_ntracked[0] = 0;
+    c->detect_uploaded = false;
+    threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
+    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_nmsmask, c->d_rowcnt, c->d_rowoff,
+                         c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
+                         nullptr, nullptr, 0, nullptr, nullptr, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    int n = 0;
+    VO_HIP_TRY(c, hipMemcpyAsync(&n, c->d_nnew, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int k = n < cap ? n : cap;
+    k = k < c->fcap ? k : c->fcap;
+    if (k > 0)
+        VO_HIP_TRY(c, hipMemcpy(pts_out, c->d_feat, sizeof(float2) * k, hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > c->fcap && cap > c->fcap) // the caller's buffer would have held them, the context's corner list does not
+        return fail(c, VO_ERR_OVERFLOW, "vo_fast_detect: more corners than the context's corner-list capacity "
+                                        "(max(4 x max_pts, 16384, max_w x max_h / 16)): only that many were written");
+    return VO_OK;
+}
+
+int vo_detect_bucket(vo_ctx *c, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
+                     float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap)
+{
+    if (!c || !n_pts || !n_ages || !pts_io || !ages_io || cap < 1 || *n_pts > cap || *n_ages > cap) // (the arrays hold cap entries)
+        return VO_ERR_ARG;
+    int rc = single_image_setup(c, img, w, h, stride);
+    if (rc != VO_OK)
+        return rc;
+    const vo_detect_params saved = c->dprm;
+    rc = vo_batch_set_detect_params(c, dp);
+    if (rc == VO_OK)
+        rc = vo_batch_set_features(c, 0, pts_io, *n_pts, ages_io, *n_ages);
+    if (rc == VO_OK)
+        rc = run_stages(c, VO_STAGE_DETECT, false);
+    int k = 0;
+    if (rc == VO_OK) {
+        VO_HIP_TRY(c, hipMemcpyAsync(&k, cur_npts(c), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (k > cap) {
+            c->dprm = saved;
+            return fail(c, VO_ERR_ARG, "vo_detect_bucket: bucketed set larger than the caller's capacity");
+        }
+        rc = vo_batch_get_features(c, 0, pts_io, ages_io, &k);
+    }
+    c->dprm = saved;
+    if (rc != VO_OK)
+        return rc;
+    *n_pts = k;
+    *n_ages = k;
+    return VO_OK;
+}
+
+int vo_integrate_odometry(double *pose, const double *R, const double *t, float *euler_out)
+{
+    if (!pose || !R || !t)
+        return VO_ERR_ARG;
+    return integrate_odometry(pose, R, t, euler_out); // vo_integrate.h: the code the sequence loop runs on the device
+}
+
+int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w,
+                   int h, int stride, const float *pts, int n, const float *P_l, const float *P_r,
+                   float *out_l0, float *out_r0, float *out_l1, float *out_r1, float *xyz_out,
+                   int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ, int *n_circ, double *rvec_io,
+                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers)
+{
+    if (!c || !P_l || !P_r)
+        return VO_ERR_ARG;
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    if (rc != VO_OK)
+        return rc;
+    rc = vo_batch_set_projection(c, P_l, P_r);
+    if (rc != VO_OK)
+        return rc;
+    rc = run_stages_auto(c, VO_STAGE_ALL, false, nullptr, /*sync_call*/ true);
+    if (rc != VO_OK)
+        return rc;
+    // Results: one kernel behind the pose solve gathers the counts, the PnpResult and every output array into one
+    // host-visible buffer, one synchronisation, host copies from there -- instead of eleven device-to-host copies and
+    // four rounds of stream synchronisation through vo_batch_get_filtered + vo_batch_get_pose (0.25 of the call's 1.45 ms).
+    vo_ctx::PoseBufs &pb = c->pb[c->last];
+    const bool mono = c->prm.mono_rotation && c->em_ready;
+    FrameGather g;
+    g.nA = c->d_nA;
+    g.nB = pb.nB;
+    g.outB = pb.outB;
+    g.xyz = pb.xyz;
+    g.idxB = pb.idxB;
+    g.idxA = c->d_idxA;
+    g.inliers = pb.inliers;
+    g.result = pb.results;
+    g.em = mono ? pb.em_results : nullptr;
+    g.cap = c->cap;
+    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0)); // `done` covers the filter, both pose chains
+    launch_frame_gather(g, c->d_gather, c->stream);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint8_t *hb = c->h_gather;
+    int hdr[3];
+    memcpy(hdr, hb, sizeof(hdr));
+    const int M = hdr[0], K = hdr[1];
+    PnpResult r;
+    memcpy(&r, hb + 16, sizeof(r));
+    const size_t cap = (size_t)c->cap;
+    const uint8_t *arr = hb + VO_GATHER_HEADER;
+    float *outs[4] = {out_l0, out_r0, out_l1, out_r1};
+    for (int k = 0; k < 4; k++)
+        if (outs[k] && K > 0)
+            memcpy(outs[k], arr + (size_t)k * cap * 8, (size_t)K * 8);
+    const uint8_t *ax = arr + 4 * cap * 8, *ak = ax + cap * 12, *ac = ak + cap * 4, *ai = ac + cap * 4;
+    if (xyz_out && K > 0)
+        memcpy(xyz_out, ax, (size_t)K * 12);
+    if (keep_idx && K > 0)
+        memcpy(keep_idx, ak, (size_t)K * 4);
+    if (keep_idx_circ && M > 0)
+        memcpy(keep_idx_circ, ac, (size_t)M * 4);
+    if (n_out)
+        *n_out = K;
+    if (n_circ)
+        *n_circ = M;
+    // the pose, by the rules of vo_batch_get_pose / fetch_pose
+    if (r.status == 0 && r.lm_iters < 0) { // P3P without a solution: rvec / tvec untouched (see get_pose_impl)
+        if (R_out && rvec_io && !c->prm.mono_rotation)
+            rodrigues_v2m(rvec_io, R_out, nullptr);
+    } else if (r.status >= 0) {
+        if (rvec_io)
+            memcpy(rvec_io, r.rvec, sizeof(r.rvec));
+        if (tvec_io)
+            memcpy(tvec_io, r.tvec, sizeof(r.tvec));
+        if (R_out && !c->prm.mono_rotation)
+            memcpy(R_out, r.R, sizeof(r.R)); // `if (!mono_rotation) Rodrigues(rvec, rotation)` (visualOdometry.cpp:186-189)
+    }
+    int em_status = 1;
+    if (mono) {
+        EmResult e;
+        memcpy(&e, hb + 256, sizeof(e));
+        if (e.status == 1 && R_out)
+            memcpy(R_out, e.R, sizeof(e.R));
+        em_status = e.status;
+    }
+    if (inliers && r.n_inliers > 0)
+        memcpy(inliers, ai, (size_t)r.n_inliers * 4);
+    if (n_inliers)
+        *n_inliers = r.n_inliers;
+    if (r.status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
+    if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
+        return VO_NO_ESSENTIAL;
+    return r.status == 1 ? VO_OK : VO_NO_MODEL;
+}
+
+#ifdef VO_DEV_VARIANTS
+// developer build only: the 100 MHz stamps the pose kernels left for frame 0 / hypothesis 0 (pnp.hip, tools/pose_phases.py)
+int vo_dev_pose_prof(vo_ctx *c, long long *out64)
+{
+    if (!c || !out64 || sync_all(c) != VO_OK)
+        return VO_ERR_ARG;
+    return vo::pose_prof_read(out64) == 0 ? VO_OK : VO_ERR_HIP;
+}
+
+} // extern "C"
+
+namespace vo_capi {
+
+#endif
+
+} // namespace vo_capi

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ row
 
 constexpr int BK_MAX_CELLS = 1024; // (rows/bucket + 1) * (cols/bucket + 1)
 constexpr int BK_MAX_FPB = 8;
+constexpr int BK_CELL_CACHE = 8192; // list entries whose cell is kept in LDS between the passes (16 KB)
 
 // one 256-thread workgroup per frame
 __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ feat /* [B][cap] */,
@@ -398,6 +399,10 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     __shared__ int s_cnt[BK_MAX_CELLS], s_last[BK_MAX_CELLS];
     __shared__ int s_first[BK_MAX_FPB][BK_MAX_CELLS];
     __shared__ int s_scan[256];
+    // the cell of the first BK_CELL_CACHE list entries, computed once: with features_per_bucket = f the list is walked f times,
+    // and every walk re-loaded point + age and re-did the two float divisions -- 70 us for ONE frame at f = 6, between the
+    // pyramids and LK on the critical path of a lock-step step (gpurun_out/r4_09 timeline)
+    __shared__ int16_t s_cell[BK_CELL_CACHE];
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int bh = rows / bucket_size, bw = cols / bucket_size;
     const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
@@ -450,6 +455,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     };
     for (int i = tid; i < n_in; i += 256) {
         const int b = cell(i);
+        if (i < BK_CELL_CACHE)
+            s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
         if (b >= 0) {
             atomicAdd(&s_cnt[b], 1);
             atomicMax(&s_last[b], i);
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     __syncthreads();
     for (int q = 1; q < fpb; q++) { // q-th eligible feature of every bucket, in list order
         for (int i = tid; i < n_in; i += 256) {
-            const int b = cell(i);
+            const int b = i < BK_CELL_CACHE ? (int)s_cell[i] : cell(i);
             if (b >= 0 && i > s_first[q - 1][b])
                 atomicMin(&s_first[q][b], i);
         }
