@@ -392,7 +392,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     if own_ctx:
         ctx = _lib.Context(local_dev, w, h, 8192, B)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
-    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()
+    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()  # w,s,p[,wide]
     n_images = 2 * (B + 1)
     # images go through torch device tensors (PyTorch = plumbing: device memory + D2D hand-off)
     dev_t = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev),
@@ -516,7 +516,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     if own_ctx:
         ctx = _lib.Context(local_dev, w, h, 4096, S)
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
-    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()
+    ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()  # w,s,p[,wide]
     ctx.batch_set_detect_params(features_per_bucket=per_bucket)
     ctx.seq_configure(S, w, h, args.ring, K + W + 8 + 280)
     ctx.batch_set_projection(*world.proj_matrices())

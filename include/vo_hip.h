@@ -97,11 +97,17 @@ int vo_set_params(vo_ctx *ctx, const vo_params *p);
  * all).  The reference has no counterpart: its calls are synchronous CPU code.
  *   pose_waves    register budget of the pose kernels in waves per SIMD: 1 = 512 registers, 2 = 256; 0 = probe
  *   pose_streams  1 or 2 pose streams (2: the chains of consecutive runs overlap); 0 = probe
- *   prepare       lock-step loop: pyramids + FAST of the new pairs one step ahead on a prepare stream; -1 = probe */
+ *   prepare       lock-step loop: pyramids + FAST of the new pairs one step ahead on a prepare stream; -1 = probe
+ *   epnp_wide_frames  see the field below; 0 = probe */
 typedef struct vo_schedule {
     int pose_waves;
     int pose_streams;
     int prepare;
+    /* round 4: the four-kernel form of the EPnP hypotheses (12 x 12 SVD by two wavefronts per hypothesis) for launches of up
+     * to this many frames: 4 or 16; 0 = probe.  Launches of <= 4 frames always take it, launches of > 16 never (the knob only
+     * acts for 5 .. 16 frames / sequences per run: at 640 x 480 the wide form wins by 10-30 % there, at 1241 x 376 it loses
+     * 3-10 % at 16 -- measured, profiles/r04_experiments.md -- so it is part of the probed schedule, not a constant). */
+    int epnp_wide_frames;
 } vo_schedule;
 /* s == NULL: probe everything (the default) */
 int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
@@ -117,7 +123,7 @@ int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
 /* what the last probe run by this context measured: *n (<= VO_PROBE_LOG_MAX) candidates and their steady-state
  * milliseconds per run (the arrays hold VO_PROBE_LOG_MAX entries); real[i] (optional) = 1 where the figure was re-measured
  * over real steps of the lock-step loop */
-#define VO_PROBE_LOG_MAX 12
+#define VO_PROBE_LOG_MAX 16
 int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands, float *ms, int *real, int *n);
 /* The process-wide table of settled schedules, out and in: a service exports it once (after a warm-up run of every shape it
  * uses) and imports it at start-up, so that no context of the new process probes -- the first run of a probed key otherwise

@@ -90,9 +90,10 @@ def main():
     expect("vo_set_params", OK, ctx, C.byref(prm))
     expect("vo_get_params", ARG, NULL, C.byref(prm))
     expect("vo_get_params", ARG, ctx, NULL)
-    sch = _lib.VoSchedule(0, 0, -1)
+    sch = _lib.VoSchedule(0, 0, -1, 0)
     expect("vo_set_schedule", ARG, NULL, C.byref(sch))
-    for bad in ((3, 0, -1), (4, 0, -1), (5, 0, -1), (-1, 0, -1), (0, 3, -1), (0, -1, -1), (0, 0, 2), (0, 0, -2)):
+    for bad in ((3, 0, -1), (4, 0, -1), (5, 0, -1), (-1, 0, -1), (0, 3, -1), (0, -1, -1), (0, 0, 2), (0, 0, -2), (0, 0, -1, 8), (0, 0, -1, -4),
+                (0, 0, -1, 32)):
         expect("vo_set_schedule", ARG, ctx, C.byref(_lib.VoSchedule(*bad)))
     expect("vo_set_schedule", OK, ctx, NULL)
     expect("vo_get_schedule", ARG, NULL, C.byref(sch), NULL)
@@ -106,9 +107,10 @@ def main():
     expect("vo_export_schedule", OK, NULL, 0, C.byref(n_out))
     expect("vo_import_schedule", ARG, NULL, 1)
     expect("vo_import_schedule", ARG, C.byref(rec), -1)
-    for key, sc in (((0, 0, 640, 480, 4, 1, 20, 0), (3, 1, 0)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 0, 0)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 1, 2)),
-                    ((-1, 0, 640, 480, 4, 1, 20, 0), (1, 1, 0)), ((0, 0, 8, 480, 4, 1, 20, 0), (1, 1, 0)), ((0, 0, 640, 480, 9, 1, 20, 0), (1, 1, 0)),
-                    ((0, 0, 640, 480, 4, 0, 20, 0), (1, 1, 0))):
+    for key, sc in (((0, 0, 640, 480, 4, 1, 20, 0), (3, 1, 0, 4)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 0, 0, 4)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 1, 2, 4)),
+                    ((0, 0, 640, 480, 4, 1, 20, 0), (1, 1, 0, 0)), ((0, 0, 640, 480, 4, 1, 20, 0), (1, 1, 0, 8)),
+                    ((-1, 0, 640, 480, 4, 1, 20, 0), (1, 1, 0, 4)), ((0, 0, 8, 480, 4, 1, 20, 0), (1, 1, 0, 4)), ((0, 0, 640, 480, 9, 1, 20, 0), (1, 1, 0, 4)),
+                    ((0, 0, 640, 480, 4, 0, 20, 0), (1, 1, 0, 4))):
         r2 = _lib.VoScheduleRecord()
         for i in range(8):
             r2.key[i] = key[i]

@@ -200,18 +200,18 @@ def test_probed_schedule_gives_the_pinned_results_and_is_remembered(volib, orc, 
     bench, S, world, lefts, rights, pts = bench_inputs
     B = 8
     res = {}
-    for tag, pin in (("probe", None), ("w1s2", (1, 2)), ("w2s1", (2, 1)), ("again", None)):
+    for tag, pin in (("probe", None), ("w1s2", (1, 2, -1, 4)), ("w2s1", (2, 1, -1, 4)), ("w1s1x16", (1, 1, -1, 16)), ("again", None)):
         ctx = volib.Context(0, world.w, world.h, 8192, B)
         try:
             if pin:
-                ctx.set_schedule(pose_waves=pin[0], pose_streams=pin[1])
+                ctx.set_schedule(pose_waves=pin[0], pose_streams=pin[1], prepare=pin[2], epnp_wide_frames=pin[3])
             frame_pts = bench.setup_batch(ctx, world, lefts, rights, pts, B, S)
             for _ in range(3):
                 ctx.batch_run(volib.STAGE_ALL)
             ctx.batch_sync()
             sched = ctx.get_schedule()
             if pin:
-                assert (sched["pose_waves"], sched["pose_streams"]) == pin and not sched["probed"]
+                assert (sched["pose_waves"], sched["pose_streams"], sched["epnp_wide_frames"]) == (pin[0], pin[1], pin[3]) and not sched["probed"]
             else:
                 assert sched["probed"] and sched["pose_waves"] in (1, 2) and sched["pose_streams"] in (1, 2)
             res[tag] = ([ctx.batch_get_filtered(b) for b in range(B)], [ctx.batch_get_pose(b) for b in range(B)], sched)
@@ -220,7 +220,7 @@ def test_probed_schedule_gives_the_pinned_results_and_is_remembered(volib, orc, 
         finally:
             ctx.close()
     assert res["again"][2] == res["probe"][2]  # the second context found the pick in the process-wide table
-    for tag in ("w1s2", "w2s1", "again"):
+    for tag in ("w1s2", "w2s1", "w1s1x16", "again"):
         for b in range(B):
             for k in ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ"):
                 assert np.array_equal(res["probe"][0][b][k], res[tag][0][b][k]), (tag, b, k)

@@ -258,11 +258,14 @@ def test_schedule_export_import_skips_the_probe(volib, small_world, small_seq):
         ctx.close()
     table = volib.export_schedules()
     mine = [r for r in table if r["key"][2] == w and r["key"][3] == h and r["key"][5] == 8 and r["key"][1] == 0]
-    assert len(mine) == 1 and (mine[0]["pose_waves"], mine[0]["pose_streams"]) == (s8["pose_waves"], s8["pose_streams"])
+    assert len(mine) == 1 and (mine[0]["pose_waves"], mine[0]["pose_streams"], mine[0]["epnp_wide_frames"]) == \
+        (s8["pose_waves"], s8["pose_streams"], s8["epnp_wide_frames"])
+    assert s8["epnp_wide_frames"] in (4, 16)          # 8 frames per run: the four-kernel EPnP is one of the probed knobs
     rec = dict(mine[0], key=list(mine[0]["key"]))
     rec["key"][5] = 6
     rec["pose_streams"] = 3 - s8["pose_streams"]
     rec["pose_waves"] = 3 - s8["pose_waves"]
+    rec["epnp_wide_frames"] = 20 - s8["epnp_wide_frames"]
     volib.import_schedules([rec])
     assert rec in volib.export_schedules()
     ctx = batch(6)
@@ -272,7 +275,8 @@ def test_schedule_export_import_skips_the_probe(volib, small_world, small_seq):
         ctx.batch_sync()
         first = time.perf_counter() - t0
         s6 = ctx.get_schedule()
-        assert (s6["pose_waves"], s6["pose_streams"], s6["probed"]) == (rec["pose_waves"], rec["pose_streams"], True)
+        assert (s6["pose_waves"], s6["pose_streams"], s6["epnp_wide_frames"], s6["probed"]) == \
+            (rec["pose_waves"], rec["pose_streams"], rec["epnp_wide_frames"], True)
         assert ctx.get_probe_log() == {} or len(ctx.get_probe_log()) == 0   # no probe ran in this context
         t0 = time.perf_counter()
         ctx.batch_run(volib.STAGE_ALL)

@@ -106,6 +106,36 @@ if has seqinline; then  # (round-4 experiment, removed from the code: filter + c
     done
     unset VO_HIP_LIB
 fi
+if has constants; then  # the two launch-size constants left in the pose chain, at the other camera shapes (developer build switches)
+    export VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so
+    for WL in zed374 rgbd374 hd4000; do
+        FR=$([ $WL = hd4000 ] && echo 128 || echo 256)
+        for CH in 128 64 32; do
+            stamp "VO_RANSAC_CHUNK=$CH bench $WL --frames $FR"
+            VO_RANSAC_CHUNK=$CH timeout 300 python bench.py --workload $WL --frames $FR --quads 4 --steps 12 --warmup 2 $LEAN --validate 0 > "$OUT/chunk${CH}_${WL}.json" 2> "$OUT/chunk${CH}_${WL}.err"
+            python -c "import json; b=json.loads(open('$OUT/chunk${CH}_${WL}.json').read().strip().splitlines()[-1]); print('  first chunk $CH  $WL x $FR frames  %.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']))" 2>&1 | tee -a "$OUT/summary.txt"
+        done
+    done
+    for WL in zed374 rgbd374; do
+        for SM in 4 16; do
+            for S in 2 4 8 16; do
+                stamp "VO_EPNP_SPLIT_MAX=$SM bench --mode sequences $WL --seqs $S"
+                VO_EPNP_SPLIT_MAX=$SM timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --quads 4 --steps 200 --warmup 4 --no-cpu-baseline --validate 0 > "$OUT/split${SM}_${WL}_${S}.json" 2> "$OUT/split${SM}_${WL}_${S}.err"
+                python -c "import json; b=json.loads(open('$OUT/split${SM}_${WL}_${S}.json').read().strip().splitlines()[-1]); print('  four-kernel EPnP up to $SM frames  $WL S=%-3d %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']))" 2>&1 | tee -a "$OUT/summary.txt"
+            done
+        done
+    done
+    unset VO_HIP_LIB
+fi
+if has wideprobe; then  # the probe with the four-kernel EPnP as one of its knobs, where the constant had lost (r4_11)
+    for WL in rgbd374 zed374 kitti374; do
+        for S in 8 16; do
+            stamp "bench --mode sequences $WL --seqs $S (probed)"
+            timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --quads 4 --steps 200 --warmup 4 --no-cpu-baseline --validate 2 > "$OUT/wp_${WL}_${S}.json" 2> "$OUT/wp_${WL}_${S}.err"
+            python -c "import json; b=json.loads(open('$OUT/wp_${WL}_${S}.json').read().strip().splitlines()[-1]); print('  probed  $WL S=%-3d %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']), b['config']['schedule'], 'val', b['validated_frames'])" 2>&1 | tee -a "$OUT/summary.txt"
+        done
+    done
+fi
 if has timeline; then
     stamp "kernel timeline of vo_track_frame"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tf" -- python "$ROOT/tools/latency_mode.py" trackonly 6 60 > "$OUT/tf.log" 2>&1)

@@ -53,8 +53,9 @@ class VoDetectParams(C.Structure):
 
 
 class VoSchedule(C.Structure):
-    """vo_schedule (include/vo_hip.h): pose_waves 0 = probe / 1 / 2, pose_streams 0 = probe / 1 / 2, prepare -1 = probe / 0 / 1"""
-    _fields_ = [("pose_waves", C.c_int), ("pose_streams", C.c_int), ("prepare", C.c_int)]
+    """vo_schedule (include/vo_hip.h): pose_waves 0 = probe / 1 / 2, pose_streams 0 = probe / 1 / 2, prepare -1 = probe / 0 / 1,
+    epnp_wide_frames 0 = probe / 4 / 16"""
+    _fields_ = [("pose_waves", C.c_int), ("pose_streams", C.c_int), ("prepare", C.c_int), ("epnp_wide_frames", C.c_int)]
 
 
 class VoError(RuntimeError):
@@ -106,7 +107,7 @@ def export_schedules():
     if rc != VO_OK:
         raise VoError(rc, "vo_export_schedule")
     return [dict(key=[int(v) for v in r.key], pose_waves=r.schedule.pose_waves, pose_streams=r.schedule.pose_streams,
-                 prepare=r.schedule.prepare) for r in recs[:n.value]]
+                 prepare=r.schedule.prepare, epnp_wide_frames=r.schedule.epnp_wide_frames) for r in recs[:n.value]]
 
 
 def import_schedules(records):
@@ -116,7 +117,7 @@ def import_schedules(records):
     for r, d in zip(recs, records):
         for i in range(8):
             r.key[i] = int(d["key"][i])
-        r.schedule = VoSchedule(int(d["pose_waves"]), int(d["pose_streams"]), int(d["prepare"]))
+        r.schedule = VoSchedule(int(d["pose_waves"]), int(d["pose_streams"]), int(d["prepare"]), int(d.get("epnp_wide_frames", 4)))
     rc = lib.vo_import_schedule(recs, len(records))
     if rc != VO_OK:
         raise VoError(rc, "vo_import_schedule: bad record")
@@ -197,24 +198,25 @@ class Context:
             setattr(p, k, v)
         self._chk(self.lib.vo_set_params(self.h, C.byref(p)))
 
-    def set_schedule(self, pose_waves=0, pose_streams=0, prepare=-1):
-        """pin knobs of the pose-chain schedule (0 / 0 / -1 = probe, the default); see vo_schedule in vo_hip.h"""
-        s = VoSchedule(int(pose_waves), int(pose_streams), int(prepare))
+    def set_schedule(self, pose_waves=0, pose_streams=0, prepare=-1, epnp_wide_frames=0):
+        """pin knobs of the pose-chain schedule (0 / 0 / -1 / 0 = probe, the default); see vo_schedule in vo_hip.h"""
+        s = VoSchedule(int(pose_waves), int(pose_streams), int(prepare), int(epnp_wide_frames))
         self._chk(self.lib.vo_set_schedule(self.h, C.byref(s)))
 
     def get_schedule(self):
         """the schedule the next run uses: dict(pose_waves, pose_streams, prepare, probed)"""
         s, probed = VoSchedule(), C.c_int(0)
         self._chk(self.lib.vo_get_schedule(self.h, C.byref(s), C.byref(probed)))
-        return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, probed=bool(probed.value),
-                    settling=probed.value == 2)
+        return dict(pose_waves=s.pose_waves, pose_streams=s.pose_streams, prepare=s.prepare, epnp_wide_frames=s.epnp_wide_frames,
+                    probed=bool(probed.value), settling=probed.value == 2)
 
     def get_probe_log(self):
         """{"w,s,p": steady-state ms per run} as measured by the last schedule probe of this context ({} if none ran)"""
-        cands, ms, real, n = (VoSchedule * 12)(), (C.c_float * 12)(), (C.c_int * 12)(), C.c_int(0)
+        cands, ms, real, n = (VoSchedule * 16)(), (C.c_float * 16)(), (C.c_int * 16)(), C.c_int(0)
         self._chk(self.lib.vo_get_probe_log(self.h, cands, ms, real, C.byref(n)))
-        return {"%d,%d,%d%s" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare, " (real steps)" if real[i] else ""):
-                float(ms[i]) for i in range(n.value)}
+        return {"%d,%d,%d%s%s" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare,
+                                  ",wide%d" % cands[i].epnp_wide_frames if cands[i].epnp_wide_frames != 4 else "",
+                                  " (real steps)" if real[i] else ""): float(ms[i]) for i in range(n.value)}
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):

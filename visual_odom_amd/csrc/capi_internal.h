@@ -129,8 +129,9 @@ struct vo_ctx {
     // remembers it for the process (tune_*).  vo_set_schedule() pins any knob instead.
     struct Schedule {
         int waves = 2, streams = 1, prep = 1;
+        int wide = 4; // four-kernel EPnP for launches of up to this many frames (4 or 16; acts for 5 .. 16 frames per run)
     } sched;
-    vo_schedule pin = {0, 0, -1};    // 0 / 0 / -1 = probe
+    vo_schedule pin = {0, 0, -1, 0}; // 0 / 0 / -1 / 0 = probe
     long long sched_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0}; // key `sched` was resolved for
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
@@ -296,6 +297,7 @@ int sync_all(vo_ctx *c);
 TuneKey tune_key(const vo_ctx *c, int stages);
 void apply_pins(const vo_ctx *c, vo_ctx::Schedule *s);
 bool all_pinned(const vo_ctx *c);
+bool wide_knob_live(const vo_ctx *c);
 int set_sched(vo_ctx *c, const vo_ctx::Schedule &s);
 int sched_resolve(vo_ctx *c, int stages);
 int seq_enqueue_inputs(vo_ctx *c, bool dry);

@@ -30,6 +30,12 @@ TuneKey tune_key(const vo_ctx *c, int stages)
     return key;
 }
 
+// the four-kernel EPnP is a choice only for 5 .. VO_EPNP_WS_MAX_FRAMES frames per launch (pnp.hip, launch_pnp_ransac)
+bool wide_knob_live(const vo_ctx *c)
+{
+    return c->n_frames > VO_EPNP_SPLIT_DEFAULT_FRAMES && c->n_frames <= VO_EPNP_WS_MAX_FRAMES && c->max_frames >= c->n_frames;
+}
+
 void apply_pins(const vo_ctx *c, vo_ctx::Schedule *s)
 {
     if (c->pin.pose_waves)
@@ -38,6 +44,10 @@ void apply_pins(const vo_ctx *c, vo_ctx::Schedule *s)
         s->streams = c->pin.pose_streams;
     if (c->pin.prepare >= 0)
         s->prep = c->pin.prepare;
+    if (c->pin.epnp_wide_frames)
+        s->wide = c->pin.epnp_wide_frames;
+    if (!wide_knob_live(c))
+        s->wide = 4; // (launches of <= 4 frames take the wide form anyway, launches of > 16 never: one value, no candidates)
     if (c->prm.mono_rotation)
         s->streams = 1; // the essential-matrix chain already runs next to the PnP chain on its own stream
     if (!c->seq.on)
@@ -46,7 +56,8 @@ void apply_pins(const vo_ctx *c, vo_ctx::Schedule *s)
 
 bool all_pinned(const vo_ctx *c)
 {
-    return c->pin.pose_waves && (c->pin.pose_streams || c->prm.mono_rotation) && (!c->seq.on || c->pin.prepare >= 0);
+    return c->pin.pose_waves && (c->pin.pose_streams || c->prm.mono_rotation) && (!c->seq.on || c->pin.prepare >= 0) &&
+           (!wide_knob_live(c) || c->pin.epnp_wide_frames);
 }
 
 // make `s` the schedule the next run uses.  Moving the lock-step loop's ingest between the plain copy stream and the
@@ -221,14 +232,16 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
     std::vector<vo_ctx::Schedule> cands;
     for (int waves = 1; waves <= 2; waves++)
         for (int streams = 1; streams <= (c->sync_call && !c->seq.on ? 1 : 2); streams++) // (a synchronous call runs on one stream)
-            for (int prep = 1; prep >= 0; prep--) {
+            for (int prep = 1; prep >= 0; prep--)
+              for (int wide = VO_EPNP_SPLIT_DEFAULT_FRAMES; wide <= VO_EPNP_WS_MAX_FRAMES; wide *= 4) {
                 vo_ctx::Schedule s, t;
                 s.waves = waves;
                 s.streams = streams;
                 s.prep = prep;
+                s.wide = wide;
                 t = s;
                 apply_pins(c, &t);
-                if (t.waves != s.waves || t.streams != s.streams || t.prep != s.prep)
+                if (t.waves != s.waves || t.streams != s.streams || t.prep != s.prep || t.wide != s.wide)
                     continue; // pinned away / not applicable
                 if (prep && !c->seq.have_corners[c->seq.on ? (c->seq.step - 1) % c->seq.ring : 0])
                     continue; // no look-ahead corners for this step's t0 pair: the prepare variant cannot be shown
@@ -252,7 +265,7 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
             best_ms = ms;
         }
         if (i < VO_PROBE_LOG_MAX) {
-            c->probe_cand[i] = vo_schedule{cands[i].waves, cands[i].streams, cands[i].prep};
+            c->probe_cand[i] = vo_schedule{cands[i].waves, cands[i].streams, cands[i].prep, cands[i].wide};
             c->probe_ms[i] = (float)ms;
             c->probe_real[i] = 0;
         }
@@ -300,9 +313,11 @@ int vo_set_schedule(vo_ctx *c, const vo_schedule *s)
 {
     if (!c)
         return VO_ERR_ARG;
-    vo_schedule p = {0, 0, -1};
+    vo_schedule p = {0, 0, -1, 0};
     if (s)
         p = *s;
+    if (p.epnp_wide_frames != 0 && p.epnp_wide_frames != VO_EPNP_SPLIT_DEFAULT_FRAMES && p.epnp_wide_frames != VO_EPNP_WS_MAX_FRAMES)
+        return fail(c, VO_ERR_ARG, "vo_set_schedule: epnp_wide_frames 0 / 4 / 16");
     const int max_waves =
 #ifdef VO_DEV_VARIANTS
         4; // the slim pose chain (pnp.hip): measured slower everywhere, kept for the record in the developer build
@@ -334,6 +349,7 @@ int vo_get_schedule(const vo_ctx *c, vo_schedule *cur, int *probed)
     cur->pose_waves = c->sched.waves;
     cur->pose_streams = c->sched.streams;
     cur->prepare = c->seq.on ? c->sched.prep : 0;
+    cur->epnp_wide_frames = c->sched.wide;
     if (probed)
         *probed = (c->seq.on && c->seq.ab_running()) ? 2 : c->sched_probed ? 1 : 0;
     return VO_OK;
@@ -371,7 +387,7 @@ int vo_export_schedule(vo_schedule_record *recs, int cap, int *n)
         if (k < cap) {
             for (int i = 0; i < 8; i++)
                 recs[k].key[i] = kv.first.k[i];
-            recs[k].schedule = vo_schedule{kv.second.waves, kv.second.streams, kv.second.prep};
+            recs[k].schedule = vo_schedule{kv.second.waves, kv.second.streams, kv.second.prep, kv.second.wide};
         }
         k++;
     }
@@ -392,7 +408,8 @@ int vo_import_schedule(const vo_schedule_record *recs, int n)
     for (int k = 0; k < n; k++) { // validate everything before anything is taken over
         const vo_schedule &sc = recs[k].schedule;
         if ((sc.pose_waves != 1 && sc.pose_waves != 2 && !(sc.pose_waves == 4 && max_waves == 4)) ||
-            (sc.pose_streams != 1 && sc.pose_streams != 2) || (sc.prepare != 0 && sc.prepare != 1) || recs[k].key[0] < 0 ||
+            (sc.pose_streams != 1 && sc.pose_streams != 2) || (sc.prepare != 0 && sc.prepare != 1) ||
+            (sc.epnp_wide_frames != VO_EPNP_SPLIT_DEFAULT_FRAMES && sc.epnp_wide_frames != VO_EPNP_WS_MAX_FRAMES) || recs[k].key[0] < 0 ||
             recs[k].key[2] < 32 || recs[k].key[3] < 32 || recs[k].key[4] < 1 || recs[k].key[4] > VO_MAX_LEVELS || recs[k].key[5] < 1)
             return VO_ERR_ARG;
     }
@@ -405,6 +422,7 @@ int vo_import_schedule(const vo_schedule_record *recs, int n)
         sc.waves = recs[k].schedule.pose_waves;
         sc.streams = recs[k].schedule.pose_streams;
         sc.prep = recs[k].schedule.prepare;
+        sc.wide = recs[k].schedule.epnp_wide_frames;
         g_tuned[key] = sc;
     }
     return VO_OK;

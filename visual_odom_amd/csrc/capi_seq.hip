@@ -424,7 +424,7 @@ int vo_seq_step(vo_ctx *c)
                 auto dry_ms = [&](const vo_ctx::Schedule &x) {
                     for (int i = 0; i < c->probe_n; i++)
                         if (c->probe_cand[i].pose_waves == x.waves && c->probe_cand[i].pose_streams == x.streams &&
-                            c->probe_cand[i].prepare == x.prep)
+                            c->probe_cand[i].prepare == x.prep && c->probe_cand[i].epnp_wide_frames == x.wide)
                             return (double)c->probe_ms[i];
                     return -1.0;
                 };
@@ -443,6 +443,7 @@ int vo_seq_step(vo_ctx *c)
                                 bi = i;
                         if (bi >= 0 && n < 4) {
                             c->ab_list[n].waves = c->probe_cand[bi].pose_waves;
+                            c->ab_list[n].wide = c->probe_cand[bi].epnp_wide_frames;
                             c->ab_list[n].streams = st;
                             c->ab_list[n].prep = pr;
                             n++;
@@ -517,7 +518,7 @@ int vo_seq_step(vo_ctx *c)
                 for (int k = 0; k < q.ab_cnt; k++) // the log shows what was measured over real steps
                     for (int i = 0; i < c->probe_n; i++)
                         if (c->probe_cand[i].pose_waves == c->ab_list[k].waves && c->probe_cand[i].pose_streams == c->ab_list[k].streams &&
-                            c->probe_cand[i].prepare == c->ab_list[k].prep) {
+                            c->probe_cand[i].prepare == c->ab_list[k].prep && c->probe_cand[i].epnp_wide_frames == c->ab_list[k].wide) {
                             c->probe_ms[i] = t[k] / q.ab_n;
                             c->probe_real[i] = 1;
                         }

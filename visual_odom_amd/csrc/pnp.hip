@@ -952,7 +952,8 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                        int waves /* 1 or 2 per SIMD: 512 / 256 registers; 4: the slim form (needs gws) */, hipStream_t stream,
                        double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames,
-                       double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */)
+                       double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */,
+                       int wide_frames /* four-kernel form for launches of up to this many frames (the schedule's knob) */)
 {
     if (n_frames <= 0)
         return;
@@ -972,7 +973,7 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
     }();
     // Small launches: the four-kernel form (epnp_prepare_kernel ...) for the first chunk; the rarely needed second chunk stays
     // with the one kernel (four launches that mostly find nothing to do would cost more than they save).
-    int split_max = VO_EPNP_SPLIT_DEFAULT_FRAMES;
+    int split_max = wide_frames > 0 ? wide_frames : VO_EPNP_SPLIT_DEFAULT_FRAMES;
 #ifdef VO_DEV_VARIANTS
     static const int split_env = [] { const char *e = getenv("VO_EPNP_SPLIT_MAX"); return e ? atoi(e) : -1; }();
     if (split_env >= 0)
@@ -1068,7 +1069,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames, double *gws)
 {
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
-                      ws_frames, gws);
+                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

@@ -178,7 +178,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 // epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
-                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws);
+                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);
