@@ -136,6 +136,22 @@ if has wideprobe; then  # the probe with the four-kernel EPnP as one of its knob
         done
     done
 fi
+if has pyrstore; then  # what bounds the level-0 pass: Scharr stores non-temporal / ordinary / none (developer build, no pose chain)
+    for SM in 0 1 2; do
+        stamp "VO_PYR_STORE=$SM kernel trace, bench --stages lk"
+        (cd /tmp && VO_PYR_STORE=$SM VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/ps$SM" -- python "$ROOT/bench.py" --stages lk --steps 6 --warmup 2 $LEAN --validate 0 > "$OUT/ps$SM.log" 2>&1)
+        python - "$OUT/ps$SM" $SM <<'PYEOF2' | tee -a "$OUT/summary.txt"
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if "pyr_pass" in r["Kernel_Name"]:
+        by[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("  store mode %s: " % sys.argv[2] + "  ".join("grid %d: avg %.0f min %.0f us" % (g, sum(v) / len(v), min(v)) for g, v in sorted(by.items(), reverse=True)))
+PYEOF2
+        rm -rf "$OUT/ps$SM"
+    done
+fi
 if has timeline; then
     stamp "kernel timeline of vo_track_frame"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tf" -- python "$ROOT/tools/latency_mode.py" trackonly 6 60 > "$OUT/tf.log" 2>&1)

@@ -505,7 +505,9 @@ __device__ __forceinline__ void border_item(const PyrImage &im, int level, int i
 // (tools/ubench/store_rate.hip: 2.44 TB/s, against 6.26 TB/s for the same non-temporal stores when the 64 lanes of an
 // instruction write one contiguous KB; round 3's scharr_nt_kernel and the first fused pass both sat at that rate).  With 4
 // pixels per lane each store instruction is one contiguous KB.
-template <bool HAS_NEXT, bool EDGE>
+// SM (developer build, VO_PYR_STORE): how the Scharr image is stored -- 0 non-temporal (product), 1 ordinary stores, 2 NOT AT
+// ALL (timing experiment only: what the pass costs without its dominant traffic)
+template <bool HAS_NEXT, bool EDGE, int SM = 0>
 __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, int b)
 {
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
@@ -619,7 +621,12 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 oa = {out[0], out[1], out[2], out[3]};
-                __builtin_nontemporal_store(oa, (VO_GLOBAL u32x4 *)o);
+                if (SM == 0)
+                    __builtin_nontemporal_store(oa, (VO_GLOBAL u32x4 *)o);
+                else if (SM == 1)
+                    *(VO_GLOBAL u32x4 *)o = oa;
+                else if ((out[0] ^ out[1] ^ out[2] ^ out[3]) == 0x12345679u) // (keeps the arithmetic alive; practically never true)
+                    *(VO_GLOBAL u32x4 *)o = oa;
 #else
                 o[0] = make_uint4(out[0], out[1], out[2], out[3]);
 #endif
@@ -633,6 +640,7 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
 // chunks.  Edge items gather single bytes through REFLECT_101 (7 loads per row instead of one) -- numbered row block by row
 // block they sat in 4 of every 10 wavefronts and the whole wavefront waited for them (gpurun_out/r4_03: level-0 pass 0.46
 // ms); grouped at the end they fill one or two wavefronts per image.
+template <int SM = 0>
 __device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int n_levels, const PassPlan &pp, int item)
 {
     if (item >= pp.n_items[level])
@@ -646,24 +654,31 @@ __device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int
     if (item < n_int) {
         const int b = item / ni, g = 1 + item - b * ni;
         if (has_next)
-            pass_item<true, false>(im, level, g, b);
+            pass_item<true, false, SM>(im, level, g, b);
         else
-            pass_item<false, false>(im, level, g, b);
+            pass_item<false, false, SM>(im, level, g, b);
         return;
     }
     const int ne = ng - ni, e = item - n_int;
     const int b = e / ne, k = e - b * ne;
     const int g = k == 0 ? 0 : ni + k; // group 0, then groups ni + 1 .. ng - 1
     if (has_next)
-        pass_item<true, true>(im, level, g, b);
+        pass_item<true, true, SM>(im, level, g, b);
     else
-        pass_item<false, true>(im, level, g, b);
+        pass_item<false, true, SM>(im, level, g, b);
 }
 
 __global__ __launch_bounds__(256) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
 {
-    pass_dispatch(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
+    pass_dispatch<0>(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
 }
+#if defined(VO_DEV_VARIANTS) && !defined(VO_HOST_EMUL)
+template <int SM>
+__global__ __launch_bounds__(256) void pyr_pass_sm_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+{
+    pass_dispatch<SM>(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+#endif
 
 #ifndef VO_HOST_EMUL
 #ifdef VO_DEV_VARIANTS
@@ -729,6 +744,19 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
     // one launch per level.  (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel,
     // pass / fence + barrier / pass -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms
     // for level 0, gpurun_out/r4_04: a few hundred workgroups of serial phases do not fill the chip.)
+#ifdef VO_DEV_VARIANTS
+    static const int sm = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
+    if (sm == 1 || sm == 2) {
+        for (int l = 0; l < n_levels; l++) {
+            const dim3 grid((pp.n_items[l] + 255) / 256, n_images);
+            if (sm == 1)
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, grid, dim3(256), 0, stream, d_imgs, l, n_levels, pp);
+            else
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, grid, dim3(256), 0, stream, d_imgs, l, n_levels, pp);
+        }
+        return;
+    }
+#endif
     for (int l = 0; l < n_levels; l++)
         hipLaunchKernelGGL(pyr_pass_kernel, dim3((pp.n_items[l] + 255) / 256, n_images), dim3(256), 0, stream, d_imgs, l, n_levels, pp);
 }
