@@ -289,3 +289,37 @@ def test_schedule_export_import_skips_the_probe(volib, small_world, small_seq):
         ctx.close()
     with pytest.raises(volib.VoError):
         volib.import_schedules([dict(rec, pose_waves=3)])
+
+
+@pytest.mark.parametrize("h,w", [(32, 32), (33, 47), (150, 70), (64, 257), (121, 1023), (480, 642)])
+def test_fused_pyramid_pass_on_small_and_odd_shapes(volib, orc, h, w):
+    """the fused pyramid pass (one launch per level: Scharr image + next level + border, 4 columns x 8 rows per lane) on the
+    shapes the KITTI / camera tests do not reach: the smallest image vo_create takes (one level only), widths of every residue
+    mod 4, levels narrower than a wavefront's 256-column span, fewer rows than a row block -- every level bit-exact against
+    the oracle's buildOpticalFlowPyramid, and the four LK hops on top of it (which read the Scharr images and the borders)
+    bit-exact for points next to all four image edges"""
+    rng = np.random.default_rng(h * 1000 + w)
+    base = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2)).astype(np.float32)
+    img = np.kron(base, np.ones((4, 4), np.float32))[:h, :w]
+    img = np.clip(img + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    shifted = np.roll(img, (1, -2), (0, 1))
+    ref = orc.build_pyramid(img, 3)
+    ctx = volib.Context(0, max(w, 32), max(h, 32), 512, 1)
+    try:
+        xs = rng.uniform(0, w - 1, 60).astype(np.float32)
+        ys = rng.uniform(0, h - 1, 60).astype(np.float32)
+        xs[:8] = [0, 0.4, w - 1, w - 1.3, 2.5, w / 2, w / 2, 7.25]
+        ys[:8] = [0, h - 1, 0.6, h - 1, h / 2, 0, h - 1, 3.75]
+        pts = np.stack([xs, ys], 1)
+        got = ctx.circular_match(img, shifted, shifted, img, pts)
+        for l in range(len(ref)):
+            lv = ctx.batch_get_pyramid_level(0, l)
+            assert lv.shape == ref[l].shape and np.array_equal(lv, ref[l]), (l, lv.shape)
+        with pytest.raises(volib.VoError):
+            ctx.batch_get_pyramid_level(0, len(ref))
+        want = orc.circular_matching(img, shifted, shifted, img, pts)
+        assert np.array_equal(got["status4"], want["status4"]) and np.array_equal(got["keep_idx"], want["keep_idx"])
+        for k in ("l0", "r0", "r1", "l1", "l0_ret"):
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        ctx.close()
