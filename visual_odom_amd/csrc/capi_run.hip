@@ -178,7 +178,12 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
     // for the filter to have consumed the points / tracks / status it is about to overwrite.
     // A synchronous drop-in call (vo_track_frame) has nothing to overlap with: everything on the tracking stream saves the
     // three cross-stream hand-offs of the chain (~12 us each in the kernel timeline of one call).
-    const bool serial = c->serial_pose || (c->sync_call && !sq.on);
+    bool serial = c->serial_pose || (c->sync_call && !sq.on);
+#ifdef VO_DEV_VARIANTS
+    static const int sync_serial_env = [] { const char *e = getenv("VO_SYNC_SERIAL"); return e ? atoi(e) : -1; }();
+    if (sync_serial_env == 0 && !c->serial_pose)
+        serial = false; // A/B: the synchronous call on the batch mode's streams
+#endif
     hipStream_t fs = serial ? c->stream : c->stream_filter;
     const bool two_pose_streams = !serial && !c->prm.mono_rotation && c->sched.streams == 2;
     hipStream_t ps = serial ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
