@@ -152,6 +152,24 @@ PYEOF2
         rm -rf "$OUT/ps$SM"
     done
 fi
+if has pyrrows; then   # rows per work item of the fused pass (libvo_hip_pf4 / _dev (8) / _pf16: pyramid.hip built with -DVO_PF_ROWS=)
+    for LIB in pf4 dev pf16; do
+        [ -f "$ROOT/visual_odom_amd/libvo_hip_$LIB.so" ] || continue
+        stamp "lib=$LIB kernel trace, bench --stages lk"
+        (cd /tmp && VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_$LIB.so timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/pr$LIB" -- python "$ROOT/bench.py" --stages lk --steps 6 --warmup 2 $LEAN --validate 2 > "$OUT/pr$LIB.log" 2>&1)
+        python - "$OUT/pr$LIB" $LIB <<'PYEOF3' | tee -a "$OUT/summary.txt"
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if "pyr_pass" in r["Kernel_Name"]:
+        by[int(r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("  lib %s: " % sys.argv[2] + "  ".join("grid %d: avg %.0f min %.0f us" % (g, sum(v) / len(v), min(v)) for g, v in sorted(by.items(), reverse=True)))
+PYEOF3
+        rm -rf "$OUT/pr$LIB"
+        tail -c 300 "$OUT/pr$LIB.log" | grep -o '"validated_frames": [0-9]*' | tee -a "$OUT/summary.txt"
+    done
+fi
 if has timeline; then
     stamp "kernel timeline of vo_track_frame"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tf" -- python "$ROOT/tools/latency_mode.py" trackonly 6 60 > "$OUT/tf.log" 2>&1)
@@ -163,6 +181,36 @@ if has timeline; then
     python tools/kernel_timeline.py "$OUT/sq" 120 > "$OUT/timeline_seq.txt" 2>&1
     rm -rf "$OUT/sq"
     tail -60 "$OUT/timeline_seq.txt"
+fi
+if has pyrpmc; then   # what the fused pass waits for: SQ / TA / TCP / TCC counters per level (bench --stages lk: no pose chain beside
+                      # it; developer build, VO_PYR_STORE 0 = product stores, 2 = no Scharr stores)
+    for SM in ${PYR_SM:-0 2}; do
+    n=0
+    for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+               "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum" \
+               "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
+               "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum" \
+               "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL TD_TC_STALL_sum"; do
+        n=$((n + 1))
+        stamp "store mode $SM pmc set $n: $SET"
+        (cd /tmp && VO_PYR_STORE=$SM VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pp$n" -- python "$ROOT/bench.py" --stages lk --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pp${SM}_$n.log" 2>&1)
+        python - "$OUT/pp$n" <<'PYEOF4' | tee -a "$OUT/summary.txt"
+import csv, glob, sys, collections
+fs = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
+if not fs:
+    print("  (no counter file)")
+    sys.exit(0)
+by = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(fs[0])):
+    if "pyr_pass" in r["Kernel_Name"]:
+        by[int(r["Grid_Size"]) if "Grid_Size" in r else 0][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for g in sorted(by, reverse=True)[:2]:
+    print("  grid %d: " % g + "  ".join("%s %.4g" % (k, sum(v) / len(v)) for k, v in sorted(by[g].items())))
+PYEOF4
+        rm -rf "$OUT/pp$n"
+    done
+    done
 fi
 if has pyrprof; then  # kernel-level split of the pyramid stage (developer build; VO_PYR_FUSED from the environment)
     stamp "rocprofv3 kernel stats, dev lib, VO_PYR_FUSED=${VO_PYR_FUSED:-default}"

@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256) void scharr_nt_kernel(const PyrImage *__restri
 // per source row (columns x4 - 2 .. x4 + 5: the 6 columns of the 3 x 3 Scharr stencil and the 7 of the 5-tap pyrDown
 // window of its 2 next-level outputs), keeps a 3-row window of lifted u16 pairs for Scharr and a 5-row window of horizontal
 // pyrDown sums in registers, and stores 16 bytes of (4 Ix | 4 Iy << 16) per row plus 2 next-level pixels every second row.
-// Rows / columns outside the image are fetched through REFLECT_101 BY INDEX (edge items gather their 7 bytes), never from
-// the level's border: the border is written by the same launch (border items appended to the grid -- the body of
+// Rows / columns outside the image are taken through REFLECT_101 BY INDEX (rows by address, columns by a byte permute of the
+// window), never from the level's border: the border is written by the same launch (border items in the grid -- the body of
 // border_fill_kernel), and the next level's border by the next pass.  Arithmetic = scharr_body / pyr_hrow / pyr_column above,
 // so the results are bit-identical to the three-kernel chain (emulator + GPU pyramid tests).
-//   pyr_pass_kernel      one level of all images: blockIdx.y = image, blockIdx.x = 256 work items (main items, then border);
+//   pyr_pass_kernel      one level of all images: grid (wavefront of column groups, tail | row block, image);
 //                        one launch per level (L instead of 2 L + 2 launches)
 #ifndef VO_PF_ROWS
 #define VO_PF_ROWS 8
@@ -429,10 +429,13 @@ constexpr int PF_ROWS = VO_PF_ROWS; // rows per work item (even)
 static_assert(PF_ROWS % 2 == 0 && PF_ROWS <= 16, "a work item starts on an even row; one REFLECT_101 step covers its halo (levels have >= 22 rows)");
 
 struct PassPlan {
-    int ng[VO_MAX_LEVELS];       // 4-column groups of a level
-    int ni[VO_MAX_LEVELS];       // of which interior: groups 1 .. ni read columns 4 g - 2 .. 4 g + 4 inside the image
-    int n_main[VO_MAX_LEVELS];   // main work items (column groups x row blocks)
-    int n_items[VO_MAX_LEVELS];  // main + border work items
+    int ng[VO_MAX_LEVELS];     // 4-column groups of a level
+    int nm[VO_MAX_LEVELS];     // of which MAIN: groups 0 .. nm - 1 find columns 4 g - 2 .. 4 g + 4 in their 8-byte window (group 0
+                               // patches its two left neighbours in registers); the rest (one group at the right end) are EDGE
+    int nb[VO_MAX_LEVELS];     // row blocks of PF_ROWS rows
+    int nci[VO_MAX_LEVELS];    // grid x: wavefronts that cover the main groups of one row block
+    int n_tail[VO_MAX_LEVELS]; // edge + border work items (grid rows nb ..)
+    int gy[VO_MAX_LEVELS];     // grid y = nb + the rows of nci wavefronts that hold the tail items
 };
 struct __attribute__((packed, aligned(2))) LkU2x { // an 8-byte row window at an even column
     uint32_t lo, hi;
@@ -449,9 +452,11 @@ inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int 
     PassPlan pp = {};
     for (int l = 0; l < n_levels; l++) {
         pp.ng[l] = (lw[l] + 3) / 4;
-        pp.ni[l] = lw[l] >= 9 ? (lw[l] - 5) >> 2 : 0; // 4 g + 4 <= w - 1
-        pp.n_main[l] = pp.ng[l] * ((lh[l] + PF_ROWS - 1) / PF_ROWS);
-        pp.n_items[l] = pp.n_main[l] + border_items(lh[l], lw[l], lstride[l]);
+        pp.nm[l] = ((lw[l] - 5) >> 2) + 1; // 4 g + 4 <= w - 1 (= ng - 1: every level is at least 22 columns, plan_levels)
+        pp.nb[l] = (lh[l] + PF_ROWS - 1) / PF_ROWS;
+        pp.nci[l] = pp.nm[l] > 0 ? (pp.nm[l] + 63) / 64 : 1;
+        pp.n_tail[l] = pp.nb[l] * (pp.ng[l] - pp.nm[l]) + border_items(lh[l], lw[l], lstride[l]);
+        pp.gy[l] = pp.nb[l] + (pp.n_tail[l] + 64 * pp.nci[l] - 1) / (64 * pp.nci[l]);
     }
     return pp;
 }
@@ -508,13 +513,13 @@ __device__ __forceinline__ void border_item(const PyrImage &im, int level, int i
 // SM (developer build, VO_PYR_STORE): how the Scharr image is stored -- 0 non-temporal (product), 1 ordinary stores, 2 NOT AT
 // ALL (timing experiment only: what the pass costs without its dominant traffic)
 template <bool HAS_NEXT, bool EDGE, int SM = 0>
-__device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, int b)
+__device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, int b, bool first_wave)
 {
     const int w = im.w[level], h = im.h[level], stride = im.stride[level];
     const VO_GLOBAL uint8_t *__restrict__ src = (const VO_GLOBAL uint8_t *)im.lvl[level];
     VO_GLOBAL uint32_t *__restrict__ der = (VO_GLOBAL uint32_t *)im.der[level];
     const int x4 = 4 * g, y0 = PF_ROWS * b, c0 = x4 - 2; // c0: column of byte 0 of the 8-byte window (bytes 0 .. 6 are used:
-                                                         // columns x4 - 2 .. x4 + 4; an EDGE item gathers them by REFLECT_101)
+                                                         // columns x4 - 2 .. x4 + 4; an EDGE item's window starts at x4 - 4)
     int dw = 0, dh = 0, dstride = 0;
     VO_GLOBAL uint8_t *__restrict__ dst = nullptr;
     if (HAS_NEXT) {
@@ -524,6 +529,9 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
         dst = (VO_GLOBAL uint8_t *)im.lvl[level + 1];
     }
     const int x2 = x4 >> 1, oy0 = y0 >> 1;
+    // (output rows through byte pointers stepped per row: scalar for a main item; the lane adds a 32-bit offset)
+    VO_GLOBAL uint8_t *der_row = (VO_GLOBAL uint8_t *)der + (ptrdiff_t)y0 * stride * 4;
+    VO_GLOBAL uint8_t *dst_row = HAS_NEXT ? dst + (ptrdiff_t)oy0 * dstride : nullptr;
     uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0; // pyrDown: horizontal sums (two u16) of the last five source rows
     uint32_t A[3], B[3], C[3];                      // Scharr: lifted column pairs (j, j + 1), j = 0, 2, 4 of the last three rows
 #pragma unroll
@@ -536,35 +544,76 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
     // a level -- are loaded too: REFLECT_101 keeps the address inside the image.)
     uint32_t W0[PF_ROWS + 3], W1[PF_ROWS + 3];
     if (!EDGE) {
+        // The row block of a main item is the same for the whole wavefront (blockIdx.y): row reflection and row addresses are
+        // scalar code and a load is `scalar row address + 32-bit lane offset`.  (Per lane and row this was a 64-bit
+        // multiply-add, a quarter-rate instruction -- 23 per item with the store addresses: 680 -> 340 vector instructions
+        // per wavefront, level-0 pass 431 -> 322 us.)  A block none of whose rows reflects -- all but the first and the last
+        // one or two of a level -- steps a row pointer by the stride instead of reflecting and multiplying per row (240 -> 150
+        // scalar instructions per wavefront; this alone did not move the time, gpurun_out/r4_24).
+        const VO_GLOBAL uint8_t *rows[PF_ROWS + 3]; // (addresses first, ONE load loop after them: with a load loop in each
+                                                    // branch the compiler merged the branches' loads into 4-byte halves at
+                                                    // 64-bit lane addresses)
+        if (y0 >= 2 && y0 + PF_ROWS < h) {
+            const VO_GLOBAL uint8_t *row = src + (ptrdiff_t)(y0 - 2) * stride;
+#pragma unroll
+            for (int r = 0; r < PF_ROWS + 3; r++) {
+                rows[r] = row;
+                row += stride;
+            }
+        } else {
+            int hq = h;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
+            asm volatile("" : "+s"(hq)); // (keeps this branch a branch: without it the compiler computes these addresses for
+                                         // every block and then overrides them -- 9 scalar instructions per row on top of
+                                         // the 2 of the branch above)
+#endif
+#pragma unroll
+            for (int r = 0; r < PF_ROWS + 3; r++) {
+                // (one reflection is enough: -2 <= row < h + PF_ROWS + 1 and every level is taller than PF_ROWS + 2 -- a
+                // level is at least 22 rows, buildOpticalFlowPyramid's stop rule; reflect101's general loop costs ~30
+                // instructions)
+                const int p = y0 - 2 + r, sy = p < 0 ? -p : p >= hq ? 2 * hq - 2 - p : p;
+                rows[r] = src + (ptrdiff_t)sy * stride;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < PF_ROWS + 3; r++) {
-            // (one reflection is enough: -2 <= row < h + PF_ROWS + 1 and every level is taller than PF_ROWS + 2 -- a level
-            // is at least 22 rows, buildOpticalFlowPyramid's stop rule; reflect101's general loop costs ~30 instructions)
-            // 32-bit unsigned offset from the (wavefront-uniform) level base: one multiply-add per row instead of a 64-bit one
-            const int p = y0 - 2 + r, sy = p < 0 ? -p : p >= h ? 2 * h - 2 - p : p;
-            const LkU2x v = *(const VO_GLOBAL LkU2x *)(src + ((uint32_t)sy * (uint32_t)stride + (uint32_t)c0));
+            const LkU2x v = *(const VO_GLOBAL LkU2x *)(rows[r] + (uint32_t)x4 - 2);
             W0[r] = v.lo;
             W1[r] = v.hi;
+        }
+        // group 0 (in the first wavefront of a row block): its window starts two bytes left of the row -- memory of the
+        // level's border, which this launch is also writing; the two bytes are replaced here, whatever they hold: columns -2,
+        // -1 = columns 2, 1 = bytes 4, 3 of the window
+        if (first_wave) {
+            const uint32_t left = g == 0 ? 0x03020304u : 0x03020100u;
+#pragma unroll
+            for (int r = 0; r < PF_ROWS + 3; r++)
+                W0[r] = perm_b32(W1[r], W0[r], left);
+        }
+    } else {
+        // an EDGE item (the group at the right end of a row block): its columns x4 - 2 .. x4 + 4 reflect into x4 - 4 .. x4 + 3
+        // whatever w mod 4 is, so it loads the 8-byte window at x4 - 4 and picks its 7 bytes with two byte permutes whose
+        // selectors hold the reflection -- all rows before the first use, like the main items.  (It gathered 7 single bytes
+        // per row inside the row loop: 11 memory round trips per edge wavefront, which made the edge wavefronts of the last
+        // images the tail of the launch.)
+        const int xs = x4 - 4; // (>= 0: a level is at least 22 columns -- plan_levels -- so the edge group is never group 0)
+        uint32_t sel[2] = {0, 0x0c000000u};
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            sel[k >> 2] |= (uint32_t)(reflect101(c0 + k, w) - xs) << (8 * (k & 3));
+#pragma unroll
+        for (int r = 0; r < PF_ROWS + 3; r++) {
+            const VO_GLOBAL uint8_t *__restrict__ row = src + (ptrdiff_t)reflect101(y0 - 2 + r, h) * stride;
+            const LkU2x v = *(const VO_GLOBAL LkU2x *)(row + xs);
+            W0[r] = perm_b32(v.hi, v.lo, sel[0]);
+            W1[r] = perm_b32(v.hi, v.lo, sel[1]);
         }
     }
 #pragma unroll
     for (int r = 0; r < PF_ROWS + 3; r++) {
         // source row y0 - 2 + r: Scharr row y0 + j reads r = j + 1 .. j + 3, next-level row oy0 + j reads r = 2 j .. 2 j + 4
-        uint32_t w0, w1;
-        if (!EDGE) {
-            w0 = W0[r];
-            w1 = W1[r];
-        } else {
-            if (r >= 5 && !(y0 + r - 3 < h) && !(HAS_NEXT && oy0 + (r - 3) / 2 < dh))
-                break; // (the last row block of a level: nothing of this item depends on the remaining rows)
-            const VO_GLOBAL uint8_t *__restrict__ row = src + (ptrdiff_t)reflect101(y0 - 2 + r, h) * stride;
-            uint32_t bt[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                bt[k] = k <= 6 ? (uint32_t)row[reflect101(c0 + k, w)] : 0u;
-            w0 = bt[0] | bt[1] << 8 | bt[2] << 16 | bt[3] << 24;
-            w1 = bt[4] | bt[5] << 8 | bt[6] << 16 | bt[7] << 24;
-        }
+        const uint32_t w0 = W0[r], w1 = W1[r];
         if (HAS_NEXT) { // horizontal [1 4 6 4 1] of the 2 next-level outputs: bytes 0 .. 4 and 2 .. 6
             const uint32_t taps = 0x04060401u;
             const uint32_t h0 = udot4(w0, taps, udot4(w1, 0x00000001u, 0));
@@ -576,12 +625,16 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
             q4 = h0 | h1 << 16;
             if (r >= 4 && (r & 1) == 0) { // source row 2 (oy0 + j) + 2 has arrived: output row oy0 + j, j = (r - 4) / 2
                 const int oy = oy0 + (r - 4) / 2;
-                if (oy < dh && x2 < dw) {
+#ifdef VO_PASS_X
+                if (!(VO_PASS_X & 2))
+#endif
+                if (oy < dh && (!EDGE || x2 < dw)) { // (4 g <= w - 1: a main group always has x2 < dw)
                     // 6 q2 + 4 (q1 + q3) + q0 + q4 + 128 <= 65408 fits 16 bits; the result is its high byte.  A second column
                     // >= dw lands in the right border, which the next level's pass rewrites
                     const uint32_t v = pk_mad_u16(q2, 6, pk_mad_u16(pk_add_u16(q1, q3), 4, pk_add_u16(pk_add_u16(q0, q4), 0x00800080u)));
-                    *(VO_GLOBAL uint16_t *)(dst + ((uint32_t)oy * (uint32_t)dstride + (uint32_t)x2)) = (uint16_t)perm_b32(0, v, 0x0c0c0301u);
+                    *(VO_GLOBAL uint16_t *)(dst_row + (uint32_t)x2) = (uint16_t)perm_b32(0, v, 0x0c0c0301u);
                 }
+                dst_row += dstride;
             }
         }
         // Scharr window: bytes 1 .. 6 of the 8 = columns x4 - 1 .. x4 + 4
@@ -617,7 +670,8 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
                         if (x4 + k >= w)
                             out[k] = 0;
                 }
-                VO_GLOBAL uint4 *o = (VO_GLOBAL uint4 *)(der + ((uint32_t)y * (uint32_t)stride + (uint32_t)x4));
+                VO_GLOBAL uint4 *o = (VO_GLOBAL uint4 *)(der_row + (uint32_t)(16 * g));
+                der_row += (ptrdiff_t)stride * 4;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_HOST_EMUL)
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 oa = {out[0], out[1], out[2], out[3]};
@@ -635,48 +689,58 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
     }
 }
 
-// Work items of a level in launch order: the INTERIOR column groups of every row block, then the EDGE groups (the first
-// group and the one or two at the right end that need a column outside the image) of every row block, then the border
-// chunks.  Edge items gather single bytes through REFLECT_101 (7 loads per row instead of one) -- numbered row block by row
-// block they sat in 4 of every 10 wavefronts and the whole wavefront waited for them (gpurun_out/r4_03: level-0 pass 0.46
-// ms); grouped at the end they fill one or two wavefronts per image.
+// Grid of a level's pass: z = image; x = wavefront of 64 main column groups, y = (after the tail rows) row block -- the row block
+// of a wavefront is a scalar (blockIdx.y), so row reflection, row addresses and the "row exists" predicates are scalar code and
+// the lanes only add their column offset.  The FIRST rows of the grid hold the TAIL items, 64 per workgroup in x-then-y order:
+// the EDGE group of every row block (the group at the right end, which needs columns beyond the image: its row pointers are
+// per lane and its window is permuted through REFLECT_101) and then the border chunks.  (Edge items numbered among the main ones sat in
+// 4 of every 10 wavefronts and the whole wavefront waited for them -- gpurun_out/r4_03; packed they are one wavefront per
+// image.  First, not last: an edge wavefront lives several times longer than a main one, and behind the main items of the
+// last image it was the tail of the launch.)
 template <int SM = 0>
-__device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int n_levels, const PassPlan &pp, int item)
+__device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int n_levels, const PassPlan &pp)
 {
-    if (item >= pp.n_items[level])
-        return;
-    if (item >= pp.n_main[level]) {
-        border_item(im, level, item - pp.n_main[level]);
-        return;
-    }
-    const int ng = pp.ng[level], ni = pp.ni[level], nb = pp.n_main[level] / ng, n_int = nb * ni;
+    const int nb = pp.nb[level], nm = pp.nm[level];
     const bool has_next = level + 1 < n_levels;
-    if (item < n_int) {
-        const int b = item / ni, g = 1 + item - b * ni;
+    const int ty = pp.gy[level] - nb; // grid rows 0 .. ty - 1: the tail items; then one grid row per row block
+    if ((int)blockIdx.y >= ty) {
+        const int g = (int)(blockIdx.x * 64 + threadIdx.x);
+        if (g >= nm)
+            return;
         if (has_next)
-            pass_item<true, false, SM>(im, level, g, b);
+            pass_item<true, false, SM>(im, level, g, (int)blockIdx.y - ty, blockIdx.x == 0);
         else
-            pass_item<false, false, SM>(im, level, g, b);
+            pass_item<false, false, SM>(im, level, g, (int)blockIdx.y - ty, blockIdx.x == 0);
         return;
     }
-    const int ne = ng - ni, e = item - n_int;
-    const int b = e / ne, k = e - b * ne;
-    const int g = k == 0 ? 0 : ni + k; // group 0, then groups ni + 1 .. ng - 1
+    int t = (int)((blockIdx.y * pp.nci[level] + blockIdx.x) * 64 + threadIdx.x);
+    if (t >= pp.n_tail[level])
+        return;
+#ifdef VO_PASS_X // (tools/ubench/pass_bench.hip: what a part of the pass costs -- 1 no border items, 2 no next-level stores, 4 no edge items)
+    if (((VO_PASS_X & 1) && t >= nb * (pp.ng[level] - nm)) || ((VO_PASS_X & 4) && t < nb * (pp.ng[level] - nm)))
+        return;
+#endif
+    const int ne = pp.ng[level] - nm, n_edge = nb * ne;
+    if (t >= n_edge) {
+        border_item(im, level, t - n_edge);
+        return;
+    }
+    const int b = t / ne, g = nm + (t - b * ne);
     if (has_next)
-        pass_item<true, true, SM>(im, level, g, b);
+        pass_item<true, true, SM>(im, level, g, b, false);
     else
-        pass_item<false, true, SM>(im, level, g, b);
+        pass_item<false, true, SM>(im, level, g, b, false);
 }
 
-__global__ __launch_bounds__(256) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+__global__ __launch_bounds__(64) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
 {
-    pass_dispatch<0>(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
+    pass_dispatch<0>(imgs[blockIdx.z], level, n_levels, pp);
 }
 #if defined(VO_DEV_VARIANTS) && !defined(VO_HOST_EMUL)
 template <int SM>
-__global__ __launch_bounds__(256) void pyr_pass_sm_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+__global__ __launch_bounds__(64) void pyr_pass_sm_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
 {
-    pass_dispatch<SM>(imgs[blockIdx.y], level, n_levels, pp, (int)(blockIdx.x * 256 + threadIdx.x));
+    pass_dispatch<SM>(imgs[blockIdx.z], level, n_levels, pp);
 }
 #endif
 
@@ -748,17 +812,17 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
     static const int sm = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
     if (sm == 1 || sm == 2) {
         for (int l = 0; l < n_levels; l++) {
-            const dim3 grid((pp.n_items[l] + 255) / 256, n_images);
+            const dim3 grid(pp.nci[l], pp.gy[l], n_images);
             if (sm == 1)
-                hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, grid, dim3(256), 0, stream, d_imgs, l, n_levels, pp);
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, grid, dim3(64), 0, stream, d_imgs, l, n_levels, pp);
             else
-                hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, grid, dim3(256), 0, stream, d_imgs, l, n_levels, pp);
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, grid, dim3(64), 0, stream, d_imgs, l, n_levels, pp);
         }
         return;
     }
 #endif
     for (int l = 0; l < n_levels; l++)
-        hipLaunchKernelGGL(pyr_pass_kernel, dim3((pp.n_items[l] + 255) / 256, n_images), dim3(256), 0, stream, d_imgs, l, n_levels, pp);
+        hipLaunchKernelGGL(pyr_pass_kernel, dim3(pp.nci[l], pp.gy[l], n_images), dim3(64), 0, stream, d_imgs, l, n_levels, pp);
 }
 
 #endif // VO_HOST_EMUL
