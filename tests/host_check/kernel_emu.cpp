@@ -67,7 +67,10 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
     if (g_pyr_lds == 2) { // the fused passes (round 4; what launch_pyramid_fused enqueues): one launch per level
         const PassPlan pp = pass_plan(p.levels, p.lw, p.lh, p.ls);
         for (int l = 0; l < p.levels; l++)
-            launch((unsigned)pp.nci[l], (unsigned)pp.gy[l], n_img, 64, [&] { pyr_pass_kernel(d_imgs, l, p.levels, pp); });
+            {
+                const uint32_t nwg = pass_grid(pp, l, (int)n_img, 1);
+                launch(nwg, 1, 1, 64, [&] { pyr_pass_kernel(d_imgs, l, p.levels, pp, (uint32_t)n_img, 1); });
+            }
         return;
     }
     // the three-kernel chain: level 0's border + Scharr image, the pyr_down chain, then the other levels

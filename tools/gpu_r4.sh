@@ -152,6 +152,16 @@ PYEOF2
         rm -rf "$OUT/ps$SM"
     done
 fi
+if has xcdab; then   # XCD-aware workgroup order of the pyramid pass against dispatch order, in the pipeline (developer build: VO_PYR_XCD)
+    for WL in kitti2000 kitti374 rgbd374 zed374 hd4000; do
+        for X in 0 1; do
+            stamp "VO_PYR_XCD=$X bench $WL"
+            FR=""; [ $WL = hd4000 ] && FR="--frames 128"
+            VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_PYR_XCD=$X timeout 300 python bench.py --workload $WL $FR --steps 20 --warmup 3 $LEAN --validate 0 --schedule 1,1,0 > "$OUT/xcd_${WL}_$X.json" 2> "$OUT/xcd_${WL}_$X.err"
+            line "$OUT/xcd_${WL}_$X.json" "$WL xcd=$X"
+        done
+    done
+fi
 if has pyrrows; then   # rows per work item of the fused pass (libvo_hip_pf4 / _dev (8) / _pf16: pyramid.hip built with -DVO_PF_ROWS=)
     for LIB in pf4 dev pf16; do
         [ -f "$ROOT/visual_odom_amd/libvo_hip_$LIB.so" ] || continue

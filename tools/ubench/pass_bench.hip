@@ -61,16 +61,17 @@ int main(int argc, char **argv)
 #define VO_PASS_X 0
 #endif
     printf("%d images %d x %d, %d levels, VO_PASS_X=%d, rows per item %d\n", NI, W, H, L, VO_PASS_X, PF_ROWS);
-    float tot[3] = {0, 0, 0};
+    float tot[4] = {0, 0, 0, 0};
     for (int l = 0; l < L; l++) {
-        const dim3 grid(pp.nci[l], pp.gy[l], NI);
-        const float t0 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, grid, dim3(64), 0, 0, d_imgs, l, L, pp); }, 20);
-        const float t1 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, grid, dim3(64), 0, 0, d_imgs, l, L, pp); }, 20);
-        const float t2 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, grid, dim3(64), 0, 0, d_imgs, l, L, pp); }, 20);
-        printf("  level %d (%4d x %3d): grid %d x %d  non-temporal %6.1f us   ordinary stores %6.1f   no Scharr stores %6.1f\n", l, lw[l], lh[l],
-               grid.x, grid.y, t0 * 1e3, t1 * 1e3, t2 * 1e3);
-        tot[0] += t0; tot[1] += t1; tot[2] += t2;
+        const uint32_t g1 = pass_grid(pp, l, NI, 1), g0 = pass_grid(pp, l, NI, 0);
+        const float t0 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
+        const float t1 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
+        const float t2 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
+        const float t3 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g0), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 0); }, 20);
+        printf("  level %d (%4d x %3d): %d x %d workgroups per image  non-temporal %6.1f us   ordinary stores %6.1f   no Scharr stores %6.1f   dispatch order (image not pinned to an XCD) %6.1f\n", l, lw[l], lh[l],
+               pp.nci[l], pp.gy[l], t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3);
+        tot[0] += t0; tot[1] += t1; tot[2] += t2; tot[3] += t3;
     }
-    printf("  all levels: %.1f / %.1f / %.1f us\n", tot[0] * 1e3, tot[1] * 1e3, tot[2] * 1e3);
+    printf("  all levels: %.1f / %.1f / %.1f / %.1f us\n", tot[0] * 1e3, tot[1] * 1e3, tot[2] * 1e3, tot[3] * 1e3);
     return 0;
 }

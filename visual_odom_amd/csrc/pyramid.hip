@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void scharr_nt_kernel(const PyrImage *__restri
 // window), never from the level's border: the border is written by the same launch (border items in the grid -- the body of
 // border_fill_kernel), and the next level's border by the next pass.  Arithmetic = scharr_body / pyr_hrow / pyr_column above,
 // so the results are bit-identical to the three-kernel chain (emulator + GPU pyramid tests).
-//   pyr_pass_kernel      one level of all images: grid (wavefront of column groups, tail | row block, image);
+//   pyr_pass_kernel      one level of all images: one wavefront per workgroup, ids in XCD-aware order -> (image, tail | row block,
+//                        wavefront of column groups);
 //                        one launch per level (L instead of 2 L + 2 launches)
 #ifndef VO_PF_ROWS
 #define VO_PF_ROWS 8
@@ -436,6 +437,8 @@ struct PassPlan {
     int nci[VO_MAX_LEVELS];    // grid x: wavefronts that cover the main groups of one row block
     int n_tail[VO_MAX_LEVELS]; // edge + border work items (grid rows nb ..)
     int gy[VO_MAX_LEVELS];     // grid y = nb + the rows of nci wavefronts that hold the tail items
+    uint32_t m_img[VO_MAX_LEVELS], m_row[VO_MAX_LEVELS]; // floor(2^32 / (nci gy)) + 1, floor(2^32 / nci) + 1: id -> (image, y, x) by
+                                                         // multiply-high (exact while id x divisor < 2^32: pass_images_per_launch)
 };
 struct __attribute__((packed, aligned(2))) LkU2x { // an 8-byte row window at an even column
     uint32_t lo, hi;
@@ -457,8 +460,24 @@ inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int 
         pp.nci[l] = pp.nm[l] > 0 ? (pp.nm[l] + 63) / 64 : 1;
         pp.n_tail[l] = pp.nb[l] * (pp.ng[l] - pp.nm[l]) + border_items(lh[l], lw[l], lstride[l]);
         pp.gy[l] = pp.nb[l] + (pp.n_tail[l] + 64 * pp.nci[l] - 1) / (64 * pp.nci[l]);
+        pp.m_img[l] = (uint32_t)((1ull << 32) / (uint32_t)(pp.nci[l] * pp.gy[l])) + 1;
+        pp.m_row[l] = (uint32_t)((1ull << 32) / (uint32_t)pp.nci[l]) + 1; // (nci = 1: 2^32 + 1 wraps to 1 -- the dispatch does not divide by 1)
     }
     return pp;
+}
+
+// workgroups of one launch over n images (XCD-aware order: padded to a multiple of 8 images)
+inline uint32_t pass_grid(const PassPlan &pp, int l, int n, int remap)
+{
+    return (uint32_t)pp.nci[l] * (uint32_t)pp.gy[l] * (uint32_t)(remap ? (n + 7) / 8 * 8 : n);
+}
+
+// images per launch for which the multiply-high divisions of the dispatch are exact (id < 2^32 / divisor)
+inline int pass_images_per_launch(const PassPlan &pp, int l)
+{
+    const uint64_t wpi = (uint64_t)pp.nci[l] * pp.gy[l];
+    const uint64_t n = ((1ull << 32) - 1) / (wpi * wpi);
+    return (int)(n > (1u << 20) ? (1u << 20) : n < 16 ? 8 : n / 8 * 8 - 8); // (a multiple of 8, padding included)
 }
 
 // one 16-byte chunk of a level's REFLECT_101 border (the work item of border_fill_kernel)
@@ -689,31 +708,53 @@ __device__ __forceinline__ void pass_item(const PyrImage &im, int level, int g, 
     }
 }
 
-// Grid of a level's pass: z = image; x = wavefront of 64 main column groups, y = (after the tail rows) row block -- the row block
-// of a wavefront is a scalar (blockIdx.y), so row reflection, row addresses and the "row exists" predicates are scalar code and
-// the lanes only add their column offset.  The FIRST rows of the grid hold the TAIL items, 64 per workgroup in x-then-y order:
-// the EDGE group of every row block (the group at the right end, which needs columns beyond the image: its row pointers are
-// per lane and its window is permuted through REFLECT_101) and then the border chunks.  (Edge items numbered among the main ones sat in
-// 4 of every 10 wavefronts and the whole wavefront waited for them -- gpurun_out/r4_03; packed they are one wavefront per
-// image.  First, not last: an edge wavefront lives several times longer than a main one, and behind the main items of the
-// last image it was the tail of the launch.)
+// Grid of a level's pass: ONE dimension, nci x gy workgroups (of one wavefront) per image.  Within an image: x = wavefront of 64
+// main column groups, y = (after the tail rows) row block -- the row block of a wavefront is a scalar, so row reflection, row
+// addresses and the "row exists" predicates are scalar code and the lanes only add their column offset.  The FIRST rows hold
+// the TAIL items, 64 per workgroup in x-then-y order: the EDGE group of every row block (the group at the right end, which
+// needs columns beyond the image: its row pointers are per lane and its window is permuted through REFLECT_101) and then the
+// border chunks.  (Edge items numbered among the main ones sat in 4 of every 10 wavefronts and the whole wavefront waited for
+// them -- gpurun_out/r4_03; packed they are one wavefront per image.  First, not last: an edge wavefront lives several times
+// longer than a main one, and behind the main items of the last image it was the tail of the launch.)
+// XCD-aware order: the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2, and neighbours in this grid share
+// data -- row blocks y and y + 1 share 3 of their 11 source rows, wavefronts x and x + 1 a cache line per row, the border
+// items re-read rows of the image.  In dispatch order those neighbours sit on DIFFERENT XCDs and every shared line came from
+// memory once per XCD (FETCH_SIZE 0.90 GB per 514-image step against 0.32 GB of pixels, profiles/r04.md).  So workgroup b is
+// given slot b / 8 of the images that XCD b % 8 owns: image z is processed entirely by XCD z % 8 (the grid is padded to 8
+// images; tools/ubench/pass_bench.hip compares this with dispatch order and with coarser / finer chunks).  Placement is a
+// speed matter only: nothing here depends on which XCD runs what.
 template <int SM = 0>
-__device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int n_levels, const PassPlan &pp)
+__device__ __forceinline__ void pass_dispatch(const PyrImage *__restrict__ imgs, int level, int n_levels, const PassPlan &pp, uint32_t n_images,
+                                              int remap)
 {
+    const uint32_t nci = (uint32_t)pp.nci[level], wpi = nci * (uint32_t)pp.gy[level];
+    uint32_t id = blockIdx.x, z, rem;
+    if (remap) {
+        const uint32_t slot = id >> 3, k = (uint32_t)(((uint64_t)slot * pp.m_img[level]) >> 32);
+        z = k * 8 + (id & 7);
+        rem = slot - k * wpi;
+        if (z >= n_images)
+            return;
+    } else {
+        z = (uint32_t)(((uint64_t)id * pp.m_img[level]) >> 32);
+        rem = id - z * wpi;
+    }
+    const uint32_t by = nci == 1 ? rem : (uint32_t)(((uint64_t)rem * pp.m_row[level]) >> 32), bx = rem - by * nci;
+    const PyrImage &im = imgs[z];
     const int nb = pp.nb[level], nm = pp.nm[level];
     const bool has_next = level + 1 < n_levels;
-    const int ty = pp.gy[level] - nb; // grid rows 0 .. ty - 1: the tail items; then one grid row per row block
-    if ((int)blockIdx.y >= ty) {
-        const int g = (int)(blockIdx.x * 64 + threadIdx.x);
+    const int ty = pp.gy[level] - nb; // rows 0 .. ty - 1 of an image's workgroups: the tail items; then one row per row block
+    if ((int)by >= ty) {
+        const int g = (int)(bx * 64 + threadIdx.x);
         if (g >= nm)
             return;
         if (has_next)
-            pass_item<true, false, SM>(im, level, g, (int)blockIdx.y - ty, blockIdx.x == 0);
+            pass_item<true, false, SM>(im, level, g, (int)by - ty, bx == 0);
         else
-            pass_item<false, false, SM>(im, level, g, (int)blockIdx.y - ty, blockIdx.x == 0);
+            pass_item<false, false, SM>(im, level, g, (int)by - ty, bx == 0);
         return;
     }
-    int t = (int)((blockIdx.y * pp.nci[level] + blockIdx.x) * 64 + threadIdx.x);
+    int t = (int)(rem * 64 + threadIdx.x);
     if (t >= pp.n_tail[level])
         return;
 #ifdef VO_PASS_X // (tools/ubench/pass_bench.hip: what a part of the pass costs -- 1 no border items, 2 no next-level stores, 4 no edge items)
@@ -732,15 +773,15 @@ __device__ __forceinline__ void pass_dispatch(const PyrImage &im, int level, int
         pass_item<false, true, SM>(im, level, g, b, false);
 }
 
-__global__ __launch_bounds__(64) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+__global__ __launch_bounds__(64) void pyr_pass_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp, uint32_t n_images, int remap)
 {
-    pass_dispatch<0>(imgs[blockIdx.z], level, n_levels, pp);
+    pass_dispatch<0>(imgs, level, n_levels, pp, n_images, remap);
 }
 #if defined(VO_DEV_VARIANTS) && !defined(VO_HOST_EMUL)
 template <int SM>
-__global__ __launch_bounds__(64) void pyr_pass_sm_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp)
+__global__ __launch_bounds__(64) void pyr_pass_sm_kernel(const PyrImage *__restrict__ imgs, int level, int n_levels, PassPlan pp, uint32_t n_images, int remap)
 {
-    pass_dispatch<SM>(imgs[blockIdx.z], level, n_levels, pp);
+    pass_dispatch<SM>(imgs, level, n_levels, pp, n_images, remap);
 }
 #endif
 
@@ -808,21 +849,32 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
     // one launch per level.  (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel,
     // pass / fence + barrier / pass -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms
     // for level 0, gpurun_out/r4_04: a few hundred workgroups of serial phases do not fill the chip.)
+    int sm = 0, remap = 1;
 #ifdef VO_DEV_VARIANTS
-    static const int sm = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
-    if (sm == 1 || sm == 2) {
-        for (int l = 0; l < n_levels; l++) {
-            const dim3 grid(pp.nci[l], pp.gy[l], n_images);
-            if (sm == 1)
-                hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, grid, dim3(64), 0, stream, d_imgs, l, n_levels, pp);
-            else
-                hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, grid, dim3(64), 0, stream, d_imgs, l, n_levels, pp);
-        }
-        return;
-    }
+    static const int sm_env = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
+    static const int xcd_env = [] { const char *e = getenv("VO_PYR_XCD"); return e ? atoi(e) : 1; }(); // 0: workgroups in dispatch order
+    sm = sm_env;
+    remap = xcd_env;
 #endif
-    for (int l = 0; l < n_levels; l++)
-        hipLaunchKernelGGL(pyr_pass_kernel, dim3(pp.nci[l], pp.gy[l], n_images), dim3(64), 0, stream, d_imgs, l, n_levels, pp);
+    for (int l = 0; l < n_levels; l++) {
+        const int per = pass_images_per_launch(pp, l);
+        for (int first = 0; first < n_images; first += per) {
+            const int n = n_images - first < per ? n_images - first : per;
+            const uint32_t nwg = pass_grid(pp, l, n, remap);
+#ifdef VO_DEV_VARIANTS
+            if (sm == 1) {
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, dim3(nwg), dim3(64), 0, stream, d_imgs + first, l, n_levels, pp, (uint32_t)n, remap);
+                continue;
+            }
+            if (sm == 2) {
+                hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, dim3(nwg), dim3(64), 0, stream, d_imgs + first, l, n_levels, pp, (uint32_t)n, remap);
+                continue;
+            }
+#endif
+            hipLaunchKernelGGL(pyr_pass_kernel, dim3(nwg), dim3(64), 0, stream, d_imgs + first, l, n_levels, pp, (uint32_t)n, remap);
+        }
+    }
+    (void)sm;
 }
 
 #endif // VO_HOST_EMUL
