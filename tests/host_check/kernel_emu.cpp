@@ -93,6 +93,55 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 extern "C" {
 void ke_set_pyr_lds(int on) { g_pyr_lds = on; }
 
+// the pyramid pass's workgroup-id decode (multiply-high divisions, XCD-aware order) against plain division: every id of a launch
+// over n images of a w x h level-0 shape (n = 0 or beyond it: the largest launch pass_images_per_launch allows, ids sampled: the first and last
+// 2^20 and every 4099th between).  Returns 0, or 1 + the level at which an id decoded wrongly / the decode was not a bijection.
+int ke_pass_decode_check(int w, int h, int max_level, int n)
+{
+    using namespace vo;
+    int lw[VO_MAX_LEVELS], lh[VO_MAX_LEVELS], ls[VO_MAX_LEVELS], L = 0;
+    for (int cw = w, ch = h;; L++) {
+        lw[L] = cw; lh[L] = ch; ls[L] = (VO_BX + cw + VO_BY + 15) / 16 * 16;
+        const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+        if (L == max_level || L + 1 >= VO_MAX_LEVELS || nw <= 21 || nh <= 21) break;
+        cw = nw; ch = nh;
+    }
+    L++;
+    const PassPlan pp = pass_plan(L, lw, lh, ls);
+    for (int l = 0; l < L; l++) {
+        const uint32_t nci = (uint32_t)pp.nci[l], wpi = nci * (uint32_t)pp.gy[l];
+        const uint32_t per = (uint32_t)pass_images_per_launch(pp, l), ni = n > 0 && (uint32_t)n < per ? (uint32_t)n : per; // (more images: a second launch)
+        for (int remap = 0; remap < 2; remap++) {
+            const uint32_t nwg = pass_grid(pp, l, (int)ni, remap);
+            if ((uint64_t)nwg != (uint64_t)wpi * (remap ? (ni + 7) / 8 * 8 : ni))
+                return 1 + l;
+            uint64_t seen = 0, expect = 0; // order-independent checksum of the decoded linear positions
+            const bool full = nwg <= (1u << 22);
+            for (uint32_t id = 0; id < nwg; id = (full || id < (1u << 20) || id + (1u << 20) >= nwg) ? id + 1 : id + 4099) {
+                uint32_t z, rem, by, bx;
+                const bool live = pass_decode(pp, l, id, ni, remap, &z, &rem, &by, &bx);
+                const uint32_t lin = remap ? id >> 3 : id;
+                const uint32_t zt = remap ? (lin / wpi) * 8 + (id & 7) : lin / wpi, rt = lin % wpi;
+                if (live != (zt < ni))
+                    return 1 + l;
+                if (!live)
+                    continue;
+                if (z != zt || rem != rt || by != rt / nci || bx != rt % nci || by >= (uint32_t)pp.gy[l] || bx >= nci)
+                    return 1 + l;
+                seen += (uint64_t)z * wpi + rem + 1;
+            }
+            if (full) {
+                const uint64_t tot = (uint64_t)ni * wpi;
+                expect = tot * (tot + 1) / 2;
+                if (seen != expect)
+                    return 1 + l;
+            }
+        }
+    }
+    return 0;
+}
+
+
 // essential.hip on the emulator, launch by launch as launch_essential does: findEssentialMat(RANSAC) + recoverPose of one frame.
 // p0, p1: n x 2 pixels.  Returns EmResult::status; E, R: 9, t: 3, mask: n, dbg: {n_inliers, n_good, niters, best}
 int ke_essential(const float *p0, const float *p1, int n, double focal, double ppx, double ppy, double prob, double threshold,

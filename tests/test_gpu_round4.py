@@ -327,3 +327,29 @@ def test_fused_pyramid_pass_on_small_and_odd_shapes(volib, orc, h, w):
             assert np.array_equal(got[k], want[k]), k
     finally:
         ctx.close()
+
+
+def test_pyramid_stage_over_more_images_than_one_launch(volib, orc):
+    """the pyramid pass takes at most 4096 images per launch (pyramid.hip, pass_images_per_launch) and decodes its workgroup id
+    per launch: 4104 small images -- the last launch holds 8 -- with distinct pictures either side of the boundary, every
+    level bit-exact against the oracle"""
+    w, h, n = 64, 44, 4104
+    rng = np.random.default_rng(4104)
+    ctx = volib.Context(0, w, h, 8, n // 6)
+    try:
+        ctx.batch_configure(n, w, h, 1)
+        picks = [0, 1, 7, 8, 4087, 4095, 4096, 4097, 4103]
+        imgs = {i: rng.integers(0, 256, (h, w), dtype=np.uint8) for i in picks}
+        blank = np.zeros((h, w), np.uint8)
+        for i in range(n):
+            ctx.batch_upload_image(i, imgs.get(i, blank))
+        ctx.batch_set_pyramid_range(0, n)
+        ctx.batch_run(volib.STAGE_PYRAMID)
+        ctx.batch_sync()
+        for i in picks:
+            ref = orc.build_pyramid(imgs[i], 3)
+            for l in range(2):  # 64 x 44 -> 32 x 22, then buildOpticalFlowPyramid stops
+                assert np.array_equal(ctx.batch_get_pyramid_level(i, l), ref[l]), (i, l)
+        assert not ctx.batch_get_pyramid_level(4094, 1).any() and not ctx.batch_get_pyramid_level(4098, 1).any()
+    finally:
+        ctx.close()

@@ -466,18 +466,46 @@ inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int 
     return pp;
 }
 
+// workgroup id -> image z, workgroup `rem` of the image = row `by`, wavefront `bx`; false = a padding workgroup.  Divisions by
+// multiply-high with the reciprocals of the plan (exact for the launch sizes pass_images_per_launch allows: checked id by id in
+// tests/test_kernel_emulation.py)
+#if defined(__HIPCC__) && !defined(VO_HOST_EMUL)
+__host__ __device__
+#endif
+inline bool pass_decode(const PassPlan &pp, int level, uint32_t id, uint32_t n_images, int remap, uint32_t *z, uint32_t *rem, uint32_t *by,
+                        uint32_t *bx)
+{
+    const uint32_t nci = (uint32_t)pp.nci[level], wpi = nci * (uint32_t)pp.gy[level];
+    if (remap) { // workgroup b runs on XCD b % 8: slot b / 8 of the images that XCD owns (z % 8 == b % 8)
+        const uint32_t slot = id >> 3, k = (uint32_t)(((uint64_t)slot * pp.m_img[level]) >> 32);
+        *z = k * 8 + (id & 7);
+        *rem = slot - k * wpi;
+        if (*z >= n_images)
+            return false;
+    } else {
+        *z = (uint32_t)(((uint64_t)id * pp.m_img[level]) >> 32);
+        *rem = id - *z * wpi;
+    }
+    *by = nci == 1 ? *rem : (uint32_t)(((uint64_t)*rem * pp.m_row[level]) >> 32);
+    *bx = *rem - *by * nci;
+    return true;
+}
+
 // workgroups of one launch over n images (XCD-aware order: padded to a multiple of 8 images)
 inline uint32_t pass_grid(const PassPlan &pp, int l, int n, int remap)
 {
     return (uint32_t)pp.nci[l] * (uint32_t)pp.gy[l] * (uint32_t)(remap ? (n + 7) / 8 * 8 : n);
 }
 
-// images per launch for which the multiply-high divisions of the dispatch are exact (id < 2^32 / divisor)
+// images per launch: at most 4096 (hundreds of thousands of workgroups: nothing left to amortise), fewer where the multiply-high
+// divisions of the dispatch would stop being exact (id < 2^32 / divisor; 4096 x 3000 images: 88); a multiple of 8.  Further images
+// go to the next launch (tests/test_gpu_round4.py runs 4104 images; the decode is checked id by id in test_kernel_emulation.py)
+constexpr int PASS_MAX_IMAGES = 4096;
 inline int pass_images_per_launch(const PassPlan &pp, int l)
 {
     const uint64_t wpi = (uint64_t)pp.nci[l] * pp.gy[l];
     const uint64_t n = ((1ull << 32) - 1) / (wpi * wpi);
-    return (int)(n > (1u << 20) ? (1u << 20) : n < 16 ? 8 : n / 8 * 8 - 8); // (a multiple of 8, padding included)
+    return (int)(n >= PASS_MAX_IMAGES + 8 ? PASS_MAX_IMAGES : n < 16 ? 8 : n / 8 * 8 - 8);
 }
 
 // one 16-byte chunk of a level's REFLECT_101 border (the work item of border_fill_kernel)
@@ -727,19 +755,9 @@ template <int SM = 0>
 __device__ __forceinline__ void pass_dispatch(const PyrImage *__restrict__ imgs, int level, int n_levels, const PassPlan &pp, uint32_t n_images,
                                               int remap)
 {
-    const uint32_t nci = (uint32_t)pp.nci[level], wpi = nci * (uint32_t)pp.gy[level];
-    uint32_t id = blockIdx.x, z, rem;
-    if (remap) {
-        const uint32_t slot = id >> 3, k = (uint32_t)(((uint64_t)slot * pp.m_img[level]) >> 32);
-        z = k * 8 + (id & 7);
-        rem = slot - k * wpi;
-        if (z >= n_images)
-            return;
-    } else {
-        z = (uint32_t)(((uint64_t)id * pp.m_img[level]) >> 32);
-        rem = id - z * wpi;
-    }
-    const uint32_t by = nci == 1 ? rem : (uint32_t)(((uint64_t)rem * pp.m_row[level]) >> 32), bx = rem - by * nci;
+    uint32_t z, rem, by, bx;
+    if (!pass_decode(pp, level, blockIdx.x, n_images, remap, &z, &rem, &by, &bx))
+        return;
     const PyrImage &im = imgs[z];
     const int nb = pp.nb[level], nm = pp.nm[level];
     const bool has_next = level + 1 < n_levels;
