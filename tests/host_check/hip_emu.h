@@ -324,6 +324,12 @@ static inline int atomicAdd(int *p, int v)
     *p = o + v;
     return o;
 }
+static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v)
+{
+    const unsigned long long o = *p;
+    *p = o | v;
+    return o;
+}
 static inline int atomicMax(int *p, int v)
 {
     int o = *p;

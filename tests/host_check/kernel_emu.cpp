@@ -463,6 +463,52 @@ long long ke_fast_compass_exhaustive(long long *n_corners, long long *n_candidat
     return bad;
 }
 
+// fast_compass_pair (two positions per packed instruction, what the tile kernel runs) against fast_compass_candidate (the
+// scalar statement the exhaustive ring test above is about): every (centre, threshold) with the four compass pixels swept over
+// the values around centre +- threshold and the ends of the byte range -- 9^4 combinations per (centre, threshold), the two
+// lanes of the pair carrying different centres.  Returns the number of disagreements.
+long long ke_fast_compass_pair_check()
+{
+    using namespace vo;
+    long long bad = 0;
+    uint8_t patch[2][7 * 7];
+    const int stride = 7;
+    static const int thresholds[] = {0, 1, 7, 20, 100, 200, 254, 255};
+    for (int threshold : thresholds)
+        for (int v0 = 0; v0 < 256; v0 += (v0 < 24 || v0 > 230 ? 1 : 5)) {
+            const int v1 = (v0 * 7 + 13) & 255; // the other lane's centre
+            int cand[2][9];
+            for (int l = 0; l < 2; l++) {
+                const int v = l ? v1 : v0;
+                const int raw[9] = {0, 255, v, v + threshold, v + threshold + 1, v - threshold, v - threshold - 1, v + threshold - 1, v - threshold + 1};
+                for (int k = 0; k < 9; k++)
+                    cand[l][k] = raw[k] < 0 ? 0 : raw[k] > 255 ? 255 : raw[k];
+            }
+            for (int code = 0; code < 9 * 9 * 9 * 9; code++) {
+                uint32_t c[4] = {0, 0, 0, 0};
+                bool want[2];
+                for (int l = 0; l < 2; l++) {
+                    memset(patch[l], 0, sizeof(patch[l]));
+                    const int k0 = code % 9, k4 = code / 9 % 9, k8 = code / 81 % 9, k12 = (code / 729 + 3 * l) % 9;
+                    const int px[4] = {cand[l][k0], cand[l][k4], cand[l][k8], cand[l][k12]};
+                    uint8_t *p = &patch[l][3 * stride + 3];
+                    p[0] = (uint8_t)(l ? v1 : v0);
+                    p[3 * stride] = (uint8_t)px[0];
+                    p[3] = (uint8_t)px[1];
+                    p[-3 * stride] = (uint8_t)px[2];
+                    p[-3] = (uint8_t)px[3];
+                    want[l] = fast_compass_candidate(p, stride, threshold);
+                    for (int k = 0; k < 4; k++)
+                        c[k] |= (uint32_t)px[k] << (16 * l);
+                }
+                const uint32_t r = fast_compass_pair((uint32_t)v0 | (uint32_t)v1 << 16, c[0], c[1], c[2], c[3], (uint32_t)threshold | (uint32_t)threshold << 16);
+                bad += ((r & 0xffffu) != 0) != want[0];
+                bad += ((r >> 16) != 0) != want[1];
+            }
+        }
+    return bad;
+}
+
 void ke_set_lk_pair(int on) { g_lk_pair = on; }
 void ke_set_fast_big(int on) { g_fast_big = on; }
 

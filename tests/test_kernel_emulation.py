@@ -266,6 +266,14 @@ def test_exact_wave_sums_at_the_extremes(kemu):
         assert [bits(o) for o in out] == [bits(r) for r in ref], k
 
 
+def test_fast_compass_pair_equals_the_scalar_pretest(kemu):
+    """the tile kernel tests two positions per packed 16-bit instruction (fast_compass_pair: saturating subtractions, minima);
+    the exhaustive ring test below is about the scalar fast_compass_candidate -- the two agree for every centre, threshold and
+    compass pixels on both sides of centre +- threshold and at the ends of the byte range (~7 M combinations)"""
+    kemu.ke_fast_compass_pair_check.restype = C.c_longlong
+    assert kemu.ke_fast_compass_pair_check() == 0
+
+
 def test_fast_compass_pretest_is_necessary_exhaustive(kemu):
     """the pre-test fast_tile_kernel compacts on (two neighbouring compass pixels both brighter or both darker) must never
     reject a TYPE_9_16 corner: checked on all 3^16 = 43 046 721 brighter / darker / similar ring patterns with the real

@@ -30,11 +30,16 @@
 //                        eligible feature -- found with LDS atomicMin / atomicMax rounds -- then an
 //                        exclusive scan over the visited cells gives the emission offsets.
 #include "vo_kernels.h"
+#include "vo_lkmath.h"
 
 #include <limits.h>
 #include <stdlib.h>
 
 namespace vo {
+
+struct __attribute__((packed, aligned(4))) FastU32x4 {
+    uint32_t a, b, c, d;
+};
 
 // (acc << 1) | (x < 0): one v_alignbit_b32 shifts a comparison's sign bit into a ring mask (a compare + select + or
 // per bit cost 2.5 x as much issue time, profiles/r02_valu_issue_cost.txt)
@@ -91,6 +96,18 @@ __device__ __forceinline__ bool fast_compass_candidate(const uint8_t *__restrict
     uint32_t m = mb | md << 8;
     m |= m << 4;
     return ((m & (m >> 1)) & 0x0f0fu) != 0;
+}
+
+// fast_compass_candidate for TWO horizontally adjacent positions, pixels as u16 pairs (v_perm_b32 lifts): a lane of the
+// result is nonzero iff that position passes.  bright_k = sat(c_k - (v + t)) != 0 <=> c_k > v + t; dark_k = sat(sat(v - t) -
+// c_k) != 0 <=> c_k < v - t; "both" of two neighbours = min != 0.  25 packed instructions per pair against 2 x 22 scalar ones.
+__device__ __forceinline__ uint32_t fast_compass_pair(uint32_t v, uint32_t c0, uint32_t c4, uint32_t c8, uint32_t c12, uint32_t t2)
+{
+    const uint32_t hi = pk_add_u16(v, t2), lo = pk_subsat_u16(v, t2);
+    const uint32_t b0 = pk_subsat_u16(c0, hi), b4 = pk_subsat_u16(c4, hi), b8 = pk_subsat_u16(c8, hi), b12 = pk_subsat_u16(c12, hi);
+    const uint32_t d0 = pk_subsat_u16(lo, c0), d4 = pk_subsat_u16(lo, c4), d8 = pk_subsat_u16(lo, c8), d12 = pk_subsat_u16(lo, c12);
+    return pk_min_u16(b0, b4) | pk_min_u16(b4, b8) | pk_min_u16(b8, b12) | pk_min_u16(b12, b0) | pk_min_u16(d0, d4) | pk_min_u16(d4, d8) |
+           pk_min_u16(d8, d12) | pk_min_u16(d12, d0);
 }
 
 // FastFeatureDetector TYPE_9_16 corner test: >= 9 contiguous circle pixels all brighter than p + t or all darker than p - t
@@ -154,20 +171,23 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, 
 // was a thread-per-pixel score kernel -- 17 global byte loads per pixel -- writing a u16 score map that a second kernel
 // read back nine times: 0.77 + 0.49 ms per 256 KITTI frames, the map alone 239 MB):
 //   A  the tile's pixels + 4-pixel apron (80 x 24 bytes, origin (x0 - 4, y0 - 4): 4-byte aligned in the bordered
-//      level-0 image, always inside its allocation) go to LDS with dword loads;
+//      level-0 image, always inside its allocation) go to LDS, 16 bytes per thread (one round trip to memory: round 4);
 //   B0 compass test (a necessary condition on 4 of the 16 circle pixels) of the 66 x 18 positions of the tile and its
-//      1-pixel halo, reading the pixels from LDS (positions inside FAST's 3-pixel image margin or outside the image are no
-//      corners); the positions that pass are appended to a list in LDS (one LDS atomic per wavefront and round, ballot
-//      ranks);
+//      1-pixel halo (positions inside FAST's 3-pixel image margin or outside the image are no corners), FOUR positions
+//      per lane from aligned LDS dwords, two per packed 16-bit instruction (round 4: fast_compass_pair); the positions
+//      that pass are appended to a list in LDS (one LDS atomic per wavefront and round, ballot ranks);
 //   B1 the full corner test of the listed candidates (8.7 % of the positions on the benchmark's frames), corners to a
 //      second list;
 //   B2 cornerScore<16> of the listed positions only, on densely packed lanes.  The score is ~4 x the work of the corner
 //      test and only a few per cent of the positions are corners, but in the one-pass form nearly every wavefront held
 //      at least one corner and so executed it for all 64 lanes (1.02 ms per 256 KITTI frames, round-2 trace);
-//   C  keep predicate of the 64 x 16 tile positions (corner, score strictly above its 8 neighbours'), one 64-bit
-//      ballot per row segment stored exactly where fast_nms_write_kernel expects it, row counts by atomicAdd (the
-//      row-scan pass turns them into offsets and zeroes them again).
+//   C  keep predicate (score strictly above its 8 neighbours') of the LISTED corners inside the tile (round 4; over all
+//      tile positions before); a kept corner sets its bit in its row segment's 64-bit mask in LDS; the masks are stored
+//      exactly where fast_nms_write_kernel expects them, row counts by atomicAdd (the row-scan pass turns them into offsets
+//      and zeroes them again).
 // Results are identical to the two-kernel form by construction (same predicate, same neighbour scores).
+// Round 4 (PMC per dispatch of 256 KITTI frames, gpurun_out/r4_34 ... r4_37): 206 M -> 152 M vector, 121 M -> 52 M scalar,
+// 32 M -> 14 M LDS instructions; 398 -> 290 us.
 // Tile size: a template parameter, chosen by launch_fast_corners (64 x 16 for fewer than 8 frames, 64 x 32 above; 128 x 32
 // was measured and is slower).  The list phases B1 / B2 keep one or two wavefronts of the workgroup busy for ~100 / ~500
 // instructions whatever the tile size (a 64 x 16 tile holds ~100 candidates and ~40 corners on the benchmark's frames).
@@ -182,11 +202,12 @@ __device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs
     constexpr int PW = W + 16, PH = H + 8;     // pixel tile in LDS (bytes x rows)
     constexpr int SW = W + 2, SH = H + 2;      // score tile incl. the 1-pixel halo
     __shared__ __attribute__((aligned(16))) uint8_t s_px[PH * PW];
-    __shared__ uint16_t s_sc[SH * SW];
+    __shared__ __attribute__((aligned(4))) uint16_t s_sc[SH * SW];
     __shared__ uint16_t s_cand[SH * SW]; // positions (index into s_sc) that passed the compass test
     __shared__ uint16_t s_list[SH * SW]; // ... and the corner test
+    __shared__ unsigned long long s_rowmask[H * SEGS]; // kept corners of each 64-pixel row segment of the tile
     __shared__ int s_ncand, s_ncorner;
-    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     if (detect && !detect[frame])
         return;
     const PyrImage &im = imgs[quads[frame].l0];
@@ -194,33 +215,78 @@ __device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs
     const int x0 = blockIdx.x * W, y0 = blockIdx.y * H;
     const VO_GLOBAL uint8_t *__restrict__ base = (const VO_GLOBAL uint8_t *)im.lvl[0] + (x0 - 4);
     const int last_row = h + VO_BY - 1; // rows past the bordered allocation are never used: read the last one instead
-    for (int i = tid; i < PH * (PW / 4); i += 256) {
-        const int row = i / (PW / 4), c = i - row * (PW / 4);
+    // (16 bytes per thread and trip: the tile's rows are 80 or 144 bytes; the global address is only 4-byte aligned.  With a dword
+    // per thread and trip every thread made 4 dependent round trips to memory -- the compiler waits for a load before the LDS
+    // write that follows it.)
+    static_assert(PW % 16 == 0, "16-byte tile loads");
+    for (int i = tid; i < PH * (PW / 16); i += 256) {
+        const int row = i / (PW / 16), c = i - row * (PW / 16);
         const int gy = y0 - 4 + row < last_row ? y0 - 4 + row : last_row;
-        *reinterpret_cast<uint32_t *>(&s_px[row * PW + 4 * c]) =
-            *reinterpret_cast<const VO_GLOBAL uint32_t *>(base + ((ptrdiff_t)gy * stride + 4 * c));
+        *reinterpret_cast<FastU32x4 *>(&s_px[row * PW + 16 * c]) =
+            *reinterpret_cast<const VO_GLOBAL FastU32x4 *>(base + ((ptrdiff_t)gy * stride + 16 * c));
     }
     if (tid == 0)
         s_ncand = s_ncorner = 0;
+    for (int q = tid; q < H * SEGS; q += 256)
+        s_rowmask[q] = 0;
     __syncthreads();
-    // B0: compass test of every position, candidates to a list (ballot ranks, one LDS atomic per wavefront and round)
-    for (int i0 = 0; i0 < SW * SH; i0 += 256) { // wave-uniform trip count: the ballot needs all lanes
-        const int i = i0 + tid;
-        bool cand = false;
-        if (i < SW * SH) {
-            const int sy = i / SW, sx = i - sy * SW;
-            const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3)
-                cand = fast_compass_candidate(&s_px[(sy + 3) * PW + sx + 3], PW, threshold);
-            s_sc[i] = 0;
+    // B0: compass test of every position, FOUR positions per lane: the lane owns one aligned dword of centre pixels of an LDS
+    // row (columns 4 m .. 4 m + 3 of the pixel tile = score-tile columns 4 m - 3 .. 4 m), reads the dwords left and right of it
+    // and the ones 3 rows above / below, and tests two positions per packed instruction.  The positions that pass are appended to
+    // the candidate list lane by lane (the order of the list does not matter: the results reach the
+    // output through the score tile and the row masks).  (Round 3: one position per lane and round, 5 LDS byte reads + ~45
+    // instructions each, ballot-ranked appends -- half of the kernel's instructions.)
+    static_assert((SH * SW) % 2 == 0, "the score tile is cleared by dwords");
+    for (int i = tid; i < SH * SW / 2; i += 256)
+        reinterpret_cast<uint32_t *>(s_sc)[i] = 0;
+    {
+        constexpr int GW = (SW + 3 + 3) / 4; // dword groups of a score-tile row: LDS columns 3 .. SW + 2
+        const uint32_t t2 = (uint32_t)threshold | (uint32_t)threshold << 16;
+        const uint32_t *__restrict__ px4 = reinterpret_cast<const uint32_t *>(s_px);
+        for (int q0 = 0; q0 < SH * GW; q0 += 256) { // wave-uniform trip count: the ballots need all lanes
+            const int q = q0 + tid;
+            const int sy = q / GW, m = q - sy * GW;
+            const int gy = y0 - 1 + sy;
+            // position j sits at score-tile column sx = 4 m - 3 + j, image column gx = x0 - 1 + sx: inside the score tile and
+            // inside FAST's 3-pixel margin for jlo <= j < jhi
+            const int sx0 = 4 * m - 3, gx0 = x0 - 1 + sx0;
+            const int jlo = max(max(-sx0, 3 - gx0), 0), jhi = min(min(SW - sx0, w - 3 - gx0), 4);
+            uint32_t pass = 0;
+            if (q < SH * GW && gy >= 3 && gy < h - 3 && jhi > jlo) {
+                const uint32_t *__restrict__ row = px4 + (sy + 3) * (PW / 4) + m;
+                const uint32_t dl = row[m > 0 ? -1 : 0], dm = row[0], dr = row[1];
+                const uint32_t up = row[-3 * (PW / 4)], dn = row[3 * (PW / 4)];
+                // bytes b0 .. b11 of {dl, dm, dr}: position j = 0 .. 3 has its centre at b[4 + j], left at b[1 + j], right at b[7 + j]
+                const uint32_t ra = fast_compass_pair(perm_b32(0, dm, 0x0c010c00u), perm_b32(0, dn, 0x0c010c00u), perm_b32(dr, dm, 0x0c040c03u),
+                                                      perm_b32(0, up, 0x0c010c00u), perm_b32(0, dl, 0x0c020c01u), t2);
+                const uint32_t rb = fast_compass_pair(perm_b32(0, dm, 0x0c030c02u), perm_b32(0, dn, 0x0c030c02u), perm_b32(0, dr, 0x0c020c01u),
+                                                      perm_b32(0, up, 0x0c030c02u), perm_b32(dm, dl, 0x0c040c03u), t2);
+                // lanes nonzero -> 1, then bits 0, 16 (ra) and 2, 18 (rb) -> bits 0 .. 3
+                pass = pk_min_u16(ra, 0x00010001u) | pk_min_u16(rb, 0x00010001u) << 2;
+                pass = (pass | pass >> 15) & ((1u << jhi) - 1u) & ~((1u << jlo) - 1u);
+            }
+            // append (lane-major): one LDS atomic per wavefront and round, ranks from four ballots.  (A per-lane atomicAdd on
+            // the counter is rewritten by the compiler into a scalar loop over the active lanes -- 9 scalar instructions per
+            // lane with a candidate.)
+            unsigned long long bm[4];
+            uint32_t rank = 0, total = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bm[j] = VO_BALLOT((pass >> j & 1u) != 0);
+                rank = VO_MBCNT(bm[j], rank, lane);
+                total += (uint32_t)VO_POPCLL(bm[j]);
+            }
+            if (total == 0)
+                continue;
+            int base_k = 0;
+            if (lane == 0)
+                base_k = atomicAdd(&s_ncand, (int)total);
+            int k = uni(base_k) + (int)rank;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (pass >> j & 1)
+                    s_cand[k++] = (uint16_t)(sy * SW + sx0 + j);
         }
-        const unsigned long long m = VO_BALLOT(cand);
-        int base_k = 0;
-        if (lane == 0 && m)
-            base_k = atomicAdd(&s_ncand, (int)VO_POPCLL(m));
-        base_k = uni(base_k);
-        if (cand)
-            s_cand[base_k + (int)VO_POPCLL(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
     // B1: the full corner test on the candidates only, corners to a second list
@@ -251,27 +317,34 @@ __device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs
         s_sc[i] = (uint16_t)(0x100 | fast_corner_score(&s_px[(sy + 3) * PW + sx + 3], PW, threshold));
     }
     __syncthreads();
-    // C: a wavefront = one 64-pixel row segment of the tile
-    for (int q = wv; q < H * SEGS; q += 4) {
+    // C: non-maximum suppression ON THE CORNER LIST -- a corner inside the tile that is kept sets its bit in the 64-bit mask of
+    // its row segment (LDS); then one thread per row segment stores the mask where fast_nms_write_kernel expects it and adds
+    // its population to the row count.  (Round 3 evaluated the keep predicate -- 9 LDS reads, 8 compares -- at all W x H tile
+    // positions, a wavefront per row segment: a quarter of the kernel's instructions for the ~2 % of positions that are
+    // corners.)
+    for (int k = tid; k < ncorner; k += 256) {
+        const int i = s_list[k];
+        const int sy = i / SW, sx = i - sy * SW;
+        if (sx < 1 || sx > W || sy < 1 || sy > H) // a halo corner: scored for its neighbours' sake only
+            continue;
+        const uint16_t *__restrict__ r = &s_sc[i];
+        const int sc = r[0] & 0xff;
+        const bool keep = !nonmax || (sc > (r[1] & 0xff) && sc > (r[-1] & 0xff) && sc > (r[-SW - 1] & 0xff) &&
+                                      sc > (r[-SW] & 0xff) && sc > (r[-SW + 1] & 0xff) && sc > (r[SW - 1] & 0xff) &&
+                                      sc > (r[SW] & 0xff) && sc > (r[SW + 1] & 0xff));
+        if (keep)
+            atomicOr(&s_rowmask[(sy - 1) * SEGS + ((sx - 1) >> 6)], 1ull << ((sx - 1) & 63));
+    }
+    __syncthreads();
+    for (int q = tid; q < H * SEGS; q += 256) {
         const int ly = q / SEGS, sg = q - ly * SEGS;
         const int gy = y0 + ly, seg = (int)blockIdx.x * SEGS + sg;
         if (gy >= h || seg >= segs)
             continue;
-        const uint16_t *__restrict__ r = &s_sc[(ly + 1) * SW + sg * 64 + lane + 1];
-        const int c = r[0];
-        bool keep = false;
-        if (c & 0x100) {
-            const int sc = c & 0xff;
-            keep = !nonmax || (sc > (r[1] & 0xff) && sc > (r[-1] & 0xff) && sc > (r[-SW - 1] & 0xff) &&
-                               sc > (r[-SW] & 0xff) && sc > (r[-SW + 1] & 0xff) && sc > (r[SW - 1] & 0xff) &&
-                               sc > (r[SW] & 0xff) && sc > (r[SW + 1] & 0xff));
-        }
-        const unsigned long long m = VO_BALLOT(keep);
-        if (lane == 0) {
-            mask[((size_t)frame * h + gy) * segs + seg] = m;
-            if (m)
-                atomicAdd(&rowcnt[(size_t)frame * h + gy], (int)VO_POPCLL(m));
-        }
+        const unsigned long long m = s_rowmask[q];
+        mask[((size_t)frame * h + gy) * segs + seg] = m;
+        if (m)
+            atomicAdd(&rowcnt[(size_t)frame * h + gy], (int)VO_POPCLL(m));
     }
 }
 

@@ -26,6 +26,7 @@
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define VO_BALLOT(p) emu_ballot(p)
 #define VO_POPCLL(m) __builtin_popcountll(m)
+#define VO_MBCNT(m, acc, lane) ((acc) + (uint32_t)__builtin_popcountll((m) & ((1ull << (lane)) - 1ull)))
 #define VO_PERMLANE32_SWAP(a, b) emu_permlane_swap((a), (b), 32)
 #define VO_PERMLANE16_SWAP(a, b) emu_permlane_swap((a), (b), 16)
 #else
@@ -35,6 +36,8 @@
 #define VO_UPDATE_DPP(old, src, ctrl, rm, bm, bc) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define VO_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 #define VO_POPCLL(m) __popcll(m)
+// acc + the number of set bits of the 64-bit mask below this lane: v_mbcnt_lo_u32_b32 + v_mbcnt_hi_u32_b32
+#define VO_MBCNT(m, acc, lane) __builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), (acc)))
 // gfx950 v_permlane32_swap_b32 a, b: lanes 32-63 of a <-> lanes 0-31 of b;
 //        v_permlane16_swap_b32 a, b: odd 16-lane rows of a <-> even rows of b  (both operands are rewritten)
 #define VO_PERMLANE32_SWAP(a, b)                                                                      \

@@ -129,6 +129,29 @@ VO_HD uint32_t pk_add_u16(uint32_t a, uint32_t b)
 #endif
 }
 
+// v_pk_sub_u16 clamp (saturating at 0) and v_pk_min_u16
+VO_HD uint32_t pk_subsat_u16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
+    return (al > bl ? al - bl : 0) | (ah > bh ? ah - bh : 0) << 16;
+#endif
+}
+
+VO_HD uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+#else
+    const uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
+    return (al < bl ? al : bl) | (ah < bh ? ah : bh) << 16;
+#endif
+}
+
 VO_HD uint32_t pk_mad_u16(uint32_t a, uint32_t k /* both lanes */, uint32_t c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
