@@ -191,6 +191,7 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, 
 // Tile size: a template parameter, chosen by launch_fast_corners (64 x 16 for fewer than 8 frames, 64 x 32 above; 128 x 32
 // was measured and is slower).  The list phases B1 / B2 keep one or two wavefronts of the workgroup busy for ~100 / ~500
 // instructions whatever the tile size (a 64 x 16 tile holds ~100 candidates and ~40 corners on the benchmark's frames).
+constexpr int BK_PF = 8; // list entries a thread of bucket_kernel holds in registers at a time
 constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
 
 template <int SEGS, int H>
@@ -379,8 +380,8 @@ __global__ __launch_bounds__(256) void fast_tile_big_kernel(const PyrImage *__re
 #endif
 
 // Corner list from the stored ballots: a wavefront per image row (4 rows per workgroup), a lane per 64-pixel segment.  The
-// lanes fetch the row's ballots with one coalesced load, the per-segment counts go through LDS for the lane's exclusive
-// prefix, then every lane walks the set bits of its own ballot: (x, y) at rows_before + rank -- row-major order =
+// lanes fetch the row's ballots with one coalesced load, the lane's exclusive prefix of the per-segment counts comes from
+// ballots of the counts' bits, then every lane walks the set bits of its own ballot: (x, y) at rows_before + rank -- row-major order =
 // cv::FAST's keypoint order.  (The first version spent most of its 0.18 ms per 256 frames in one thread's chain of 20
 // dependent global loads per row.)
 __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long long *__restrict__ mask, int segs,
@@ -389,21 +390,28 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
                                                               const int *__restrict__ n_tracked, int cap,
                                                               float2 *__restrict__ feat /* [B][cap] */)
 {
-    __shared__ int s_cnt[4][FAST_MAX_SEGS];
     const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int y = blockIdx.x * 4 + wv;
     if (detect && !detect[frame])
         return;
+    if (y >= h)
+        return;
     unsigned long long m = 0;
-    if (y < h && lane < segs)
+    if (lane < segs)
         m = mask[((size_t)frame * h + y) * segs + lane];
-    s_cnt[wv][lane] = (int)VO_POPCLL(m);
-    __syncthreads();
+    // corners of the segments left of this lane's: the exclusive prefix of the per-lane counts (0 .. 64), bit slice by bit
+    // slice -- a ballot of bit b of every lane's count, v_mbcnt of it, shifted.  (Round 3 put the counts in LDS and every lane
+    // summed the entries before its own in a loop of dependent LDS reads behind a workgroup barrier.)
+    const uint32_t c = (uint32_t)VO_POPCLL(m);
+    if (VO_BALLOT(c != 0) == 0ull)
+        return;
+    uint32_t before = 0;
+#pragma unroll
+    for (int bit = 0; bit < 7; bit++)
+        before += VO_MBCNT(VO_BALLOT((c >> bit & 1u) != 0), 0u, lane) << bit;
     if (m == 0ull)
         return;
-    int o = (n_tracked ? n_tracked[frame] : 0) + rowoff[(size_t)frame * h + y];
-    for (int j = 0; j < lane; j++)
-        o += s_cnt[wv][j];
+    int o = (n_tracked ? n_tracked[frame] : 0) + rowoff[(size_t)frame * h + y] + (int)before;
     float2 *__restrict__ out = feat + (size_t)frame * cap;
     do {
         const int b = __builtin_ctzll(m);
@@ -526,14 +534,35 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         const int idx = hidx * bw + widx;
         return (idx < 0 || idx >= nb || age(i) >= 10) ? -1 : idx;
     };
-    for (int i = tid; i < n_in; i += 256) {
-        const int b = cell(i);
-        if (i < BK_CELL_CACHE)
-            s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
-        if (b >= 0) {
-            atomicAdd(&s_cnt[b], 1);
-            atomicMax(&s_last[b], i);
-            atomicMin(&s_first[0][b], i);
+    // BK_PF list entries per thread at a time: their points and ages are requested before the first one is used (the walk was a
+    // chain of dependent global loads -- one memory round trip per 256 features, ~14 per frame -- in a kernel that has the chip
+    // to itself: one workgroup per frame)
+    for (int i0 = tid; i0 < n_in; i0 += 256 * BK_PF) {
+        float2 pt[BK_PF];
+        int ag[BK_PF];
+#pragma unroll
+        for (int k = 0; k < BK_PF; k++) {
+            const int i = i0 + 256 * k;
+            if (i < n_in) {
+                pt[k] = point(i);
+                ag[k] = age(i);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BK_PF; k++) {
+            const int i = i0 + 256 * k;
+            if (i < n_in) {
+                const int hidx = (int)(pt[k].y / (float)bucket_size), widx = (int)(pt[k].x / (float)bucket_size);
+                const int idx = hidx * bw + widx;
+                const int b = (idx < 0 || idx >= nb || ag[k] >= 10) ? -1 : idx;
+                if (i < BK_CELL_CACHE)
+                    s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
+                if (b >= 0) {
+                    atomicAdd(&s_cnt[b], 1);
+                    atomicMax(&s_last[b], i);
+                    atomicMin(&s_first[0][b], i);
+                }
+            }
         }
     }
     __syncthreads();
