@@ -492,7 +492,8 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                          "valu_issue_imported": measured_issue(args.workload, B) if profiled_config else None,
                          "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
                          "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1),
-                         "other_stages": pyramid_roofline(ctx, w, h, n_images, stage_ms)},
+                         "other_stages": pyramid_roofline(ctx, w, h, n_images, stage_ms,
+                                                          args.workload if profiled_config else None)},
         }
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(lefts, rights, pts, world, min(args.cpu_frames, S), args.stages)
@@ -676,7 +677,7 @@ def latency_leg(ctx, n_calls=100, n_steps=400):
     return out
 
 
-def pyramid_roofline(ctx, w, h, n_images, stage_ms):
+def pyramid_roofline(ctx, w, h, n_images, stage_ms, profiled_workload=None):
     """the pyramid stage against the HBM roof, next to the LK entry: its ALGORITHMIC bytes (every level read
     once, every level >= 1 written once) and the bytes the stage moves BY DESIGN -- it also stores a 4-byte Scharr pixel
     (2 x int16) per pyramid pixel, which 8d's model does not count"""
@@ -698,7 +699,9 @@ def pyramid_roofline(ctx, w, h, n_images, stage_ms):
                         "achieved_designed": moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": algo / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms > 0 else 0.0,
-                        "frac_designed": moved / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms > 0 else 0.0}}
+                        "frac_designed": moved / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if ms > 0 else 0.0,
+                        # HBM bytes of the stage from the PMC passes (imported, like roofline.traffic): against designed_bytes
+                        "traffic": measured_pyramid_traffic(profiled_workload, n_images) if profiled_workload else None}}
 
 
 def spawn_ranks(args, argv):
@@ -749,6 +752,20 @@ def valu_issue_frac(workload, frames, points_per_launch, launch_ms):
         return None
     issue_s = per_feature * points_per_launch * cyc / (1024.0 * clock_hz)
     return issue_s / (launch_ms * 1e-3)
+
+
+def measured_pyramid_traffic(workload, n_images):
+    """HBM bytes per pyramid stage from the same committed PMC passes (profiles/lk_traffic.json, `pyramid_stage`); None when the
+    passes were not taken at this configuration"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "lk_traffic.json")) as f:
+            rec = json.load(f)
+        ps = rec.get("pyramid_stage") or {}
+        if rec.get("workload") == workload and ps.get("images_per_step") == n_images:
+            return ps.get("hbm_bytes_per_step")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def measured_traffic(workload, frames):

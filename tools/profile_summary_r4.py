@@ -81,6 +81,11 @@ def main(src):
                        salu_instructions_per_feature=mean(lk["SQ_INSTS_SALU"]) / waves, lds_instructions_per_feature=mean(lk["SQ_INSTS_LDS"]) / waves,
                        shader_cycles_per_launch=cycles, simd_cycles_per_valu_instruction=cycles * 1024.0 / valu)
             old["measured_over_bound"] = old["simd_cycles_per_valu_instruction"] / old["issue_cost_bound_cycles_per_valu_instruction"]
+            old["source"] = ("r04 (gpurun_out/%s): rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES "
+                             "SQ_BUSY_CYCLES (its own run of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg "
+                             "--no-configs`), means over the lk_circular_kernel dispatches; the bound = sum over the hot loop's opcodes of count x measured "
+                             "issue cost (tools/isa_histogram.py with profiles/r02_valu_issue_cost.txt: 80 VALU / 324 cycles per iteration), "
+                             "profiles/r02_lk_issue_bound.md" % tag)
             json.dump(old, open(os.path.join(ROOT, "profiles", "lk_issue.json"), "w"), indent=1)
         if lk and lk.get("FETCH_SIZE") and lk.get("WRITE_SIZE"):
             old = json.load(open(os.path.join(ROOT, "profiles", "lk_traffic.json")))
@@ -88,6 +93,15 @@ def main(src):
             old["write_bytes_per_launch"] = mean(lk["WRITE_SIZE"]) * 1024.0
             old["hbm_bytes_per_launch"] = 2.0 * old["fetch_bytes_per_launch"] + old["write_bytes_per_launch"]
             old["hbm_bytes_per_launch_uncorrected"] = old["fetch_bytes_per_launch"] + old["write_bytes_per_launch"]
+            old["source"] = ("r04 (gpurun_out/%s): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of `python bench.py --steps 3 --warmup 1 "
+                             "--no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg --no-configs`; KB -> bytes; FETCH_SIZE doubled (gfx950 correction, "
+                             "calibrated in profiles/r01_fetch_calibration.txt); WRITE_SIZE as reported" % tag)
+            pp_ = pmc.get("vo::pyr_pass_kernel")
+            if pp_ and pp_.get("FETCH_SIZE") and pp_.get("WRITE_SIZE"):
+                # four dispatches per step (levels 0 .. 3): per-step totals = 4 x the mean per dispatch
+                pf, pw = 4 * mean(pp_["FETCH_SIZE"]) * 1024.0, 4 * mean(pp_["WRITE_SIZE"]) * 1024.0
+                old["pyramid_stage"] = {"images_per_step": 514, "fetch_bytes_per_step": 2.0 * pf, "write_bytes_per_step": pw,
+                                        "hbm_bytes_per_step": 2.0 * pf + pw, "kernel": "pyr_pass_kernel (4 launches per step)"}
             json.dump(old, open(os.path.join(ROOT, "profiles", "lk_traffic.json"), "w"), indent=1)
     # the fused pyramid pass level by level (consecutive launches of a step = levels 0 .. L-1) and its HBM traffic
     tr = glob.glob(os.path.join(src, "prof_overlap", "*", "*_kernel_trace.csv")) + glob.glob(os.path.join(src, "prof_overlap", "*_kernel_trace.csv"))
