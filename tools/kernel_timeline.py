@@ -3,6 +3,7 @@ where one synchronous call's time goes, kernel by kernel and launch gap by launc
 
     rocprofv3 --kernel-trace --output-format csv -d out -- python tools/latency_mode.py track 6 30
     python tools/kernel_timeline.py out 45
+    python tools/kernel_timeline.py out 60 lk_circular:3      # 60 kernels starting at the 3rd-last lk_circular_kernel
 """
 import csv
 import glob
@@ -20,7 +21,13 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-40:], r.get("Queue_Id", "")))
     rows.sort()
-    rows = rows[-n:]
+    if len(sys.argv) > 3:  # start at the k-th last kernel whose name contains the substring
+        sub, k = sys.argv[3].split(":")
+        hits = [i for i, r in enumerate(rows) if sub in r[2]]
+        start = hits[-int(k)] if len(hits) >= int(k) else 0
+        rows = rows[start:start + n]
+    else:
+        rows = rows[-n:]
     t0 = rows[0][0]
     prev_end = rows[0][0]
     print("%10s %9s %9s  %-6s %s" % ("start_us", "dur_us", "gap_us", "queue", "kernel"))
