@@ -633,12 +633,13 @@ def test_emulated_frame_loop_matches_the_oracle_chain(kemu, orc, small_world):
     assert np.abs(rows[n - 2, :12] - o_pose[:3].ravel()).max() <= 1e-6
 
 
-@pytest.mark.parametrize("shape", [(1241, 376, 3), (640, 480, 3), (1920, 1080, 4), (1280, 720, 3), (4096, 3000, 4), (33, 32, 3), (45, 4000, 3)])
+@pytest.mark.parametrize("shape", [(1241, 376, 3), (640, 480, 3), (1920, 1080, 4), (1280, 720, 3), (4096, 3000, 4), (33, 32, 3), (45, 4000, 3),
+                                   (16384, 16384, 4), (256, 60000, 2)])
 def test_pyramid_pass_workgroup_decode(kemu, shape):
     """pyr_pass_kernel turns its one-dimensional workgroup id into (image, row, wavefront) with multiply-high divisions, in
-    XCD-aware order (image z on XCD z % 8) or in dispatch order: every id of the largest launch the host allows
-    (pass_images_per_launch: further images go to a second launch), and of small launches whose image count is not a
-    multiple of 8, against plain division; the decode of a full launch is a bijection"""
+    XCD-aware order (image z on XCD z % 8) or in dispatch order: ids of the largest launch the host allows
+    (pass_images_per_launch: further images go to a second launch; up to 2^31 workgroups for the absurd shapes), and of small
+    launches whose image count is not a multiple of 8, against plain division; the decode of a full launch is a bijection"""
     w, h, ml = shape
     for n in (0, 1, 7, 8, 9, 514):
         assert kemu.ke_pass_decode_check(w, h, ml, n) == 0, (shape, n)

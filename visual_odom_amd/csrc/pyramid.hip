@@ -437,8 +437,8 @@ struct PassPlan {
     int nci[VO_MAX_LEVELS];    // grid x: wavefronts that cover the main groups of one row block
     int n_tail[VO_MAX_LEVELS]; // edge + border work items (grid rows nb ..)
     int gy[VO_MAX_LEVELS];     // grid y = nb + the rows of nci wavefronts that hold the tail items
-    uint32_t m_img[VO_MAX_LEVELS], m_row[VO_MAX_LEVELS]; // floor(2^32 / (nci gy)) + 1, floor(2^32 / nci) + 1: id -> (image, y, x) by
-                                                         // multiply-high (exact while id x divisor < 2^32: pass_images_per_launch)
+    uint64_t m_img[VO_MAX_LEVELS], m_row[VO_MAX_LEVELS]; // floor(2^64 / (nci gy)) + 1, floor(2^64 / nci) + 1: id -> (image, y, x) by
+                                                         // multiply-high, exact for every 32-bit id (pass_div)
 };
 struct __attribute__((packed, aligned(2))) LkU2x { // an 8-byte row window at an even column
     uint32_t lo, hi;
@@ -460,15 +460,27 @@ inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int 
         pp.nci[l] = pp.nm[l] > 0 ? (pp.nm[l] + 63) / 64 : 1;
         pp.n_tail[l] = pp.nb[l] * (pp.ng[l] - pp.nm[l]) + border_items(lh[l], lw[l], lstride[l]);
         pp.gy[l] = pp.nb[l] + (pp.n_tail[l] + 64 * pp.nci[l] - 1) / (64 * pp.nci[l]);
-        pp.m_img[l] = (uint32_t)((1ull << 32) / (uint32_t)(pp.nci[l] * pp.gy[l])) + 1;
-        pp.m_row[l] = (uint32_t)((1ull << 32) / (uint32_t)pp.nci[l]) + 1; // (nci = 1: 2^32 + 1 wraps to 1 -- the dispatch does not divide by 1)
+        pp.m_img[l] = ~0ull / (uint64_t)(pp.nci[l] * pp.gy[l]) + 1; // (floor((2^64 - 1) / d) = floor(2^64 / d) unless d is a power of two,
+        pp.m_row[l] = ~0ull / (uint64_t)pp.nci[l] + 1;               //  where it is one less and the + 1 lands exactly on 2^64 / d: also exact;
+                                                                     //  d = 1 wraps to 0 -- the dispatch does not divide by 1)
     }
     return pp;
 }
 
-// workgroup id -> image z, workgroup `rem` of the image = row `by`, wavefront `bx`; false = a padding workgroup.  Divisions by
-// multiply-high with the reciprocals of the plan (exact for the launch sizes pass_images_per_launch allows: checked id by id in
-// tests/test_kernel_emulation.py)
+// floor(n / d) for a 32-bit n through m = floor(2^64 / d) + 1 (or exactly 2^64 / d): floor(n m / 2^64).  Exact for every n < 2^32:
+// n m / 2^64 = n / d + n e / 2^64 with 0 <= e <= 1, and n e / 2^64 < 2^-32 <= 1 / d cannot reach the next integer.  Scalar code in
+// the kernel (two s_mul_i32 + two s_mul_hi_u32); an integer division is ~30 instructions.
+#if defined(__HIPCC__) && !defined(VO_HOST_EMUL)
+__host__ __device__
+#endif
+inline uint32_t pass_div(uint32_t n, uint64_t m)
+{
+    const uint64_t lo = (uint64_t)n * (uint32_t)m, hi = (uint64_t)n * (uint32_t)(m >> 32);
+    return (uint32_t)((hi + (lo >> 32)) >> 32);
+}
+
+// workgroup id -> image z, workgroup `rem` of the image = row `by`, wavefront `bx`; false = a padding workgroup (checked id by id
+// against plain division in tests/test_kernel_emulation.py)
 #if defined(__HIPCC__) && !defined(VO_HOST_EMUL)
 __host__ __device__
 #endif
@@ -477,16 +489,16 @@ inline bool pass_decode(const PassPlan &pp, int level, uint32_t id, uint32_t n_i
 {
     const uint32_t nci = (uint32_t)pp.nci[level], wpi = nci * (uint32_t)pp.gy[level];
     if (remap) { // workgroup b runs on XCD b % 8: slot b / 8 of the images that XCD owns (z % 8 == b % 8)
-        const uint32_t slot = id >> 3, k = (uint32_t)(((uint64_t)slot * pp.m_img[level]) >> 32);
+        const uint32_t slot = id >> 3, k = pass_div(slot, pp.m_img[level]);
         *z = k * 8 + (id & 7);
         *rem = slot - k * wpi;
         if (*z >= n_images)
             return false;
     } else {
-        *z = (uint32_t)(((uint64_t)id * pp.m_img[level]) >> 32);
+        *z = pass_div(id, pp.m_img[level]);
         *rem = id - *z * wpi;
     }
-    *by = nci == 1 ? *rem : (uint32_t)(((uint64_t)*rem * pp.m_row[level]) >> 32);
+    *by = nci == 1 ? *rem : pass_div(*rem, pp.m_row[level]);
     *bx = *rem - *by * nci;
     return true;
 }
@@ -497,14 +509,13 @@ inline uint32_t pass_grid(const PassPlan &pp, int l, int n, int remap)
     return (uint32_t)pp.nci[l] * (uint32_t)pp.gy[l] * (uint32_t)(remap ? (n + 7) / 8 * 8 : n);
 }
 
-// images per launch: at most 4096 (hundreds of thousands of workgroups: nothing left to amortise), fewer where the multiply-high
-// divisions of the dispatch would stop being exact (id < 2^32 / divisor; 4096 x 3000 images: 88); a multiple of 8.  Further images
-// go to the next launch (tests/test_gpu_round4.py runs 4104 images; the decode is checked id by id in test_kernel_emulation.py)
+// images per launch: at most 4096 (hundreds of thousands of workgroups: nothing left to amortise), fewer where the workgroup
+// count would not fit 31 bits; a multiple of 8.  Further images go to the next launch (tests/test_gpu_round4.py runs 4104 images)
 constexpr int PASS_MAX_IMAGES = 4096;
 inline int pass_images_per_launch(const PassPlan &pp, int l)
 {
     const uint64_t wpi = (uint64_t)pp.nci[l] * pp.gy[l];
-    const uint64_t n = ((1ull << 32) - 1) / (wpi * wpi);
+    const uint64_t n = ((1ull << 31) - 1) / wpi;
     return (int)(n >= PASS_MAX_IMAGES + 8 ? PASS_MAX_IMAGES : n < 16 ? 8 : n / 8 * 8 - 8);
 }
 
