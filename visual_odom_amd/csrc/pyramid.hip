@@ -434,9 +434,9 @@ struct PassPlan {
     int nm[VO_MAX_LEVELS];     // of which MAIN: groups 0 .. nm - 1 find columns 4 g - 2 .. 4 g + 4 in their 8-byte window (group 0
                                // patches its two left neighbours in registers); the rest (one group at the right end) are EDGE
     int nb[VO_MAX_LEVELS];     // row blocks of PF_ROWS rows
-    int nci[VO_MAX_LEVELS];    // grid x: wavefronts that cover the main groups of one row block
-    int n_tail[VO_MAX_LEVELS]; // edge + border work items (grid rows nb ..)
-    int gy[VO_MAX_LEVELS];     // grid y = nb + the rows of nci wavefronts that hold the tail items
+    int nci[VO_MAX_LEVELS];    // wavefronts (= workgroups) that cover the main groups of one row block: a `row` of the image's workgroups
+    int n_tail[VO_MAX_LEVELS]; // edge + border work items (the first rows of an image's workgroups)
+    int gy[VO_MAX_LEVELS];     // rows of workgroups per image = the rows that hold the tail items + nb
     uint64_t m_img[VO_MAX_LEVELS], m_row[VO_MAX_LEVELS]; // floor(2^64 / (nci gy)) + 1, floor(2^64 / nci) + 1: id -> (image, y, x) by
                                                          // multiply-high, exact for every 32-bit id (pass_div)
 };
