@@ -37,7 +37,7 @@ int main(int argc, char **argv)
         cw = nw; ch = nh;
     }
     L++;
-    const size_t img_bytes = off;
+    const size_t img_bytes = off + (argc > 4 ? (size_t)atol(argv[4]) : 0); // (4th argument: padding between images, bytes -- channel-aliasing experiment)
     uint8_t *pix; uint32_t *der; PyrImage *d_imgs;
     (void)hipMalloc((void **)&pix, img_bytes * NI);
     (void)hipMalloc((void **)&der, img_bytes * NI * 4);
@@ -60,7 +60,7 @@ int main(int argc, char **argv)
 #ifndef VO_PASS_X
 #define VO_PASS_X 0
 #endif
-    printf("%d images %d x %d, %d levels, VO_PASS_X=%d, rows per item %d\n", NI, W, H, L, VO_PASS_X, PF_ROWS);
+    printf("%d images %d x %d, %d levels, VO_PASS_X=%d, rows per item %d, image pitch %zu B (x 4 for the Scharr images)\n", NI, W, H, L, VO_PASS_X, PF_ROWS, img_bytes);
     float tot[4] = {0, 0, 0, 0};
     for (int l = 0; l < L; l++) {
         const uint32_t g1 = pass_grid(pp, l, NI, 1), g0 = pass_grid(pp, l, NI, 0);
