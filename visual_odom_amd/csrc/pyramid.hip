@@ -878,12 +878,12 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
     // one launch per level.  (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel,
     // pass / fence + barrier / pass -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms
     // for level 0, gpurun_out/r4_04: a few hundred workgroups of serial phases do not fill the chip.)
-    int sm = 0, remap = 1;
+    int sm = 0, remap = n_images >= 16; // (fewer images than two per XCD: pinning images to XCDs would leave XCDs without work)
 #ifdef VO_DEV_VARIANTS
     static const int sm_env = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
     static const int xcd_env = [] { const char *e = getenv("VO_PYR_XCD"); return e ? atoi(e) : 1; }(); // 0: workgroups in dispatch order
     sm = sm_env;
-    remap = xcd_env;
+    remap = remap && xcd_env;
 #endif
     for (int l = 0; l < n_levels; l++) {
         const int per = pass_images_per_launch(pp, l);
