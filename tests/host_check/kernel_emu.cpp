@@ -634,7 +634,7 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
     else
         launch(segs, (h + 15) / 16, 1, 256, [&] { fast_tile_kernel(&im, &quad, &do_detect, threshold, nonmax, nmsmask.data(), segs, rowcnt.data()); });
     launch(1, 1, 1, 256, [&] { fast_rowscan_kernel(rowcnt.data(), rowoff.data(), h, &do_detect, &n_new); });
-    launch((h + 3) / 4, 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowoff.data(), &n_tracked, fcap, feat.data()); });
+    launch((h + 4 * fast_nms_rows_per_wave(segs) - 1) / (4 * fast_nms_rows_per_wave(segs)), 1, 1, 256, [&] { fast_nms_write_kernel(nmsmask.data(), segs, h, &do_detect, rowoff.data(), &n_tracked, fcap, feat.data()); });
     if (bucket_size <= 0) {
         const int k = n_new < out_cap ? n_new : out_cap;
         memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);

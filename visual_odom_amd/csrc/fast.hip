@@ -22,7 +22,7 @@
 //                        cornerScore<16> for corners; NMS predicate on the LDS score tile, one 64-bit ballot per
 //                        64-pixel row segment, row counts by atomicAdd
 //   fast_rowscan_kernel  workgroup per frame: exclusive scan of the row counts
-//   fast_nms_write_kernel wavefront per image row, lane per 64-pixel segment: (x, y) at rows_before + rank from the stored
+//   fast_nms_write_kernel wavefront per 64 / segs image rows, lane per 64-pixel segment: (x, y) at rows_before + rank from the stored
 //                        ballots (row-major)
 //   bucket_kernel        workgroup per frame.  The sequential bucket fill is restated as order
 //                        statistics: a bucket ends up holding (slot 0) its LAST eligible feature if
@@ -379,11 +379,14 @@ __global__ __launch_bounds__(256) void fast_tile_big_kernel(const PyrImage *__re
 }
 #endif
 
-// Corner list from the stored ballots: a wavefront per image row (4 rows per workgroup), a lane per 64-pixel segment.  The
+// Corner list from the stored ballots: a wavefront per 64 / segs image rows, a lane per 64-pixel segment.  The
 // lanes fetch the row's ballots with one coalesced load, the lane's exclusive prefix of the per-segment counts comes from
 // ballots of the counts' bits, then every lane walks the set bits of its own ballot: (x, y) at rows_before + rank -- row-major order =
 // cv::FAST's keypoint order.  (The first version spent most of its 0.18 ms per 256 frames in one thread's chain of 20
 // dependent global loads per row.)
+// rows of an image one wavefront of fast_nms_write_kernel covers: as many as fit its 64 lanes at `segs` lanes per row
+inline int fast_nms_rows_per_wave(int segs) { return segs >= 64 ? 1 : 64 / segs; }
+
 __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long long *__restrict__ mask, int segs,
                                                               int h, const int *__restrict__ detect,
                                                               const int *__restrict__ rowoff /* [B][h] exclusive */,
@@ -391,24 +394,28 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
                                                               float2 *__restrict__ feat /* [B][cap] */)
 {
     const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int y = blockIdx.x * 4 + wv;
     if (detect && !detect[frame])
         return;
-    if (y >= h)
-        return;
+    // a wavefront = rpw consecutive image rows, `segs` lanes each (a 1241-pixel row has 20 segments: three rows per wavefront;
+    // one row per wavefront left 44 of its 64 lanes idle)
+    const int rpw = segs >= 64 ? 1 : 64 / segs;
+    const int rw = lane / segs, seg = lane - rw * segs; // (rw >= rpw: a spare lane)
+    const int y = ((int)blockIdx.x * 4 + wv) * rpw + rw;
     unsigned long long m = 0;
-    if (lane < segs)
-        m = mask[((size_t)frame * h + y) * segs + lane];
-    // corners of the segments left of this lane's: the exclusive prefix of the per-lane counts (0 .. 64), bit slice by bit
-    // slice -- a ballot of bit b of every lane's count, v_mbcnt of it, shifted.  (Round 3 put the counts in LDS and every lane
-    // summed the entries before its own in a loop of dependent LDS reads behind a workgroup barrier.)
+    if (rw < rpw && y < h)
+        m = mask[((size_t)frame * h + y) * segs + seg];
+    // corners of the row's segments left of this lane's: the exclusive prefix of the per-lane counts (0 .. 64) WITHIN the lanes
+    // of the row, bit slice by bit slice -- a ballot of bit b of every lane's count, masked to the row's lanes, v_mbcnt of it,
+    // shifted.  (Round 3 put the counts in LDS and every lane summed the entries before its own in a loop of dependent LDS
+    // reads behind a workgroup barrier.)
     const uint32_t c = (uint32_t)VO_POPCLL(m);
     if (VO_BALLOT(c != 0) == 0ull)
         return;
+    const unsigned long long row_lanes = (segs >= 64 ? ~0ull : (1ull << segs) - 1ull) << (rw * segs & 63);
     uint32_t before = 0;
 #pragma unroll
     for (int bit = 0; bit < 7; bit++)
-        before += VO_MBCNT(VO_BALLOT((c >> bit & 1u) != 0), 0u, lane) << bit;
+        before += VO_MBCNT(VO_BALLOT((c >> bit & 1u) != 0) & row_lanes, 0u, lane) << bit;
     if (m == 0ull)
         return;
     int o = (n_tracked ? n_tracked[frame] : 0) + rowoff[(size_t)frame * h + y] + (int)before;
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256) void fast_nms_write_kernel(const unsigned long
     do {
         const int b = __builtin_ctzll(m);
         if (o < cap)
-            out[o] = make_float2((float)(lane * 64 + b), (float)y);
+            out[o] = make_float2((float)(seg * 64 + b), (float)y);
         o++;
         m &= m - 1ull;
     } while (m);
@@ -643,7 +650,8 @@ void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int 
                            d_quads, d_detect, threshold, nonmax, d_nmsmask, segs, d_rowcnt);
     hipLaunchKernelGGL(fast_rowscan_kernel, dim3(n_frames), dim3(256), 0, stream, d_rowcnt, d_rowoff, h, d_detect,
                        d_nnew);
-    hipLaunchKernelGGL(fast_nms_write_kernel, dim3((h + 3) / 4, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
+    const int rows_per_wg = 4 * fast_nms_rows_per_wave(segs);
+    hipLaunchKernelGGL(fast_nms_write_kernel, dim3((h + rows_per_wg - 1) / rows_per_wg, n_frames), dim3(256), 0, stream, d_nmsmask, segs, h, d_detect,
                        d_rowoff, d_ntracked, cap, d_out);
 }
 
