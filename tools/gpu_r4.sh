@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-4 GPU session driver.  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh <tag> <part> [<part> ...]'
-# parts: tests slimab slimdev seqab bench prof pmc latency
+# parts: tests slimab slimdev seqab pyrab bench prof latency seqinline constants wideprobe pyrstore pyrrows xcdab timeline pyrpmc pyrprof
+# (PYTEST_K=<expr> narrows `tests`; pyrpmc keeps to SQ_* / GRBM_* counters -- TCP_* / TCC_* derived counters hang rocprofv3 on this pool)
 TAG=${1:-r4}
 shift
 PARTS="$*"
@@ -192,16 +193,12 @@ if has timeline; then
     rm -rf "$OUT/sq"
     tail -60 "$OUT/timeline_seq.txt"
 fi
-if has pyrpmc; then   # what the fused pass waits for: SQ / TA / TCP / TCC counters per level (bench --stages lk: no pose chain beside
+if has pyrpmc; then   # what the fused pass waits for: SQ counters per level (bench --stages lk: no pose chain beside
                       # it; developer build, VO_PYR_STORE 0 = product stores, 2 = no Scharr stores)
     for SM in ${PYR_SM:-0 2}; do
     n=0
     for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
-               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
-               "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum" \
-               "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
-               "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum" \
-               "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL TD_TC_STALL_sum"; do
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
         n=$((n + 1))
         stamp "store mode $SM pmc set $n: $SET"
         (cd /tmp && VO_PYR_STORE=$SM VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pp$n" -- python "$ROOT/bench.py" --stages lk --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pp${SM}_$n.log" 2>&1)
