@@ -64,12 +64,14 @@ int g_pyr_lds = 0; // ke_set_pyr_lds: which pyramid chain build_pyramids emulate
 void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
 {
     using namespace vo;
-    if (g_pyr_lds == 2) { // the fused passes (round 4; what launch_pyramid_fused enqueues): one launch per level
+    if (g_pyr_lds == 2 || g_pyr_lds == 3) { // the fused passes (3: workgroups in dispatch order, what launches of fewer than 16 images use)
+        const int remap = g_pyr_lds == 2;
+        // the fused passes (round 4; what launch_pyramid_fused enqueues): one launch per level
         const PassPlan pp = pass_plan(p.levels, p.lw, p.lh, p.ls);
         for (int l = 0; l < p.levels; l++)
             {
-                const uint32_t nwg = pass_grid(pp, l, (int)n_img, 1);
-                launch(nwg, 1, 1, 64, [&] { pyr_pass_kernel(d_imgs, l, p.levels, pp, (uint32_t)n_img, 1); });
+                const uint32_t nwg = pass_grid(pp, l, (int)n_img, remap);
+                launch(nwg, 1, 1, 64, [&] { pyr_pass_kernel(d_imgs, l, p.levels, pp, (uint32_t)n_img, remap); });
             }
         return;
     }

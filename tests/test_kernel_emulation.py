@@ -56,10 +56,10 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.fixture(params=[2, 0, 1], ids=["fused-pass", "column-walk", "lds-tile"])
+@pytest.fixture(params=[2, 3, 0, 1], ids=["fused-pass", "fused-pass-dispatch-order", "column-walk", "lds-tile"])
 def pyr_kernel(kemu, request):
-    """the product's pyramid chain (round 4: the fused passes, pyr_pass_kernel level by level) and the three-kernel chain it
-    replaced with either of its pyr_down kernels"""
+    """the product's pyramid chain (round 4: the fused passes, pyr_pass_kernel level by level, in XCD-aware and in dispatch
+    order of the workgroups) and the three-kernel chain it replaced with either of its pyr_down kernels"""
     kemu.ke_set_pyr_lds(request.param)
     yield request.param
     kemu.ke_set_pyr_lds(0)
@@ -226,6 +226,21 @@ def test_emulated_fast_matches_oracle(kemu, orc, small_seq, fast_variant):
     assert np.array_equal(got, orc.fast_detect(noise, 20, True))
     flat = np.full((32, 32), 77, np.uint8)
     assert len(ke_detect(kemu, flat)[0]) == 0
+
+
+@pytest.mark.parametrize("shape", [(33, 70), (40, 200), (34, 1241), (32, 4096), (45, 2000)])
+def test_emulated_fast_row_packing(kemu, orc, shape):
+    """fast_nms_write_kernel packs 64 / segs image rows into a wavefront (segs = 64-pixel segments per row) and ranks a
+    lane's corners within the lanes of its row: widths with 2, 4, 20 (three rows, four spare lanes), 32 and 64 (one row)
+    segments, heights that leave the last wavefront's rows partly outside the image; corner list in cv::FAST's row-major
+    order, bit for bit"""
+    h, w = shape
+    rng = np.random.default_rng(h * w)
+    base = rng.integers(0, 256, (h // 3 + 2, w // 3 + 2)).astype(np.float32)
+    img = np.kron(base, np.ones((3, 3), np.float32))[:h, :w].astype(np.uint8)
+    got, _ = ke_detect(kemu, img, threshold=20, nonmax=1, cap=65536)
+    ref = orc.fast_detect(img, 20, True)
+    assert len(ref) > 20 and np.array_equal(got, ref)
 
 
 def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq, fast_variant):
