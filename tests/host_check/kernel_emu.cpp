@@ -58,7 +58,7 @@ void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
                 emu::run_block(threads, x, y, z, body);
 }
 
-int g_pyr_lds = 0; // ke_set_pyr_lds: which pyramid chain build_pyramids emulates (0 / 1: three kernels with the column-walk / LDS pyr_down; 2: fused passes)
+int g_pyr_lds = 2; // (default: the product chain) ke_set_pyr_lds: which pyramid chain build_pyramids emulates (0 / 1: three kernels with the column-walk / LDS pyr_down; 2: fused passes)
 
 // the PYRAMID stage of capi.hip's run_stages with the emulated kernels
 void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)

@@ -62,7 +62,7 @@ def pyr_kernel(kemu, request):
     order of the workgroups) and the three-kernel chain it replaced with either of its pyr_down kernels"""
     kemu.ke_set_pyr_lds(request.param)
     yield request.param
-    kemu.ke_set_pyr_lds(0)
+    kemu.ke_set_pyr_lds(2)
 
 
 @pytest.mark.parametrize("shape", [(100, 200), (97, 131), (45, 53), (150, 70)])
