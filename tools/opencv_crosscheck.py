@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Close the loop on "parity unpinned": diff the CPU oracle (oracle/*.c, a restatement of OpenCV 4.5.x written without
-OpenCV at hand) against a REAL OpenCV, on machines that have one (`import cv2`).  The authoring container and the GPU
-boxes do not, so this tool is shipped unexecuted; it exits with code 2 and a message when cv2 is missing.
+OpenCV at hand) against a REAL OpenCV, on machines that have one (`import cv2`).  Neither the authoring container nor the
+GPU boxes have one by any route -- import under every interpreter, pkg-config, a filesystem search for libopencv* / cv2*.so
+/ wheels, pip against a package index (PIP_NO_INDEX=1, no DNS, connections refused): tools/opencv_probe.sh, log of the
+round-5 GPU-box run in profiles/r05_opencv_probe.txt -- so this tool is shipped unexecuted; it exits with code 2 and a
+message when cv2 is missing.
 
     python tools/opencv_crosscheck.py                 # diff every call of the hot path, print a table, exit 0 / 1
     python tools/opencv_crosscheck.py --write-golden  # also dump cv2's outputs to tests/golden/opencv_<version>.npz
