@@ -11,7 +11,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libvo_oracle.so")
+# VO_SANITIZE=1 (the sanitizer tier, tests/test_sanitize.py): the ASan + UBSan build of the same sources, `make SAN=1`; the
+# process must have been started with LD_PRELOAD=libasan.so
+_SAN = os.environ.get("VO_SANITIZE", "0") not in ("", "0")
+_MAKE = ["make", "-s", "-C", _HERE] + (["SAN=1"] if _SAN else [])
+_SO = os.path.join(_HERE, "_build", *(["san"] if _SAN else []), "libvo_oracle.so")
 _lib = None
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
@@ -27,7 +31,7 @@ def build(force=False):
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    subprocess.check_call(_MAKE)
     return _SO
 
 
@@ -376,7 +380,7 @@ def recover_pose(E, pts1, pts2, focal, pp, mask=None):
 
 
 # ---- oracle/_ref: the reference's OWN glue sources (feature.cpp, bucket.cpp) compiled where they lie ----------
-_REF_SO = os.path.join(_HERE, "_ref", "libvo_refglue.so")
+_REF_SO = os.path.join(_HERE, "_ref", *(["san"] if _SAN else []), "libvo_refglue.so")
 _ref = None
 
 
@@ -385,7 +389,7 @@ def build_ref():
     prebuilt oracle/_ref/libvo_refglue.so that travelled with the snapshot is used.  Returns the path or None."""
     if os.path.exists("/root/reference/src/feature.cpp"):
         build()
-        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(_MAKE + ["ref"])
     return _REF_SO if os.path.exists(_REF_SO) else None
 
 

@@ -213,8 +213,8 @@ int recoverPose(const Mat &E, const std::vector<Point2f> &points1, const std::ve
 
 /* the reference prints progress lines to cout / cerr: keep the test output clean */
 struct Quiet {
+    std::ostringstream sink; // (first: members are constructed in declaration order, and o / e use it -- UBSan, round 5)
     std::streambuf *o, *e;
-    std::ostringstream sink;
     Quiet() : o(std::cout.rdbuf(sink.rdbuf())), e(std::cerr.rdbuf(sink.rdbuf())) {}
     ~Quiet()
     {

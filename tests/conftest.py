@@ -17,8 +17,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The sanitizer tier (tests/test_sanitize.py starts it): with VO_SANITIZE=1 every host library the tests
+# build -- the kernel emulator (all product kernel sources), the device-math headers, the oracle, the reference glue -- is
+# compiled with ASan + UBSan into .../_build/san and the process runs under LD_PRELOAD=libasan.so.
+SANITIZE = os.environ.get("VO_SANITIZE", "0") not in ("", "0")
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if SANITIZE else []
+BUILD_DIR = os.path.join(ROOT, "tests", "_build", *(["san"] if SANITIZE else []))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "sanitize: the full ASan + UBSan tier (minutes; `pytest -m sanitize`), beside the quick one of the CPU suite")
 
 
 @pytest.fixture(scope="session")
@@ -64,12 +73,12 @@ def host_check():
     """device-side math headers compiled for the host with g++ (unit test of the kernel code)"""
     import ctypes
     src = os.path.join(ROOT, "tests", "host_check", "host_check.cpp")
-    out_dir = os.path.join(ROOT, "tests", "_build")
+    out_dir = BUILD_DIR
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhost_check.so")
     deps = [src] + [os.path.join(ROOT, "visual_odom_amd", "csrc", f) for f in ("vo_linalg.h", "vo_epnp.h", "vo_tri.h", "vo_lkmath.h", "vo_fivept.h", "vo_p3p.h", "vo_math.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + SAN_FLAGS + ["-o", so, src])
     return ctypes.CDLL(so)
 
 

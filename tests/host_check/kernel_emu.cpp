@@ -12,6 +12,7 @@
 #include "../../visual_odom_amd/csrc/essential.hip"
 #include "../../visual_odom_amd/csrc/seq.hip"
 
+#include <memory>
 #include <vector>
 
 namespace {
@@ -45,6 +46,41 @@ Plan plan(int w, int h, int max_level)
     p.total = off;
     return p;
 }
+
+// The image table of the emulated runs: every level of every image in its OWN heap block of exactly ls * (lh + 2 VO_BY)
+// bytes / dwords.  That is tighter than the product's table (capi.hip: levels one after the other at 256-byte boundaries, the
+// images one after the other, vo_create's worst-case slack behind the last): under AddressSanitizer (VO_SANITIZE=1,
+// tests/test_sanitize.py) any kernel access outside a level's bordered allocation aborts, whichever level, image or pyramid
+// depth it belongs to.  Pixels are poisoned with 0xA5 (a read of border the build did not write shows up), derivatives zero.
+struct Heap {
+    Plan p;
+    std::vector<std::unique_ptr<uint8_t[]>> pix;
+    std::vector<std::unique_ptr<uint32_t[]>> der;
+    std::vector<vo::PyrImage> tab;
+    size_t level_elems(int l) const { return (size_t)p.ls[l] * (p.lh[l] + 2 * VO_BY); }
+    uint8_t *pix_block(int i, int l) { return pix[(size_t)i * p.levels + l].get(); }
+    uint32_t *der_block(int i, int l) { return der[(size_t)i * p.levels + l].get(); }
+    Heap(const Plan &plan_, int n_img, const uint8_t *imgs, int w, int h) : p(plan_), tab(n_img)
+    {
+        for (int i = 0; i < n_img; i++) {
+            memset(&tab[i], 0, sizeof(vo::PyrImage));
+            for (int l = 0; l < p.levels; l++) {
+                const size_t n = level_elems(l), org = (size_t)VO_BY * p.ls[l] + VO_BX;
+                pix.emplace_back(new uint8_t[n]);
+                der.emplace_back(new uint32_t[n]);
+                memset(pix.back().get(), 0xA5, n);
+                memset(der.back().get(), 0, 4 * n);
+                tab[i].lvl[l] = pix.back().get() + org;
+                tab[i].der[l] = der.back().get() + org;
+                tab[i].w[l] = p.lw[l];
+                tab[i].h[l] = p.lh[l];
+                tab[i].stride[l] = p.ls[l];
+            }
+            for (int y = 0; y < h; y++)
+                memcpy(tab[i].lvl[0] + (ptrdiff_t)y * p.ls[0], imgs + ((size_t)i * h + y) * w, w);
+        }
+    }
+};
 
 int g_fast_big = 0; // ke_set_fast_big: tile form of the FAST kernel (0: 64 x 16, 1: 64 x 32, 2: 128 x 32)
 int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead
@@ -408,26 +444,13 @@ int ke_bordered_level(const uint8_t *img, int w, int h, int max_level, int level
     Plan p = plan(w, h, max_level);
     if (level < 0 || level >= p.levels)
         return -1;
-    std::vector<uint8_t> pix(p.total, 0xA5);
-    std::vector<uint32_t> der(p.total, 0);
-    PyrImage im;
-    memset(&im, 0, sizeof(im));
-    for (int l = 0; l < p.levels; l++) {
-        size_t org = p.off[l] + (size_t)VO_BY * p.ls[l] + VO_BX;
-        im.lvl[l] = pix.data() + org;
-        im.der[l] = der.data() + org;
-        im.w[l] = p.lw[l];
-        im.h[l] = p.lh[l];
-        im.stride[l] = p.ls[l];
-    }
-    for (int y = 0; y < h; y++)
-        memcpy(im.lvl[0] + (ptrdiff_t)y * p.ls[0], img + (size_t)y * w, w);
-    build_pyramids(p, &im, 1);
-    const int n = p.ls[level] * (p.lh[level] + 2 * VO_BY);
+    Heap heap(p, 1, img, w, h);
+    build_pyramids(p, heap.tab.data(), 1);
+    const int n = (int)heap.level_elems(level);
     if (n > cap)
         return -2;
-    memcpy(pix_out, pix.data() + p.off[level], n);
-    memcpy(der_out, der.data() + p.off[level], 4 * (size_t)n);
+    memcpy(pix_out, heap.pix_block(0, level), n);
+    memcpy(der_out, heap.der_block(0, level), 4 * (size_t)n);
     *lvl_w = p.lw[level];
     *lvl_h = p.lh[level];
     *lvl_stride = p.ls[level];
@@ -523,22 +546,8 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
 {
     using namespace vo;
     Plan p = plan(w, h, max_level);
-    std::vector<uint8_t> pix(p.total * n_img, 0xA5); // poison: any read of unwritten border shows up
-    std::vector<uint32_t> der(p.total * n_img, 0);
-    std::vector<PyrImage> tab(n_img);
-    for (int i = 0; i < n_img; i++) {
-        memset(&tab[i], 0, sizeof(PyrImage));
-        for (int l = 0; l < p.levels; l++) {
-            size_t org = (size_t)i * p.total + p.off[l] + (size_t)VO_BY * p.ls[l] + VO_BX;
-            tab[i].lvl[l] = pix.data() + org;
-            tab[i].der[l] = der.data() + org;
-            tab[i].w[l] = p.lw[l];
-            tab[i].h[l] = p.lh[l];
-            tab[i].stride[l] = p.ls[l];
-        }
-        for (int y = 0; y < h; y++)
-            memcpy(tab[i].lvl[0] + (ptrdiff_t)y * p.ls[0], imgs + ((size_t)i * h + y) * w, w);
-    }
+    Heap heap(p, n_img, imgs, w, h);
+    std::vector<PyrImage> &tab = heap.tab;
     const PyrImage *d_imgs = tab.data();
     build_pyramids(p, d_imgs, n_img);
 
@@ -611,15 +620,8 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
 {
     using namespace vo;
     Plan p = plan(w, h, 0);
-    std::vector<uint8_t> pix(p.total, 0xA5);
-    PyrImage im;
-    memset(&im, 0, sizeof(im));
-    im.lvl[0] = pix.data() + p.off[0] + (size_t)VO_BY * p.ls[0] + VO_BX;
-    im.w[0] = w;
-    im.h[0] = h;
-    im.stride[0] = p.ls[0];
-    for (int y = 0; y < h; y++)
-        memcpy(im.lvl[0] + (ptrdiff_t)y * p.ls[0], img + (size_t)y * w, w);
+    Heap heap(p, 1, img, w, h); // (a one-level pyramid: nothing follows level 0)
+    PyrImage &im = heap.tab[0];
     Quad quad{0, 0, 0, 0};
     const int fcap = 1 << 17;
     std::vector<int> rowcnt(h, 0), rowoff(h, -1), fages(fcap, 0);

@@ -11,13 +11,13 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, vp
+from conftest import BUILD_DIR, ROOT, SAN_FLAGS, vp
 
 
 @pytest.fixture(scope="module")
 def kemu():
     src_dir = os.path.join(ROOT, "tests", "host_check")
-    out_dir = os.path.join(ROOT, "tests", "_build")
+    out_dir = BUILD_DIR
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libkernel_emu.so")
     csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
@@ -28,7 +28,7 @@ def kemu():
                                                "essential.hip", "vo_fivept.h", "seq.hip")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wno-unknown-pragmas", "-Wno-attributes", "-o", so,
+                               "-Wno-unknown-pragmas", "-Wno-attributes"] + SAN_FLAGS + ["-o", so,
                                os.path.join(src_dir, "kernel_emu.cpp")])
     lib = C.CDLL(so)
     lib.ke_run.restype = C.c_int
@@ -241,6 +241,40 @@ def test_emulated_fast_row_packing(kemu, orc, shape):
     got, _ = ke_detect(kemu, img, threshold=20, nonmax=1, cap=65536)
     ref = orc.fast_detect(img, 20, True)
     assert len(ref) > 20 and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("h,w", [(32, 32), (33, 47), (150, 70), (64, 257), (121, 1023), (480, 642)])
+def test_emulated_small_and_odd_shapes(kemu, orc, h, w, fast_variant):
+    """the shapes of tests/test_gpu_round4.py::test_fused_pyramid_pass_on_small_and_odd_shapes on the emulator, whose image
+    table gives every level its own exactly-sized block (one-level pyramids, widths of every residue mod 4, levels narrower
+    than a wavefront's span): pyramid levels, the four LK hops next to all four image edges and the FAST corner list (every
+    tile form: the tiles of the last tile column hang over the row end) bit-exact against the oracle -- and, in the
+    sanitizer tier, without one access outside a level's allocation"""
+    rng = np.random.default_rng(h * 1000 + w)
+    base = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2)).astype(np.float32)
+    img = np.kron(base, np.ones((4, 4), np.float32))[:h, :w]
+    img = np.clip(img + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    got, _ = ke_detect(kemu, img, threshold=20, nonmax=1, cap=65536)
+    assert np.array_equal(got, orc.fast_detect(img, 20, True))
+    if fast_variant:
+        return                                           # (pyramids and LK do not depend on the FAST tile form)
+    shifted = np.roll(img, (1, -2), (0, 1))
+    ref = orc.build_pyramid(img, 3)
+    n_levels, cw, ch = 1, w, h
+    while n_levels < 4 and (cw + 1) // 2 > 21 and (ch + 1) // 2 > 21:
+        cw, ch, n_levels = (cw + 1) // 2, (ch + 1) // 2, n_levels + 1
+    xs = rng.uniform(0, w - 1, 24).astype(np.float32)
+    ys = rng.uniform(0, h - 1, 24).astype(np.float32)
+    xs[:8] = [0, 0.4, w - 1, w - 1.3, 2.5, w / 2, w / 2, 7.25]
+    ys[:8] = [0, h - 1, 0.6, h - 1, h / 2, 0, h - 1, 3.75]
+    pts = np.stack([xs, ys], 1)
+    imgs = [img, shifted, shifted, img]
+    for l in range(n_levels):
+        r = ke_run(kemu, imgs, pts if l == 0 else None, want_level=l)
+        assert r["levels"] == n_levels and np.array_equal(r["lvl"], ref[l]), l
+        if l == 0:
+            want, st = _oracle_hops(orc, *imgs, pts, max_level=n_levels - 1)
+            assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(want))
 
 
 def test_emulated_bucketing_matches_oracle(kemu, orc, small_seq, fast_variant):

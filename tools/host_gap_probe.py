@@ -28,6 +28,25 @@ def timed(f, n=300):
 
 
 print("vo_track_frame                      %7.1f us" % timed(lambda: ctx.track_frame(L[0], R[0], L[1], R[1], pts, P_l, P_r)))
+if hasattr(ctx.lib, "vo_dev_host_stamps"):  # developer build: where the call's host side goes (steady-clock stamps inside vo_track_frame)
+    import ctypes as C
+    acc, prev_exit, n = np.zeros(11), None, 0
+    for i in range(220):
+        ctx.track_frame(L[0], R[0], L[1], R[1], pts, P_l, P_r)
+        buf = (C.c_longlong * 16)()
+        ctx.lib.vo_dev_host_stamps(buf)
+        t = np.array(buf[:10], dtype=np.float64) / 1e3
+        if i >= 20:
+            acc[:9] += np.diff(t)
+            acc[9] += t[9] - t[0]
+            acc[10] += t[0] - prev_exit
+            n += 1
+        prev_exit = t[9]
+    names = ["configure + sync_all", "image 0 staged + copy enqueued", "image 1", "image 2", "image 3", "points enqueued",
+             "set_projection + run_stages (all kernels enqueued)", "final stream synchronisation", "results copied out",
+             "inside vo_track_frame", "between two calls (python harness)"]
+    for k, v in zip(names, acc / n):
+        print("    %-52s %7.1f us" % (k, v))
 ctx.batch_configure(4, world.w, world.h, 1)
 print("vo_batch_configure (same shape)     %7.1f us" % timed(lambda: ctx.batch_configure(4, world.w, world.h, 1)))
 QUAD = (L[0], R[0], L[1], R[1])

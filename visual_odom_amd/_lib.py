@@ -318,22 +318,25 @@ class Context:
         pts = _f32(pts_l0, (-1, 2))
         n = pts.shape[0]
         P_l, P_r = _f32(P_l, (3, 4)), _f32(P_r, (3, 4))
-        o = [np.zeros((max(n, 1), 2), np.float32) for _ in range(4)]
-        xyz = np.zeros((max(n, 1), 3), np.float32)
-        keep, keepc, inl = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        # (fresh, uninitialised output arrays, returned as views of the part the call filled: zero-filling eight arrays and
+        # copying eight slices was 55 us per call of python between two calls -- tools/host_gap_probe.py, round 5)
+        m = max(n, 1)
+        o = np.empty((4, m, 2), np.float32)
+        xyz = np.empty((m, 3), np.float32)
+        idx = np.empty((3, m), np.int32)
         n_out, n_circ, ninl = C.c_int(0), C.c_int(0), C.c_int(0)
-        rv = np.zeros(3) if rvec is None else np.array(rvec, np.float64).reshape(3).copy()
-        tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3).copy()
+        rv = np.zeros(3) if rvec is None else np.array(rvec, np.float64).reshape(3)
+        tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3)
         R = np.zeros((3, 3))
+        ob, ib = o.ctypes.data, idx.ctypes.data
         rc = self._chk(self.lib.vo_track_frame(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
-                                               w, h, stride, _p(pts), n, _p(P_l), _p(P_r), _p(o[0]), _p(o[1]),
-                                               _p(o[2]), _p(o[3]), _p(xyz), _p(keep), C.byref(n_out),
-                                               _p(keepc), C.byref(n_circ), _p(rv), _p(tv), _p(R), _p(inl),
+                                               w, h, stride, _p(pts), n, _p(P_l), _p(P_r), C.c_void_p(ob), C.c_void_p(ob + 8 * m),
+                                               C.c_void_p(ob + 16 * m), C.c_void_p(ob + 24 * m), _p(xyz), C.c_void_p(ib), C.byref(n_out),
+                                               C.c_void_p(ib + 4 * m), C.byref(n_circ), _p(rv), _p(tv), _p(R), C.c_void_p(ib + 8 * m),
                                                C.byref(ninl)), allow=(VO_NO_MODEL, VO_NO_ESSENTIAL, VO_ERR_TOO_FEW))
         k = n_out.value
-        return dict(rc=rc, l0=o[0][:k].copy(), r0=o[1][:k].copy(), l1=o[2][:k].copy(), r1=o[3][:k].copy(),
-                    xyz=xyz[:k].copy(), keep_idx=keep[:k].copy(), keep_idx_circ=keepc[:n_circ.value].copy(),
-                    rvec=rv, tvec=tv, R=R, inliers=inl[:ninl.value].copy())
+        return dict(rc=rc, l0=o[0, :k], r0=o[1, :k], l1=o[2, :k], r1=o[3, :k], xyz=xyz[:k], keep_idx=idx[0, :k],
+                    keep_idx_circ=idx[1, :n_circ.value], rvec=rv, tvec=tv, R=R, inliers=idx[2, :ninl.value])
 
     # ---- batched device-resident API ------------------------------------------------------
     def batch_configure(self, n_images, w, h, n_frames):

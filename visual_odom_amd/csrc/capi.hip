@@ -179,6 +179,8 @@ void vo_destroy(vo_ctx *c)
         (void)hipHostFree(c->h_stage);
     if (c->h_gather)
         (void)hipHostFree(c->h_gather);
+    if (c->h_pts_stage)
+        (void)hipHostFree(c->h_pts_stage);
     for (auto &e : c->ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -245,9 +247,12 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         c->pix_capacity = per * (size_t)c->max_images;
     }
     c->stage_slot = (size_t)level_stride(max_w) * max_h;
-    ok = ok && hipHostMalloc((void **)&c->h_stage, c->stage_slot * VO_STAGE_SLOTS, hipHostMallocDefault) == hipSuccess;
+    c->stage_slot = (c->stage_slot + 255) / 256 * 256; // (slots stay 16-byte aligned for launch_pull_image)
+    ok = ok && hipHostMalloc((void **)&c->h_stage, c->stage_slot * VO_STAGE_SLOTS, hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void **)&c->d_stage, c->h_stage, 0) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_gather, frame_gather_bytes(c->cap), hipHostMallocMapped) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void **)&c->d_gather, c->h_gather, 0) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_pts_stage, sizeof(float2) * (size_t)c->cap + 16, hipHostMallocDefault) == hipSuccess;
     ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_der, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
@@ -421,7 +426,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
 
 namespace vo_capi {
 
-int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind)
+int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -442,14 +447,20 @@ int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind 
         // last interior pixel.  The bytes between two rows land in border columns, which the pyramid
         // stage's border fill rewrites before anything reads them.
         const size_t pitch = (size_t)c->lstride[0];
-        if (c->stage_next == 0) // all slots may still be in flight from the previous round of uploads
+        if (c->stage_next == 0 && !idle) // all slots may still be in flight from the previous round of uploads
             VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         uint8_t *slot = c->h_stage + c->stage_slot * (size_t)c->stage_next;
         c->stage_next = (c->stage_next + 1) % VO_STAGE_SLOTS;
         for (int y = 0; y < c->h; y++)
             memcpy(slot + (size_t)y * pitch, (const uint8_t *)src + (size_t)y * stride, (size_t)c->w);
-        VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, pitch * (size_t)(c->h - 1) + (size_t)c->w, hipMemcpyHostToDevice,
-                                     c->stream));
+        const size_t bytes = pitch * (size_t)(c->h - 1) + (size_t)c->w;
+        if (idle) { // a synchronous drop-in call: the GPU pulls the slot itself (pyramid.hip, launch_pull_image; the 16-byte
+                    // round-up of the last row stays inside the row's pitch)
+            launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream);
+            VO_HIP_TRY(c, hipGetLastError());
+        } else {
+            VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+        }
         return VO_OK;
     }
     VO_HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->lstride[0], src, (size_t)stride, (size_t)c->w, (size_t)c->h,

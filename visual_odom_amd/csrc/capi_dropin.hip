@@ -1,11 +1,30 @@
 // capi_dropin.hip -- the synchronous drop-in calls (host buffers in, host buffers out): vo_circular_match, vo_triangulate,
 // vo_pnp_ransac, vo_fast_detect, vo_detect_bucket, vo_integrate_odometry, vo_track_frame.
 #include "capi_internal.h"
+#ifdef VO_DEV_VARIANTS
+#include <chrono>
+#endif
 
 namespace vo_capi {
 
+#ifdef VO_DEV_VARIANTS
+// developer build: host-side time stamps of the last vo_track_frame (ns, steady clock): [0] entry, [1] configure + sync_all
+// done, [2..5] image k staged and its copy enqueued, [6] points enqueued, [7] run_stages returned (everything enqueued),
+// [8] the final stream synchronisation returned, [9] results copied out (tools/host_gap_probe.py)
+long long g_host_stamp[16];
+#define VO_HOST_STAMP(k) (g_host_stamp[k] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count())
+#else
+#define VO_HOST_STAMP(k) ((void)0)
+#endif
+
 /* ---------------------------------- drop-in calls ---------------------------------------- */
 
+// The inputs of a single-frame drop-in call on their way to the device WITHOUT a synchronisation in between (round 5): one
+// sync_all up front (idle streams: a few microseconds; after it every staging buffer is free and nothing reads the points),
+// then four image copies from the pinned staging slots, the points and their count from pinned staging too, all queued on the
+// tracking stream -- the caller's run_stages queues its kernels behind them while the pixels are still crossing PCIe.  Round 4
+// went through vo_batch_set_points here: sync_all + a pageable copy + a stream synchronisation, i.e. the host waited for the
+// four uploads (~80 us for KITTI) before it launched anything (108 + 21 us of the call, profiles/r04_experiments.md section 7).
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
                               const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
 {
@@ -16,17 +35,37 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
     int rc = vo_batch_configure(c, 4, w, h, 1);
     if (rc != VO_OK)
         return rc;
+    rc = sync_all(c); // a queued run of the batch API may still read the points / write the staging slots
+    if (rc != VO_OK)
+        return rc;
+    static_assert(VO_STAGE_SLOTS >= 4, "one staging slot per image of the call");
+    VO_HOST_STAMP(1);
+    c->stage_next = 0;
     const uint8_t *imgs[4] = {l0, r0, l1, r1};
     for (int i = 0; i < 4; i++) {
-        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice);
+        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true);
         if (rc != VO_OK)
             return rc;
+        VO_HOST_STAMP(2 + i);
     }
     const int32_t quad[4] = {0, 1, 2, 3};
     rc = vo_batch_set_quads(c, quad, 1);
     if (rc != VO_OK)
         return rc;
-    return vo_batch_set_points(c, 0, pts, n);
+    if (c->pts_sel >= 0) // the feature set of a VO_STAGE_DETECT run is current: the general path moves it over first
+        return vo_batch_set_points(c, 0, pts, n);
+    int *cnt = reinterpret_cast<int *>(c->h_pts_stage + sizeof(float2) * (size_t)c->cap);
+    *cnt = n;
+    if (n > 0) {
+        memcpy(c->h_pts_stage, pts, sizeof(float2) * (size_t)n);
+        VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts, c->h_pts_stage, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    VO_HIP_TRY(c, hipMemcpyAsync(c->d_npts, cnt, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->h_npts[0] = n;
+    c->pts_on_device = false;
+    c->max_pts_set = n;
+    VO_HOST_STAMP(6);
+    return VO_OK;
 }
 
 } // namespace vo_capi
@@ -259,6 +298,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
 {
     if (!c || !P_l || !P_r)
         return VO_ERR_ARG;
+    VO_HOST_STAMP(0);
     int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
     if (rc != VO_OK)
         return rc;
@@ -268,6 +308,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     rc = run_stages_auto(c, VO_STAGE_ALL, false, nullptr, /*sync_call*/ true);
     if (rc != VO_OK)
         return rc;
+    VO_HOST_STAMP(7);
     // Results: one kernel behind the pose solve gathers the counts, the PnpResult and every output array into one
     // host-visible buffer, one synchronisation, host copies from there -- instead of eleven device-to-host copies and
     // four rounds of stream synchronisation through vo_batch_get_filtered + vo_batch_get_pose (0.25 of the call's 1.45 ms).
@@ -284,9 +325,13 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     g.result = pb.results;
     g.em = mono ? pb.em_results : nullptr;
     g.cap = c->cap;
-    VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0)); // `done` covers the filter, both pose chains
+    if (pb.pending) { // (the chain ran on other streams: `done` covers the filter and both pose chains)
+        VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, pb.done, 0));
+        pb.pending = false;
+    }
     launch_frame_gather(g, c->d_gather, c->stream);
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VO_HOST_STAMP(8);
     const uint8_t *hb = c->h_gather;
     int hdr[3];
     memcpy(hdr, hb, sizeof(hdr));
@@ -334,6 +379,7 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
         memcpy(inliers, ai, (size_t)r.n_inliers * 4);
     if (n_inliers)
         *n_inliers = r.n_inliers;
+    VO_HOST_STAMP(9);
     if (r.status < 0)
         return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
     if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
@@ -343,6 +389,14 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
 
 #ifdef VO_DEV_VARIANTS
 // developer build only: the 100 MHz stamps the pose kernels left for frame 0 / hypothesis 0 (pnp.hip, tools/pose_phases.py)
+int vo_dev_host_stamps(long long *out16)
+{
+    if (!out16)
+        return VO_ERR_ARG;
+    memcpy(out16, g_host_stamp, sizeof(g_host_stamp));
+    return VO_OK;
+}
+
 int vo_dev_pose_prof(vo_ctx *c, long long *out64)
 {
     if (!c || !out64 || sync_all(c) != VO_OK)

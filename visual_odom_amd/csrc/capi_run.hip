@@ -31,9 +31,8 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
-            // Two launches, no LDS (round 4): level 0 is read once and gives its Scharr image, level 1 and its own border; the
-            // small levels follow in one launch, a workgroup per image (pyramid.hip).  (Round 3: eight launches of three
-            // kernels that each fetched the level again.)
+            // One launch per level, no LDS (round 4): a level is read once and gives its Scharr image, the next level and its
+            // own border (pyramid.hip).  (Round 3: eight launches of three kernels that each fetched the level again.)
 #ifdef VO_DEV_VARIANTS
             static const bool fused = [] { const char *e = getenv("VO_PYR_FUSED"); return !(e && e[0] == '0'); }();
             if (!fused) {
@@ -187,9 +186,14 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
     hipStream_t fs = serial ? c->stream : c->stream_filter;
     const bool two_pose_streams = !serial && !c->prm.mono_rotation && c->sched.streams == 2;
     hipStream_t ps = serial ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;
+    // (serial: filter, triangulation and pose chain follow LK on the tracking stream itself -- stream order is the dependency,
+    // and none of the events that hand work from one stream to the next is recorded: each cost ~6 us of idle GPU between two
+    // kernels of the synchronous call, three of them per call, profiles/r04_track_frame_timeline.txt)
     if (touches_pose) {
-        VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
-        VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
+        if (!serial) {
+            VO_HIP_TRY(c, hipEventRecord(pb.ready, c->stream));
+            VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.ready, 0));
+        }
         if (pb.pending) {
             VO_HIP_TRY(c, hipStreamWaitEvent(fs, pb.done, 0));
             pb.pending = false;
@@ -212,9 +216,11 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
             VO_HIP_TRY(c, hipEventRecord(sq.ev_carry, fs));
             sq.carry_pending = true;
         }
-        VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->trk_last], fs));
-        c->trk_busy[c->trk_last] = true;
-        if (c->pts_sel >= 0 && c->pts_sel != c->trk_last) {
+        if (!serial) {
+            VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->trk_last], fs));
+            c->trk_busy[c->trk_last] = true;
+        }
+        if (!serial && c->pts_sel >= 0 && c->pts_sel != c->trk_last) {
             // the points / ages this filter read belong to the OTHER set (a run without DETECT after a run with it):
             // the next DETECT into that set must wait for this filter too
             VO_HIP_TRY(c, hipEventRecord(c->ev_trk_free[c->pts_sel], fs));
@@ -231,8 +237,10 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts)); // evs[6]: end of triangulation
     e++;
     if (stages & VO_STAGE_PNP) {
-        VO_HIP_TRY(c, hipEventRecord(pb.tri_done, fs));
-        VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.tri_done, 0));
+        if (!serial) {
+            VO_HIP_TRY(c, hipEventRecord(pb.tri_done, fs));
+            VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.tri_done, 0));
+        }
         PnpParams pp;
         pp.iters = c->prm.ransac_iterations;
         pp.reproj = c->prm.ransac_reproj_error;
@@ -257,15 +265,17 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
             // its own stream: the two chains only share their inputs, and together they would outlast the LK
             // launch they hide behind
             hipStream_t es = serial ? c->stream : c->stream_em;
-            VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
+            if (!serial)
+                VO_HIP_TRY(c, hipStreamWaitEvent(es, pb.tri_done, 0));
             launch_essential(pb.outB, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, ep, c->em, pb.em_results,
                              /*crowded*/ crowded, es);
-            VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
+            if (!serial)
+                VO_HIP_TRY(c, hipEventRecord(pb.em_done, es));
         }
         launch_pnp_ransac(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                           pb.rstate, c->sched.waves, ps, pb.epnp_ws,
                           c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES, pb.epnp_gws, c->sched.wide);
-        if (c->prm.mono_rotation)
+        if (c->prm.mono_rotation && !serial)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
         SeqTail tail;
         // frame_pose is chained: step k integrates after step k - 1, whichever stream ran it -- only the refinement kernels of
@@ -293,8 +303,10 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         c->last_pose_stream = ps;
         if (timed)
             VO_HIP_TRY(c, hipEventRecord(evs[e], ps)); // evs[7]: pose solve timed from the end of triangulation
-        VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
-        pb.pending = true;
+        if (!serial) { // (serial: whoever needs the results waits for the tracking stream)
+            VO_HIP_TRY(c, hipEventRecord(pb.done, ps));
+            pb.pending = true;
+        }
     } else if (timed) {
         VO_HIP_TRY(c, hipEventRecord(evs[e], ts));
     }

@@ -219,12 +219,20 @@ __device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs
     // (16 bytes per thread and trip: the tile's rows are 80 or 144 bytes; the global address is only 4-byte aligned.  With a dword
     // per thread and trip every thread made 4 dependent round trips to memory -- the compiler waits for a load before the LDS
     // write that follows it.)
+    // No load leaves its row of the bordered allocation (vo_dev.h, "reads stay inside their row"): the tile of the last tile
+    // column reaches up to W + 11 columns past the image, more than the right border holds, so a chunk that would cross the
+    // row end reads the row's last 16 bytes instead.  Those chunks start past column w + VO_BY - 16 >= w + 8, and no position
+    // tested below reads a pixel right of column w - 1 (positions stop at w - 4, the circle's radius is 3): their bytes are
+    // never used.  (Round 4 read on into the next row -- on the allocation's last row into whatever followed the image.)
     static_assert(PW % 16 == 0, "16-byte tile loads");
+    static_assert(VO_BX % 4 == 0 && VO_BY >= 16 + 4, "the clamped chunk stays 4-byte aligned and right of the last pixel read");
+    const int last_chunk = stride - VO_BX - 16 - (x0 - 4); // byte offset (from base) of the last 16 bytes of a row, a multiple of 4
     for (int i = tid; i < PH * (PW / 16); i += 256) {
         const int row = i / (PW / 16), c = i - row * (PW / 16);
         const int gy = y0 - 4 + row < last_row ? y0 - 4 + row : last_row;
+        const int gc = 16 * c < last_chunk ? 16 * c : last_chunk;
         *reinterpret_cast<FastU32x4 *>(&s_px[row * PW + 16 * c]) =
-            *reinterpret_cast<const VO_GLOBAL FastU32x4 *>(base + ((ptrdiff_t)gy * stride + 16 * c));
+            *reinterpret_cast<const VO_GLOBAL FastU32x4 *>(base + ((ptrdiff_t)gy * stride + gc));
     }
     if (tid == 0)
         s_ncand = s_ncorner = 0;

@@ -867,28 +867,31 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
 }
 #endif // VO_DEV_VARIANTS
 
-// the whole pyramid build of a range of images: level 0's pass, then levels 1 .. L-1 in one launch (two launches instead of
-// eight; a one-level pyramid is one launch)
+// the whole pyramid build of a range of images: one launch of pyr_pass_kernel per level (more when a level's images exceed
+// pass_images_per_launch) -- four launches for the reference's maxLevel 3 instead of round 3's eight of three kernels
 void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh, const int *lstride,
                           hipStream_t stream)
 {
     if (n_images <= 0 || n_levels <= 0)
         return;
     const PassPlan pp = pass_plan(n_levels, lw, lh, lstride);
-    // one launch per level.  (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel,
-    // pass / fence + barrier / pass -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms
-    // for level 0, gpurun_out/r4_04: a few hundred workgroups of serial phases do not fill the chip.)
-    int sm = 0, remap = n_images >= 16; // (fewer images than two per XCD: pinning images to XCDs would leave XCDs without work)
+    // (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel, pass / fence + barrier / pass
+    // -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms for level 0, gpurun_out/r4_04: a
+    // few hundred workgroups of serial phases do not fill the chip.)
 #ifdef VO_DEV_VARIANTS
-    static const int sm_env = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
+    static const int sm = [] { const char *e = getenv("VO_PYR_STORE"); return e ? atoi(e) : 0; }();
     static const int xcd_env = [] { const char *e = getenv("VO_PYR_XCD"); return e ? atoi(e) : 1; }(); // 0: workgroups in dispatch order
-    sm = sm_env;
-    remap = remap && xcd_env;
 #endif
     for (int l = 0; l < n_levels; l++) {
         const int per = pass_images_per_launch(pp, l);
         for (int first = 0; first < n_images; first += per) {
             const int n = n_images - first < per ? n_images - first : per;
+            // XCD-pinned workgroup order per LAUNCH (it was decided from the total, so the 8 images left over from
+            // 4104 ran pinned): with fewer than two images per XCD pinning would leave XCDs without work
+            int remap = n >= 16;
+#ifdef VO_DEV_VARIANTS
+            remap = remap && xcd_env;
+#endif
             const uint32_t nwg = pass_grid(pp, l, n, remap);
 #ifdef VO_DEV_VARIANTS
             if (sm == 1) {
@@ -903,7 +906,24 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
             hipLaunchKernelGGL(pyr_pass_kernel, dim3(nwg), dim3(64), 0, stream, d_imgs + first, l, n_levels, pp, (uint32_t)n, remap);
         }
     }
-    (void)sm;
+}
+
+// One staged host image -> pixel (0, 0) ... of its level-0 rows, read by the GPU over PCIe straight from the page-locked
+// staging slot (the slot already has the device's row pitch, slot and destination are 16-byte aligned): 16 bytes per lane.
+// The synchronous drop-in calls use it instead of hipMemcpyAsync: four separate copies cost 81 us from the first enqueue to a
+// kernel behind them (7-10 us of fixed cost each), one 1.97 MB copy or one such kernel 52 us -- the link's rate -- and a
+// kernel per image starts moving image k while the host still repacks image k + 1 (tools/ubench/h2d_probe.hip, round 5).
+__global__ __launch_bounds__(256) void pull_image_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16)
+        dst[i] = src[i];
+}
+
+void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    hipLaunchKernelGGL(pull_image_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (const uint4 *)src_pinned_dev, (uint4 *)dst, n16);
 }
 
 #endif // VO_HOST_EMUL

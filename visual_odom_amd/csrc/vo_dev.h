@@ -13,6 +13,20 @@
 //   * a "frame" (one stereo pair at t0 and t1 = the unit of work of circularMatching(),
 //     reference feature.h:61-65) is a Quad of four image-table indices (l0, r0, l1, r1).
 //   * per frame SoA feature arrays with a fixed capacity `cap`: float2 points, u8 status.
+//
+// Reads stay inside their level (round 5).  A level's bordered allocation is rows -VO_BY .. h + VO_BY - 1
+// of `stride` bytes (dwords for the Scharr image), each row holding columns -VO_BX .. stride - VO_BX - 1.  EVERY load of pixel
+// or derivative memory by a kernel stays inside that rectangle -- no load runs over the end of a row into the next one, none
+// leaves the level -- so a level may be the last thing in its buffer (a one-level pyramid, the last image of the table) and
+// nothing depends on what follows it (another level, another image, vo_create's slack).  Who reads what:
+//   pyr_pass_kernel   8-byte windows at columns 4 g - 2 .. 4 g + 5 (4 g <= w - 1; group 0's two border bytes are replaced),
+//                     edge items at x4 - 4 .. x4 + 3; rows reflected into 0 .. h - 1                       (pyramid.hip)
+//   lk_circular_*     I-window rows and the 48 x 40 search tile: tile origin clamped to [-VO_BX, stride - VO_BX - 48] x
+//                     [-VO_BY, h + VO_BY - 40], 16-byte chunks; derivative dwords of the 21 x 21 window          (lk.hip)
+//   fast_tile_*       16-byte chunks of rows y0 - 4 .. (clamped to h + VO_BY - 1), columns x0 - 4 ..; a chunk that would cross
+//                     the row end reads the row's last 16 bytes instead (its bytes are never used)                  (fast.hip)
+// Checked by the sanitizer tier: the CPU emulator (tests/host_check/kernel_emu.cpp) runs these kernel sources with every level
+// in its own exactly-sized heap block under AddressSanitizer (tests/test_sanitize.py).
 #pragma once
 
 #include <stdint.h>
@@ -66,6 +80,7 @@
 #define VO_MAX_LEVELS 5
 #define VO_BX 32 /* left border columns (>= 21 + tile slack, keeps x = 0 16-byte aligned) */
 #define VO_BY 24 /* top / bottom border rows and minimum right border columns (>= 21) */
+static_assert(VO_BX % 16 == 0 && VO_BX >= 21 && VO_BY >= 21, "pixel (0, 0) of a row is 16-byte aligned; 21 x 21 windows at -21 read border, not the neighbour row");
 
 namespace vo {
 

@@ -122,6 +122,7 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
 #endif
 void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh, const int *lstride,
                           hipStream_t stream);
+void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream); // pyramid.hip: a staged host image over PCIe by a kernel
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
