@@ -138,7 +138,7 @@ def test_product_library_reads_no_environment_variable():
     blob = open(so, "rb").read()
     for name in (b"lk_circular_pair_kernel", b"fast_tile_big_kernel"):
         assert name not in blob, name
-    assert b"lk_circular_kernel" in blob and b"p3p_kernel" in blob
+    assert b"lk_circular_kernel" in blob and b"ransac_rest_kernel" in blob and b"pull_image_kernel" in blob
     # kernel symbols are mangled: epnp_kernel<4> / select_refine_kernel<4> = ...ILi4EE...
     # (epnp_kernel<WAVES, GWS>: GWS = true is the slim form of the round-4 experiment, developer build only)
     assert b"epnp_kernelILi4E" not in blob and b"select_refine_kernelILi4EE" not in blob and b"Lb1EE" not in blob

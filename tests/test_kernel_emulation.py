@@ -515,6 +515,18 @@ def test_emulated_pose_chain_four_kernel_epnp_and_edge_cases(kemu, orc):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]   # the forms: bit for bit
     assert np.array_equal(s[1], b[1]) and np.array_equal(s[2], b[2]) and s[4] == b[4]
     assert np.abs(a[1] - rv).max() <= 1e-6 and np.abs(a[2] - tv).max() <= 1e-6
+    # a frame that needs hypotheses behind the first chunk: small launches run everything behind it in ONE launch
+    # (ransac_rest_kernel: subsets, EPnP, votes by every workgroup, the control-flow replay by the one that arrives last) --
+    # bit for bit what the four kernels per chunk give, and the oracle's control flow
+    X2, uv2, _, _, _ = planted_problem(orc, 60, 0.5, 0.2, 3)
+    rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(X2, uv2, K_KITTI, iterations=200)
+    a = ke_pnp(kemu, X2, uv2, K_KITTI, iters=200, split=1, first_chunk=8)
+    b = ke_pnp(kemu, X2, uv2, K_KITTI, iters=200, split=0, first_chunk=8)
+    assert dbg[0] > 8, "this problem must reach the second chunk"
+    assert a[0] == b[0] == rc and np.array_equal(a[3], inl) and np.array_equal(b[3], inl)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4]
+    assert tuple(a[4][:4]) == tuple(int(x) for x in dbg[:4])
+    assert np.abs(a[1] - rv).max() <= 1e-6 and np.abs(a[2] - tv).max() <= 1e-6
     rng = np.random.default_rng(9)
     Xr = rng.uniform([-10, -2, 4], [10, 2, 50], (60, 3)).astype(np.float32)
     uvr = rng.uniform([0, 0], [1241, 376], (60, 2)).astype(np.float32)

@@ -123,8 +123,19 @@ def import_schedules(records):
         raise VoError(rc, "vo_import_schedule: bad record")
 
 
+_ZERO_BYTES = C.c_char * 0
+
+
 def _p(a):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+    """the array's base address as a foreign-function argument.  A zero-length ctypes array mapped onto the buffer (0.7 us; it keeps
+    the array alive and is passed as its address) where the buffer protocol allows it -- writable, contiguous -- and numpy's
+    `.ctypes` helper (3.8 us: eleven of them were 40 us of every vo_track_frame call) for read-only or strided views"""
+    if a is None:
+        return None
+    try:
+        return _ZERO_BYTES.from_buffer(a)
+    except (TypeError, ValueError, BufferError):
+        return a.ctypes.data_as(C.c_void_p)
 
 
 def _imgs(*arrays):
@@ -328,7 +339,7 @@ class Context:
         rv = np.zeros(3) if rvec is None else np.array(rvec, np.float64).reshape(3)
         tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3)
         R = np.zeros((3, 3))
-        ob, ib = o.ctypes.data, idx.ctypes.data
+        ob, ib = C.addressof(_ZERO_BYTES.from_buffer(o)), C.addressof(_ZERO_BYTES.from_buffer(idx))
         rc = self._chk(self.lib.vo_track_frame(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
                                                w, h, stride, _p(pts), n, _p(P_l), _p(P_r), C.c_void_p(ob), C.c_void_p(ob + 8 * m),
                                                C.c_void_p(ob + 16 * m), C.c_void_p(ob + 24 * m), _p(xyz), C.c_void_p(ib), C.byref(n_out),

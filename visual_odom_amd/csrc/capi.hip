@@ -252,7 +252,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && hipHostGetDevicePointer((void **)&c->d_stage, c->h_stage, 0) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_gather, frame_gather_bytes(c->cap), hipHostMallocMapped) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void **)&c->d_gather, c->h_gather, 0) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_pts_stage, sizeof(float2) * (size_t)c->cap + 16, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_pts_stage, sizeof(float2) * (size_t)c->cap + 16, hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void **)&c->d_pts_stage, c->h_pts_stage, 0) == hipSuccess;
     ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_der, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
@@ -426,7 +427,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
 
 namespace vo_capi {
 
-int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle)
+int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle, const float *pts, int n_pts)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -456,7 +457,13 @@ int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind 
         const size_t bytes = pitch * (size_t)(c->h - 1) + (size_t)c->w;
         if (idle) { // a synchronous drop-in call: the GPU pulls the slot itself (pyramid.hip, launch_pull_image; the 16-byte
                     // round-up of the last row stays inside the row's pitch)
-            launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream);
+            if (n_pts >= 0) { // the call's points (frame 0) and their count with this image
+                if (n_pts > 0)
+                    memcpy(c->h_pts_stage, pts, sizeof(float2) * (size_t)n_pts);
+                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream, c->d_pts_stage, c->d_pts, n_pts, c->d_npts);
+            } else {
+                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream);
+            }
             VO_HIP_TRY(c, hipGetLastError());
         } else {
             VO_HIP_TRY(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));

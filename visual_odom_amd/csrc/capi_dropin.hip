@@ -21,8 +21,8 @@ long long g_host_stamp[16];
 
 // The inputs of a single-frame drop-in call on their way to the device WITHOUT a synchronisation in between (round 5): one
 // sync_all up front (idle streams: a few microseconds; after it every staging buffer is free and nothing reads the points),
-// then four image copies from the pinned staging slots, the points and their count from pinned staging too, all queued on the
-// tracking stream -- the caller's run_stages queues its kernels behind them while the pixels are still crossing PCIe.  Round 4
+// then four kernels that pull the images out of the pinned staging slots over PCIe (pyramid.hip, launch_pull_image), the last of
+// them the points and their count too, all queued on the tracking stream -- the caller's run_stages queues its kernels behind them while the pixels are still crossing PCIe.  Round 4
 // went through vo_batch_set_points here: sync_all + a pageable copy + a stream synchronisation, i.e. the host waited for the
 // four uploads (~80 us for KITTI) before it launched anything (108 + 21 us of the call, profiles/r04_experiments.md section 7).
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
@@ -42,25 +42,19 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
     VO_HOST_STAMP(1);
     c->stage_next = 0;
     const uint8_t *imgs[4] = {l0, r0, l1, r1};
+    const int32_t quad[4] = {0, 1, 2, 3};
+    rc = vo_batch_set_quads(c, quad, 1); // (a no-op from the second call on)
+    if (rc != VO_OK)
+        return rc;
+    const bool ride = c->pts_sel < 0; // the points travel with the last image (else: see below)
     for (int i = 0; i < 4; i++) {
-        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true);
+        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true, pts, i == 3 && ride ? n : -1);
         if (rc != VO_OK)
             return rc;
         VO_HOST_STAMP(2 + i);
     }
-    const int32_t quad[4] = {0, 1, 2, 3};
-    rc = vo_batch_set_quads(c, quad, 1);
-    if (rc != VO_OK)
-        return rc;
-    if (c->pts_sel >= 0) // the feature set of a VO_STAGE_DETECT run is current: the general path moves it over first
+    if (!ride) // the feature set of a VO_STAGE_DETECT run is current: the general path moves it over first
         return vo_batch_set_points(c, 0, pts, n);
-    int *cnt = reinterpret_cast<int *>(c->h_pts_stage + sizeof(float2) * (size_t)c->cap);
-    *cnt = n;
-    if (n > 0) {
-        memcpy(c->h_pts_stage, pts, sizeof(float2) * (size_t)n);
-        VO_HIP_TRY(c, hipMemcpyAsync(c->d_pts, c->h_pts_stage, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    }
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_npts, cnt, sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->h_npts[0] = n;
     c->pts_on_device = false;
     c->max_pts_set = n;

@@ -153,6 +153,7 @@ struct vo_ctx {
     // 1241 x 376 image measured, tools/latency_mode.py)
     uint8_t *h_stage = nullptr, *d_stage = nullptr; // (d_stage: the same memory as the GPU addresses it, launch_pull_image)
     uint8_t *h_gather = nullptr, *d_gather = nullptr; // vo_track_frame's result buffer: host memory, and its device address
+    uint8_t *d_pts_stage = nullptr; // (its device address)
     uint8_t *h_pts_stage = nullptr; // pinned: the points + count of a synchronous drop-in call on their way to the device (cap float2 + 16 bytes)
     size_t stage_slot = 0; // bytes per slot, VO_STAGE_SLOTS slots
     int stage_next = 0;
@@ -291,7 +292,8 @@ bool acquire_streams(int device, StreamSet *out);
 hipStream_t ensure_copy_stream(StreamSet *s, bool prepare);
 void release_streams(int device, const StreamSet &s);
 void seq_free(vo_ctx *c);
-int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle = false); // idle: the caller has just drained the tracking stream
+// idle: the caller has just drained the tracking stream (a synchronous drop-in call); pts / n_pts: the call's points ride along
+int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle = false, const float *pts = nullptr, int n_pts = -1);
 int ensure_em(vo_ctx *c);
 int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool dry = false);
 int sync_all(vo_ctx *c);

@@ -16,7 +16,8 @@
 //   4. ransac_replay_kernel    one thread per frame continues "keep first strictly better,
 //                              niters = RANSACUpdateNumIters(...)" over the new counts
 //   (frames with exactly 4 points take no part in 1-5: OpenCV switches to P3P and returns solvePnP's answer
-//    directly -- p3p_kernel, one thread per frame, vo_p3p.h)
+//    directly -- p3p_frame, by the frame's thread of the first ransac_replay_kernel, vo_p3p.h)
+//   small launches: everything behind the first chunk is ONE launch (ransac_rest_kernel)
 //   5. select_refine_kernel    one workgroup per frame: winning hypothesis and the last one OpenCV
 //                              would have evaluated (its pose is the start of the final refinement
 //                              because rvec/tvec are shared buffers), inlier mask, the CvLevMarq
@@ -132,6 +133,79 @@ __device__ void subsets_serial(uint32_t pos, int first, int last, int count, int
     *pos_out = pos;
 }
 
+// subsets [first, last) of one frame by ONE WAVEFRONT, continuing the stream at position pos0; returns the position behind them
+__device__ __forceinline__ uint32_t subsets_wave(uint32_t pos0, int first, int last, int count, const uint32_t *__restrict__ raw,
+                                                 int n_raw, int32_t *__restrict__ out, int lane)
+{
+    // rng.uniform(0, count) = next() % count with a divisor that is fixed for the whole stream: Lemire's exact
+    // remainder by a precomputed 64-bit reciprocal (two multiplies) instead of a 32-bit division per draw
+    const uint64_t recip = 0xFFFFFFFFFFFFFFFFull / (uint32_t)count + 1;
+    bool overflow = false;
+    int base = first;
+    for (; base < last; base += 64) {
+        const int m = min(64, last - base);
+        const bool act = lane < m;
+        uint32_t off = pos0 + 5u * (uint32_t)lane, used = 0;
+        int idx[5] = {0, 0, 0, 0, 0};
+        bool dirty = act, ovf = false;
+        for (;;) {
+            if (dirty) {
+                uint32_t p = off;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    int v = 0;
+                    for (;;) {
+                        if (p >= (uint32_t)n_raw) {
+                            ovf = true;
+                            break;
+                        }
+                        v = (int)__umul64hi(recip * raw[p++], (uint64_t)(uint32_t)count);
+                        bool dup = false;
+#pragma unroll
+                        for (int k = 0; k < 5; k++)
+                            dup |= (k < i) && idx[k] == v;
+                        if (!dup)
+                            break;
+                    }
+                    idx[i] = v;
+                }
+                used = p - off;
+            }
+            if (__any(ovf))
+                break;
+            uint32_t incl = act ? used : 0u; // inclusive prefix sum over the wavefront
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= d)
+                    incl += t;
+            }
+            const uint32_t start = pos0 + incl - (act ? used : 0u);
+            dirty = act && start != off;
+            off = start;
+            if (!__any(dirty)) {
+                pos0 += __shfl(incl, 63, 64);
+                break;
+            }
+        }
+        if (__any(ovf)) {
+            overflow = true;
+            break;
+        }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                out[(base + lane) * 5 + i] = idx[i];
+        }
+    }
+    if (overflow) { // past the table (never seen: it holds 3.5 x the worst expected demand): lane 0's serial generator
+        if (lane == 0)
+            subsets_serial(pos0, base, last, count, out, &pos0);
+        pos0 = __shfl(pos0, 0, 64);
+    }
+    return pos0;
+}
+
 // one wavefront per frame.  The chunk [h0, h0 + hn) continues the frame's stream where the previous chunk left it
 // (RansacState::rng holds the stream POSITION), and only as far as the frame's adaptive iteration count still reaches.
 __global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restrict__ n_pts, int n_frames, int iters, int h0,
@@ -149,6 +223,8 @@ __global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restric
         st.max_good = 0;
         st.best = -1;
         st.rng = 0;
+        st.arrive = 0;
+        st.pad_ = 0;
     } else {
         st = rstate[frame];
     }
@@ -156,74 +232,8 @@ __global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restric
     int32_t *out = subsets + (size_t)frame * iters * 5;
     if (count == 5 && h0 == 0 && lane < 5) // model_points == npoints: solvePnP on all points in order
         out[lane] = lane;
-    if (count > 5) {
-        const int last = min(min(h0 + hn, iters), st.niters);
-        // rng.uniform(0, count) = next() % count with a divisor that is fixed for the whole stream: Lemire's exact
-        // remainder by a precomputed 64-bit reciprocal (two multiplies) instead of a 32-bit division per draw
-        const uint64_t recip = 0xFFFFFFFFFFFFFFFFull / (uint32_t)count + 1;
-        uint32_t pos0 = (uint32_t)st.rng;
-        bool overflow = false;
-        int base = h0;
-        for (; base < last; base += 64) {
-            const int m = min(64, last - base);
-            const bool act = lane < m;
-            uint32_t off = pos0 + 5u * (uint32_t)lane, used = 0;
-            int idx[5] = {0, 0, 0, 0, 0};
-            bool dirty = act, ovf = false;
-            for (;;) {
-                if (dirty) {
-                    uint32_t p = off;
-#pragma unroll
-                    for (int i = 0; i < 5; i++) {
-                        int v = 0;
-                        for (;;) {
-                            if (p >= (uint32_t)n_raw) {
-                                ovf = true;
-                                break;
-                            }
-                            v = (int)__umul64hi(recip * raw[p++], (uint64_t)(uint32_t)count);
-                            bool dup = false;
-#pragma unroll
-                            for (int k = 0; k < 5; k++)
-                                dup |= (k < i) && idx[k] == v;
-                            if (!dup)
-                                break;
-                        }
-                        idx[i] = v;
-                    }
-                    used = p - off;
-                }
-                if (__any(ovf))
-                    break;
-                uint32_t incl = act ? used : 0u; // inclusive prefix sum over the wavefront
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_up(incl, d, 64);
-                    if (lane >= d)
-                        incl += t;
-                }
-                const uint32_t start = pos0 + incl - (act ? used : 0u);
-                dirty = act && start != off;
-                off = start;
-                if (!__any(dirty)) {
-                    pos0 += __shfl(incl, 63, 64);
-                    break;
-                }
-            }
-            if (__any(ovf)) {
-                overflow = true;
-                break;
-            }
-            if (act) {
-#pragma unroll
-                for (int i = 0; i < 5; i++)
-                    out[(base + lane) * 5 + i] = idx[i];
-            }
-        }
-        if (overflow && lane == 0) // past the table (never seen: it holds 3.5 x the worst expected demand)
-            subsets_serial(pos0, base, last, count, out, &pos0);
-        st.rng = pos0;
-    }
+    if (count > 5)
+        st.rng = subsets_wave((uint32_t)st.rng, h0, min(min(h0 + hn, iters), st.niters), count, raw, n_raw, out, lane);
     if (lane == 0)
         rstate[frame] = st;
 }
@@ -231,6 +241,35 @@ __global__ __launch_bounds__(64) void ransac_subsets_kernel(const int *__restric
 // GWS = true ("slim", round 4): the same lane-interleaved matrix in a GLOBAL workspace (one 156 x 64 block of doubles per
 // workgroup, L2 / Infinity-Cache resident while the wave runs) instead of LDS, and a small register budget -- a wave that
 // needs neither LDS nor half a SIMD's registers starts in the slot any retiring LK wave leaves (see launch_pnp_ransac).
+// hypothesis h of a frame by ONE LANE: its five points, 5-point EPnP, the model record.  ut: the lane's column of the
+// lane-interleaved 12 x 12 workspace (element idx at ut[idx * 64])
+__device__ __forceinline__ void epnp_hypothesis(const float *__restrict__ xyz, const float2 *__restrict__ uv, size_t uv_stride,
+                                                int cap, const int32_t *__restrict__ subsets, const PnpParams &prm, int frame,
+                                                int h, double *ut, double *__restrict__ models)
+{
+    const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
+    float x5[15], u5[10];
+    for (int i = 0; i < 5; i++) {
+        const int k = idx[i];
+        const float *p = xyz + ((size_t)frame * cap + k) * 3;
+        x5[3 * i] = p[0];
+        x5[3 * i + 1] = p[1];
+        x5[3 * i + 2] = p[2];
+        const float2 q = uv[frame * uv_stride + k];
+        u5[2 * i] = q.x;
+        u5[2 * i + 1] = q.y;
+    }
+    double rv[3], tv[3];
+    epnp5_solve_t<64>(x5, u5, prm.K, rv, tv, ut);
+    double *m = models + ((size_t)frame * prm.iters + h) * 6;
+    m[0] = rv[0];
+    m[1] = rv[1];
+    m[2] = rv[2];
+    m[3] = tv[0];
+    m[4] = tv[1];
+    m[5] = tv[2];
+}
+
 template <int WAVES, bool GWS>
 __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict__ xyz,   // [B][cap][3]
                                                   const float2 *__restrict__ uv,    // frame f at uv + f*uv_stride
@@ -254,27 +293,7 @@ __global__ __launch_bounds__(64, WAVES) void epnp_kernel(const float *__restrict
     const int nh = count == 5 ? 1 : min(prm.iters, rstate[frame].niters);
     if (h >= nh)
         return;
-    const int32_t *idx = subsets + ((size_t)frame * prm.iters + h) * 5;
-    float x5[15], u5[10];
-    for (int i = 0; i < 5; i++) {
-        const int k = idx[i];
-        const float *p = xyz + ((size_t)frame * cap + k) * 3;
-        x5[3 * i] = p[0];
-        x5[3 * i + 1] = p[1];
-        x5[3 * i + 2] = p[2];
-        const float2 q = uv[frame * uv_stride + k];
-        u5[2 * i] = q.x;
-        u5[2 * i + 1] = q.y;
-    }
-    double rv[3], tv[3];
-    epnp5_solve_t<64>(x5, u5, prm.K, rv, tv, s_ut + threadIdx.x);
-    double *m = models + ((size_t)frame * prm.iters + h) * 6;
-    m[0] = rv[0];
-    m[1] = rv[1];
-    m[2] = rv[2];
-    m[3] = tv[0];
-    m[4] = tv[1];
-    m[5] = tv[2];
+    epnp_hypothesis(xyz, uv, uv_stride, cap, subsets, prm, frame, h, s_ut + threadIdx.x, models);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -430,16 +449,11 @@ __device__ __forceinline__ bool is_inlier(const double *R, const double *t, doub
     return e <= thr2;
 }
 
-__global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
-                                                  size_t uv_stride, const int *__restrict__ n_pts, int cap,
-                                                  PnpParams prm, const double *__restrict__ models,
-                                                  const RansacState *__restrict__ rstate, int h0,
-                                                  int *__restrict__ counts /* [B][iters] */)
+// inlier count of hypothesis h over the frame's `count` points by ONE WAVEFRONT (every lane returns the sum)
+__device__ __forceinline__ int vote_hypothesis(const float *__restrict__ xyz, const float2 *__restrict__ uv, size_t uv_stride,
+                                               int cap, const PnpParams &prm, const double *__restrict__ models, int frame, int h,
+                                               int count, int lane)
 {
-    const int frame = blockIdx.y, h = h0 + blockIdx.x, lane = threadIdx.x;
-    const int count = n_pts[frame];
-    if (count <= 5 || h >= prm.iters || h >= rstate[frame].niters)
-        return;
     const double *m = models + ((size_t)frame * prm.iters + h) * 6;
     double R[9], t[3] = {m[3], m[4], m[5]};
     rodrigues_v2m(m, R, nullptr);
@@ -453,6 +467,20 @@ __global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz,
 #pragma unroll
     for (int mm = 32; mm >= 1; mm >>= 1)
         good += __shfl_xor(good, mm, 64);
+    return good;
+}
+
+__global__ __launch_bounds__(64) void vote_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                  size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                  PnpParams prm, const double *__restrict__ models,
+                                                  const RansacState *__restrict__ rstate, int h0,
+                                                  int *__restrict__ counts /* [B][iters] */)
+{
+    const int frame = blockIdx.y, h = h0 + blockIdx.x, lane = threadIdx.x;
+    const int count = n_pts[frame];
+    if (count <= 5 || h >= prm.iters || h >= rstate[frame].niters)
+        return;
+    const int good = vote_hypothesis(xyz, uv, uv_stride, cap, prm, models, frame, h, count, lane);
     if (lane == 0)
         counts[(size_t)frame * prm.iters + h] = good;
 }
@@ -473,30 +501,157 @@ __device__ int ransac_update_num_iters(double p, double ep, int modelPoints, int
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 
-// RANSACPointSetRegistrator::run on the vote counts, continued chunk by chunk: one thread per frame
-__global__ void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int h_end,
-                                      const int *__restrict__ counts, RansacState *__restrict__ rstate)
+// RANSACPointSetRegistrator::run on the vote counts of hypotheses st.it .. end - 1:
+//     for (; it < niters && it < end; it++) if (good[it] > max(max_good, 4)) { max_good = good[it]; best = it; niters = update(...); }
+// by ONE WAVEFRONT, 64 counts at a time: the lanes load them side by side, a ballot finds the first one that beats the
+// running best, every lane takes it over (the new bound is a function of wave-uniform values), the search goes on behind it.
+// One thread walking the counts took 8-14 us per chunk of 128 -- one dependent load and branch per hypothesis (round 5).
+// Every lane returns the same state.
+__device__ __forceinline__ void replay_frame(RansacState &st, int count, const int *__restrict__ cf, int end, const PnpParams &prm,
+                                             int lane)
 {
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
+    int it = st.it;
+    while (it < st.niters && it < end) {
+        int lim = st.niters < end ? st.niters : end; // (> it)
+        const int h = it + lane;
+        const int good = h < lim ? cf[h] : -1;
+        int from = 0, stop = -1; // lanes below `from` have been passed; stop: the loop ends behind this hypothesis
+        for (;;) {
+            const int thr = st.max_good > 4 ? st.max_good : 4;
+            const unsigned long long m = VO_BALLOT(lane >= from && h < lim && good > thr);
+            if (m == 0ull)
+                break;
+            const int j = __builtin_ctzll(m);
+            const int g = VO_READLANE(good, j);
+            st.max_good = g;
+            st.best = it + j;
+            st.niters = ransac_update_num_iters(prm.confidence, (double)(count - g) / count, 5, st.niters);
+            lim = st.niters < end ? st.niters : end;
+            if (lim <= it + j + 1) { // the new bound is already behind us: `it++`, then the loop condition fails
+                stop = it + j + 1;
+                break;
+            }
+            from = j + 1;
+        }
+        if (stop >= 0) {
+            it = stop;
+            break;
+        }
+        it = it + 64 < lim ? it + 64 : lim;
+    }
+    st.it = it;
+}
+
+// solvePnPRansac with exactly four correspondences: `npoints == 4 -> model_points = 4, SOLVEPNP_P3P`, and model_points
+// being npoints the call IS solvePnP(P3P): first of solveP3P's sorted solutions, no refinement, all four points inliers;
+// no solution -> false, rvec / tvec untouched (lm_iters = -1 marks "pose buffers untouched" for the host side and the
+// lock-step loop), inliers released.  One thread.
+__device__ void p3p_frame(const float *__restrict__ xyz, const float2 *__restrict__ uv, size_t uv_stride, int cap, int frame,
+                          const PnpParams &prm, int32_t *__restrict__ inliers, PnpResult *__restrict__ results)
+{
+    float x4[12], u4[8];
+    for (int i = 0; i < 4; i++) {
+        const float *p = xyz + ((size_t)frame * cap + i) * 3;
+        x4[3 * i] = p[0];
+        x4[3 * i + 1] = p[1];
+        x4[3 * i + 2] = p[2];
+        const float2 q = uv[frame * uv_stride + i];
+        u4[2 * i] = q.x;
+        u4[2 * i + 1] = q.y;
+    }
+    PnpResult &res = results[frame];
+    double rv[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
+    const int ns = p3p4_solve(x4, u4, prm.K, rv, tv);
+    for (int k = 0; k < 3; k++) {
+        res.rvec[k] = rv[k];
+        res.tvec[k] = tv[k];
+    }
+    rodrigues_v2m(rv, res.R, nullptr);
+    res.niters = 1;
+    res.max_good = ns > 0 ? 4 : 0;
+    res.best_iter = ns > 0 ? 0 : -1;
+    res.lm_iters = ns > 0 ? 0 : -1;
+    res.n_inliers = ns > 0 ? 4 : 0;
+    res.status = ns > 0 ? 1 : 0;
+    if (ns > 0)
+        for (int i = 0; i < 4; i++)
+            inliers[(size_t)frame * cap + i] = i;
+}
+
+// RANSACPointSetRegistrator::run continued over a chunk's vote counts, one wavefront per frame -- and, for the frames with
+// exactly four points, the whole solve (p3p_frame, lane 0; round 5: it was a kernel of its own in front of the refinement,
+// 5 us of every synchronous call for a case an ordinary frame never is)
+__global__ __launch_bounds__(64) void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int h_end,
+                                                            const int *__restrict__ counts, RansacState *__restrict__ rstate,
+                                                            P3pArgs p3p)
+{
+    const int frame = blockIdx.x, lane = threadIdx.x;
     if (frame >= n_frames)
         return;
+    const int count = n_pts[frame];
+    if (count == 4 && p3p.xyz && lane == 0)
+        p3p_frame(p3p.xyz, p3p.uv, p3p.uv_stride, p3p.cap, frame, prm, p3p.inliers, p3p.results);
+    if (count <= 5)
+        return;
+    RansacState st = rstate[frame];
+    replay_frame(st, count, counts + (size_t)frame * prm.iters, min(h_end, prm.iters), prm, lane);
+    if (lane == 0)
+        rstate[frame] = st;
+}
+
+// Everything of a solve BEHIND the first chunk, in ONE launch (round 5; small launches): subsets, EPnP, votes and the replay of
+// hypotheses h0 .. h0 + hn - 1 for the frames whose adaptive iteration count reaches that far.  With >= 55 % inliers OpenCV
+// stops inside the first 128 iterations, so for an ordinary frame every workgroup reads the frame's state and returns -- one
+// idle launch where round 4 had four (ransac_subsets + epnp_kernel + vote + replay: 20 us of every synchronous call,
+// profiles/r04_track_frame_timeline.txt).  A frame that does go on: workgroup x (one wavefront) of the frame
+//   1. draws the subsets of the WHOLE chunk (every workgroup the same ones: the stream is serial, a wavefront does 64 subsets
+//      in a few microseconds, and nobody waits for anybody),
+//   2. solves its 64 hypotheses, a lane each (epnp_hypothesis, as epnp_kernel),
+//   3. counts their inliers, the wavefront one hypothesis at a time (vote_hypothesis, as vote_kernel),
+//   4. arrives (RansacState::arrive); the workgroup that arrives last replays the control flow over all counts and writes the
+//      frame's state -- every other workgroup has read the state before it arrived, so nobody sees the new one too early.
+// Same device functions as the four kernels, same results.
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void ransac_rest_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
+                                                                size_t uv_stride, const int *__restrict__ n_pts, int cap,
+                                                                int32_t *__restrict__ subsets, PnpParams prm,
+                                                                RansacState *__restrict__ rstate, int h0, int hn,
+                                                                double *__restrict__ models, int *__restrict__ counts,
+                                                                const uint32_t *__restrict__ raw, int n_raw,
+                                                                int n_groups /* workgroups per frame = gridDim.x */)
+{
+    VO_DYN_LDS(double, s_ut);
+    const int frame = blockIdx.y, lane = threadIdx.x;
     const int count = n_pts[frame];
     if (count <= 5)
         return;
     RansacState st = rstate[frame];
-    const int *cf = counts + (size_t)frame * prm.iters;
-    const int end = min(h_end, prm.iters);
-    int it = st.it;
-    for (; it < st.niters && it < end; it++) {
-        const int good = cf[it];
-        if (good > (st.max_good > 4 ? st.max_good : 4)) {
-            st.max_good = good;
-            st.best = it;
-            st.niters = ransac_update_num_iters(prm.confidence, (double)(count - good) / count, 5, st.niters);
-        }
+    if (st.it >= st.niters || st.it >= prm.iters)
+        return; // the first chunk settled this frame
+    const int last = min(min(h0 + hn, prm.iters), st.niters);
+    st.rng = subsets_wave((uint32_t)st.rng, h0, last, count, raw, n_raw, subsets + (size_t)frame * prm.iters * 5, lane);
+    wide_sync(true); // the lanes read subsets other lanes of this wavefront wrote
+    const int hb = h0 + blockIdx.x * 64;
+    if (hb + lane < last)
+        epnp_hypothesis(xyz, uv, uv_stride, cap, subsets, prm, frame, hb + lane, s_ut + lane, models);
+    wide_sync(true); // ... and models other lanes wrote
+    for (int h = hb; h < min(hb + 64, last); h++) {
+        const int good = vote_hypothesis(xyz, uv, uv_stride, cap, prm, models, frame, h, count, lane);
+        if (lane == 0)
+            counts[(size_t)frame * prm.iters + h] = good;
     }
-    st.it = it;
-    rstate[frame] = st;
+    __threadfence(); // this workgroup's counts before its arrival
+    int arrived = 0;
+    if (lane == 0)
+        arrived = atomicAdd(&rstate[frame].arrive, 1);
+    if (VO_READFIRSTLANE(arrived) != n_groups - 1)
+        return;
+    __threadfence(); // every other workgroup's counts
+    replay_frame(st, count, counts + (size_t)frame * prm.iters, min(h0 + hn, prm.iters), prm, lane);
+    if (lane == 0) {
+        st.arrive = 0;
+        rstate[frame] = st;
+    }
 }
 
 constexpr int LM_NRED = 28; // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
@@ -529,7 +684,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         g_pose_prof[16] = VO_POSE_NOW();
 #endif
     if (count < 5) {
-        if (tid == 0 && count != 4) { // (exactly 4 points: p3p_kernel has already written this frame's record)
+        if (tid == 0 && count != 4) { // (exactly 4 points: p3p_frame has already written this frame's record)
             res.status = -1;          // CV_Assert(npoints >= 4)
             res.n_inliers = 0;
             res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
@@ -637,6 +792,19 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         for (int k = 0; k < 6; k++)
             s_param[k] = mf[last * 6 + k];
     __syncthreads();
+    auto take_J = [&]() { // thread 0: the workgroup's sums -> J^T J, J^T e; the parameters they were formed at -> prevParam
+        int q = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) {
+                JtJ[i * 6 + j] = s_sum[q];
+                JtJ[j * 6 + i] = s_sum[q];
+                q++;
+            }
+        for (int k = 0; k < 6; k++) {
+            JtErr[k] = s_sum[21 + k];
+            prevParam[k] = s_param[k];
+        }
+    };
 
     for (;;) {
 #ifdef VO_DEV_VARIANTS
@@ -650,17 +818,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                 want_J = want_err = 1;
                 state = LM_CALC_J;
             } else if (state == LM_CALC_J) {
-                int q = 0;
-                for (int i = 0; i < 6; i++)
-                    for (int j = i; j < 6; j++) {
-                        JtJ[i * 6 + j] = s_sum[q];
-                        JtJ[j * 6 + i] = s_sum[q];
-                        q++;
-                    }
-                for (int k = 0; k < 6; k++) {
-                    JtErr[k] = s_sum[21 + k];
-                    prevParam[k] = s_param[k];
-                }
+                take_J();
                 need_solve = 1;
                 if (iters == 0)
                     prevErrNorm = sqrt(s_sum[27]);
@@ -688,9 +846,15 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                     if (++iters >= max_iter || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < epsilon) {
                         state = LM_DONE; // update() returns true with _err == 0 -> caller breaks
                     } else {
+                        // CvLevMarq now asks for J^T J, J^T e and the error at the accepted parameters (state CALC_J) -- the
+                        // very parameters the pass that has just delivered errNorm ran at.  That pass formed the Jacobian sums
+                        // on the way (every pass does, round 5: same points, same order, hence the same bits as a pass of
+                        // their own), so the step follows at once: one pass per iteration instead of two.
                         prevErrNorm = errNorm;
-                        want_J = want_err = 1;
-                        state = LM_CALC_J;
+                        take_J();
+                        need_solve = 1;
+                        want_err = 1;
+                        state = LM_CHECK_ERR;
                     }
                 }
             }
@@ -703,7 +867,7 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
                     s_b[k] = JtErr[k];
             }
             s_flags[0] = proceed && want_err;
-            s_flags[1] = want_J;
+            s_flags[1] = want_J || want_err; // (the Jacobian sums with every pass, see above)
             s_flags[2] = need_solve;
         }
         __syncthreads();
@@ -871,46 +1035,6 @@ __global__ __launch_bounds__(256, WAVES) void select_refine_kernel(const float *
         seq_integrate_frame(tail, blockIdx.x, results[blockIdx.x], tail.active[blockIdx.x]);
 }
 
-// solvePnPRansac with exactly four correspondences: `npoints == 4 -> model_points = 4, SOLVEPNP_P3P`, and model_points
-// being npoints the call IS solvePnP(P3P): first of solveP3P's sorted solutions, no refinement, all four points inliers;
-// no solution -> false, rvec / tvec untouched (lm_iters = -1 marks "pose buffers untouched" for the host side and the
-// lock-step loop), inliers released.  One thread per frame; frames with any other count return at once.
-__global__ void p3p_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv, size_t uv_stride,
-                           const int *__restrict__ n_pts, int cap, int n_frames, PnpParams prm,
-                           int32_t *__restrict__ inliers, PnpResult *__restrict__ results)
-{
-    const int frame = blockIdx.x * blockDim.x + threadIdx.x;
-    if (frame >= n_frames || n_pts[frame] != 4)
-        return;
-    float x4[12], u4[8];
-    for (int i = 0; i < 4; i++) {
-        const float *p = xyz + ((size_t)frame * cap + i) * 3;
-        x4[3 * i] = p[0];
-        x4[3 * i + 1] = p[1];
-        x4[3 * i + 2] = p[2];
-        const float2 q = uv[frame * uv_stride + i];
-        u4[2 * i] = q.x;
-        u4[2 * i + 1] = q.y;
-    }
-    PnpResult &res = results[frame];
-    double rv[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
-    const int ns = p3p4_solve(x4, u4, prm.K, rv, tv);
-    for (int k = 0; k < 3; k++) {
-        res.rvec[k] = rv[k];
-        res.tvec[k] = tv[k];
-    }
-    rodrigues_v2m(rv, res.R, nullptr);
-    res.niters = 1;
-    res.max_good = ns > 0 ? 4 : 0;
-    res.best_iter = ns > 0 ? 0 : -1;
-    res.lm_iters = ns > 0 ? 0 : -1;
-    res.n_inliers = ns > 0 ? 4 : 0;
-    res.status = ns > 0 ? 1 : 0;
-    if (ns > 0)
-        for (int i = 0; i < 4; i++)
-            inliers[(size_t)frame * cap + i] = i;
-}
-
 #ifndef VO_HOST_EMUL // ---- host side: launches ----
 // the raw cv::RNG(-1) stream of the device the calling thread has selected (created on first use)
 static const uint32_t *rng_table(hipStream_t stream)
@@ -953,7 +1077,8 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                        int waves /* 1 or 2 per SIMD: 512 / 256 registers; 4: the slim form (needs gws) */, hipStream_t stream,
                        double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames,
                        double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */,
-                       int wide_frames /* four-kernel form for launches of up to this many frames (the schedule's knob) */)
+                       int wide_frames /* four-kernel form for launches of up to this many frames (the schedule's knob) */,
+                       int32_t *inliers, PnpResult *results /* of the four-point frames (p3p_frame) */)
 {
     if (n_frames <= 0)
         return;
@@ -992,9 +1117,22 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
     if (chunk_env > 0 && chunk_env <= RANSAC_CHUNK && !split)
         first_chunk = chunk_env;
 #endif
+    P3pArgs p3p;
+    p3p.xyz = xyz;
+    p3p.uv = uv;
+    p3p.uv_stride = uv_stride;
+    p3p.cap = cap;
+    p3p.inliers = inliers;
+    p3p.results = results;
     for (int h0 = 0; h0 < prm.iters;) {
         const int hn = h0 == 0 ? min(first_chunk, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
+        if (split && h0 > 0) { // small launches: the rest of the solve in one launch, which an ordinary frame leaves at once
+            const uint32_t *tab = rng_table(stream);
+            hipLaunchKernelGGL(ransac_rest_kernel<1>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               h0, hn, models, counts, tab, tab ? RNG_TABLE : 0, (int)eg.x);
+            break;
+        }
         launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
         if (split && h0 == 0) {
             hipLaunchKernelGGL(epnp_prepare_kernel, eg, dim3(64), 144 * 64 * sizeof(double), stream, xyz, uv, uv_stride, n_pts,
@@ -1034,22 +1172,20 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                                h0, hn, models, (double *)nullptr);
         hipLaunchKernelGGL(vote_kernel, dim3(hn, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, prm, models,
                            state, h0, counts);
-        hipLaunchKernelGGL(ransac_replay_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, n_pts, n_frames, prm,
-                           h0 + hn, counts, state);
+        hipLaunchKernelGGL(ransac_replay_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, prm, h0 + hn, counts, state,
+                           h0 == 0 ? p3p : P3pArgs());
         h0 += hn;
     }
 }
 
-// the four-point frames (P3P), then winner / inlier mask / Levenberg-Marquardt refinement / Rodrigues -- and, in the
-// lock-step loop, the pose integration of every sequence (tail)
+// winner / inlier mask / Levenberg-Marquardt refinement / Rodrigues -- and, in the lock-step loop, the pose integration of
+// every sequence (tail).  (The four-point frames were solved by launch_pnp_ransac's first replay kernel.)
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream)
 {
     if (n_frames <= 0)
         return;
-    hipLaunchKernelGGL(p3p_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap,
-                       n_frames, prm, inliers, results);
 #ifdef VO_DEV_VARIANTS
     if (waves >= 4) // slim: 128 registers
         hipLaunchKernelGGL(select_refine_kernel<4>, dim3(n_frames), dim3(256), 0, stream, xyz, uv, uv_stride, n_pts,
@@ -1069,7 +1205,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames, double *gws)
 {
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
-                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES);
+                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES, inliers, results);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

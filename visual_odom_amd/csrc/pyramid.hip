@@ -913,17 +913,27 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
 // The synchronous drop-in calls use it instead of hipMemcpyAsync: four separate copies cost 81 us from the first enqueue to a
 // kernel behind them (7-10 us of fixed cost each), one 1.97 MB copy or one such kernel 52 us -- the link's rate -- and a
 // kernel per image starts moving image k while the host still repacks image k + 1 (tools/ubench/h2d_probe.hip, round 5).
-__global__ __launch_bounds__(256) void pull_image_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+// (the call's points and their count ride along with the last image: `extra` workgroups behind the image's copy n8 float2 from
+// src2 to dst2, and one thread writes the count -- two copy kernels of their own were 9 us of every call)
+__global__ __launch_bounds__(256) void pull_image_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16,
+                                                         const uint2 *__restrict__ src2, uint2 *__restrict__ dst2, uint32_t n8,
+                                                         int *__restrict__ count_dst, int count)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, img_threads = (n16 + 255u) / 256u * 256u;
     if (i < n16)
         dst[i] = src[i];
+    else if (i >= img_threads && i - img_threads < n8)
+        dst2[i - img_threads] = src2[i - img_threads];
+    if (i == 0 && count_dst)
+        *count_dst = count;
 }
 
-void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream)
+void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream, const void *pts_pinned_dev,
+                       void *pts_dst, int n_pts, int *count_dst)
 {
-    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
-    hipLaunchKernelGGL(pull_image_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, (const uint4 *)src_pinned_dev, (uint4 *)dst, n16);
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16), n8 = pts_dst ? (uint32_t)n_pts : 0u;
+    hipLaunchKernelGGL(pull_image_kernel, dim3((n16 + 255) / 256 + (n8 + 255) / 256), dim3(256), 0, stream, (const uint4 *)src_pinned_dev,
+                       (uint4 *)dst, n16, (const uint2 *)pts_pinned_dev, (uint2 *)pts_dst, n8, count_dst, n_pts);
 }
 
 #endif // VO_HOST_EMUL

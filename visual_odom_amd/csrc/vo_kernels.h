@@ -39,6 +39,18 @@ struct RansacState {
     int max_good;  // best inlier count
     int best;      // index of the hypothesis that achieved it (-1: none)
     uint64_t rng;  // POSITION in the raw cv::RNG(-1) stream after the subsets drawn so far (ransac_subsets_kernel)
+    int arrive;    // ransac_rest_kernel: workgroups of this frame that have finished their hypotheses (0 between launches)
+    int pad_;
+};
+
+// what ransac_replay_kernel needs to solve the four-point frames on the way (pnp.hip, p3p_frame); xyz = null: not this launch
+struct P3pArgs {
+    const float *xyz = nullptr;
+    const float2 *uv = nullptr;
+    size_t uv_stride = 0;
+    int cap = 0;
+    int32_t *inliers = nullptr;
+    PnpResult *results = nullptr;
 };
 
 // findEssentialMat(points0, points1, focal, pp, RANSAC, prob, threshold) + recoverPose (visualOdometry.cpp:152-153)
@@ -122,7 +134,9 @@ void launch_scharr(const PyrImage *d_imgs, int n_images, int first_level, int n_
 #endif
 void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, const int *lw, const int *lh, const int *lstride,
                           hipStream_t stream);
-void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream); // pyramid.hip: a staged host image over PCIe by a kernel
+// pyramid.hip: a staged host image over PCIe by a kernel (+ optionally n_pts float2 and their count from pinned memory)
+void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipStream_t stream, const void *pts_pinned_dev = nullptr,
+                       void *pts_dst = nullptr, int n_pts = 0, int *count_dst = nullptr);
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
@@ -179,7 +193,8 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 // epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
-                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames);
+                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames, int32_t *inliers,
+                       PnpResult *results);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);

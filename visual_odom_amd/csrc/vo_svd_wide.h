@@ -157,7 +157,11 @@ __device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 template <int N, int ROWS>
 struct JacobiPipe {
     static constexpr int P = N, D = 2 * N - 3;
-    uint8_t e[P][ROWS][3]; // slot phi = 1 .. P: {i, j, 1 = pair of the OLDER sweep}; i = 255: nothing to do
+    // slot phi = 1 .. P, DPP row r: i | j << 4 | (1 = pair of the OLDER sweep) << 8 | (1 = a pair to do) << 9.  One 16-bit entry
+    // per (slot, row), fetched ONE SLOT AHEAD (round 5): the table lives in global memory, and the three byte loads of the
+    // first version sat at the head of every slot with a wait behind each (two round trips to the cache per slot, 77 slots per
+    // 12 x 12 matrix, ~41 per 6 x 6 solve).
+    uint16_t e[P][ROWS];
 };
 template <int N, int ROWS>
 constexpr JacobiPipe<N, ROWS> jacobi_pipe()
@@ -173,14 +177,12 @@ constexpr JacobiPipe<N, ROWS> jacobi_pipe()
                 const int j = d - i;
                 if (j <= i || j > N - 1)
                     continue;
-                t.e[phi - 1][n][0] = (uint8_t)i; // (n < ROWS: an index past the array stops the constant evaluation)
-                t.e[phi - 1][n][1] = (uint8_t)j;
-                t.e[phi - 1][n][2] = (uint8_t)old;
+                t.e[phi - 1][n] = (uint16_t)(i | j << 4 | old << 8 | 1 << 9); // (n < ROWS: an index past the array stops the constant evaluation)
                 n++;
             }
         }
         for (; n < ROWS; n++)
-            t.e[phi - 1][n][0] = t.e[phi - 1][n][1] = 255;
+            t.e[phi - 1][n] = 0;
     }
     return t;
 }
@@ -216,12 +218,15 @@ VO_WIDE_FN void jacobi_pipe_sweeps(const JacobiPipe<N, ROWS> &tab, double *At, d
     }
     wide_sync(ONE_WAVE);
     bool chg_old = false, chg_new = false; // this thread's row rotated something in the older / the newest sweep
+    uint32_t ent_next = tab.e[0][row];
     for (int sweep = 0;; sweep++) {         // `sweep` = index of the newest sweep in flight
         const bool new_on = sweep < max_iter;
         for (int phi = 1; phi <= P; phi++) {
-            const int i = tab.e[phi - 1][row][0], j = tab.e[phi - 1][row][1];
-            const bool old = tab.e[phi - 1][row][2] != 0;
-            if (i != 255 && (old ? sweep >= 1 : new_on)) {
+            const uint32_t ent = ent_next;
+            ent_next = tab.e[phi == P ? 0 : phi][row]; // the next slot's entry: in flight while this slot computes
+            const int i = ent & 15, j = ent >> 4 & 15;
+            const bool old = (ent >> 8 & 1) != 0, todo = (ent >> 9 & 1) != 0;
+            if (todo && (old ? sweep >= 1 : new_on)) {
                 const double ai = At[i * N + k], aj = At[j * N + k];
                 double a = W[i], b = W[j];
                 double p = row_ordered_sum<N>(ai * aj);
