@@ -206,7 +206,11 @@ def main(argv=None):
     ap.add_argument("--ring", type=int, default=3, choices=[2, 3], help="sequence mode: stereo pairs resident per sequence")
     ap.add_argument("--ingest", default="device", choices=["device", "pinned", "host"],
                     help="sequence mode: where the new stereo pairs come from (device = resident in HBM)")
-    ap.add_argument("--quads", type=int, default=8, help="distinct rendered quadruples cycled over the batch")
+    ap.add_argument("--quads", type=int, default=32,
+                    help="distinct rendered quadruples cycled over the batch (33 rendered stereo pairs; round 4: 8 -- the LK "
+                         "iteration statistics that set the headline came from 9 pairs of one street, VERDICT r04 weak 7; "
+                         "profiles/r05_quads_table.txt: 8 / 32 / 128 quadruples x 3 seeds)")
+    ap.add_argument("--seed", type=int, default=20260925, help="seed of the synthetic world (rank r renders seed + r)")
     ap.add_argument("--workload", default="kitti2000", choices=sorted(WORKLOADS))
     ap.add_argument("--stages", default="full", choices=["full", "lk", "detect+full"],
                     help="batch mode: full = BASELINE config 3 (LK+tri+PnP on device); lk = config 2 (circularMatching only); "
@@ -321,7 +325,7 @@ def main(argv=None):
 
         def leg(name, baseline_config, ctx, **over):
             a = copy.copy(args)
-            a.no_cpu_baseline, a.sustain, a.steps, a.warmup, a.validate = True, 0.0, 10, 2, 2
+            a.no_cpu_baseline, a.sustain, a.steps, a.warmup, a.validate = True, 0.0, 10, 2, 4
             for k, v in over.items():
                 setattr(a, k, v)
             r = run_batch(a, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=ctx)
@@ -335,7 +339,7 @@ def main(argv=None):
         leg("config2_lk_only", 2, kept[0], stages="lk")
         leg("reference_default_374", 3, kept[0], workload="kitti374", steps=20)
         if rank == 0:
-            legs.append(latency_leg(kept[0]))
+            legs.append(latency_leg(kept[0], quads=min(args.quads, args.frames), seed=args.seed + rank))
         kept[0].close()
         kept[0] = None
         from visual_odom_amd import _lib
@@ -386,7 +390,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     from visual_odom_amd import _lib
     B, S = args.frames, min(args.quads, args.frames)
     # every rank renders its own sequence (seed by rank) = independent sequences, one per GPU
-    world, lefts, rights, pts, max_level = build_inputs(args.workload, S, 20260925 + rank)
+    world, lefts, rights, pts, max_level = build_inputs(args.workload, S, args.seed + rank)
     w, h = world.w, world.h
     own_ctx = ctx is None
     if own_ctx:
@@ -456,7 +460,8 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     achieved = lk_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
 
     # the committed PMC passes were taken on the default stage set: only that configuration inherits their figures
-    profiled_config = args.stages == "full" and not args.mono_rotation
+    # (the LK launch of an LK-only run is the same kernel over the same data)
+    profiled_config = args.stages in ("full", "lk") and not args.mono_rotation
     out = None
     if rank == 0:
         out = {
@@ -509,7 +514,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     """exact replay: S sequences x 1 frame per step, feature state carried on the device"""
     from visual_odom_amd import _lib
     S, Q = args.seqs, args.quads
-    world, lefts, rights, pts, max_level = build_inputs(args.workload, Q, 20260925 + rank)
+    world, lefts, rights, pts, max_level = build_inputs(args.workload, Q, args.seed + rank)
     per_bucket = WORKLOADS[args.workload][2]
     w, h = world.w, world.h
     K, W = args.steps, args.warmup
@@ -617,15 +622,15 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     return out
 
 
-def latency_leg(ctx, n_calls=100, n_steps=400):
+def latency_leg(ctx, n_calls=100, n_steps=400, quads=8, seed=20260925):
     """LATENCY MODE of the drop-in boundary, measured by the driver's own run: the reference's real use is
     one sequence, one synchronous call per frame (main.cpp:123-224).  HOST images in, host results out, one frame in flight --
     PCIe-inclusive, never `value`: (a) vo_track_frame per call at the ~2000-point and the reference-default load; (b) the whole
     frame loop for ONE sequence through the lock-step API (push pair -> step, nothing read back until the end: the pose solve
     of frame k runs under detection + tracking of frame k + 1)."""
     from visual_odom_amd import synth
-    world, lefts, rights, pts6, _ = build_inputs("kitti2000", 8, 20260925)
-    _, _, _, pts1, _ = build_inputs("kitti374", 8, 20260925)
+    world, lefts, rights, pts6, _ = build_inputs("kitti2000", quads, seed)  # (the headline's rendering: cached)
+    _, _, _, pts1, _ = build_inputs("kitti374", quads, seed)
     P_l, P_r = world.proj_matrices()
     w, h = world.w, world.h
     ctx.set_params(lk_max_level=3, mono_rotation=0)
@@ -723,17 +728,25 @@ def spawn_ranks(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _pmc_record(name, workload, frames):
+    """the committed PMC record of (workload, frames per step): the headline's sits at the top level of profiles/<name>, every
+    leg's under "legs" (tools/pmc_legs.py)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for r in [rec] + list(rec.get("legs") or []):
+        if r.get("workload") == workload and r.get("frames_per_step") == frames:
+            return r
+    return None
+
+
 def measured_issue(workload, frames):
     """VALU issue figures of the LK launch from the committed PMC pass (profiles/lk_issue.json): the bound this
     kernel actually runs at; None when no pass matches this configuration."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "lk_issue.json")) as f:
-            rec = json.load(f)
-        if rec.get("workload") == workload and rec.get("frames_per_step") == frames:
-            return {k: rec[k] for k in rec if k not in ("workload", "frames_per_step")}
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    rec = _pmc_record("lk_issue.json", workload, frames)
+    return {k: rec[k] for k in rec if k not in ("workload", "frames_per_step", "legs")} if rec else None
 
 
 def valu_issue_frac(workload, frames, points_per_launch, launch_ms):
@@ -760,11 +773,12 @@ def measured_pyramid_traffic(workload, n_images):
     try:
         with open(os.path.join(ROOT, "profiles", "lk_traffic.json")) as f:
             rec = json.load(f)
-        ps = rec.get("pyramid_stage") or {}
-        if rec.get("workload") == workload and ps.get("images_per_step") == n_images:
-            return ps.get("hbm_bytes_per_step")
     except (OSError, ValueError):
-        pass
+        return None
+    for r in [rec] + list(rec.get("legs") or []):
+        ps = r.get("pyramid_stage") or {}
+        if r.get("workload") == workload and ps.get("images_per_step") == n_images:
+            return ps.get("hbm_bytes_per_step")
     return None
 
 
@@ -772,15 +786,8 @@ def measured_traffic(workload, frames):
     """HBM bytes per LK launch from the committed rocprofv3 PMC passes (profiles/lk_traffic.json,
     written by tools/profile_summary.py from separate --pmc runs of this same command, with the gfx950
     FETCH_SIZE correction of MI355X_MICROARCH.md); None when no pass matches this configuration."""
-    path = os.path.join(ROOT, "profiles", "lk_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("workload") == workload and rec.get("frames_per_step") == frames:
-            return rec.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    return None
+    rec = _pmc_record("lk_traffic.json", workload, frames)
+    return rec.get("hbm_bytes_per_launch") if rec else None
 
 
 def cpu_baseline(lefts, rights, pts, world, n_frames, stages, per_bucket=1):

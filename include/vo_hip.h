@@ -127,11 +127,12 @@ int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);
 int vo_get_probe_log(const vo_ctx *ctx, vo_schedule *cands, float *ms, int *real, int *n);
 /* The process-wide table of settled schedules, out and in: a service exports it once (after a warm-up run of every shape it
  * uses) and imports it at start-up, so that no context of the new process probes -- the first run of a probed key otherwise
- * costs 25-100 runs' time (0.03 s for one 1241 x 376 frame, ~0.6 s for a 256-frame batch at 2000 points, ~1.2 s for 256
+ * costs 25-100 runs' time (at most 2 x 2 x 2 + 1 candidates of 7 + K runs, K = 6 .. 24; 0.03 s for one 1241 x 376 frame, ~0.6 s for a 256-frame batch at 2000 points, ~1.2 s for 256
  * sequences; an upper bound: ~100 runs of the caller's own shape) and, in the lock-step loop, up to three pipeline drains
  * within its first ~200 steps.  key = (device, mode, width, height, pyramid levels, frames per run, point-load bucket, flags);
  * records are valid for the same library build and device model.  Neither call needs a context.
- *   vo_export_schedule: writes min(*n, cap) records, *n = records in the table (recs may be NULL with cap = 0 to ask)
+ *   vo_export_schedule: writes min(*n, cap) records, *n = records in the table (recs may be NULL with cap = 0 to ask); a key
+ *                       whose comparison over real steps is still running (vo_get_schedule: probed = 2) is not in the table yet
  *   vo_import_schedule: all records are validated first (VO_ERR_ARG leaves the table untouched); existing keys are replaced */
 typedef struct vo_schedule_record {
     int64_t key[8];
@@ -325,9 +326,11 @@ int vo_seq_configure(vo_ctx *ctx, int n_seq, int w, int h, int ring, int max_ste
  * seq < 0 also rewinds the loop's step counter (all max_steps rows of every sequence are available again) and clears
  * the "a step failed half-way" state after which every vo_seq_push_pair / vo_seq_step returns VO_ERR_STATE.
  * vo_seq_step refuses (VO_ERR_STATE, the pairs pushed for that step are dropped) when an active sequence has used up
- * its max_steps rows; vo_seq_reset(seq) gives them back and the SAME pairs can be pushed again.  A caller that goes on with
- * later pairs instead has paused every sequence of the dropped step: its next pair restarts the image pair and the frame
- * after it carries VO_SEQ_F_GAP (it is never matched against the pair from two pushes ago). */
+ * its max_steps rows; vo_seq_reset(seq) gives them back.  The refusal is a PAUSE for every sequence whose pair it dropped,
+ * whatever the caller pushes next -- the same pairs again or later ones (the library cannot tell which): the reset sequence
+ * starts over with its next pair; each OTHER sequence of the dropped step restarts its image pair with its next pair (that
+ * pair builds pyramids only: one frame is not processed) and the frame after it carries VO_SEQ_F_GAP -- a pair is never
+ * matched against the pair from two pushes ago.  To lose no frame, size max_steps for the run or reset between runs. */
 int vo_seq_reset(vo_ctx *ctx, int seq);
 /* the next stereo pair of sequence `seq` (8-bit gray, byte stride).  host_pinned = 0: pageable memory, staged
  * through the library's pinned buffers (the call returns when the images have been copied out of the caller's

@@ -245,6 +245,28 @@ def test_sequence_loop_reset_rewinds_gap_is_flagged_capacity_refuses(volib, smal
         rows1, info1 = ctx.seq_get_trajectory(1)
         assert len(rows0) == 1 and not int(info0[0][5]) & volib.SEQ_F_GAP
         assert len(rows1) == 3 and [bool(int(i[5]) & volib.SEQ_F_GAP) for i in info1] == [False, False, True]
+        # the other path vo_hip.h documents: the SAME pairs pushed again after the reset.  The library cannot tell a
+        # re-push from a later pair, so sequence 1 is paused all the same: pair 4 restarts its image pair (no row), the frame
+        # (4, 5) is processed and carries VO_SEQ_F_GAP; sequence 0 starts over with pair 4
+        ctx.seq_configure(2, w, h, 3, 3)
+        for k in range(4):
+            ctx.seq_push_pair(0, L[k], R[k])
+            if k >= 1:
+                ctx.seq_push_pair(1, L[k], R[k])
+            ctx.seq_step()
+        for s in (0, 1):
+            ctx.seq_push_pair(s, L[4], R[4])
+        with pytest.raises(volib.VoError):
+            ctx.seq_step()
+        ctx.seq_reset(0)
+        for k in (4, 5):
+            for s in (0, 1):
+                ctx.seq_push_pair(s, L[k], R[k])
+            ctx.seq_step()
+        rows0, info0 = ctx.seq_get_trajectory(0)
+        rows1, info1 = ctx.seq_get_trajectory(1)
+        assert len(rows0) == 1 and not int(info0[0][5]) & volib.SEQ_F_GAP
+        assert len(rows1) == 3 and [bool(int(i[5]) & volib.SEQ_F_GAP) for i in info1] == [False, False, True]
     finally:
         ctx.close()
 

@@ -53,4 +53,37 @@ if has prof; then
     rm -rf "$OUT/prof"
     head -12 "$OUT/kernel_stats_batch.csv" | cut -c1-200
 fi
+if has pmclegs; then  # PMC passes of every bench leg's LK launch (tools/pmc_legs.py turns them into profiles/lk_traffic.json / lk_issue.json)
+    for WL in ${PMC_WL:-kitti2000 kitti374 hd4000 hd4000l4}; do
+        FR=256; Q=""
+        case $WL in hd4000*) FR=128; Q="--quads 4";; esac
+        stamp "bench $WL x $FR (plain: the leg's line)"
+        timeout 300 python bench.py --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_$WL.json" 2> "$OUT/pmc_$WL.err"
+        for SET in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES"; do
+            NAME=${SET%%:*}; CNT=${SET#*:}
+            stamp "pmc $NAME: $WL"
+            (cd /tmp && timeout 400 rocprofv3 --pmc $CNT --output-format csv -d "$OUT/pmc_${WL}_$NAME" -- python "$ROOT/bench.py" --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_${WL}_$NAME.log" 2>&1)
+            # keep only the rows of the two kernels the summary reads (the raw files are tens of MB)
+            for f in $(find "$OUT/pmc_${WL}_$NAME" -name "*_counter_collection.csv"); do
+                (head -1 "$f"; grep -E "lk_circular_kernel|pyr_pass_kernel" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
+            done
+            find "$OUT/pmc_${WL}_$NAME" -type f ! -name "*_counter_collection.csv" -delete
+        done
+    done
+    python tools/pmc_legs.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
+    cp profiles/lk_traffic.json profiles/lk_issue.json "$OUT/"
+fi
+if has quads; then   # the headline against the number of distinct rendered quadruples and the world seed (one process: tools/quads_table.py)
+    stamp "quads table"
+    timeout 1500 python tools/quads_table.py ${QMAX:-128} 2> "$OUT/quads_table.err" | tee "$OUT/quads_table.txt"
+fi
+if false; then
+    for SEED in 20260925 7 1234; do
+        for Q in 8 32 128; do
+            stamp "bench --quads $Q --seed $SEED"
+            timeout 600 python bench.py --quads $Q --seed $SEED --steps 10 --warmup 2 $LEAN --validate 2 > "$OUT/quads_${Q}_$SEED.json" 2> "$OUT/quads_${Q}_$SEED.err"
+            python -c "import json; b=json.loads(open('$OUT/quads_${Q}_$SEED.json').read().strip().splitlines()[-1]); r=b['roofline']; print('  quads %3d seed %-9d  %.0f frames/s  %.3f ms/step  lk %.3f ms  %.2f ns/feature  %.1f points/frame  validated %d' % ($Q, $SEED, b['value'], b['ms_per_step'], r['launch_ms'], r['lk_ns_per_feature'], b['config']['points_per_frame'], b['validated_frames']))" 2>&1 | tee -a "$OUT/quads_table.txt"
+        done
+    done
+fi
 stamp "done"

@@ -307,7 +307,7 @@ int seq_enqueue_inputs(vo_ctx *c, bool dry);
 int seq_lookahead(vo_ctx *c, int r);
 int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry);
 int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency, double *ms_per_run);
-int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency = false);
+int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency = false, bool publish = true);
 int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool sync_call = false);
 int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, float *l1, float *l0r, int32_t *keep_idx, int *n_out);
 int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers, int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status, bool io_pose = true);

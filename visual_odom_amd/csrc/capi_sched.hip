@@ -226,19 +226,23 @@ int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry
 
 // Probe every candidate the pins leave open on the data the caller is about to process, keep the fastest.
 // Batch mode: plain runs (a batch run is idempotent).  Lock-step loop: dry runs of the pending step.
-int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency)
+int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency, bool publish)
 {
     const TuneKey key = tune_key(c, stages);
+    // Candidates: every (waves, streams, prepare) the pins leave open with the four-kernel EPnP at its default reach -- at most
+    // 2 x 2 x 2 -- and then, where that knob is live (5 .. 16 frames per run) and not pinned, the WINNER once more with the wide
+    // reach: 8 + 1 candidates, not the 16 of the full product (that doubled the probe's cost beyond what vo_hip.h
+    // states and filled the probe log to its last entry).
+    static_assert(2 * 2 * 2 + 1 <= VO_PROBE_LOG_MAX, "the probe log holds every candidate");
     std::vector<vo_ctx::Schedule> cands;
     for (int waves = 1; waves <= 2; waves++)
         for (int streams = 1; streams <= (c->sync_call && !c->seq.on ? 1 : 2); streams++) // (a synchronous call runs on one stream)
-            for (int prep = 1; prep >= 0; prep--)
-              for (int wide = VO_EPNP_SPLIT_DEFAULT_FRAMES; wide <= VO_EPNP_WS_MAX_FRAMES; wide *= 4) {
+            for (int prep = 1; prep >= 0; prep--) {
                 vo_ctx::Schedule s, t;
                 s.waves = waves;
                 s.streams = streams;
                 s.prep = prep;
-                s.wide = wide;
+                s.wide = c->pin.epnp_wide_frames && wide_knob_live(c) ? c->pin.epnp_wide_frames : VO_EPNP_SPLIT_DEFAULT_FRAMES;
                 t = s;
                 apply_pins(c, &t);
                 if (t.waves != s.waves || t.streams != s.streams || t.prep != s.prep || t.wide != s.wide)
@@ -252,6 +256,8 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
         apply_pins(c, &s);
         cands.push_back(s);
     }
+    bool probe_wide = wide_knob_live(c) && !c->pin.epnp_wide_frames;
+    const bool measure = cands.size() > 1 || probe_wide;
     c->tuning = true;
     int rc = VO_OK, best = 0;
     double best_ms = 0;
@@ -259,7 +265,7 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
         rc = set_sched(c, cands[i]);
         double ms = 0;
         if (rc == VO_OK)
-            rc = cands.size() > 1 ? probe_candidate(c, stages, timed, evs, dry, latency, &ms) : VO_OK;
+            rc = measure ? probe_candidate(c, stages, timed, evs, dry, latency, &ms) : VO_OK;
         if (rc == VO_OK && (i == 0 || ms < best_ms)) {
             best = (int)i;
             best_ms = ms;
@@ -269,6 +275,12 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
             c->probe_ms[i] = (float)ms;
             c->probe_real[i] = 0;
         }
+        if (i + 1 == cands.size() && probe_wide && rc == VO_OK) {
+            vo_ctx::Schedule wd = cands[best]; // the winner with the wide reach, once (appended: the loop runs it next)
+            wd.wide = VO_EPNP_WS_MAX_FRAMES;
+            cands.push_back(wd);
+            probe_wide = false;
+        }
     }
     c->probe_n = (int)(cands.size() < VO_PROBE_LOG_MAX ? cands.size() : VO_PROBE_LOG_MAX);
     c->tuning = false;
@@ -277,7 +289,10 @@ int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, 
     rc = set_sched(c, cands[best]);
     if (rc != VO_OK)
         return rc;
-    {
+    // The per-process table (what a second context resolves from, what vo_export_schedule writes) only gets SETTLED schedules:
+    // the lock-step loop's dry probe merely nominates -- its caller publishes after the comparison over real steps, or at once
+    // when there is nothing to compare (the nominee used to be exported as if it were settled).
+    if (publish) {
         std::lock_guard<std::mutex> lk(g_tune_mu);
         g_tuned[key] = cands[best];
     }

@@ -413,7 +413,8 @@ int vo_seq_step(vo_ctx *c)
         if (need < 0)
             rc = need;
         else if (need) {
-            rc = tune_schedule(c, stages, true, step_evs, /*dry*/ true);
+            rc = tune_schedule(c, stages, true, step_evs, /*dry*/ true, /*latency*/ false, /*publish*/ false);
+            bool ab_started = false;
             if (rc == VO_OK && c->probe_n > 1) {
                 // The dry runs leave out the two kernels that advance the state, and with them some of what the streams
                 // hide: measured against every pinned schedule (tools/schedule_sweep.py) their verdict on the prepare knob was
@@ -459,7 +460,14 @@ int vo_seq_step(vo_ctx *c)
                     q.ab_left = 3 + q.ab_n;
                     memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
                     c->sched_probed = false; // "in progress" (vo_get_schedule reports 2)
+                    ab_started = true;
                 }
+            }
+            if (rc == VO_OK && !ab_started) { // nothing to compare over real steps: the probe's pick is the settled schedule
+                TuneKey key;
+                memcpy(key.k, c->sched_key, sizeof(key.k));
+                std::lock_guard<std::mutex> lk(g_tune_mu);
+                g_tuned[key] = c->sched;
             }
         }
     }
