@@ -249,9 +249,14 @@ def main(argv=None):
             raise SystemExit("bench.py: --gpus %d contradicts the launcher's WORLD_SIZE=%d" % (args.gpus, env_ws))
         return spawn_ranks(args, sys.argv[1:] if argv is None else list(argv))
 
-    import torch
     from visual_odom_amd import replicas
     rank, local_rank, world_size = replicas.rank_info()
+    # One rank per GPU also means one host per GPU: each rank keeps a contiguous slice of the node's cores (its OpenMP teams --
+    # the validation's oracle, the CPU baseline -- and its staging threads stay off the other ranks' cores), sized before the
+    # first OpenMP runtime of the process starts; once the GPU is known the slice moves to the GPU's NUMA node (below).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world_size)))
+    pin = replicas.pin_rank(local_rank, local_world)
+    import torch
     if args.selftest_replicas:
         dist = replicas.init("gloo")
         if dist is not None:
@@ -261,6 +266,17 @@ def main(argv=None):
                "unit": "frames/s", "n_gpus": world_size, "ranks": world_size, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "data": "SELFTEST of the multi-rank control flow: no GPU work, fabricated timings -- not a measurement"}
+        # ... and of the config-5 leg's (one sequence per GPU: per-GPU figures gathered, aggregate = frames of all ranks / the
+        # slowest rank's time) and of the per-rank core slices
+        t5 = 0.5 + 0.01 * rank
+        e5, f5 = replicas.aggregate(dist, t5, 200)
+        per_gpu = replicas.gather_values(dist, 200 / t5)
+        cpus = replicas.gather_values(dist, pin.get("cpus") or 0)
+        first = replicas.gather_values(dist, -1 if pin.get("first_cpu") is None else pin["first_cpu"])
+        out["configs"] = [{"name": "config5_one_sequence_per_gpu", "baseline_config": 5, "value": f5 / e5, "unit": "frames/s",
+                           "per_gpu_value": per_gpu, "ranks": world_size, "sequences_per_gpu": 1}]
+        out["host_cores_per_rank"] = {"cpus": [int(c) for c in cpus], "first_cpu": [int(c) for c in first],
+                                      "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist is not None:
@@ -281,6 +297,17 @@ def main(argv=None):
     local_dev = local_rank % n_dev  # one GPU per rank on a real node
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    if local_world > 1:  # the slice again, now on the NUMA node each rank's GPU hangs off (sysfs; contiguous split where it is silent)
+        numa = {}
+        for r in range(local_world):
+            p = torch.cuda.get_device_properties(r % n_dev)
+            bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+            numa[r] = replicas.gpu_numa_cpus(bus)
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))  # (undo the first slice: plan from the node's whole core set)
+        except OSError:
+            pass
+        pin = replicas.pin_rank(local_rank, local_world, numa)
 
     def barrier(ctx):
         ctx.batch_sync()
@@ -378,6 +405,8 @@ def main(argv=None):
                 "schedule": r5["config"]["schedule"], "stage_ms": r5["config"]["stage_ms"], "roofline": r5["roofline"]})
     if kept and kept[0] is not None:
         kept[0].close()
+    if rank == 0 and out is not None and world_size > 1:
+        out["config"]["host_cores_rank0"] = pin  # this rank's slice of the node's cores (replicas.pin_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -841,29 +870,10 @@ def cpu_baseline(lefts, rights, pts, world, n_frames, stages, per_bucket=1):
     best_t = min(med, key=med.get)
     best = timed(best_t, n_frames, 10.0)
     single = timed(1, min(n_frames, 2), 6.0)
-    # the same port built the way a tuned CPU build would be (-O3 -march=native) with OpenCV's x86 accumulation order in the LK
-    # sums (accum_mode 2, oracle/vo_oracle.h) -- still the scalar restatement, but neither -O2 nor exact-integer sums handicap it
-    native = None
-    try:
-        nat = orc.native_variant()
-        if nat is not None:
-            def one_native(k, threads):
-                r = nat.circular_matching(lefts[k], rights[k], lefts[k + 1], rights[k + 1], pts[k], nthreads=threads, accum_mode=2)
-                (l0, r0, l1, r1), _ = orc.check_valid_and_remove(r["l0"], r["r0"], r["l1"], r["r1"], r["l0_ret"])
-                if stages != "lk" and len(l0) >= 5:
-                    nat.solve_pnp_ransac(nat.triangulate(P_l, P_r, l0, r0), l1, K)
-            one_native(0, best_t)
-            t0 = time.perf_counter()
-            n = 0
-            while time.perf_counter() - t0 < 6.0:
-                for k in range(n_frames):
-                    one_native(k, best_t)
-                n += n_frames
-            native = {"value": n / (time.perf_counter() - t0), "unit": "frames/s", "cores": best_t, "kind": "port",
-                      "build": "-O3 -march=native, LK sums in OpenCV's x86 SIMD accumulation order (accum_mode 2)"}
-    except Exception as e:  # the baseline never fails the benchmark
-        native = {"error": str(e)[:200]}
-    return {"value": best, "unit": "frames/s", "cores": best_t, "kind": "port", "native_build": native,
+    # (rounds 3-4 also timed a `-O3 -march=native` build of the same sources in OpenCV's x86 accumulation order as "native_build":
+    # it emulates SIMD lanes with scalar volatile floats, ran SLOWER than this port (43.8 vs 53.7 frames/s) and said nothing about
+    # OpenCV's speed -- dropped, VERDICT r04 weak 9.  The figure below is a port's, reported, never a target.)
+    return {"value": best, "unit": "frames/s", "cores": best_t, "kind": "port",
             "single_thread": {"value": single, "unit": "frames/s", "cores": 1},
             "width_sweep_s_per_frame": {str(t): med[t] for t in widths},
             "sample": "passes over %d frame quadruples of the same workload for ~10 s (best width) and ~6 s (1 thread); "

@@ -18,6 +18,9 @@
 #include <cstring>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
+
 int main(int argc, char **argv)
 {
     std::vector<int> devices;
@@ -55,10 +58,41 @@ int main(int argc, char **argv)
         share[s % W].push_back(dirs[s]);
         ids[s % W].push_back(s);
     }
+    // One host per GPU: worker k (its submitting thread and the decoder threads it starts, which inherit the mask) keeps the k-th
+    // contiguous slice of the cores this process may use -- what bench.py does per rank (visual_odom_amd/replicas.py,
+    // plan_affinity); with more workers than cores the workers share cores round-robin.
+    std::vector<int> avail;
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0)
+            for (int c = 0; c < CPU_SETSIZE; c++)
+                if (CPU_ISSET(c, &set))
+                    avail.push_back(c);
+    }
+    std::vector<int> slice_first(W, -1), slice_n(W, 0);
     std::vector<vohost::WorkerResult> res(W);
     std::vector<std::thread> threads;
     for (int k = 0; k < W; k++)
-        threads.emplace_back([&, k] { res[k] = vohost::run_worker(devices[k], share[k], cal, max_frames, per_bucket, decode_threads); });
+        threads.emplace_back([&, k] {
+            if (W > 1 && !avail.empty()) {
+                cpu_set_t mine;
+                CPU_ZERO(&mine);
+                const int per = (int)avail.size() / W;
+                if (per >= 1) {
+                    for (int c = k * per; c < (k + 1) * per; c++)
+                        CPU_SET(avail[c], &mine);
+                    slice_first[k] = avail[k * per];
+                    slice_n[k] = per;
+                } else {
+                    CPU_SET(avail[k % avail.size()], &mine);
+                    slice_first[k] = avail[k % avail.size()];
+                    slice_n[k] = 1;
+                }
+                (void)pthread_setaffinity_np(pthread_self(), sizeof(mine), &mine);
+            }
+            res[k] = vohost::run_worker(devices[k], share[k], cal, max_frames, per_bucket, decode_threads);
+        });
     for (auto &t : threads)
         t.join();
 
@@ -79,9 +113,10 @@ int main(int argc, char **argv)
     }
     printf("{\"workers\": [");
     for (int k = 0; k < W; k++)
-        printf("%s{\"device\": %d, \"sequences\": %zu, \"frames\": %ld, \"seconds\": %.6f, \"fps\": %.3f, \"decode_wait_s\": %.6f}",
+        printf("%s{\"device\": %d, \"sequences\": %zu, \"frames\": %ld, \"seconds\": %.6f, \"fps\": %.3f, \"decode_wait_s\": %.6f, "
+               "\"host_cores\": %d, \"first_core\": %d}",
                k ? ", " : "", devices[k], share[k].size(), res[k].frames, res[k].seconds,
-               res[k].seconds > 0 ? res[k].frames / res[k].seconds : 0.0, res[k].decode_seconds);
+               res[k].seconds > 0 ? res[k].frames / res[k].seconds : 0.0, res[k].decode_seconds, slice_n[k], slice_first[k]);
     printf("], \"frames\": %ld, \"seconds\": %.6f, \"fps\": %.3f, \"parallelism\": \"replicas x%d (one host thread + one vo_ctx "
            "per worker, no collective)\"}\n", frames, slowest, slowest > 0 ? frames / slowest : 0.0, W);
     return 0;

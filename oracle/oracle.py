@@ -48,46 +48,6 @@ def lib():
     return _lib
 
 
-class _Variant:
-    """another build of the same sources behind the functions bench.py's CPU baseline times (never the checker)"""
-
-    def __init__(self, so):
-        self._so = C.CDLL(so)
-        self._so.orc_lk_last_iteration_count.restype = C.c_longlong
-
-    def _call(self, fn, *a, accum_mode=None, **kw):
-        global _lib
-        saved = _lib
-        _lib = self._so
-        try:
-            if accum_mode is not None:
-                self._so.orc_set_circular_matching_accum_mode(int(accum_mode))
-            return fn(*a, **kw)
-        finally:
-            _lib = saved
-
-    def circular_matching(self, *a, accum_mode=0, **kw):
-        return self._call(circular_matching, *a, accum_mode=accum_mode, **kw)
-
-    def triangulate(self, *a, **kw):
-        return self._call(triangulate, *a, **kw)
-
-    def solve_pnp_ransac(self, *a, **kw):
-        return self._call(solve_pnp_ransac, *a, **kw)
-
-
-def native_variant():
-    """oracle/_build/libvo_oracle_native.so (-O3 -march=native, built on THIS host: the GPU box's CPU is not the authoring
-    container's); None when it cannot be built"""
-    so = os.path.join(_HERE, "_build", "libvo_oracle_native.so")
-    try:
-        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        lib()  # (the OpenMP environment defaults)
-        return _Variant(so)
-    except (OSError, subprocess.CalledProcessError):
-        return None
-
-
 def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -16,6 +16,78 @@ def shard_sequences(n_sequences, rank, world_size):
     return [s for s in range(n_sequences) if s % world_size == rank]
 
 
+def plan_affinity(avail_cpus, local_rank, local_world, numa_cpus=None, ranks_on_my_node=None):
+    """Which host cores rank `local_rank` of `local_world` ranks on this node keeps (a pure function: tests/test_replicas_gloo.py).
+    One process per GPU also means one image decoder / staging thread / oracle validation per GPU; left alone, eight ranks'
+    OpenMP teams of 32 land on the same cores and on the wrong socket.
+      * numa_cpus (the cores of the NUMA node this rank's GPU hangs off) and ranks_on_my_node (the local ranks whose GPUs share
+        that node, sorted) known: the node's available cores split contiguously among those ranks;
+      * else: all available cores split contiguously by local rank.
+    A slice is never empty: with more ranks than cores the ranks share cores round-robin."""
+    avail = sorted(set(int(c) for c in avail_cpus))
+    if not avail or local_world <= 1:
+        return avail
+    pool, idx, n = avail, local_rank, local_world
+    if numa_cpus and ranks_on_my_node and local_rank in ranks_on_my_node:
+        node = sorted(set(int(c) for c in numa_cpus) & set(avail))
+        if node:
+            pool, idx, n = node, sorted(ranks_on_my_node).index(local_rank), len(ranks_on_my_node)
+    if len(pool) < n:
+        return [pool[idx % len(pool)]]
+    per = len(pool) // n
+    return pool[idx * per:(idx + 1) * per]
+
+
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def gpu_numa_cpus(pci_bus_id):
+    """cores of the NUMA node of the GPU at `pci_bus_id` ("0000:c1:00.0"), from sysfs; None when the kernel does not say"""
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
+        if node < 0:
+            return None, None
+        return node, _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+    except (OSError, ValueError):
+        return None, None
+
+
+def pin_rank(local_rank, local_world, numa_of_local_rank=None, omp_cap=32):
+    """sched_setaffinity of this process to its slice of the node's cores (plan_affinity) and OMP_NUM_THREADS to match -- call it
+    before the first OpenMP runtime of the process starts.  numa_of_local_rank: {local rank: (node, [cpus])} when known.
+    Returns what was done (bench.py reports it per rank); never raises."""
+    info = {"local_rank": local_rank, "local_world": local_world, "pinned": False}
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return info
+    numa_cpus = ranks_here = None
+    if numa_of_local_rank and numa_of_local_rank.get(local_rank, (None, None))[0] is not None:
+        node, numa_cpus = numa_of_local_rank[local_rank]
+        ranks_here = [r for r, (nd, _) in numa_of_local_rank.items() if nd == node]
+        info["numa_node"] = node
+    mine = plan_affinity(avail, local_rank, local_world, numa_cpus, ranks_here)
+    if local_world > 1 and mine:
+        try:
+            os.sched_setaffinity(0, mine)
+            info["pinned"] = True
+        except OSError:
+            pass
+    info["cpus"] = len(mine)
+    info["first_cpu"], info["last_cpu"] = (mine[0], mine[-1]) if mine else (None, None)
+    if local_world > 1:
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(len(mine), omp_cap)))
+    return info
+
+
 def init(backend=None):
     """process-group init for the aggregation only; returns torch.distributed or None for 1 rank"""
     rank, local_rank, world_size = rank_info()
