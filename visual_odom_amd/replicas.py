@@ -18,7 +18,7 @@ def shard_sequences(n_sequences, rank, world_size):
 
 def plan_affinity(avail_cpus, local_rank, local_world, numa_cpus=None, ranks_on_my_node=None):
     """Which host cores rank `local_rank` of `local_world` ranks on this node keeps (a pure function: tests/test_replicas_gloo.py).
-    One process per GPU also means one image decoder / staging thread / oracle validation per GPU; left alone, eight ranks'
+    One process per GPU also means one image decoder / staging thread / CPU-side validation per GPU; left alone, eight ranks'
     OpenMP teams of 32 land on the same cores and on the wrong socket.
       * numa_cpus (the cores of the NUMA node this rank's GPU hangs off) and ranks_on_my_node (the local ranks whose GPUs share
         that node, sorted) known: the node's available cores split contiguously among those ranks;
