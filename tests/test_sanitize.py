@@ -7,9 +7,10 @@ reference's own glue sources), and the emulator gives every pyramid level of eve
 an access of a kernel outside a level's bordered allocation aborts the run.  An instrumented library can only be loaded into
 a process that has the ASan runtime first in its link order, so the tier is a child pytest under LD_PRELOAD=libasan.so:
 
-    quick  (part of the CPU suite, ~1.5 min):  FAST tiles of every form, pyramid passes + borders, the LK kernel at small sizes,
-                                             the device-math headers on the host, the oracle's LK / FAST / glue tests
-    full   (`pytest -m sanitize`, ~15 min):    all of tests/test_kernel_emulation.py + every oracle / host-math test file
+    quick  (part of the CPU suite, ~1.3 min):  FAST tiles of every form, pyramid passes + borders, the LK kernel on the small and odd
+                                             shapes, the device-math headers on the host, the oracle's LK / FAST / glue tests, the
+                                             reference's own glue sources
+    full   (`pytest -m sanitize`, ~10 min):    all of tests/test_kernel_emulation.py + every oracle / host-math test file
 
 detect_stack_use_after_return=0: the emulator's wavefronts are ucontext coroutines on their own stacks; detect_leaks=0: the
 interpreter itself leaks by design."""
@@ -22,7 +23,7 @@ import pytest
 from conftest import ROOT
 
 QUICK = ["tests/test_kernel_emulation.py", "-k",
-         "fast or borders or pyramid_and_scharr or pyramid_extremes or decode or lk_kernel_bit_exact or lk_negative",
+         "(fast or borders or pyramid_and_scharr or decode or lk_negative or small_and_odd) and not exhaustive and not row_packing",
          ]
 QUICK_ORACLE = ["tests/test_device_math_on_host.py", "tests/test_oracle_images.py", "tests/test_oracle_glue.py", "tests/test_vo_math.py",
                 "tests/test_reference_glue.py"]
