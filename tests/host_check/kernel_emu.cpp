@@ -103,7 +103,8 @@ void build_pyramids(const Plan &p, const vo::PyrImage *d_imgs, int n_img)
     if (g_pyr_lds == 2 || g_pyr_lds == 3) { // the fused passes (3: workgroups in dispatch order, what launches of fewer than 16 images use)
         const int remap = g_pyr_lds == 2;
         // the fused passes (round 4; what launch_pyramid_fused enqueues): one launch per level
-        const PassPlan pp = pass_plan(p.levels, p.lw, p.lh, p.ls);
+        const PassPlan pp = pass_plan(p.levels, p.lw, p.lh, p.ls, /*wide border items*/ remap != 0); // (the product's two regimes: many images =
+                                                                                                       //  XCD-pinned order + wide items, a few = dispatch order + thin)
         for (int l = 0; l < p.levels; l++)
             {
                 const uint32_t nwg = pass_grid(pp, l, (int)n_img, remap);

@@ -38,6 +38,9 @@ struct __attribute__((packed, aligned(1))) U8x12 {
 struct __attribute__((packed, aligned(4))) U32x4 {
     uint32_t a, b, c, d;
 };
+struct __attribute__((packed, aligned(1))) U8x16 { // 16 bytes at any address
+    uint32_t a, b, c, d;
+};
 
 #if defined(VO_DEV_VARIANTS) || defined(VO_HOST_EMUL)
 // ROUND-3 CHAIN (developer build and CPU emulator only: the A/B partner of the fused passes below, VO_PYR_FUSED=0):
@@ -437,6 +440,7 @@ struct PassPlan {
     int nci[VO_MAX_LEVELS];    // wavefronts (= workgroups) that cover the main groups of one row block: a `row` of the image's workgroups
     int n_tail[VO_MAX_LEVELS]; // edge + border work items (the first rows of an image's workgroups)
     int gy[VO_MAX_LEVELS];     // rows of workgroups per image = the rows that hold the tail items + nb
+    int wide;                  // border work items: 1 = four rows / all side chunks of a row per lane, 0 = one 16-byte chunk per lane
     uint64_t m_img[VO_MAX_LEVELS], m_row[VO_MAX_LEVELS]; // floor(2^64 / (nci gy)) + 1, floor(2^64 / nci) + 1: id -> (image, y, x) by
                                                          // multiply-high, exact for every 32-bit id (pass_div)
 };
@@ -444,21 +448,33 @@ struct __attribute__((packed, aligned(2))) LkU2x { // an 8-byte row window at an
     uint32_t lo, hi;
 };
 
-inline int border_items(int h, int w, int stride)
+// Border work items of the fused pass (round 5): a lane takes one 16-byte chunk column of FOUR rows above / below the image
+// (neighbouring lanes neighbouring chunks: every store instruction of the wavefront writes one contiguous run of a row), or ALL
+// side chunks of one image row (the two left ones and the two to four at the right end) -- 22 wavefronts per KITTI level-0
+// image where one chunk per lane made 91 next to the 235 of the main items (tools/pass_ab.sh, profiles/r05_pyramid_ab.txt).
+// That is the WIDE form, for launches over many images (PassPlan::wide).  A launch over a few images (the synchronous drop-in
+// call: four) is a handful of wavefronts whose slowest lane is the launch's time: there every chunk stays a lane of its own
+// (the THIN form; with the wide one the four passes of a call took 35 us instead of 28, gpurun_out/r5_18).
+constexpr int BORDER_ROWS_PER_ITEM = 4; // outside rows per lane (wide form)
+static_assert((2 * VO_BY) % BORDER_ROWS_PER_ITEM == 0, "row groups of the outside rows");
+inline int border_items(int h, int w, int stride, bool wide)
 {
-    const int cpr = stride >> 4, xr0 = w & ~15;
-    return 2 * VO_BY * cpr + h * (VO_BX / 16 + ((stride - VO_BX - xr0) >> 4));
+    const int cpr = stride >> 4;
+    if (wide)
+        return 2 * VO_BY / BORDER_ROWS_PER_ITEM * cpr + h;
+    return 2 * VO_BY * cpr + h * (VO_BX / 16 + ((stride - VO_BX - (w & ~15)) >> 4));
 }
 
-inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int *lstride)
+inline PassPlan pass_plan(int n_levels, const int *lw, const int *lh, const int *lstride, bool wide = true)
 {
     PassPlan pp = {};
+    pp.wide = wide ? 1 : 0;
     for (int l = 0; l < n_levels; l++) {
         pp.ng[l] = (lw[l] + 3) / 4;
         pp.nm[l] = ((lw[l] - 5) >> 2) + 1; // 4 g + 4 <= w - 1 (= ng - 1: every level is at least 22 columns, plan_levels)
         pp.nb[l] = (lh[l] + PF_ROWS - 1) / PF_ROWS;
         pp.nci[l] = pp.nm[l] > 0 ? (pp.nm[l] + 63) / 64 : 1;
-        pp.n_tail[l] = pp.nb[l] * (pp.ng[l] - pp.nm[l]) + border_items(lh[l], lw[l], lstride[l]);
+        pp.n_tail[l] = pp.nb[l] * (pp.ng[l] - pp.nm[l]) + border_items(lh[l], lw[l], lstride[l], wide);
         pp.gy[l] = pp.nb[l] + (pp.n_tail[l] + 64 * pp.nci[l] - 1) / (64 * pp.nci[l]);
         pp.m_img[l] = ~0ull / (uint64_t)(pp.nci[l] * pp.gy[l]) + 1; // (floor((2^64 - 1) / d) = floor(2^64 / d) unless d is a power of two,
         pp.m_row[l] = ~0ull / (uint64_t)pp.nci[l] + 1;               //  where it is one less and the + 1 lands exactly on 2^64 / d: also exact;
@@ -519,36 +535,48 @@ inline int pass_images_per_launch(const PassPlan &pp, int l)
     return (int)(n >= PASS_MAX_IMAGES + 8 ? PASS_MAX_IMAGES : n < 16 ? 8 : n / 8 * 8 - 8);
 }
 
-// one 16-byte chunk of a level's REFLECT_101 border (the work item of border_fill_kernel)
-__device__ __forceinline__ void border_item(const PyrImage &im, int level, int item)
+// one 16-byte chunk of a level's REFLECT_101 border: columns x0 .. x0 + 15 of bordered row y from the image row `src` it mirrors.
+//   inside the image            the same 16 bytes
+//   left of it / right of it    ONE 16-byte load at the mirrored position, bytes reversed (4 v_perm_b32) -- where a single
+//                               reflection stays inside the row, i.e. everywhere but in levels narrower than the border
+//   straddling the right edge, or a level narrower than the border: byte by byte through reflect101 (one chunk per row)
+// (Round 4 gathered every side chunk byte by byte: 16 loads where one does.)
+__device__ __forceinline__ void border_chunk(VO_GLOBAL uint8_t *__restrict__ p, const VO_GLOBAL uint8_t *__restrict__ src, int y, int x0, int w,
+                                             int stride)
 {
-    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
-    VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
-    const int cpr = stride >> 4;
-    const int xr0 = w & ~15;
-    const int nb = VO_BX / 16 + ((stride - VO_BX - xr0) >> 4);
-    const int n_out = 2 * VO_BY * cpr;
-    int y, x0;
-    if (item < n_out) {
-        const int r = item / cpr;
-        y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
-        x0 = 16 * (item - r * cpr) - VO_BX;
-    } else {
-        item -= n_out;
-        const int r = item / nb, k = item - r * nb;
-        if (r >= h)
-            return;
-        y = r;
-        x0 = k < VO_BX / 16 ? 16 * k - VO_BX : xr0 + 16 * (k - VO_BX / 16);
-    }
-    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)reflect101(y, h) * stride;
     uint32_t v[4];
+    const int xm = x0 + 15 < 0 ? -(x0 + 15) : x0 >= w ? 2 * (w - 1) - (x0 + 15) : -1; // first column of the mirrored run
     if (x0 >= 0 && x0 + 15 < w) {
         const U32x4 t = *(const VO_GLOBAL U32x4 *)(src + x0);
         v[0] = t.a;
         v[1] = t.b;
         v[2] = t.c;
         v[3] = t.d;
+    } else if (xm >= 0 && xm + 15 < w) {
+        const U8x16 t = *(const VO_GLOBAL U8x16 *)(src + xm); // columns xm .. xm + 15 = the chunk's columns in reverse order
+        v[0] = perm_b32(0, t.d, 0x00010203u);
+        v[1] = perm_b32(0, t.c, 0x00010203u);
+        v[2] = perm_b32(0, t.b, 0x00010203u);
+        v[3] = perm_b32(0, t.a, 0x00010203u);
+    } else if (x0 >= 0 && x0 < w && 2 * (w - 1) - (x0 + 15) >= 0) {
+        // the chunk that straddles the right edge (widths that are no multiple of 16: every KITTI level): its first k = w - x0
+        // bytes are the image's, the rest mirror columns w - 2, w - 3 ...: the 16 bytes at x0 as they are (the tail of that load
+        // is border memory of this row, whatever it holds) blended with the reversed 16 bytes at 2 (w - 1) - (x0 + 15), one
+        // v_perm_b32 per dword whose selector takes byte q from the image while 4 d + q < k.  (Byte by byte through reflect101
+        // this one chunk made the lane that owns a row's side chunks the slowest of its wavefront: KITTI level 2 43 us against
+        // 26 without any border work, gpurun_out/r5_14.)
+        const int k = w - x0; // 1 .. 15
+        const U32x4 a = *(const VO_GLOBAL U32x4 *)(src + x0);
+        const U8x16 t = *(const VO_GLOBAL U8x16 *)(src + (2 * (w - 1) - (x0 + 15)));
+        const uint32_t img[4] = {a.a, a.b, a.c, a.d};
+        const uint32_t rev[4] = {perm_b32(0, t.d, 0x00010203u), perm_b32(0, t.c, 0x00010203u), perm_b32(0, t.b, 0x00010203u),
+                                 perm_b32(0, t.a, 0x00010203u)};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int n = k - 4 * d; // bytes of this dword that belong to the image
+            const uint32_t mirrored = n >= 4 ? 0u : n <= 0 ? 0xffffffffu : 0xffffffffu << (8 * n);
+            v[d] = perm_b32(rev[d], img[d], 0x03020100u + (0x04040404u & mirrored));
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -558,6 +586,56 @@ __device__ __forceinline__ void border_item(const PyrImage &im, int level, int i
         }
     }
     *(VO_GLOBAL uint4 *)(p + (ptrdiff_t)y * stride + x0) = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// a border work item of the fused pass (border_items above): items 0 .. 2 VO_BY / 4 cpr - 1 are chunk column c of the four
+// outside rows 4 rg .. 4 rg + 3 (rows 0 .. VO_BY - 1 above the image, the rest below), the next h items the side chunks of one
+// image row each
+__device__ __forceinline__ void border_item(const PyrImage &im, int level, int item, int wide)
+{
+    const int w = im.w[level], h = im.h[level], stride = im.stride[level];
+    VO_GLOBAL uint8_t *__restrict__ p = (VO_GLOBAL uint8_t *)im.lvl[level];
+    const int cpr = stride >> 4;
+    if (!wide) { // one chunk: first the rows above / below the image chunk by chunk, then the side chunks of the image rows
+        const int xr0 = w & ~15, nbc = VO_BX / 16 + ((stride - VO_BX - xr0) >> 4), n_rows = 2 * VO_BY * cpr;
+        int y, x0;
+        if (item < n_rows) {
+            const int r = item / cpr;
+            y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
+            x0 = 16 * (item - r * cpr) - VO_BX;
+        } else {
+            item -= n_rows;
+            const int r = item / nbc, k = item - r * nbc;
+            if (r >= h)
+                return;
+            y = r;
+            x0 = k < VO_BX / 16 ? 16 * k - VO_BX : xr0 + 16 * (k - VO_BX / 16);
+        }
+        border_chunk(p, p + (ptrdiff_t)reflect101(y, h) * stride, y, x0, w, stride);
+        return;
+    }
+    const int n_out = 2 * VO_BY / BORDER_ROWS_PER_ITEM * cpr;
+    if (item < n_out) {
+        const int rg = item / cpr, c = item - rg * cpr;
+#pragma unroll
+        for (int k = 0; k < BORDER_ROWS_PER_ITEM; k++) {
+            const int r = BORDER_ROWS_PER_ITEM * rg + k;
+            const int y = r < VO_BY ? r - VO_BY : h + (r - VO_BY);
+            border_chunk(p, p + (ptrdiff_t)reflect101(y, h) * stride, y, 16 * c - VO_BX, w, stride);
+        }
+        return;
+    }
+    const int y = item - n_out;
+    if (y >= h)
+        return;
+    const VO_GLOBAL uint8_t *__restrict__ src = p + (ptrdiff_t)y * stride;
+#pragma unroll
+    for (int k = 0; k < VO_BX / 16; k++)
+        border_chunk(p, src, y, 16 * k - VO_BX, w, stride);
+    // from the chunk that holds pixel w - 1 (or starts at w) to the end of the row; a chunk that straddles the image edge
+    // rewrites its interior bytes with the values they already have
+    for (int x0 = w & ~15; x0 < stride - VO_BX; x0 += 16)
+        border_chunk(p, src, y, x0, w, stride);
 }
 
 // main work item: column group g (columns 4 g .. 4 g + 3), row block b (rows PF_ROWS b ..)
@@ -792,7 +870,7 @@ __device__ __forceinline__ void pass_dispatch(const PyrImage *__restrict__ imgs,
 #endif
     const int ne = pp.ng[level] - nm, n_edge = nb * ne;
     if (t >= n_edge) {
-        border_item(im, level, t - n_edge);
+        border_item(im, level, t - n_edge, pp.wide);
         return;
     }
     const int b = t / ne, g = nm + (t - b * ne);
@@ -874,7 +952,7 @@ void launch_pyramid_fused(const PyrImage *d_imgs, int n_images, int n_levels, co
 {
     if (n_images <= 0 || n_levels <= 0)
         return;
-    const PassPlan pp = pass_plan(n_levels, lw, lh, lstride);
+    const PassPlan pp = pass_plan(n_levels, lw, lh, lstride, /*wide border items*/ n_images >= 16);
     // (Levels 1 .. L-1 of an image in ONE launch by one workgroup per image -- pyr_tail_kernel, pass / fence + barrier / pass
     // -- was measured first: 0.86 ms for the three small levels of 514 images against 0.46 ms for level 0, gpurun_out/r4_04: a
     // few hundred workgroups of serial phases do not fill the chip.)
