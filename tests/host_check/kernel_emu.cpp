@@ -241,7 +241,7 @@ int ke_post(const float *pts, const float *trk, const uint8_t *status, int n, in
 {
     const int cap = n > 1 ? n : 1;
     int n_pts = n;
-    launch(1, 1, 1, 256, [&] {
+    launch(1, 1, 1, 1024, [&] {
         vo::compact_kernel((const float2 *)pts, (const float2 *)trk, status, &n_pts, cap, threshold, (float2 *)outA, idxA, nA,
                            (float2 *)outB, idxB, nB);
     });
