@@ -292,7 +292,8 @@ static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const f
         const int hn = h0 == 0 ? std::min(first_chunk, iters) : iters - h0;
         const unsigned eg = (unsigned)(hn + 63) / 64;
         if (split == 1 && h0 > 0) { // small launches: the rest of the solve in one launch (ransac_rest_kernel)
-            launch(eg, 1, 1, 64, [&] { ransac_rest_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data(), counts.data(), raw.data(), RNG_TABLE, (int)eg); });
+            std::vector<double> rest_ws((size_t)eg * VO_EPNP_UT_DOUBLES * 64); // (the test picks its own first chunk: sized by this launch)
+            launch(eg, 1, 1, 64, [&] { ransac_rest_kernel<2>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data(), counts.data(), raw.data(), RNG_TABLE, (int)eg, rest_ws.data()); });
             break;
         }
         launch(1, 1, 1, 64, [&] { ransac_subsets_kernel(&n_pts, 1, iters, h0, hn, raw.data(), RNG_TABLE, subsets.data(), &st); });

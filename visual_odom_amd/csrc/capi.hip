@@ -152,7 +152,7 @@ void vo_destroy(vo_ctx *c)
     seq_free(c);
     for (auto &b : c->pb) {
         void *q[] = {b.outB, b.idxB, b.nB, b.xyz, b.subsets, b.inliers, b.models, b.counts, b.rstate, b.results,
-                     b.em_results, b.epnp_ws, b.epnp_gws};
+                     b.em_results, b.epnp_ws, b.epnp_gws, b.rest_ws};
         for (void *p : q)
             if (p)
                 (void)hipFree(p);
@@ -281,6 +281,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
         ok = ok && dmalloc(&b.rstate, B) == hipSuccess;
         ok = ok && dmalloc(&b.epnp_ws, (size_t)(c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES) *
                                            VO_EPNP_WS_HYPS * VO_EPNP_WS_DOUBLES) == hipSuccess;
+        ok = ok && dmalloc(&b.rest_ws, (size_t)(c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES) *
+                                           pnp_rest_ws_doubles(c->ransac_cap)) == hipSuccess;
 #ifdef VO_DEV_VARIANTS
         ok = ok && dmalloc(&b.epnp_gws, B * VO_EPNP_GWS_BLOCKS * VO_EPNP_UT_DOUBLES * 64) == hipSuccess;
 #endif

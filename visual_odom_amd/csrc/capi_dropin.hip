@@ -183,7 +183,7 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
-               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1, pb.epnp_gws);
+               pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1, pb.epnp_gws, pb.rest_ws);
     VO_HIP_TRY(c, hipGetLastError());
     return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
 }

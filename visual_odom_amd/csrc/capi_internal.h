@@ -88,6 +88,7 @@ struct vo_ctx {
         PnpResult *results = nullptr;
         EmResult *em_results = nullptr; // mono_rotation branch (allocated with the rest of `em` on first use)
         double *epnp_ws = nullptr;      // workspace of the four-kernel EPnP (small launches, pnp.hip)
+        double *rest_ws = nullptr;      // ransac_rest_kernel's 12 x 12 matrices [min(max_frames, VO_EPNP_WS_MAX_FRAMES)][groups][156][64]
         double *epnp_gws = nullptr;     // developer build: the slim chain's 12 x 12 matrices [max_frames][VO_EPNP_GWS_BLOCKS][156][64]
         hipEvent_t ready = nullptr, tri_done = nullptr, done = nullptr; // LK done / triangulation done / pose solve done
         hipEvent_t em_done = nullptr; // essential-matrix chain done (mono_rotation)

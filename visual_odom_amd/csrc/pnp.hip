@@ -611,6 +611,10 @@ __global__ __launch_bounds__(64) void ransac_replay_kernel(const int *__restrict
 //   4. arrives (RansacState::arrive); the workgroup that arrives last replays the control flow over all counts and writes the
 //      frame's state -- every other workgroup has read the state before it arrived, so nobody sees the new one too early.
 // Same device functions as the four kernels, same results.
+// The 12 x 12 matrices of its 64 hypotheses live in a GLOBAL workspace (`rest_ws`: the lane-interleaved block epnp_kernel keeps
+// in 78 KB of LDS) and the kernel is built for two waves per SIMD: next to the following frame's LK launch (the lock-step loop)
+// a wavefront that wants a whole SIMD's registers and half a CU's LDS waited 22-46 us for them -- to find out that it has nothing
+// to do (gpurun_out/r5_21).  The rare frame that does go on pays for it with a slower solve.
 template <int WAVES>
 __global__ __launch_bounds__(64, WAVES) void ransac_rest_kernel(const float *__restrict__ xyz, const float2 *__restrict__ uv,
                                                                 size_t uv_stride, const int *__restrict__ n_pts, int cap,
@@ -618,10 +622,11 @@ __global__ __launch_bounds__(64, WAVES) void ransac_rest_kernel(const float *__r
                                                                 RansacState *__restrict__ rstate, int h0, int hn,
                                                                 double *__restrict__ models, int *__restrict__ counts,
                                                                 const uint32_t *__restrict__ raw, int n_raw,
-                                                                int n_groups /* workgroups per frame = gridDim.x */)
+                                                                int n_groups /* workgroups per frame = gridDim.x */,
+                                                                double *__restrict__ rest_ws /* [frames][n_groups][156][64] */)
 {
-    VO_DYN_LDS(double, s_ut);
     const int frame = blockIdx.y, lane = threadIdx.x;
+    double *s_ut = rest_ws + ((size_t)frame * n_groups + blockIdx.x) * (EPNP_UT_DOUBLES * 64);
     const int count = n_pts[frame];
     if (count <= 5)
         return;
@@ -1078,7 +1083,8 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                        double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames,
                        double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */,
                        int wide_frames /* four-kernel form for launches of up to this many frames (the schedule's knob) */,
-                       int32_t *inliers, PnpResult *results /* of the four-point frames (p3p_frame) */)
+                       int32_t *inliers, PnpResult *results /* of the four-point frames (p3p_frame) */,
+                       double *rest_ws /* [ws_frames][pnp_rest_groups(iters)][156][64]: ransac_rest_kernel's matrices, or null */)
 {
     if (n_frames <= 0)
         return;
@@ -1127,10 +1133,10 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
     for (int h0 = 0; h0 < prm.iters;) {
         const int hn = h0 == 0 ? min(first_chunk, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
-        if (split && h0 > 0) { // small launches: the rest of the solve in one launch, which an ordinary frame leaves at once
+        if (split && h0 > 0 && rest_ws) { // small launches: the rest of the solve in one launch, which an ordinary frame leaves at once
             const uint32_t *tab = rng_table(stream);
-            hipLaunchKernelGGL(ransac_rest_kernel<1>, eg, dim3(64), lds, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
-                               h0, hn, models, counts, tab, tab ? RNG_TABLE : 0, (int)eg.x);
+            hipLaunchKernelGGL(ransac_rest_kernel<2>, eg, dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, subsets, prm, state,
+                               h0, hn, models, counts, tab, tab ? RNG_TABLE : 0, (int)eg.x, rest_ws);
             break;
         }
         launch_ransac_subsets(n_pts, n_frames, prm.iters, h0, hn, subsets, state, stream);
@@ -1202,10 +1208,11 @@ void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, con
 
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
-                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames, double *gws)
+                int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws, int ws_frames, double *gws,
+                double *rest_ws)
 {
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
-                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES, inliers, results);
+                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES, inliers, results, rest_ws);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

@@ -112,6 +112,9 @@ struct SeqIngest {
 // workspace, lane-interleaved per 64-hypothesis block: [frames][VO_EPNP_GWS_BLOCKS][VO_EPNP_UT_DOUBLES][64] doubles
 constexpr int VO_EPNP_UT_DOUBLES = 144 + 12, VO_EPNP_GWS_BLOCKS = 2;
 constexpr int VO_EPNP_WS_DOUBLES = 288, VO_EPNP_WS_HYPS = 128, VO_EPNP_WS_MAX_FRAMES = 16, VO_EPNP_SPLIT_DEFAULT_FRAMES = 4;
+// workgroups per frame of ransac_rest_kernel (64 hypotheses each) and the doubles of its global workspace per frame
+inline int pnp_rest_groups(int iters) { return iters > VO_EPNP_WS_HYPS ? (iters - VO_EPNP_WS_HYPS + 63) / 64 : 1; }
+inline size_t pnp_rest_ws_doubles(int iters) { return (size_t)pnp_rest_groups(iters) * VO_EPNP_UT_DOUBLES * 64; }
 
 #ifndef VO_HOST_EMUL
 struct EmBufs {
@@ -189,12 +192,12 @@ void launch_triangulate(const float *Pl, const float *Pr, const float2 *pl, cons
 void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                 const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state,
                 int32_t *inliers, PnpResult *results, int waves, hipStream_t stream, double *epnp_ws = nullptr,
-                int ws_frames = 0, double *gws = nullptr);
+                int ws_frames = 0, double *gws = nullptr, double *rest_ws = nullptr);
 // epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
                        hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames, int32_t *inliers,
-                       PnpResult *results);
+                       PnpResult *results, double *rest_ws);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);
