@@ -252,7 +252,7 @@ int ke_post(const float *pts, const float *trk, const uint8_t *status, int n, in
 }
 
 // The whole pose solve of ONE frame on the CPU emulator, kernel by kernel in launch_pnp's order: raw RNG table -> per chunk
-// (subsets -> EPnP -> votes -> control-flow replay, the four-point frames' P3P in the first replay; with split = 1 everything behind the first chunk in ransac_rest_kernel) -> winner / inlier mask / Levenberg-Marquardt refinement.
+// (subsets -> EPnP -> votes -> control-flow replay; with split = 1 everything behind the first chunk in ransac_rest_kernel) -> the four-point frames' P3P / winner / inlier mask / Levenberg-Marquardt refinement.
 // split = 1: the first chunk's EPnP as the four kernels small launches use (epnp_prepare / svd12_wave / epnp_approx /
 // epnp_select), 0: epnp_kernel<1>.  first_chunk: 128 or 64 (big launches).  Returns the PnpResult fields and the inliers.
 static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const float *K9, int iters, float reproj,
@@ -281,12 +281,6 @@ static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const f
     PnpResult res;
     memset(&res, 0, sizeof(res));
     int n_pts = n;
-    P3pArgs p3p;
-    p3p.xyz = X.data();
-    p3p.uv = U.data();
-    p3p.cap = cap;
-    p3p.inliers = inl.data();
-    p3p.results = &res;
     emu::dyn_shared() = lds.data();
     for (int h0 = 0; h0 < iters;) {
         const int hn = h0 == 0 ? std::min(first_chunk, iters) : iters - h0;
@@ -310,7 +304,7 @@ static int pnp_ransac_emulated(const float *xyz, const float *uv, int n, const f
                 launch(eg, 1, 1, 64, [&] { epnp_kernel<1, false>(X.data(), U.data(), 0, &n_pts, cap, subsets.data(), prm, &st, h0, hn, models.data(), nullptr); });
         }
         launch((unsigned)hn, 1, 1, 64, [&] { vote_kernel(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, h0, counts.data()); });
-        launch(1, 1, 1, 64, [&] { ransac_replay_kernel(&n_pts, 1, prm, h0 + hn, counts.data(), &st, h0 == 0 ? p3p : P3pArgs()); });
+        launch(1, 1, 1, 64, [&] { ransac_replay_kernel(&n_pts, 1, prm, h0 + hn, counts.data(), &st); });
         h0 += hn;
     }
     launch(1, 1, 1, 256, [&] { select_refine_kernel<1>(X.data(), U.data(), 0, &n_pts, cap, prm, models.data(), &st, inl.data(), &res, tail); });

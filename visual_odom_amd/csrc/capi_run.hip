@@ -275,7 +275,7 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         launch_pnp_ransac(pb.xyz, pb.outB + 2 * cap, (size_t)4 * cap, pb.nB, cap, B, pp, pb.subsets, pb.models, pb.counts,
                           pb.rstate, c->sched.waves, ps, pb.epnp_ws,
                           c->max_frames < VO_EPNP_WS_MAX_FRAMES ? c->max_frames : VO_EPNP_WS_MAX_FRAMES, pb.epnp_gws, c->sched.wide,
-                          pb.inliers, pb.results, pb.rest_ws);
+                          pb.rest_ws);
         if (c->prm.mono_rotation && !serial)
             VO_HIP_TRY(c, hipStreamWaitEvent(ps, pb.em_done, 0)); // `done` covers both chains; the tail below reads E's rotation
         SeqTail tail;

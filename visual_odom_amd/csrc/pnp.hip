@@ -15,8 +15,8 @@
 //                              squared error <= thr^2, wave sum -> inlier count
 //   4. ransac_replay_kernel    one thread per frame continues "keep first strictly better,
 //                              niters = RANSACUpdateNumIters(...)" over the new counts
-//   (frames with exactly 4 points take no part in 1-5: OpenCV switches to P3P and returns solvePnP's answer
-//    directly -- p3p_frame, by the frame's thread of the first ransac_replay_kernel, vo_p3p.h)
+//   (frames with exactly 4 points take no part in 1-4: OpenCV switches to P3P and returns solvePnP's answer
+//    directly -- p3p_frame, thread 0 of the frame's select_refine workgroup, vo_p3p.h)
 //   small launches: everything behind the first chunk is ONE launch (ransac_rest_kernel)
 //   5. select_refine_kernel    one workgroup per frame: winning hypothesis and the last one OpenCV
 //                              would have evaluated (its pose is the start of the final refinement
@@ -578,19 +578,17 @@ __device__ void p3p_frame(const float *__restrict__ xyz, const float2 *__restric
             inliers[(size_t)frame * cap + i] = i;
 }
 
-// RANSACPointSetRegistrator::run continued over a chunk's vote counts, one wavefront per frame -- and, for the frames with
-// exactly four points, the whole solve (p3p_frame, lane 0; round 5: it was a kernel of its own in front of the refinement,
-// 5 us of every synchronous call for a case an ordinary frame never is)
+// RANSACPointSetRegistrator::run continued over a chunk's vote counts, one wavefront per frame.  (A light kernel on purpose:
+// in batch mode it runs next to the following step's LK launch and must fit into whatever an LK wave leaves free -- with the
+// four-point solve inlined here it needed 128 registers + 1 KB of scratch per lane and its 256 wavefronts took 3 ms on average
+// to find room, profiles/r05_kernel_stats_batch_p3p_in_replay.csv.  The four-point frames are solved by the refinement kernel.)
 __global__ __launch_bounds__(64) void ransac_replay_kernel(const int *__restrict__ n_pts, int n_frames, PnpParams prm, int h_end,
-                                                            const int *__restrict__ counts, RansacState *__restrict__ rstate,
-                                                            P3pArgs p3p)
+                                                            const int *__restrict__ counts, RansacState *__restrict__ rstate)
 {
     const int frame = blockIdx.x, lane = threadIdx.x;
     if (frame >= n_frames)
         return;
     const int count = n_pts[frame];
-    if (count == 4 && p3p.xyz && lane == 0)
-        p3p_frame(p3p.xyz, p3p.uv, p3p.uv_stride, p3p.cap, frame, prm, p3p.inliers, p3p.results);
     if (count <= 5)
         return;
     RansacState st = rstate[frame];
@@ -689,10 +687,15 @@ __device__ __forceinline__ void select_refine_frame(const float *__restrict__ xy
         g_pose_prof[16] = VO_POSE_NOW();
 #endif
     if (count < 5) {
-        if (tid == 0 && count != 4) { // (exactly 4 points: p3p_frame has already written this frame's record)
-            res.status = -1;          // CV_Assert(npoints >= 4)
-            res.n_inliers = 0;
-            res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
+        if (tid == 0) {
+            if (count == 4) { // OpenCV's SOLVEPNP_P3P switch: the whole solve by one thread (round 5: a kernel of its own in
+                              // front of this one -- 5 us of every synchronous call for a case an ordinary frame never is)
+                p3p_frame(xyz, uv, uv_stride, cap, frame, prm, inliers, results);
+            } else {
+                res.status = -1; // CV_Assert(npoints >= 4)
+                res.n_inliers = 0;
+                res.niters = res.best_iter = res.max_good = res.lm_iters = 0;
+            }
         }
         return;
     }
@@ -1083,7 +1086,6 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                        double *epnp_ws /* [ws_frames][VO_EPNP_WS_HYPS][VO_EPNP_WS_DOUBLES] or null */, int ws_frames,
                        double *gws /* [n_frames][VO_EPNP_GWS_BLOCKS][156][64] or null */,
                        int wide_frames /* four-kernel form for launches of up to this many frames (the schedule's knob) */,
-                       int32_t *inliers, PnpResult *results /* of the four-point frames (p3p_frame) */,
                        double *rest_ws /* [ws_frames][pnp_rest_groups(iters)][156][64]: ransac_rest_kernel's matrices, or null */)
 {
     if (n_frames <= 0)
@@ -1123,13 +1125,6 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
     if (chunk_env > 0 && chunk_env <= RANSAC_CHUNK && !split)
         first_chunk = chunk_env;
 #endif
-    P3pArgs p3p;
-    p3p.xyz = xyz;
-    p3p.uv = uv;
-    p3p.uv_stride = uv_stride;
-    p3p.cap = cap;
-    p3p.inliers = inliers;
-    p3p.results = results;
     for (int h0 = 0; h0 < prm.iters;) {
         const int hn = h0 == 0 ? min(first_chunk, prm.iters) : prm.iters - h0;
         const dim3 eg((hn + 63) / 64, n_frames);
@@ -1178,14 +1173,13 @@ void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, con
                                h0, hn, models, (double *)nullptr);
         hipLaunchKernelGGL(vote_kernel, dim3(hn, n_frames), dim3(64), 0, stream, xyz, uv, uv_stride, n_pts, cap, prm, models,
                            state, h0, counts);
-        hipLaunchKernelGGL(ransac_replay_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, prm, h0 + hn, counts, state,
-                           h0 == 0 ? p3p : P3pArgs());
+        hipLaunchKernelGGL(ransac_replay_kernel, dim3(n_frames), dim3(64), 0, stream, n_pts, n_frames, prm, h0 + hn, counts, state);
         h0 += hn;
     }
 }
 
-// winner / inlier mask / Levenberg-Marquardt refinement / Rodrigues -- and, in the lock-step loop, the pose integration of
-// every sequence (tail).  (The four-point frames were solved by launch_pnp_ransac's first replay kernel.)
+// the four-point frames (P3P), winner / inlier mask / Levenberg-Marquardt refinement / Rodrigues -- and, in the lock-step loop,
+// the pose integration of every sequence (tail)
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream)
@@ -1212,7 +1206,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
                 double *rest_ws)
 {
     launch_pnp_ransac(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, subsets, models, counts, state, waves, stream, epnp_ws,
-                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES, inliers, results, rest_ws);
+                      ws_frames, gws, VO_EPNP_SPLIT_DEFAULT_FRAMES, rest_ws);
     launch_pnp_refine(xyz, uv, uv_stride, n_pts, cap, n_frames, prm, models, state, inliers, results, waves, SeqTail(), stream);
 }
 

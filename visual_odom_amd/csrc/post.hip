@@ -12,9 +12,9 @@
 
 namespace vo {
 
-// one workgroup per frame, of any whole number of wavefronts up to 16 (round 5: launched with 1024 threads -- a frame's ~2000
-// features in two rounds of loads instead of eight, 15 -> 8 us in the synchronous call's timeline; the rounds are bound by
-// the latency of their loads, not by their arithmetic)
+// one workgroup per frame, of any whole number of wavefronts up to 16 (round 5: small launches use 1024 threads -- a frame's
+// ~2000 features in two rounds of loads instead of eight, 15 -> 8 us in the synchronous call's timeline; the rounds are bound
+// by the latency of their loads, not by their arithmetic; launch_compact)
 __global__ __launch_bounds__(1024) void compact_kernel(const float2 *__restrict__ pts_in,   // [B][cap]
                                                       const float2 *__restrict__ trk,      // [B][4][cap]
                                                       const uint8_t *__restrict__ status,  // [B][4][cap]
@@ -177,7 +177,11 @@ void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *stat
 {
     if (n_frames <= 0)
         return;
-    hipLaunchKernelGGL(compact_kernel, dim3(n_frames), dim3(1024), 0, stream, pts_in, trk, status, n_pts, cap,
+    // 16 wavefronts per frame where the launch is the latency of a call (a handful of frames on an idle GPU); 4 in big launches,
+    // which run next to the following step's LK: a 1024-thread workgroup needs four free wave slots on every SIMD of a CU at
+    // once and waited 4 ms on average for them there (profiles/r05_kernel_stats_batch.csv of gpurun_out/r5_final2)
+    const int threads = n_frames <= 4 ? 1024 : 256;
+    hipLaunchKernelGGL(compact_kernel, dim3(n_frames), dim3(threads), 0, stream, pts_in, trk, status, n_pts, cap,
                        threshold, outA, idxA, nA, outB, idxB, nB);
 }
 

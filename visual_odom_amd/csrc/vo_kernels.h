@@ -43,16 +43,6 @@ struct RansacState {
     int pad_;
 };
 
-// what ransac_replay_kernel needs to solve the four-point frames on the way (pnp.hip, p3p_frame); xyz = null: not this launch
-struct P3pArgs {
-    const float *xyz = nullptr;
-    const float2 *uv = nullptr;
-    size_t uv_stride = 0;
-    int cap = 0;
-    int32_t *inliers = nullptr;
-    PnpResult *results = nullptr;
-};
-
 // findEssentialMat(points0, points1, focal, pp, RANSAC, prob, threshold) + recoverPose (visualOdometry.cpp:152-153)
 struct EmParams {
     double focal, ppx, ppy; // projMatrl(0,0), (0,2), (1,2) as doubles (visualOdometry.cpp:146-147)
@@ -196,8 +186,7 @@ void launch_pnp(const float *xyz, const float2 *uv, size_t uv_stride, const int 
 // epnp_ws: workspace of the four-kernel EPnP used for small launches (pnp.hip; constants above); null = always the one-kernel form
 void launch_pnp_ransac(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, int32_t *subsets, double *models, int *counts, RansacState *state, int waves,
-                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames, int32_t *inliers,
-                       PnpResult *results, double *rest_ws);
+                       hipStream_t stream, double *epnp_ws, int ws_frames, double *gws, int wide_frames, double *rest_ws);
 void launch_pnp_refine(const float *xyz, const float2 *uv, size_t uv_stride, const int *n_pts, int cap, int n_frames,
                        const PnpParams &prm, const double *models, const RansacState *state, int32_t *inliers,
                        PnpResult *results, int waves, const SeqTail &tail, hipStream_t stream);
