@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 GPU session driver.  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r5.sh <tag> <part> [<part> ...]'
-# parts: tests latency phases timeline bench prof pyrab quads pmclegs
+# parts: tests latency phases timeline bench prof seq pmclegs quads
 TAG=${1:-r5}
 shift
 PARTS="$*"
@@ -52,6 +52,20 @@ if has prof; then
     find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_batch.csv"
     rm -rf "$OUT/prof"
     head -12 "$OUT/kernel_stats_batch.csv" | cut -c1-200
+fi
+if has seq; then      # the lock-step loop at the reference-default load, pairs resident in HBM, and PCIe-inclusive at 256 / 8 sequences
+    for S in 256 64 16 8 1; do
+        stamp "bench --mode sequences --seqs $S"
+        timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline ${QUADS:+--quads $QUADS} --validate $([ $S = 256 ] && echo 3 || echo 0) > "$OUT/bench_seq_${S}.json" 2> "$OUT/bench_seq_${S}.err"
+        python -c "import json; b=json.loads(open('$OUT/bench_seq_${S}.json').read().strip().splitlines()[-1]); print('  S=%-4d %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']), b['config']['schedule'])" 2>&1 | tee -a "$OUT/summary.txt"
+    done
+    for ING in pinned host; do
+        for S in 256 8; do
+            stamp "bench --mode sequences --seqs $S --ingest $ING (PCIe-inclusive)"
+            timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 --ingest $ING > "$OUT/bench_seq_${S}_${ING}.json" 2> "$OUT/bench_seq_${S}_${ING}.err"
+            python -c "import json; b=json.loads(open('$OUT/bench_seq_${S}_${ING}.json').read().strip().splitlines()[-1]); print('  S=%-4d $ING %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']))" 2>&1 | tee -a "$OUT/summary.txt"
+        done
+    done
 fi
 if has pmclegs; then  # PMC passes of every bench leg's LK launch (tools/pmc_legs.py turns them into profiles/lk_traffic.json / lk_issue.json)
     for WL in ${PMC_WL:-kitti2000 kitti374 hd4000 hd4000l4}; do

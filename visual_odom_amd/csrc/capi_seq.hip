@@ -444,7 +444,10 @@ int vo_seq_step(vo_ctx *c)
                                 bi = i;
                         if (bi >= 0 && n < 4) {
                             c->ab_list[n].waves = c->probe_cand[bi].pose_waves;
-                            c->ab_list[n].wide = c->probe_cand[bi].epnp_wide_frames;
+                            // the reach of the four-kernel EPnP the dry probe preferred at ITS winner goes to every nominee
+                            // (round 5: the probe tries the wide reach once, at the winner, instead of doubling the candidate
+                            // set; where it helped in round 4's full product it helped every (streams, prepare) pair)
+                            c->ab_list[n].wide = c->sched.wide;
                             c->ab_list[n].streams = st;
                             c->ab_list[n].prep = pr;
                             n++;
@@ -523,13 +526,22 @@ int vo_seq_step(vo_ctx *c)
                     std::lock_guard<std::mutex> lk(g_tune_mu);
                     g_tuned[key] = c->ab_list[best];
                 }
-                for (int k = 0; k < q.ab_cnt; k++) // the log shows what was measured over real steps
+                for (int k = 0; k < q.ab_cnt; k++) { // the log shows what was measured over real steps
+                    bool logged = false;
                     for (int i = 0; i < c->probe_n; i++)
                         if (c->probe_cand[i].pose_waves == c->ab_list[k].waves && c->probe_cand[i].pose_streams == c->ab_list[k].streams &&
                             c->probe_cand[i].prepare == c->ab_list[k].prep && c->probe_cand[i].epnp_wide_frames == c->ab_list[k].wide) {
                             c->probe_ms[i] = t[k] / q.ab_n;
                             c->probe_real[i] = 1;
+                            logged = true;
                         }
+                    if (!logged && c->probe_n < VO_PROBE_LOG_MAX) { // a nominee the dry probe did not run in this form (the wide reach)
+                        const int i = c->probe_n++;
+                        c->probe_cand[i] = vo_schedule{c->ab_list[k].waves, c->ab_list[k].streams, c->ab_list[k].prep, c->ab_list[k].wide};
+                        c->probe_ms[i] = t[k] / q.ab_n;
+                        c->probe_real[i] = 1;
+                    }
+                }
                 q.ab_phase = q.ab_cnt + 1;
                 c->sched_probed = true;
             }
