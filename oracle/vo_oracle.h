@@ -9,8 +9,9 @@
  * convertPointsFromHomogeneous, solvePnPRansac/EPnP/LevMarq, Rodrigues).
  *
  * PARITY UNPINNED: the reference ships no tests / golden vectors and OpenCV is
- * not installed in the authoring container, so this restatement could not be
- * diffed against the real library.  It is pinned instead by analytic ground
+ * installed neither in the authoring container nor on the GPU boxes (probed by
+ * every route in round 5: tools/opencv_probe.sh, profiles/r05_opencv_probe.txt),
+ * so this restatement could not be diffed against the real library.  It is pinned instead by analytic ground
  * truth and independent numpy re-derivations (tests/test_oracle_*.py).  The
  * reference's OWN logic around those algorithms is pinned for real: `make ref`
  * compiles /root/reference/src/{feature,bucket,visualOdometry,utils}.cpp where

@@ -309,7 +309,7 @@ def test_second_context_runs_at_the_speed_of_the_first(volib, small_world):
 
 def test_pnp_ransac_with_exactly_four_points_is_opencv_p3p_switch(volib, orc, host_check):
     """visualOdometry.cpp:176 with K = 4 survivors: OpenCV's `npoints == 4 -> SOLVEPNP_P3P`, solvePnP's answer as is.
-    p3p_kernel (a) against the HOST build of the same header (tests/host_check): bit for bit -- the cubic's cube root / acos /
+    p3p_frame (thread 0 of the refinement workgroup of a four-point frame) (a) against the HOST build of the same header (tests/host_check): bit for bit -- the cubic's cube root / acos /
     cos are vo_math.h's, IEEE operations only, so nothing platform-specific is left in the path; (b) against oracle/orc_p3p.c
     (glibc's pow / acos / cos, like OpenCV): same solution count, inliers 0..3, no refinement, WORST case <= 1e-6 like every
     other pose test (round 3 only bounded the median and the 90th percentile); a quadruple without a P3P

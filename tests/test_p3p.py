@@ -111,7 +111,7 @@ def test_solve_pnp_ransac_with_four_points_is_p3p(orc):
 
 
 def test_device_p3p_source_on_the_host_equals_the_checker(orc, host_check):
-    """csrc/vo_p3p.h (what p3p_kernel runs) compiled by g++ against oracle/orc_p3p.c on planted quadruples: same number of
+    """csrc/vo_p3p.h (what p3p_frame runs on the device) compiled by g++ against oracle/orc_p3p.c on planted quadruples: same number of
     solutions, same first solution.  The header's cubic uses vo_math.h's cbrt / acos / cos (the same bits on the device), the
     oracle glibc's pow / acos / cos like OpenCV: both within one ulp, so ~95 % of the quadruples agree to the bit and the
     rest to what the quartic's closed form makes of one ulp -- WORST case <= 1e-6 like every other pose path (observed
