@@ -9,6 +9,9 @@
 #include <string.h>
 
 using namespace vo;
+#ifndef PASS_BENCH_REPS
+#define PASS_BENCH_REPS 20 // launches per figure (3 under a counter pass: tools/pass_pmc.sh)
+#endif
 
 template <typename F> static float timeit(F launch, int reps)
 {
@@ -64,10 +67,10 @@ int main(int argc, char **argv)
     float tot[4] = {0, 0, 0, 0};
     for (int l = 0; l < L; l++) {
         const uint32_t g1 = pass_grid(pp, l, NI, 1), g0 = pass_grid(pp, l, NI, 0);
-        const float t0 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
-        const float t1 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
-        const float t2 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, 20);
-        const float t3 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g0), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 0); }, 20);
+        const float t0 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, PASS_BENCH_REPS);
+        const float t1 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<1>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, PASS_BENCH_REPS);
+        const float t2 = timeit([&] { hipLaunchKernelGGL(pyr_pass_sm_kernel<2>, dim3(g1), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 1); }, PASS_BENCH_REPS);
+        const float t3 = timeit([&] { hipLaunchKernelGGL(pyr_pass_kernel, dim3(g0), dim3(64), 0, 0, d_imgs, l, L, pp, (uint32_t)NI, 0); }, PASS_BENCH_REPS);
         printf("  level %d (%4d x %3d): %d x %d workgroups per image  non-temporal %6.1f us   ordinary stores %6.1f   no Scharr stores %6.1f   dispatch order (image not pinned to an XCD) %6.1f\n", l, lw[l], lh[l],
                pp.nci[l], pp.gy[l], t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3);
         tot[0] += t0; tot[1] += t1; tot[2] += t2; tot[3] += t3;
