@@ -91,13 +91,4 @@ if has quads; then   # the headline against the number of distinct rendered quad
     stamp "quads table"
     timeout 1500 python tools/quads_table.py ${QMAX:-128} 2> "$OUT/quads_table.err" | tee "$OUT/quads_table.txt"
 fi
-if false; then
-    for SEED in 20260925 7 1234; do
-        for Q in 8 32 128; do
-            stamp "bench --quads $Q --seed $SEED"
-            timeout 600 python bench.py --quads $Q --seed $SEED --steps 10 --warmup 2 $LEAN --validate 2 > "$OUT/quads_${Q}_$SEED.json" 2> "$OUT/quads_${Q}_$SEED.err"
-            python -c "import json; b=json.loads(open('$OUT/quads_${Q}_$SEED.json').read().strip().splitlines()[-1]); r=b['roofline']; print('  quads %3d seed %-9d  %.0f frames/s  %.3f ms/step  lk %.3f ms  %.2f ns/feature  %.1f points/frame  validated %d' % ($Q, $SEED, b['value'], b['ms_per_step'], r['launch_ms'], r['lk_ns_per_feature'], b['config']['points_per_frame'], b['validated_frames']))" 2>&1 | tee -a "$OUT/quads_table.txt"
-        done
-    done
-fi
 stamp "done"
