@@ -232,7 +232,12 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             float prevDX = 0.f, prevDY = 0.f;
             int jx0 = 0, jy0 = 0;
             bool have_tile = false;
-            // tile origins that keep the 40 x 48 tile inside the bordered allocation
+            // tile origins that keep the 40 x 48 tile inside the level's rectangle (vo_dev.h, "reads stay inside their level"):
+            // the last tile ends exactly at the row end (column jstride - VO_BX - 1) and at the last border row
+            static_assert(LK_JT_W % 16 == 0 && VO_BX % 4 == 0, "16-byte tile chunks at 4-byte aligned origins");
+            static_assert(VO_BY >= LK_WIN && LK_JT_W >= LK_WIN + 1 + 12 + 3 && LK_JT_H >= LK_WIN + 1 + 9,
+                          "a tile clamped to the row end / the last border row still covers the window of every corner the "
+                          "reference admits (up to w - 1, h - 1: the borders are at least a window wide)");
             const int jx_max = jstride - VO_BX - LK_JT_W, jy_max = jh + VO_BY - LK_JT_H;
 
             // The window corner stays in the same pixel cell for two iterations out of three, so the Gauss-Newton
