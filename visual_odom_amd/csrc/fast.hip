@@ -551,8 +551,22 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     };
     // BK_PF list entries per thread at a time: their points and ages are requested before the first one is used (the walk was a
     // chain of dependent global loads -- one memory round trip per 256 features, ~14 per frame -- in a kernel that has the chip
-    // to itself: one workgroup per frame)
-    for (int i0 = tid; i0 < n_in; i0 += 256 * BK_PF) {
+    // to itself: one workgroup per frame).
+    // LDS atomics per RUN, not per entry (round 5): the list is "carried features, then FAST's corners in row-major order", so
+    // the 64 consecutive entries a wavefront holds fall into a handful of cells in long runs -- and 64 lanes adding to the same
+    // LDS word are executed one after the other (a frame's ~5 000 entries x 3 atomics: most of the kernel's 32 us in the
+    // one-sequence timeline).  The first lane of a run of equal cells adds the run's length, offers its own index as the
+    // cell's first and the run's last index as its last; counts, first and last are order-free, so the result is the same.
+    const int lane = tid & 63;
+    auto run_of = [&](int b, int *len) { // is this lane the head of a run of equal cells among the wavefront's lanes?  (all 64 lanes call)
+        const int prevb = __shfl_up(b, 1, 64);
+        const bool head = lane == 0 || b != prevb;
+        const unsigned long long H = VO_BALLOT(head), above = H & ~((2ull << lane) - 1ull);
+        *len = (above ? __builtin_ctzll(above) : 64) - lane;
+        return head && b >= 0;
+    };
+    for (int base = 0; base < n_in; base += 256 * BK_PF) { // (wave-uniform trip count: the ballots need all lanes)
+        const int i0 = base + tid;
         float2 pt[BK_PF];
         int ag[BK_PF];
 #pragma unroll
@@ -565,27 +579,34 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < BK_PF; k++) {
-            const int i = i0 + 256 * k;
+            const int i = i0 + 256 * k; // (the wavefront's lanes hold 64 CONSECUTIVE list entries)
+            int b = -2;                 // beyond the list: never equal to a cell or to "ignored" (-1)
             if (i < n_in) {
                 const int hidx = (int)(pt[k].y / (float)bucket_size), widx = (int)(pt[k].x / (float)bucket_size);
                 const int idx = hidx * bw + widx;
-                const int b = (idx < 0 || idx >= nb || ag[k] >= 10) ? -1 : idx;
+                b = (idx < 0 || idx >= nb || ag[k] >= 10) ? -1 : idx;
                 if (i < BK_CELL_CACHE)
                     s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
-                if (b >= 0) {
-                    atomicAdd(&s_cnt[b], 1);
-                    atomicMax(&s_last[b], i);
-                    atomicMin(&s_first[0][b], i);
-                }
+            }
+            int len;
+            if (run_of(b, &len)) {
+                atomicAdd(&s_cnt[b], len);
+                atomicMax(&s_last[b], i + len - 1);
+                atomicMin(&s_first[0][b], i);
             }
         }
     }
     __syncthreads();
     for (int q = 1; q < fpb; q++) { // q-th eligible feature of every bucket, in list order
-        for (int i = tid; i < n_in; i += 256) {
-            const int b = i < BK_CELL_CACHE ? (int)s_cell[i] : cell(i);
-            if (b >= 0 && i > s_first[q - 1][b])
-                atomicMin(&s_first[q][b], i);
+        for (int base = 0; base < n_in; base += 256) {
+            const int i = base + tid;
+            const int b = i >= n_in ? -2 : i < BK_CELL_CACHE ? (int)s_cell[i] : cell(i);
+            int len;
+            if (run_of(b, &len)) { // the run's first entry behind the cell's (q - 1)-th feature, if it has one
+                const int prev = s_first[q - 1][b], cand = i > prev ? i : prev == INT_MAX ? INT_MAX : prev + 1;
+                if (cand <= i + len - 1)
+                    atomicMin(&s_first[q][b], cand);
+            }
         }
         __syncthreads();
     }
