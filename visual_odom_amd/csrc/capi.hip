@@ -80,8 +80,10 @@ bool acquire_streams(int device, StreamSet *out)
 // carries the ingest kernel and keeps the default priority -- at the highest priority that kernel runs into the current
 // step's pyramid / detection / LK kernels and costs each ~0.2 ms at 256 sequences (measured, round 3: 22.4 k -> 21.1 k
 // frames/s).
-hipStream_t ensure_copy_stream(StreamSet *s, bool prepare)
+hipStream_t ensure_copy_stream(StreamSet *s, bool prepare, bool partitioned)
 {
+    if (partitioned) // (created with the rest of the partitioned set)
+        return prepare ? s->part[6] : s->part[5];
     hipStream_t &st = prepare ? s->prep : s->copy;
     if (st)
         return st;
@@ -92,9 +94,69 @@ hipStream_t ensure_copy_stream(StreamSet *s, bool prepare)
     return ok ? st : nullptr;
 }
 
+// The PARTITIONED twin of a stream set (round 5): the post-LK streams get half of the GPU's compute units for themselves
+// and the tracking / copy / prepare streams the other half (hipExtStreamCreateWithCUMask).  For ONE sequence in the
+// lock-step loop: its step is two latency-bound chains of small kernels -- detection + LK of frame k + 1, the pose solve of
+// frame k -- that otherwise land on the same CUs and slow each other (kernel trace of the loop: the refinement 152-162 us
+// against 115 alone, bucketing 48 against 10, LK 230 against 200).  Measured (tools/cu_mask_ab.sh, pairs resident): 2 763 ->
+// 3 115 frames/s with 128 + 128 CUs and two pose streams; 64 / 96 CUs for the pose side 3 014 / 2 978; with ONE pose stream
+// the partition loses (1 445), and at 8 sequences it loses with any split (13.7 k -> 12.9 k): vo_seq_configure uses it for
+// n_seq == 1 only and the schedule probe settles the rest.  part[]: stream, pnp, pnp2, filter, em, copy, prep.
+bool ensure_partitioned_streams(StreamSet *s, int device)
+{
+    if (s->part_tried)
+        return s->part[0] != nullptr;
+    s->part_tried = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return false;
+    int n_cu = prop.multiProcessorCount, pose_cus = n_cu / 2;
+#ifdef VO_DEV_VARIANTS
+    if (const char *e = getenv("VO_POSE_CUS")) // developer build: 0 = no partition, n = CUs of the pose side
+        pose_cus = atoi(e);
+#endif
+    if (n_cu < 16 || n_cu > 1024 || pose_cus <= 0 || pose_cus >= n_cu)
+        return false;
+    std::vector<uint32_t> pose_mask((size_t)(n_cu + 31) / 32, 0u), trk_mask(pose_mask.size(), 0u);
+    for (int cu = 0; cu < n_cu; cu++)
+        (cu < pose_cus ? pose_mask : trk_mask)[(size_t)cu >> 5] |= 1u << (cu & 31);
+    const uint32_t words = (uint32_t)pose_mask.size();
+    hipStream_t t[7] = {};
+    bool ok = true;
+    for (int k = 0; k < 7 && ok; k++) // stream, pnp, pnp2, filter, em, copy, prep
+        ok = hipExtStreamCreateWithCUMask(&t[k], words, (k == 0 || k >= 5 ? trk_mask : pose_mask).data()) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (hipStream_t st : t)
+            if (st)
+                (void)hipStreamDestroy(st);
+        return false;
+    }
+    for (int k = 0; k < 7; k++)
+        s->part[k] = t[k];
+    return true;
+}
+
+// which twin of its stream set a context enqueues on; the caller has drained every stream (sync_all)
+int select_streams(vo_ctx *c, bool partitioned)
+{
+    if (partitioned && !ensure_partitioned_streams(&c->streams, c->device))
+        partitioned = false; // (no CU masks on this device / runtime: the ordinary set)
+    const StreamSet &s = c->streams;
+    c->partitioned = partitioned;
+    c->stream = partitioned ? s.part[0] : s.stream;
+    c->stream_pnp = partitioned ? s.part[1] : s.pnp;
+    c->stream_pnp2 = partitioned ? s.part[2] : s.pnp2;
+    c->stream_filter = partitioned ? s.part[3] : s.filter;
+    c->stream_em = partitioned ? s.part[4] : s.em;
+    c->last_pose_stream = nullptr;
+    return VO_OK;
+}
+
 void release_streams(int device, const StreamSet &s)
 {
-    hipStream_t all[] = {s.stream, s.pnp, s.pnp2, s.filter, s.em, s.copy, s.prep};
+    hipStream_t all[] = {s.stream, s.pnp, s.pnp2, s.filter, s.em, s.copy, s.prep, s.part[0], s.part[1], s.part[2], s.part[3],
+                         s.part[4], s.part[5], s.part[6]};
     for (hipStream_t st : all)
         if (st)
             (void)hipStreamSynchronize(st);
@@ -373,6 +435,7 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
         if (rcs != VO_OK)
             return rcs;
         c->seq.on = false;
+        (void)select_streams(c, false); // (the one-sequence loop runs on the partitioned streams)
         c->quads_cur = c->d_quads;
         c->n_images = 0; // force the full re-plan below
     }

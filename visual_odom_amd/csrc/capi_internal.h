@@ -32,6 +32,10 @@ using namespace vo;
 struct StreamSet {
     hipStream_t stream = nullptr, pnp = nullptr, pnp2 = nullptr, filter = nullptr, em = nullptr;
     hipStream_t copy = nullptr, prep = nullptr; // lock-step loop: plain copy stream / highest-priority prepare stream
+    // the PARTITIONED twin (capi.hip, ensure_partitioned_streams): stream, pnp, pnp2, filter, em, copy, prep on two disjoint
+    // halves of the compute units -- the one-sequence lock-step loop runs on it
+    hipStream_t part[7] = {};
+    bool part_tried = false;
     int id = 0; // creation rank on its device: the pool hands out the oldest free set first
 };
 
@@ -146,6 +150,7 @@ struct vo_ctx {
     int probe_real[VO_PROBE_LOG_MAX] = {};          // 1: probe_ms[i] was (re)measured over real steps of the lock-step loop
     hipStream_t last_pose_stream = nullptr; // stream the latest pose chain was enqueued on
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
+    bool partitioned = false; // stream / stream_pnp ... are the partitioned twin of `streams` (select_streams)
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
     bool serial_pose = false; // -DVO_DEV_VARIANTS + VO_SERIAL_POSE=1: the whole chain on the tracking stream (profiling)
     bool lk_pair = false;     // -DVO_DEV_VARIANTS + VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip)
@@ -290,7 +295,9 @@ extern std::mutex g_tune_mu;
 extern std::map<TuneKey, vo_ctx::Schedule> g_tuned; // per process: a second context of the same shape starts tuned
 int plan_levels(vo_ctx *c, int w, int h);
 bool acquire_streams(int device, StreamSet *out);
-hipStream_t ensure_copy_stream(StreamSet *s, bool prepare);
+hipStream_t ensure_copy_stream(StreamSet *s, bool prepare, bool partitioned = false);
+bool ensure_partitioned_streams(StreamSet *s, int device);
+int select_streams(vo_ctx *c, bool partitioned); // call with every stream idle
 void release_streams(int device, const StreamSet &s);
 void seq_free(vo_ctx *c);
 // idle: the caller has just drained the tracking stream (a synchronous drop-in call); pts / n_pts: the call's points ride along

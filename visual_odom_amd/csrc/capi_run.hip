@@ -332,6 +332,9 @@ int sync_all(vo_ctx *c)
         VO_HIP_TRY(c, hipStreamSynchronize(c->streams.copy));
     if (c->streams.prep)
         VO_HIP_TRY(c, hipStreamSynchronize(c->streams.prep));
+    if (c->partitioned) // (the copy / prepare streams of the partitioned twin; its other streams are the ones above)
+        for (int k = 5; k < 7; k++)
+            VO_HIP_TRY(c, hipStreamSynchronize(c->streams.part[k]));
     return VO_OK;
 }
 

@@ -69,7 +69,7 @@ int set_sched(vo_ctx *c, const vo_ctx::Schedule &s)
         int rc = sync_all(c);
         if (rc != VO_OK)
             return rc;
-        c->seq.copy = ensure_copy_stream(&c->streams, s.prep != 0);
+        c->seq.copy = ensure_copy_stream(&c->streams, s.prep != 0, c->partitioned);
         if (!c->seq.copy)
             return fail(c, VO_ERR_HIP, "could not create the copy stream");
         for (auto &b : c->seq.fast_pending)

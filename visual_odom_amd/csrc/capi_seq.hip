@@ -62,6 +62,11 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     if (rc != VO_OK)
         return rc;
     seq_free(c);
+    // ONE sequence: the loop's two chains of small kernels on disjoint halves of the compute units (capi.hip,
+    // ensure_partitioned_streams); more sequences fill the chip and want all of it
+    rc = select_streams(c, n_seq == 1);
+    if (rc != VO_OK)
+        return rc;
     vo_ctx::Seq &q = c->seq;
     const size_t S = (size_t)n_seq;
     q.S = n_seq;
@@ -98,7 +103,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
             memcpy(c->sched_key, key.k, sizeof(key.k));
         else
             c->sched_key[0] = -1; // the first full step probes
-        q.copy = ensure_copy_stream(&c->streams, sc.prep != 0);
+        q.copy = ensure_copy_stream(&c->streams, sc.prep != 0, c->partitioned);
         ok = q.copy != nullptr;
     }
     ok = ok && dmalloc(&q.d_corners, (size_t)ring * S * c->fcap) == hipSuccess;
