@@ -146,3 +146,48 @@ def test_three_frames_one_small_launch_at_a_tight_threshold(volib, orc, small_wo
         assert max(iters) > 128, iters                         # at least one frame went through the rest kernel's work
     finally:
         ctx.close()
+
+
+def test_one_sequence_on_the_partitioned_streams_equals_two_sequences(volib, small_world):
+    """vo_seq_configure(1) runs on the CU-partitioned twin of the context's streams (post-LK streams and tracking streams on
+    disjoint halves of the compute units), every other configuration on the plain set: the same pairs give the same state and
+    trajectory bit for bit through 1 sequence, 2 sequences and 1 sequence again on ONE context, and a synchronous call between
+    the modes (back on the plain set) equals a fresh context's"""
+    from visual_odom_amd import synth
+    L, R, _, _ = small_world.render_sequence(7)
+    pts0 = synth.select_keypoints(L[0], bucket=16, per_bucket=2)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    ctx = volib.Context(0, w, h, 2048, 2)
+    fresh = volib.Context(0, w, h, 2048, 2)
+    try:
+        def loop(n_seq):
+            ctx.seq_configure(n_seq, w, h, 3, 64)
+            ctx.batch_set_projection(P_l, P_r)
+            for k in range(7):
+                for s in range(n_seq):
+                    ctx.seq_push_pair(s, L[k], R[k])
+                ctx.seq_step()
+            ctx.seq_sync()
+            out = []
+            for s in range(n_seq):
+                p, a, pose = ctx.seq_get_state(s)
+                rows, info = ctx.seq_get_trajectory(s)
+                out.append((p, a, pose, rows, info))
+            return out
+
+        one = loop(1)
+        imgs = [L[0], R[0], L[1], R[1]]
+        want = fresh.track_frame(*imgs, pts0, P_l, P_r)
+        got = ctx.track_frame(*imgs, pts0, P_l, P_r)
+        for k in ("l0", "r0", "l1", "r1", "xyz", "inliers", "rvec", "tvec"):
+            assert np.array_equal(got[k], want[k]), k
+        two = loop(2)
+        again = loop(1)
+        assert len(one[0][3]) == 7
+        for a, b in ((one[0], two[0]), (one[0], two[1]), (one[0], again[0])):
+            for x, y in zip(a, b):
+                assert x.shape == y.shape and x.tobytes() == y.tobytes()
+    finally:
+        ctx.close()
+        fresh.close()
