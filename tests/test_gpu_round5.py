@@ -184,7 +184,7 @@ def test_one_sequence_on_the_partitioned_streams_equals_two_sequences(volib, sma
             assert np.array_equal(got[k], want[k]), k
         two = loop(2)
         again = loop(1)
-        assert len(one[0][3]) == 7
+        assert len(one[0][3]) == 6          # 7 pairs: 6 motions
         for a, b in ((one[0], two[0]), (one[0], two[1]), (one[0], again[0])):
             for x, y in zip(a, b):
                 assert x.shape == y.shape and x.tobytes() == y.tobytes()
