@@ -310,6 +310,10 @@ int vo_batch_get_essential(vo_ctx *ctx, int frame, double *E, double *R, double 
  *   Detection / LK / RANSAC parameters: vo_set_params and vo_batch_set_detect_params before vo_seq_configure (or at
  *   least before the first vo_seq_step: with few sequences FAST runs on a pair's left image as soon as the pair is on
  *   the device, one step before its corners are needed), vo_batch_set_projection before the first step.
+ *   S == 1 runs on a second set of the context's streams whose kernels are confined to disjoint halves of the
+ *   device's compute units (tracking / copies on one, everything behind LK on the other): one sequence is two
+ *   latency-bound chains that otherwise slow each other.  Same results; any other configuration call returns the
+ *   context to its ordinary streams.
  * ------------------------------------------------------------------------------------------ */
 #define VO_SEQ_ROW 27          /* doubles per trajectory row: frame_pose 3x4 (12), rvec (3), tvec (3), rotation (9) */
 #define VO_SEQ_INFO 8          /* ints per row: n_bucketed, n_circ, n_tracked, n_inliers, pnp_status, flags,
