@@ -682,6 +682,23 @@ def latency_leg(ctx, n_calls=100, n_steps=400, quads=8, seed=20260925):
         t = np.array(t) * 1e3
         out["track_frame_ms_%s" % tag] = {"median": float(np.median(t)), "mean": float(t.mean()), "p95": float(np.percentile(t, 95)),
                                           "points": int(len(pts[0])), "calls": n_calls, "inliers_last": int(len(r["inliers"]))}
+        # the same frames the way the reference's loop hands them over (main.cpp:157-158: the t1 pair of one frame is the t0
+        # pair of the next): no t0 images, the pair the previous call kept on the device -- two uploads, two pyramids per call
+        def call_kept(i):
+            a, b = order[i % 8], order[(i + 1) % 8]
+            return ctx.track_frame(None, None, lefts[b], rights[b], pts[a], P_l, P_r)
+        ctx.track_frame(lefts[0], rights[0], lefts[1], rights[1], pts[0], P_l, P_r)
+        for i in range(1, 9):
+            call_kept(i)
+        t = []
+        for i in range(9, 9 + n_calls):
+            t0 = time.perf_counter()
+            r = call_kept(i)
+            t.append(time.perf_counter() - t0)
+        t = np.array(t) * 1e3
+        out["track_frame_kept_pair_ms_%s" % tag] = {"median": float(np.median(t)), "mean": float(t.mean()),
+                                                    "p95": float(np.percentile(t, 95)), "calls": n_calls,
+                                                    "inliers_last": int(len(r["inliers"]))}
     for tag, fpb in (("2000", 6), ("374", 1)):
         ctx.batch_set_detect_params(features_per_bucket=fpb)
         ctx.seq_configure(1, w, h, 3, n_steps + 64)

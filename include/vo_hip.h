@@ -152,7 +152,8 @@ int vo_get_params(const vo_ctx *ctx, vo_params *p);
  * status4 (optional, [4][n]): raw LK status of the 4 hops before compaction.
  * keep_idx (optional, [n]): input index of each survivor (the adapter compacts `ages` with it).
  * apply_consistency != 0 additionally applies checkValidMatch(thr) + removeInvalidPoints
- * (visualOdometry.cpp:44-77,119-125) so the outputs are the K points that reach triangulation. */
+ * (visualOdometry.cpp:44-77,119-125) so the outputs are the K points that reach triangulation.
+ * img_l0 == img_r0 == NULL: the t0 pair is the previous call's t1 pair (see vo_track_frame, THE KEPT PAIR). */
 int vo_circular_match(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
                       const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
                       float *out_l0, float *out_r0, float *out_r1, float *out_l1, float *out_l0_ret,
@@ -196,7 +197,8 @@ int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, in
  * when the set has fewer than redetect_below points (feature.cpp:255-262), then bucketingFeatures()
  * (feature.cpp:206-253, bucket.cpp:14-51, quirks of SURVEY.md App. B1-B3 reproduced).
  * pts_io [2 * cap] / ages_io [cap]: in: *n_pts points and *n_ages ages (n_ages >= n_pts allowed, as in
- * the reference after a consistency filter); out: the bucketed set (*n_pts == *n_ages). */
+ * the reference after a consistency filter); out: the bucketed set (*n_pts == *n_ages).
+ * img == NULL (also vo_fast_detect): the left image of the pair vo_track_frame kept (see there). */
 int vo_detect_bucket(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
                      float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap);
 
@@ -214,7 +216,16 @@ int vo_integrate_odometry(double *pose16, const double *R9, const double *t3, fl
  * -> survivors of deleteUnmatchFeaturesCircle alone (what `ages` is compacted with, quirk B3).
  * Images and points are pageable host memory; the caller's buffers are free on return.  (Inside: each image is
  * repacked into a page-locked slot and read by the GPU over PCIe while the host repacks the next one, nothing
- * synchronises before the results -- 0.65-0.68 ms per KITTI frame at ~2000 points on an MI355X) */
+ * synchronises before the results -- 0.65-0.68 ms per KITTI frame at ~2000 points on an MI355X)
+ *
+ * THE KEPT PAIR (the reference's `imageLeft_t0 = imageLeft_t1; imageRight_t0 = imageRight_t1`, main.cpp:157-158):
+ * img_l0 == NULL and img_r0 == NULL name the stereo pair the previous vo_track_frame / vo_circular_match of this context
+ * received as (img_l1, img_r1) -- it is still on the device with its pyramids, so only the new pair crosses the link and
+ * only its pyramids are built; results are those of the call with all four images.  vo_detect_bucket / vo_fast_detect
+ * with img == NULL read the kept pair's LEFT image (what matchingFeatures detects on next, visualOdometry.cpp:95-108);
+ * with an image of their own they leave the kept pair alone.  VO_ERR_STATE when there is no kept pair of this size:
+ * first call, another w x h, or a vo_batch_* upload / configure of another shape / vo_seq_configure since (they own the
+ * image table from then on).  One NULL and one non-NULL t0 image is VO_ERR_ARG. */
 int vo_track_frame(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
                    const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
                    const float *P_l, const float *P_r, float *out_l0, float *out_r0, float *out_l1,

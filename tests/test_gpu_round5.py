@@ -191,3 +191,100 @@ def test_one_sequence_on_the_partitioned_streams_equals_two_sequences(volib, sma
     finally:
         ctx.close()
         fresh.close()
+
+
+def test_kept_pair_calls_equal_four_image_calls(volib, small_world):
+    """the drop-in calls without t0 images (the previous call's t1 pair is this call's t0 pair, kept on the device with its
+    pyramids -- main.cpp:157-158) against the same calls with all four images: every output of vo_track_frame /
+    vo_circular_match / vo_detect_bucket / vo_fast_detect identical frame after frame, strided t1 images, a detection on an
+    image of its own in between, and VO_ERR_STATE / VO_ERR_ARG wherever no such pair exists"""
+    from visual_odom_amd import synth
+    L, R, _, _ = small_world.render_sequence(6)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    keys = ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ", "inliers", "rvec", "tvec", "R")
+    ctx = volib.Context(0, w + 40, h + 8, 2048, 1)
+    ref = volib.Context(0, w + 40, h + 8, 2048, 1)
+    try:
+        with pytest.raises(volib.VoError) as e:                 # nothing kept yet
+            ctx.track_frame(None, None, L[1], R[1], np.zeros((4, 2), np.float32), P_l, P_r)
+        assert e.value.code == volib.VO_ERR_STATE
+        pts, ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
+        for k in range(5):
+            t0 = (L[k], R[k]) if k == 0 else (None, None)
+            if k == 3:                                           # a padded buffer's views as the new pair
+                pad = [np.zeros((h + 5, w + 29), np.uint8) for _ in range(2)]
+                pad[0][3:3 + h, 7:7 + w], pad[1][3:3 + h, 7:7 + w] = L[k + 1], R[k + 1]
+                t1 = (pad[0][3:3 + h, 7:7 + w], pad[1][3:3 + h, 7:7 + w])
+            else:
+                t1 = (L[k + 1], R[k + 1])
+            # detection + bucketing on the kept pair's left image against the same on the image itself
+            want_p, want_a = ref.detect_bucket(L[k], pts, ages, features_per_bucket=2)
+            got_p, got_a = ctx.detect_bucket(None if k else L[k], pts, ages, features_per_bucket=2)
+            assert np.array_equal(got_p, want_p) and np.array_equal(got_a, want_a) and len(got_p) > 50, k
+            if k == 2:    # FAST alone on the kept image, and a detection on some other image: the kept pair stays
+                assert np.array_equal(ctx.fast_detect(None), ref.fast_detect(L[k]))
+                other_p, _ = ctx.detect_bucket(R[4], pts, ages, features_per_bucket=2)
+                assert np.array_equal(other_p, ref.detect_bucket(R[4], pts, ages, features_per_bucket=2)[0])
+            want = ref.track_frame(L[k], R[k], L[k + 1], R[k + 1], want_p, P_l, P_r)
+            got = ctx.track_frame(*t0, *t1, got_p, P_l, P_r)
+            assert got["rc"] == want["rc"] and len(got["inliers"]) > 20, k
+            for key in keys:
+                assert np.array_equal(got[key], want[key]), (k, key)
+            pts, ages = want["l1"].copy(), (want_a + 1)[want["keep_idx_circ"]]
+        # circularMatching alone: frame 4 -> 5 on the kept pair, raw status and survivors
+        wantc = ref.circular_match(L[5], R[5], L[4], R[4], pts)
+        gotc = ctx.circular_match(None, None, L[4], R[4], pts)
+        for key in ("l0", "r0", "r1", "l1", "l0_ret", "status4", "keep_idx"):
+            assert np.array_equal(gotc[key], wantc[key]), key
+        # one of the two t0 images missing: an argument error; the batch API / another size / the sequence loop take the
+        # image table over: a state error until a call with four images has run again
+        with pytest.raises(volib.VoError) as e:
+            ctx.track_frame(None, R[4], L[5], R[5], pts, P_l, P_r)
+        assert e.value.code == volib.VO_ERR_ARG
+        ctx.track_frame(None, None, L[5], R[5], pts, P_l, P_r)                       # (still fine after the refused call)
+        ctx.batch_upload_image(1, R[0])
+        for call in (lambda: ctx.track_frame(None, None, L[1], R[1], pts, P_l, P_r),
+                     lambda: ctx.detect_bucket(None, pts, ages), lambda: ctx.fast_detect(None)):
+            with pytest.raises(volib.VoError) as e:
+                call()
+            assert e.value.code == volib.VO_ERR_STATE
+        ctx.track_frame(L[0], R[0], L[1], R[1], pts, P_l, P_r)
+        ctx.track_frame(None, None, L[2], R[2], pts, P_l, P_r)
+        with pytest.raises(volib.VoError) as e:                                     # another size
+            ctx.track_frame(None, None, L[3][:h - 8], R[3][:h - 8], pts, P_l, P_r)
+        assert e.value.code == volib.VO_ERR_STATE
+        ctx.track_frame(None, None, L[3], R[3], pts, P_l, P_r)                       # (the refused call changed nothing)
+        ctx.seq_configure(1, w, h, 2, 8)                                             # ring 2 x 1 sequence: the same 4 images
+        with pytest.raises(volib.VoError) as e:
+            ctx.track_frame(None, None, L[4], R[4], pts, P_l, P_r)
+        assert e.value.code == volib.VO_ERR_STATE
+        got = ctx.track_frame(L[4], R[4], L[5], R[5], want_p, P_l, P_r)
+        for key in keys:
+            assert np.array_equal(got[key], want[key]), key
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_frame_loop_with_the_kept_pair_equals_the_other_loops(volib, small_world):
+    """StereoOdometry over 7 pairs: the drop-in calls with the kept pair (two uploads per frame), the stateless calls (four)
+    and the streaming ring give the same trajectory, feature sets and per-frame records"""
+    from visual_odom_amd import odometry
+    L, R, _, _ = small_world.render_sequence(7)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    runs = []
+    for kw in (dict(streaming=False, keep_pair=True), dict(streaming=False, keep_pair=False), dict(streaming=True)):
+        vo = odometry.StereoOdometry(P_l, P_r, 0, w, h, 2048, features_per_bucket=2, **kw)
+        try:
+            for k in range(7):
+                vo.process(L[k], R[k])
+            runs.append((np.array(vo.trajectory), vo.points.copy(), vo.ages.copy(),
+                         [(r["n_bucketed"], r["n_tracked"], r["n_inliers"], r["integrated"]) for r in vo.log]))
+        finally:
+            vo.close()
+    assert len(runs[0][0]) == 7 and runs[0][3][0][2] > 20
+    for other in runs[1:]:
+        assert runs[0][0].tobytes() == other[0].tobytes()
+        assert np.array_equal(runs[0][1], other[1]) and np.array_equal(runs[0][2], other[2]) and runs[0][3] == other[3]

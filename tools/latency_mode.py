@@ -1,6 +1,7 @@
 """Latency mode of the drop-in boundary: vo_track_frame per call with HOST images (4 uploads of 466 KB
 over PCIe, one download, synchronous), one frame in flight -- the honest "switch the reference over"
-number -- next to the whole frame loop through the streaming ring, through the stateless calls, and PIPELINED
+number -- and with the t0 pair kept on the device from the previous call (2 uploads), next to the whole frame loop through
+the streaming ring, through the stateless calls, through the calls on the kept pair, and PIPELINED
 through the lock-step sequence API with one sequence.  Never bench.py's `value` (that one has inputs resident
 in HBM); quoted in DESIGN.md section 5.
 
@@ -23,7 +24,7 @@ def inputs(per_bucket):
     world = synth.StereoWorld(seed=20260925)
     L, R, poses, _ = world.render_sequence(5)
     P_l, P_r = world.proj_matrices()
-    pts = [synth.select_keypoints(L[k], bucket=37, per_bucket=per_bucket) for k in range(4)]
+    pts = [synth.select_keypoints(L[k], bucket=37, per_bucket=per_bucket) for k in range(5)]
     return world, L, R, P_l, P_r, pts
 
 
@@ -55,8 +56,25 @@ def run(what, per_bucket, n):
         dt2 = time.perf_counter() - t1
         print("  track_frame %.2f ms/frame = %.0f frames/s (PCIe-inclusive, %d points); detect_bucket %.2f ms/frame"
               % (1e3 * dt / n, n / dt, len(pts[0]), 1e3 * dt2 / n))
-    elif what in ("ring", "stateless"):
-        vo = odometry.StereoOdometry(P_l, P_r, streaming=what == "ring", features_per_bucket=per_bucket)
+    elif what == "trackkept":  # the t0 pair = the previous call's t1 pair, kept on the device: two images per call
+        ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+        ctx.track_frame(L[0], R[0], L[1], R[1], pts[0], P_l, P_r)
+        for i in range(1, 9):
+            a, b = ORDER[i % 8], ORDER[(i + 1) % 8]
+            ctx.track_frame(None, None, L[b], R[b], pts[a], P_l, P_r)
+        t0 = time.perf_counter()
+        for i in range(9, 9 + n):
+            a, b = ORDER[i % 8], ORDER[(i + 1) % 8]
+            ctx.track_frame(None, None, L[b], R[b], pts[a], P_l, P_r)
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for i in range(n):
+            ctx.detect_bucket(None, np.zeros((0, 2), np.float32), np.zeros(0, np.int32), features_per_bucket=per_bucket)
+        dt2 = time.perf_counter() - t1
+        print("  track_frame on the kept pair (2 new images per call) %.2f ms/frame = %.0f frames/s (PCIe-inclusive, ~%d points); "
+              "detect_bucket on the kept image %.2f ms/frame" % (1e3 * dt / n, n / dt, len(pts[0]), 1e3 * dt2 / n))
+    elif what in ("ring", "stateless", "kept"):
+        vo = odometry.StereoOdometry(P_l, P_r, streaming=what == "ring", keep_pair=what == "kept", features_per_bucket=per_bucket)
         for i in range(9):
             vo.process(L[ORDER[i % 8]], R[ORDER[i % 8]])
         t2 = time.perf_counter()
@@ -64,7 +82,8 @@ def run(what, per_bucket, n):
             vo.process(L[ORDER[i % 8]], R[ORDER[i % 8]])
         dt3 = time.perf_counter() - t2
         print("  frame loop incl. FAST + bucketing + pose integration, %s: %.2f ms/frame = %.0f frames/s"
-              % ("streaming ring (synchronous)" if what == "ring" else "stateless drop-in calls", 1e3 * dt3 / n, n / dt3))
+              % ({"ring": "streaming ring (synchronous)", "stateless": "stateless drop-in calls (4 images per frame)",
+                 "kept": "drop-in calls on the kept pair (2 images per frame)"}[what], 1e3 * dt3 / n, n / dt3))
     else:  # pipelined: vo_seq_* with one sequence, host images; nothing comes back until the trajectory is asked for
         vo = odometry.MultiSequenceOdometry(P_l, P_r, 1, world.w, world.h, ring=3, max_steps=5 * n + 32,
                                             features_per_bucket=per_bucket)
@@ -89,5 +108,5 @@ if __name__ == "__main__":
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
         for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default (1 per bucket)", 1)):
             print(name + ":", flush=True)
-            for what in ("track", "ring", "stateless", "pipelined"):
+            for what in ("track", "trackkept", "ring", "stateless", "kept", "pipelined"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), what, str(per_bucket), str(n)], check=False)

@@ -149,6 +149,18 @@ def _imgs(*arrays):
     return arrs, int(arrs[0].strides[0])
 
 
+def _imgs_opt(*arrays):
+    """_imgs over the images that are given; None stays None (the C ABI's NULL: vo_hip.h, THE KEPT PAIR)"""
+    arrs, stride = _imgs(*[a for a in arrays if a is not None])
+    it = iter(arrs)
+    return [None if a is None else next(it) for a in arrays], stride
+
+
+def _pn(a):
+    """_p, or NULL for None"""
+    return None if a is None else _p(a)
+
+
 def _f32(a, shape=None):
     a = np.ascontiguousarray(a, np.float32)
     return a if shape is None else a.reshape(shape)
@@ -178,6 +190,7 @@ class Context:
         self.h = C.c_void_p(self.h)
         self.max_pts, self.max_frames = max_pts, max_frames
         self.n_frames = 0
+        self._kept_shape = (0, 0)   # (h, w) of the pair the last track_frame kept on the device
 
     def close(self):
         if getattr(self, "h", None):
@@ -231,8 +244,9 @@ class Context:
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):
-        imgs, stride = _imgs(l0, r0, l1, r1)
-        h, w = imgs[0].shape
+        imgs, stride = _imgs_opt(l0, r0, l1, r1)   # (l0 = r0 = None: the pair the previous call kept, see track_frame)
+        h, w = imgs[2].shape
+        self._kept_shape = (h, w)
         pts = _f32(pts_l0, (-1, 2))
         n = pts.shape[0]
         outs = [np.zeros((max(n, 1), 2), np.float32) for _ in range(5)]
@@ -240,7 +254,7 @@ class Context:
         keep = np.zeros(max(n, 1), np.int32)
         n_out = C.c_int(0)
         st_flat = np.zeros(4 * max(n, 1), np.uint8)
-        self._chk(self.lib.vo_circular_match(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
+        self._chk(self.lib.vo_circular_match(self.h, _pn(imgs[0]), _pn(imgs[1]), _p(imgs[2]), _p(imgs[3]),
                                              w, h, stride, _p(pts), n, _p(outs[0]), _p(outs[1]), _p(outs[2]),
                                              _p(outs[3]), _p(outs[4]), _p(st_flat), _p(keep),
                                              C.byref(n_out), int(apply_consistency)))
@@ -295,11 +309,14 @@ class Context:
 
     def fast_detect(self, img, threshold=20, nonmax=True, cap=65536):
         """featureDetectionFast (feature.cpp:39-47): corners in row-major order, (n, 2) float32"""
-        (img,), stride = _imgs(img)
-        h, w = img.shape
+        if img is None:   # the left image of the pair the last track_frame kept
+            (h, w), stride = self._kept_shape, self._kept_shape[1]
+        else:
+            (img,), stride = _imgs(img)
+            h, w = img.shape
         pts = np.zeros((cap, 2), np.float32)
         n = C.c_int(0)
-        self._chk(self.lib.vo_fast_detect(self.h, _p(img), w, h, stride, int(threshold), int(bool(nonmax)), _p(pts), cap,
+        self._chk(self.lib.vo_fast_detect(self.h, _pn(img), w, h, stride, int(threshold), int(bool(nonmax)), _p(pts), cap,
                                           C.byref(n)))
         if n.value > cap:
             raise VoError(VO_ERR_ARG, "fast_detect: %d corners exceed cap %d" % (n.value, cap))
@@ -307,9 +324,13 @@ class Context:
 
     def detect_bucket(self, img, pts, ages, **detect_kw):
         """appendNewFeatures (if fewer than redetect_below points) + bucketingFeatures
-        (visualOdometry.cpp:95-108); returns (points, ages) of the bucketed set"""
-        (img,), stride = _imgs(img)
-        h, w = img.shape
+        (visualOdometry.cpp:95-108); returns (points, ages) of the bucketed set.  img is None: the left image of the pair
+        the last track_frame kept (its l1)"""
+        if img is None:
+            (h, w), stride = self._kept_shape, self._kept_shape[1]
+        else:
+            (img,), stride = _imgs(img)
+            h, w = img.shape
         pts = _f32(pts, (-1, 2))
         ages = np.ascontiguousarray(ages, np.int32).reshape(-1)
         cap = max(self.max_pts, len(ages), 1)
@@ -319,13 +340,16 @@ class Context:
         a_io[:len(ages)] = ages
         n_pts, n_ages = C.c_int(len(pts)), C.c_int(len(ages))
         dp = self.detect_params(**detect_kw)
-        self._chk(self.lib.vo_detect_bucket(self.h, _p(img), w, h, stride, C.byref(dp), _p(p_io), C.byref(n_pts), _p(a_io),
+        self._chk(self.lib.vo_detect_bucket(self.h, _pn(img), w, h, stride, C.byref(dp), _p(p_io), C.byref(n_pts), _p(a_io),
                                             C.byref(n_ages), cap))
         return p_io[:n_pts.value].copy(), a_io[:n_ages.value].copy()
 
     def track_frame(self, l0, r0, l1, r1, pts_l0, P_l, P_r, rvec=None, tvec=None):
-        imgs, stride = _imgs(l0, r0, l1, r1)
-        h, w = imgs[0].shape
+        """l0 is None and r0 is None: the t0 pair is the pair the previous call received as (l1, r1) -- kept on the device
+        with its pyramids (vo_hip.h, THE KEPT PAIR; main.cpp:157-158)"""
+        imgs, stride = _imgs_opt(l0, r0, l1, r1)
+        h, w = imgs[2].shape
+        self._kept_shape = (h, w)
         pts = _f32(pts_l0, (-1, 2))
         n = pts.shape[0]
         P_l, P_r = _f32(P_l, (3, 4)), _f32(P_r, (3, 4))
@@ -340,7 +364,7 @@ class Context:
         tv = np.zeros(3) if tvec is None else np.array(tvec, np.float64).reshape(3)
         R = np.zeros((3, 3))
         ob, ib = C.addressof(_ZERO_BYTES.from_buffer(o)), C.addressof(_ZERO_BYTES.from_buffer(idx))
-        rc = self._chk(self.lib.vo_track_frame(self.h, _p(imgs[0]), _p(imgs[1]), _p(imgs[2]), _p(imgs[3]),
+        rc = self._chk(self.lib.vo_track_frame(self.h, _pn(imgs[0]), _pn(imgs[1]), _p(imgs[2]), _p(imgs[3]),
                                                w, h, stride, _p(pts), n, _p(P_l), _p(P_r), C.c_void_p(ob), C.c_void_p(ob + 8 * m),
                                                C.c_void_p(ob + 16 * m), C.c_void_p(ob + 24 * m), _p(xyz), C.c_void_p(ib), C.byref(n_out),
                                                C.c_void_p(ib + 4 * m), C.byref(n_circ), _p(rv), _p(tv), _p(R), C.c_void_p(ib + 8 * m),

@@ -319,7 +319,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_pix, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_der, c->pix_capacity) == hipSuccess;
     ok = ok && dmalloc(&c->d_imgs, (size_t)c->max_images) == hipSuccess;
-    ok = ok && dmalloc(&c->d_quads, B) == hipSuccess;
+    ok = ok && dmalloc(&c->d_quads, B + VO_CONST_QUADS) == hipSuccess; // (the table + const_quad()'s four)
     ok = ok && dmalloc(&c->d_pts, B * cap) == hipSuccess;
     for (int k = 0; k < 2; k++) {
         ok = ok && dmalloc(&c->d_trk2[k], B * 4 * cap) == hipSuccess;
@@ -398,6 +398,10 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->h_quads.assign(B, Quad{0, 0, 0, 0});
     c->img_stale.assign((size_t)c->max_images, 0);
     c->quads_cur = c->d_quads;
+    if (hipMemcpy(c->d_quads + B, VO_CONST_QUAD_TABLE, sizeof(Quad) * VO_CONST_QUADS, hipMemcpyHostToDevice) != hipSuccess) {
+        vo_destroy(c);
+        return nullptr;
+    }
     return c;
 }
 
@@ -445,6 +449,8 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
         return VO_OK;
     }
     c->sched_key[0] = -1; // a new shape: the schedule is resolved again at its first run
+    c->tf_base = -1;      // (and the image table is laid out again)
+    c->quads_cur = c->d_quads;
     plan_levels(c, w, h);
     if (c->img_bytes * (size_t)n_images > c->pix_capacity)
         return fail(c, VO_ERR_ARG, "vo_batch_configure: pyramid storage exceeds capacity");
@@ -546,6 +552,8 @@ extern "C" {
 
 int vo_batch_upload_image(vo_ctx *c, int idx, const uint8_t *host, int stride)
 {
+    if (c)
+        c->tf_base = -1; // the caller owns the image table now (see vo_ctx::tf_base)
     int rc = upload_image(c, idx, host, stride, hipMemcpyHostToDevice);
     if (rc == VO_OK) // pageable host memory: make the call safe to return from
         VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -554,6 +562,8 @@ int vo_batch_upload_image(vo_ctx *c, int idx, const uint8_t *host, int stride)
 
 int vo_batch_upload_image_dev(vo_ctx *c, int idx, const void *dev, int stride)
 {
+    if (c)
+        c->tf_base = -1;
     return upload_image(c, idx, dev, stride, hipMemcpyDeviceToDevice);
 }
 
@@ -575,6 +585,7 @@ int vo_batch_set_quads(vo_ctx *c, const int32_t *quads4, int n_frames)
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(c->h_quads.data(), quads4, sizeof(Quad) * n_frames);
     c->quads_set = true;
+    c->quads_cur = c->d_quads; // (a synchronous drop-in call may have left it at one of its constant quadruples)
     return VO_OK;
 }
 

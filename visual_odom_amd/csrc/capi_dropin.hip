@@ -28,10 +28,16 @@ long long g_host_stamp[16];
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
                               const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
 {
-    if (!l0 || !r0 || !l1 || !r1 || n < 0 || (n > 0 && !pts))
+    // no t0 images: the t0 pair is the pair the previous call received as t1 (the reference's loop keeps it the same way,
+    // main.cpp:157-158) -- it is on the device with its pyramids, two images cross the link instead of four
+    const bool keep = !l0 && !r0;
+    if ((!keep && (!l0 || !r0)) || !l1 || !r1 || n < 0 || (n > 0 && !pts))
         return fail(c, VO_ERR_ARG, "null image / points");
     if (n > c->cap)
         return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    if (keep && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
+        return fail(c, VO_ERR_STATE, "no t0 images given, and the context does not hold the t1 pair of a previous call of this "
+                                     "size (first call, another size, or the batch / sequence API used the images since)");
     int rc = vo_batch_configure(c, 4, w, h, 1);
     if (rc != VO_OK)
         return rc;
@@ -41,20 +47,24 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
     static_assert(VO_STAGE_SLOTS >= 4, "one staging slot per image of the call");
     VO_HOST_STAMP(1);
     c->stage_next = 0;
+    const int t0 = keep ? c->tf_base : 0, t1 = t0 ^ 2; // image slots of the two pairs
     const uint8_t *imgs[4] = {l0, r0, l1, r1};
-    const int32_t quad[4] = {0, 1, 2, 3};
-    rc = vo_batch_set_quads(c, quad, 1); // (a no-op from the second call on)
-    if (rc != VO_OK)
-        return rc;
-    const bool ride = c->pts_sel < 0; // the points travel with the last image (else: see below)
-    for (int i = 0; i < 4; i++) {
-        rc = upload_image(c, i, imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true, pts, i == 3 && ride ? n : -1);
+    use_const_quad(c, t0 == 0 ? 0 : 1);
+    c->tf_base = -1; // (until every image of the call is on its way)
+    // one frame: the call's points replace the whole current set, also the bucketed set a VO_STAGE_DETECT run left
+    // current (nothing reads that one any more: sync_all above)
+    c->pts_sel = -1;
+    for (int i = keep ? 2 : 0; i < 4; i++) { // the points travel with the last image
+        rc = upload_image(c, (i < 2 ? t0 : t1) + (i & 1), imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true, pts, i == 3 ? n : -1);
         if (rc != VO_OK)
             return rc;
         VO_HOST_STAMP(2 + i);
     }
-    if (!ride) // the feature set of a VO_STAGE_DETECT run is current: the general path moves it over first
-        return vo_batch_set_points(c, 0, pts, n);
+    if (keep) {
+        c->pyr_first = t1; // (vo_batch_configure above restored "every pyramid")
+        c->pyr_count = 2;
+    }
+    c->tf_base = t1;
     c->h_npts[0] = n;
     c->pts_on_device = false;
     c->max_pts_set = n;
@@ -193,18 +203,29 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
 namespace vo_capi {
 
 // one image as a 1-frame batch whose quad points at image 0 four times
+// img == nullptr: the LEFT image of the t1 pair of the previous vo_track_frame / vo_circular_match (what the reference's
+// loop detects on next, visualOdometry.cpp:95-108 on imageLeft_t0 = the previous imageLeft_t1) -- nothing is uploaded.
+// An image that is given goes to the slot pair that does not hold that t1 pair, which stays valid.
 int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
 {
-    if (!img)
-        return fail(c, VO_ERR_ARG, "null image");
+    if (!img && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
+        return fail(c, VO_ERR_STATE, "no image given, and the context does not hold the t1 pair of a previous vo_track_frame "
+                                     "of this size");
     int rc = vo_batch_configure(c, 4, w, h, 1);
     if (rc != VO_OK)
         return rc;
-    rc = upload_image(c, 0, img, stride, hipMemcpyHostToDevice);
+    if (!img) {
+        use_const_quad(c, c->tf_base == 0 ? 2 : 3);
+        return VO_OK;
+    }
+    const int slot = c->tf_base == 0 ? 2 : 0;
+    const int keep = c->tf_base; // (upload_image itself does not touch it; the batch API's wrappers do)
+    rc = upload_image(c, slot, img, stride, hipMemcpyHostToDevice);
+    c->tf_base = rc == VO_OK ? keep : -1;
     if (rc != VO_OK)
         return rc;
-    const int32_t quad[4] = {0, 0, 0, 0};
-    return vo_batch_set_quads(c, quad, 1);
+    use_const_quad(c, slot == 0 ? 2 : 3);
+    return VO_OK;
 }
 
 } // namespace vo_capi
@@ -227,7 +248,7 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     c->h_ntracked[0] = 0;
     c->detect_uploaded = false;
     threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
-    launch_detect_bucket(c->d_imgs, c->d_quads, c->d_detect, 1, w, h, threshold, nonmax, c->d_nmsmask, c->d_rowcnt, c->d_rowoff,
+    launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, 1, w, h, threshold, nonmax, c->d_nmsmask, c->d_rowcnt, c->d_rowoff,
                          c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
                          nullptr, nullptr, 0, nullptr, nullptr, c->stream);
     VO_HIP_TRY(c, hipGetLastError());

@@ -152,6 +152,11 @@ struct vo_ctx {
     hipStream_t stream_em = nullptr; // essential-matrix chain of the mono_rotation branch, next to the PnP chain
     bool partitioned = false; // stream / stream_pnp ... are the partitioned twin of `streams` (select_streams)
     bool quads_set = false; // d_quads holds h_quads (cleared whenever the table is zeroed)
+    // synchronous drop-in calls (capi_dropin.hip): image slot of the LEFT image of the stereo pair the last vo_track_frame /
+    // vo_circular_match received as its t1 pair (0 or 2; its right image follows it), pyramids built -- the next call may name it
+    // as its t0 pair by passing no t0 images (main.cpp:157-158: imageLeft_t0 = imageLeft_t1).  -1: no such pair (no call yet,
+    // or the batch / sequence API has touched the image table since)
+    int tf_base = -1;
     bool serial_pose = false; // -DVO_DEV_VARIANTS + VO_SERIAL_POSE=1: the whole chain on the tracking stream (profiling)
     bool lk_pair = false;     // -DVO_DEV_VARIANTS + VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip)
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over
@@ -226,6 +231,11 @@ struct vo_ctx {
 };
 
 #define VO_STAGE_SLOTS 4
+// the quadruples of the synchronous drop-in calls, resident behind the context's own table (d_quads + max_frames) from
+// vo_create on: a call selects one (use_const_quad) instead of uploading it -- the stateless frame loop alternates between
+// a detection quadruple and a tracking quadruple twice per frame, and an upload is a copy plus a stream synchronisation
+#define VO_CONST_QUADS 4
+static const vo::Quad VO_CONST_QUAD_TABLE[VO_CONST_QUADS] = {{0, 1, 2, 3}, {2, 3, 0, 1}, {0, 0, 0, 0}, {2, 2, 2, 2}};
 
 #define VO_HIP_TRY(ctx, call)                                                                         \
     do {                                                                                              \
@@ -246,6 +256,12 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // register budget of the pose kernels for the stand-alone calls (vo_pnp_ransac, vo_essential_pose): nothing runs beside
 // them, so the full 512 registers unless the caller pinned the other variant
 inline int standalone_waves(const vo_ctx *c) { return c->pin.pose_waves ? c->pin.pose_waves : 1; }
+inline void use_const_quad(vo_ctx *c, int k) // frame 0 of a one-frame configuration reads VO_CONST_QUAD_TABLE[k]
+{
+    c->quads_cur = c->d_quads + c->max_frames + k;
+    c->h_quads[0] = VO_CONST_QUAD_TABLE[k];
+    c->quads_set = false; // d_quads itself no longer says what h_quads says: the next vo_batch_set_quads uploads
+}
 // the current feature set (see vo_ctx::pts_sel)
 inline float2 *cur_pts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_pts : c->d_pts_det[c->pts_sel]; }
 inline int *cur_npts(vo_ctx *c) { return c->pts_sel < 0 ? c->d_npts : c->d_npts_det[c->pts_sel]; }

@@ -62,6 +62,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     if (rc != VO_OK)
         return rc;
     seq_free(c);
+    c->tf_base = -1; // the ring owns the image table (with ring 2 and one sequence the configure above changed nothing)
     // ONE sequence: the loop's two chains of small kernels on disjoint halves of the compute units (capi.hip,
     // ensure_partitioned_streams); more sequences fill the chip and want all of it
     rc = select_streams(c, n_seq == 1);

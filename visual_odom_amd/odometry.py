@@ -20,17 +20,20 @@ class StereoOdometry:
     """streaming=True (default) keeps the two most recent stereo pairs resident on the device: every new
     pair is uploaded once and only its two pyramids are built (the t1 pyramids of one frame are the t0
     pyramids of the next), detection / bucketing, tracking and the pose solve run as one batch of one
-    frame without intermediate host round trips.  streaming=False goes through the stateless drop-in calls
-    (vo_detect_bucket + vo_track_frame: four uploads and four pyramids per frame).  Same results."""
+    frame without intermediate host round trips.  streaming=False goes through the drop-in calls (vo_detect_bucket +
+    vo_track_frame); keep_pair=True (default) lets them name the previous call's t1 pair as this call's t0 pair (two
+    uploads and two pyramids per frame, as the reference's loop keeps imageLeft_t0 / imageRight_t0, main.cpp:157-158),
+    keep_pair=False hands all four images over every frame (the stateless form).  Same results."""
 
     def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=True,
-                 mono_rotation=False, **detect_kw):
+                 mono_rotation=False, keep_pair=True, **detect_kw):
         self.P_l = np.ascontiguousarray(P_l, np.float32).reshape(3, 4)
         self.P_r = np.ascontiguousarray(P_r, np.float32).reshape(3, 4)
         self.ctx = ctx if ctx is not None else _lib.Context(device, max_w, max_h, max_pts, 1)
         self._own = ctx is None
         self.detect_kw = detect_kw
         self.streaming = streaming
+        self.keep_pair, self._kept = bool(keep_pair), False
         # trackingFrame2Frame's `mono_rotation` (visualOdometry.h:42; main.cpp:181 passes false)
         self.mono_rotation = bool(mono_rotation)
         self.ctx.set_params(mono_rotation=int(self.mono_rotation))
@@ -62,9 +65,19 @@ class StereoOdometry:
                 return None
             (l0, r0), (l1, r1) = self.prev, cur
             # matchingFeatures: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
-            pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
+            pts = None
+            if self._kept:   # the previous call's t1 pair is this call's t0 pair and still on the device (main.cpp:157-158)
+                try:
+                    pts, ages = self.ctx.detect_bucket(None, self.points, self.ages, **self.detect_kw)
+                    l0 = r0 = None
+                except _lib.VoError as e:   # somebody else used the context's images in between: all four again
+                    if e.code != _lib.VO_ERR_STATE:
+                        raise
+            if pts is None:
+                pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
             # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
             out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
+            self._kept = self.keep_pair
         # deleteUnmatchFeaturesCircle: ages += 1, compacted with the circular-matching survivors only
         # (feature.cpp:83-86,111); the consistency filter does not touch ages (quirk B3)
         self.ages = (ages + 1)[out["keep_idx_circ"]]
