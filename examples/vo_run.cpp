@@ -113,12 +113,17 @@ int main(int argc, char **argv)
         if (!read_pgm(frame_path(dir, 0, id), l1) || !read_pgm(frame_path(dir, 1, id), r1))
             break; // the reference runs until imread fails (main.cpp:123)
         // matchingFeatures head: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
-        CHECK(vo_detect_bucket(ctx, l0.px.data(), l0.w, l0.h, l0.w, &dp, points.data(), &n_pts, ages.data(), &n_ages, cap));
+        // From the second iteration on the t0 pair is the pair the previous vo_track_frame received as t1 (main.cpp:157-158)
+        // and the library still holds it, pyramids and all: NULL instead of the t0 images (vo_hip.h, THE KEPT PAIR)
+        const bool kept = id > 1;
+        CHECK(vo_detect_bucket(ctx, kept ? nullptr : l0.px.data(), l0.w, l0.h, l0.w, &dp, points.data(), &n_pts, ages.data(), &n_ages,
+                               cap));
         const int n_in = n_pts;
         // circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
         int k_out = 0, m_circ = 0, n_inl = 0;
         double rvec[3] = {0, 0, 0}; // visualOdometry.cpp:162
-        int rc = vo_track_frame(ctx, l0.px.data(), r0.px.data(), l1.px.data(), r1.px.data(), l0.w, l0.h, l0.w, points.data(),
+        int rc = vo_track_frame(ctx, kept ? nullptr : l0.px.data(), kept ? nullptr : r0.px.data(), l1.px.data(), r1.px.data(), l0.w,
+                                l0.h, l0.w, points.data(),
                                 n_in, P_l, P_r, pl0.data(), pr0.data(), pl1.data(), pr1.data(), xyz.data(), keep.data(), &k_out,
                                 keep_circ.data(), &m_circ, rvec, translation, rotation, inliers.data(), &n_inl);
         if (rc == VO_ERR_TOO_FEW) {
