@@ -445,8 +445,8 @@ def test_sequence_trajectory_matches_oracle_and_ground_truth(gpu_ctx, orc, small
     P_l, P_r = small_world.proj_matrices()
     K = small_world.K()
     h, w = L[0].shape
-    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, features_per_bucket=3)                    # streaming
-    vo_dropin = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, streaming=False, features_per_bucket=3)
+    vo = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, streaming=True, features_per_bucket=3)    # the batch-API ring
+    vo_dropin = odometry.StereoOdometry(P_l, P_r, ctx=gpu_ctx, streaming=False, keep_pair=False, features_per_bucket=3)
     o_pts, o_ages = np.zeros((0, 2), np.float32), np.zeros(0, np.int32)
     o_pose, o_t = np.eye(4), np.zeros(3)
     o_traj = [o_pose[:3].copy()]

@@ -17,15 +17,14 @@ from . import _lib
 
 
 class StereoOdometry:
-    """streaming=True (default) keeps the two most recent stereo pairs resident on the device: every new
-    pair is uploaded once and only its two pyramids are built (the t1 pyramids of one frame are the t0
-    pyramids of the next), detection / bucketing, tracking and the pose solve run as one batch of one
-    frame without intermediate host round trips.  streaming=False goes through the drop-in calls (vo_detect_bucket +
-    vo_track_frame); keep_pair=True (default) lets them name the previous call's t1 pair as this call's t0 pair (two
-    uploads and two pyramids per frame, as the reference's loop keeps imageLeft_t0 / imageRight_t0, main.cpp:157-158),
-    keep_pair=False hands all four images over every frame (the stateless form).  Same results."""
+    """The frame loop of main.cpp:123-224 over the synchronous drop-in calls (vo_detect_bucket + vo_track_frame), the way the
+    INTEGRATION.md adapter runs it.  keep_pair=True (default): from the second frame on the calls name the previous call's t1
+    pair as their t0 pair (two uploads and two pyramids per frame, as the reference keeps imageLeft_t0 / imageRight_t0,
+    main.cpp:157-158); keep_pair=False hands all four images over every frame (the stateless form).  streaming=True runs the
+    same loop through the batch API instead (a device-resident ring of two pairs, detection .. pose solve as one batch of one
+    frame) -- the slowest of the three since round 5 (tools/latency_mode.py: 1.16 / 0.93 / 0.86 ms per frame).  Same results."""
 
-    def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=True,
+    def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=False,
                  mono_rotation=False, keep_pair=True, **detect_kw):
         self.P_l = np.ascontiguousarray(P_l, np.float32).reshape(3, 4)
         self.P_r = np.ascontiguousarray(P_r, np.float32).reshape(3, 4)
