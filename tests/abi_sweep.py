@@ -277,7 +277,11 @@ def main():
            C.c_double(1.0), vp(dbuf), vp(dbuf), vp(dbuf), NULL, NULL)
     corners = np.zeros((4096, 2), np.float32)
     expect("vo_fast_detect", ARG, NULL, vp(img), W, H, W, 20, 1, vp(corners), 4096, C.byref(n_out))
-    for bad in ((NULL, W, H, W, vp(corners), 4096, C.byref(n_out)), (vp(img), W + 1, H, W + 1, vp(corners), 4096, C.byref(n_out)),
+    # img == NULL: the left image of the pair the last vo_circular_match / vo_track_frame kept (there is one: the call above);
+    # no such pair of another size
+    expect("vo_fast_detect", OK, ctx, NULL, W, H, W, 20, 1, vp(corners), 4096, C.byref(n_out))
+    expect("vo_fast_detect", STATE, ctx, NULL, W - 8, H, W - 8, 20, 1, vp(corners), 4096, C.byref(n_out))
+    for bad in ((vp(img), W + 1, H, W + 1, vp(corners), 4096, C.byref(n_out)),
                 (vp(img), W, H + 1, W, vp(corners), 4096, C.byref(n_out)), (vp(img), W, H, W - 1, vp(corners), 4096, C.byref(n_out)),
                 (vp(img), 8, H, 8, vp(corners), 4096, C.byref(n_out)), (vp(img), W, H, W, vp(corners), -1, C.byref(n_out)),
                 (vp(img), W, H, W, NULL, 4096, C.byref(n_out)), (vp(img), W, H, W, vp(corners), 4096, NULL)):
@@ -286,8 +290,10 @@ def main():
     ages = np.zeros(CAP + 8, np.int32)
     np_, na_ = C.c_int(0), C.c_int(0)
     expect("vo_detect_bucket", ARG, NULL, vp(img), W, H, W, NULL, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP)
-    for bad in ((NULL, W, H, W, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP),
-                (vp(img), W + 1, H, W + 1, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP),
+    expect("vo_detect_bucket", OK, ctx, NULL, W, H, W, NULL, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP)   # (the kept pair)
+    expect("vo_detect_bucket", STATE, ctx, NULL, W - 8, H, W - 8, NULL, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP)
+    np_.value = na_.value = 0
+    for bad in ((vp(img), W + 1, H, W + 1, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP),
                 (vp(img), W, H, W - 1, vp(pts), C.byref(np_), vp(ages), C.byref(na_), CAP),
                 (vp(img), W, H, W, NULL, C.byref(np_), vp(ages), C.byref(na_), CAP),
                 (vp(img), W, H, W, vp(pts), NULL, vp(ages), C.byref(na_), CAP),
@@ -316,6 +322,18 @@ def main():
     expect("vo_track_frame", ARG, *tf(ctx, vp(img), W, H, W, vp(pts), 4, vp(P), NULL))
     expect("vo_track_frame", (OK, TOO_FEW, 1), *tf(ctx, vp(img), W, H, W, vp(pts), 4, vp(P), vp(Pr), NULL))  # n_out is optional
     expect("vo_track_frame", (OK, TOO_FEW, 1), *tf(ctx, vp(img), W, H, W, vp(pts), 4, vp(P), vp(Pr)))  # blank images: nothing tracks
+    # both t0 images NULL: the kept pair (the call above left one); refused calls (a bad stride, another size) leave it alone
+    def tfk(w, h, stride):
+        t = list(tf(ctx, NULL, w, h, stride, vp(pts), 4, vp(P), vp(Pr)))
+        t[2] = NULL
+        return t
+    expect("vo_track_frame", ARG, *tfk(W, H, W - 1))
+    expect("vo_track_frame", STATE, *tfk(W - 8, H, W - 8))
+    expect("vo_track_frame", (OK, TOO_FEW, 1), *tfk(W, H, W))
+    expect("vo_batch_upload_image", OK, ctx, 0, vp(img), W)          # the batch API takes the image table over
+    expect("vo_track_frame", STATE, *tfk(W, H, W))
+    expect("vo_fast_detect", STATE, ctx, NULL, W, H, W, 20, 1, vp(corners), 4096, C.byref(n_out))
+    expect("vo_track_frame", (OK, TOO_FEW, 1), *tf(ctx, vp(img), W, H, W, vp(pts), 4, vp(P), vp(Pr)))
 
     # ---- lock-step sequence loop ----
     expect("vo_seq_configure", ARG, NULL, 2, W, H, 3, 8)

@@ -35,6 +35,8 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
         return fail(c, VO_ERR_ARG, "null image / points");
     if (n > c->cap)
         return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
+    if (stride < w) // (before anything changes: a refused call leaves the kept pair as it is)
+        return fail(c, VO_ERR_ARG, "stride smaller than the width");
     if (keep && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
         return fail(c, VO_ERR_STATE, "no t0 images given, and the context does not hold the t1 pair of a previous call of this "
                                      "size (first call, another size, or the batch / sequence API used the images since)");
@@ -208,6 +210,8 @@ namespace vo_capi {
 // An image that is given goes to the slot pair that does not hold that t1 pair, which stays valid.
 int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
 {
+    if (img && stride < w)
+        return fail(c, VO_ERR_ARG, "stride smaller than the width");
     if (!img && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
         return fail(c, VO_ERR_STATE, "no image given, and the context does not hold the t1 pair of a previous vo_track_frame "
                                      "of this size");
