@@ -157,3 +157,58 @@ def test_product_library_exports_only_the_header():
     out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("vo_")}
     assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
+
+
+def test_frame_loop_host_logic_of_the_kept_pair():
+    """host side of the kept pair (no device): NULL t0 images stay NULL on their way to the C ABI next to images that share
+    a stride; StereoOdometry names the kept pair from its second frame on and hands all four images over again when the
+    library says that it holds none (VO_ERR_STATE), without swallowing any other error"""
+    import numpy as np
+    from visual_odom_amd import _lib, odometry
+    img = np.zeros((40, 64), np.uint8)
+    pad = np.zeros((44, 80), np.uint8)
+    arrs, stride = _lib._imgs_opt(None, None, pad[2:42, 8:72], pad[1:41, 3:67])
+    assert arrs[0] is None and arrs[1] is None and stride == 80 and arrs[2].shape == (40, 64)
+    arrs, stride = _lib._imgs_opt(None, img, img, pad[2:42, 8:72])           # (one NULL: the C ABI answers VO_ERR_ARG)
+    assert arrs[0] is None and stride == 64 and all(a.flags["C_CONTIGUOUS"] for a in arrs[1:])
+    assert _lib._pn(None) is None
+
+    class FakeCtx:
+        def __init__(self):
+            self.calls, self.refuse, self.fail_code = [], False, _lib.VO_ERR_STATE
+
+        def set_params(self, **kw):
+            pass
+
+        def detect_bucket(self, image, pts, ages, **kw):
+            self.calls.append(("detect", image is None))
+            if image is None and self.refuse:
+                raise _lib.VoError(self.fail_code, "no kept pair")
+            return np.zeros((8, 2), np.float32), np.zeros(8, np.int32)
+
+        def track_frame(self, l0, r0, l1, r1, pts, P_l, P_r, tvec=None):
+            self.calls.append(("track", l0 is None, r0 is None))
+            k = np.arange(6, dtype=np.int32)
+            return dict(rc=0, l1=np.ones((6, 2), np.float32), keep_idx_circ=k, inliers=k, rvec=np.zeros(3),
+                        tvec=np.array([0., 0., 0.5]), R=np.eye(3))
+
+    P = np.hstack([np.eye(3), np.zeros((3, 1))]).astype(np.float32)
+    fake = FakeCtx()
+    vo = odometry.StereoOdometry(P, P, ctx=fake)
+    for _ in range(3):
+        vo.process(img, img)
+    assert fake.calls == [("detect", False), ("track", False, False), ("detect", True), ("track", True, True)]
+    fake.calls, fake.refuse = [], True                                        # somebody else used the context's images
+    vo.process(img, img)
+    assert fake.calls == [("detect", True), ("detect", False), ("track", False, False)]
+    fake.calls, fake.refuse = [], False
+    vo.process(img, img)
+    assert fake.calls == [("detect", True), ("track", True, True)]             # (kept again after a four-image call)
+    fake.refuse, fake.fail_code = True, _lib.VO_ERR_HIP
+    with pytest.raises(_lib.VoError):
+        vo.process(img, img)
+    fake2 = FakeCtx()
+    vo2 = odometry.StereoOdometry(P, P, ctx=fake2, keep_pair=False)
+    for _ in range(3):
+        vo2.process(img, img)
+    assert all(c[1] is False for c in fake2.calls)
