@@ -243,6 +243,8 @@ void vo_destroy(vo_ctx *c)
         (void)hipHostFree(c->h_gather);
     if (c->h_pts_stage)
         (void)hipHostFree(c->h_pts_stage);
+    if (c->h_feat_stage)
+        (void)hipHostFree(c->h_feat_stage);
     for (auto &e : c->ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -370,6 +372,8 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     ok = ok && dmalloc(&c->d_nnew, B) == hipSuccess;
     ok = ok && dmalloc(&c->d_feat, B * (size_t)c->fcap) == hipSuccess;
     ok = ok && dmalloc(&c->d_fages, B * (size_t)c->fcap) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_feat_stage, features_stage_bytes(c->fcap), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void **)&c->d_feat_stage, c->h_feat_stage, 0) == hipSuccess;
     ok = ok && dmalloc(&c->d_ages, B * cap) == hipSuccess;
     ok = ok && dmalloc(&c->d_overflow, B) == hipSuccess;
     ok = ok && hipMemset(c->d_overflow, 0, B * sizeof(int)) == hipSuccess;

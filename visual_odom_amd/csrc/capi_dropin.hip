@@ -22,9 +22,10 @@ long long g_host_stamp[16];
 // The inputs of a single-frame drop-in call on their way to the device WITHOUT a synchronisation in between (round 5): one
 // sync_all up front (idle streams: a few microseconds; after it every staging buffer is free and nothing reads the points),
 // then four kernels that pull the images out of the pinned staging slots over PCIe (pyramid.hip, launch_pull_image), the last of
-// them the points and their count too, all queued on the tracking stream -- the caller's run_stages queues its kernels behind them while the pixels are still crossing PCIe.  Round 4
-// went through vo_batch_set_points here: sync_all + a pageable copy + a stream synchronisation, i.e. the host waited for the
-// four uploads (~80 us for KITTI) before it launched anything (108 + 21 us of the call, profiles/r04_experiments.md section 7).
+// them the points and their count too, all queued on the tracking stream -- the caller's run_stages queues its kernels behind
+// them while the pixels are still crossing PCIe.  Round 4 went through vo_batch_set_points here: sync_all + a pageable copy +
+// a stream synchronisation, i.e. the host waited for the four uploads (~80 us for KITTI) before it launched anything (108 +
+// 21 us of the call, profiles/r04_experiments.md section 7).
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
                               const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
 {
@@ -218,13 +219,17 @@ int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
     int rc = vo_batch_configure(c, 4, w, h, 1);
     if (rc != VO_OK)
         return rc;
+    rc = sync_all(c); // a queued run of the batch API may still read the feature lists / the staging slots
+    if (rc != VO_OK)
+        return rc;
     if (!img) {
         use_const_quad(c, c->tf_base == 0 ? 2 : 3);
         return VO_OK;
     }
     const int slot = c->tf_base == 0 ? 2 : 0;
     const int keep = c->tf_base; // (upload_image itself does not touch it; the batch API's wrappers do)
-    rc = upload_image(c, slot, img, stride, hipMemcpyHostToDevice);
+    c->stage_next = 0;           // (drained above: every staging slot is free, the GPU pulls the image itself)
+    rc = upload_image(c, slot, img, stride, hipMemcpyHostToDevice, /*idle*/ true);
     c->tf_base = rc == VO_OK ? keep : -1;
     if (rc != VO_OK)
         return rc;
@@ -275,30 +280,49 @@ int vo_detect_bucket(vo_ctx *c, const uint8_t *img, int w, int h, int stride, co
 {
     if (!c || !n_pts || !n_ages || !pts_io || !ages_io || cap < 1 || *n_pts > cap || *n_ages > cap) // (the arrays hold cap entries)
         return VO_ERR_ARG;
+    const int np = *n_pts, na = *n_ages;
+    if (np < 0 || na < np || na > c->fcap)
+        return fail(c, VO_ERR_ARG, "vo_detect_bucket: bad counts (need 0 <= n_pts <= n_ages <= capacity)");
     int rc = single_image_setup(c, img, w, h, stride);
     if (rc != VO_OK)
         return rc;
     const vo_detect_params saved = c->dprm;
     rc = vo_batch_set_detect_params(c, dp);
-    if (rc == VO_OK)
-        rc = vo_batch_set_features(c, 0, pts_io, *n_pts, ages_io, *n_ages);
-    if (rc == VO_OK)
-        rc = run_stages(c, VO_STAGE_DETECT, false);
-    int k = 0;
-    if (rc == VO_OK) {
-        VO_HIP_TRY(c, hipMemcpyAsync(&k, cur_npts(c), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (k > cap) {
-            c->dprm = saved;
-            return fail(c, VO_ERR_ARG, "vo_detect_bucket: bucketed set larger than the caller's capacity");
-        }
-        rc = vo_batch_get_features(c, 0, pts_io, ages_io, &k);
-    }
+    if (rc != VO_OK)
+        return rc;
+    // The carried set in and the bucketed set out through page-locked memory the kernels address themselves, ONE
+    // synchronisation per call (round 5; the batch API's setters and getters cost this call seven copies and five
+    // synchronisations, 0.15 of its 0.18 ms on an idle GPU).  single_image_setup has drained the context.
+    if (np > 0)
+        memcpy(c->h_feat_stage, pts_io, sizeof(float2) * (size_t)np);
+    const size_t ages_off = sizeof(float2) * (size_t)c->fcap;
+    if (na > 0)
+        memcpy(c->h_feat_stage + ages_off, ages_io, sizeof(int32_t) * (size_t)na);
+    const int detect = np < c->dprm.redetect_below ? 1 : 0; // appendNewFeatures only then (visualOdometry.cpp:95)
+    launch_features_in(c->d_feat_stage, ages_off, np, na, detect, c->d_feat, c->d_fages, c->fcap, c->d_ntracked, c->d_detect,
+                       c->stream);
+    c->h_ntracked[0] = np;
+    c->h_detect[0] = detect; // (what run_stages would upload: it finds the flag on the device already)
+    c->detect_uploaded = true;
+    rc = run_stages(c, VO_STAGE_DETECT, false);
     c->dprm = saved;
     if (rc != VO_OK)
         return rc;
+    launch_features_out(cur_pts(c), cur_ages(c), cur_npts(c), c->d_overflow, c->cap, c->d_gather, c->stream);
+    VO_HIP_TRY(c, hipGetLastError());
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int k = reinterpret_cast<const int *>(c->h_gather)[0], ovf = reinterpret_cast<const int *>(c->h_gather)[1];
+    if (k > cap)
+        return fail(c, VO_ERR_ARG, "vo_detect_bucket: bucketed set larger than the caller's capacity");
+    const int kc = k < c->cap ? k : c->cap;
+    memcpy(pts_io, c->h_gather + 16, sizeof(float2) * (size_t)kc);
+    memcpy(ages_io, c->h_gather + 16 + sizeof(float2) * (size_t)c->cap, sizeof(int32_t) * (size_t)kc);
     *n_pts = k;
     *n_ages = k;
+    if (ovf)
+        return fail(c, VO_ERR_OVERFLOW, ovf & 1 ? "VO_STAGE_DETECT: carried + detected features exceed the feature-list "
+                                                  "capacity (4 x max_pts, >= 16384, >= w * h / 16): bucketed set truncated"
+                                                : "VO_STAGE_DETECT: the bucketed set exceeds max_pts");
     return VO_OK;
 }
 

@@ -165,6 +165,7 @@ struct vo_ctx {
     uint8_t *h_stage = nullptr, *d_stage = nullptr; // (d_stage: the same memory as the GPU addresses it, launch_pull_image)
     uint8_t *h_gather = nullptr, *d_gather = nullptr; // vo_track_frame's result buffer: host memory, and its device address
     uint8_t *d_pts_stage = nullptr; // (its device address)
+    uint8_t *h_feat_stage = nullptr, *d_feat_stage = nullptr; // pinned + its device address: vo_detect_bucket's carried feature set on its way in (fcap float2 + fcap int32)
     uint8_t *h_pts_stage = nullptr; // pinned: the points + count of a synchronous drop-in call on their way to the device (cap float2 + 16 bytes)
     size_t stage_slot = 0; // bytes per slot, VO_STAGE_SLOTS slots
     int stage_next = 0;

@@ -192,7 +192,7 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *__restrict__ p, 
 // was measured and is slower).  The list phases B1 / B2 keep one or two wavefronts of the workgroup busy for ~100 / ~500
 // instructions whatever the tile size (a 64 x 16 tile holds ~100 candidates and ~40 corners on the benchmark's frames).
 constexpr int BK_PF = 8; // list entries a thread of bucket_kernel holds in registers at a time
-constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
+[[maybe_unused]] constexpr int FAST_MAX_SEGS = 64; // 64-pixel segments per row: images up to 4096 pixels wide
 
 template <int SEGS, int H>
 __device__ __forceinline__ void fast_tile_body(const PyrImage *__restrict__ imgs, const Quad *__restrict__ quads,

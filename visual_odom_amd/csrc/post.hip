@@ -166,6 +166,60 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(FrameGather g, uint8_
         oi[i] = g.inliers[i];
 }
 
+// vo_detect_bucket's hand-over in both directions without a copy call (round 5; capi_dropin.hip).  IN: the carried feature
+// set of frame 0 read out of page-locked host memory (pts [n_pts] float2, then ages [n_ages] int32 at `ages_off` bytes) into the
+// DETECT stage's lists -- ages beyond n_ages read 0, the age of a freshly appended corner (feature.cpp:260) -- with the
+// frame's tracked count and its "detect again" flag.  OUT: the bucketed set and the overflow flags into page-locked host
+// memory: k, overflow at bytes 0 / 4, pts at byte 16, ages behind cap points.
+__global__ __launch_bounds__(256) void features_in_kernel(const uint8_t *__restrict__ src, size_t ages_off, int n_pts, int n_ages,
+                                                          int detect, float2 *__restrict__ feat, int *__restrict__ fages,
+                                                          int fcap, int *__restrict__ n_tracked, int *__restrict__ detect_flag)
+{
+    const float2 *sp = reinterpret_cast<const float2 *>(src);
+    const int *sa = reinterpret_cast<const int *>(src + ages_off);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (int i = tid; i < fcap; i += nth) {
+        if (i < n_pts)
+            feat[i] = sp[i];
+        fages[i] = i < n_ages ? sa[i] : 0;
+    }
+    if (tid == 0) {
+        n_tracked[0] = n_pts;
+        detect_flag[0] = detect;
+    }
+}
+
+__global__ __launch_bounds__(256) void features_out_kernel(const float2 *__restrict__ pts, const int *__restrict__ ages,
+                                                           const int *__restrict__ n, const int *__restrict__ overflow, int cap,
+                                                           uint8_t *__restrict__ out)
+{
+    const int k = n[0] < cap ? n[0] : cap;
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid == 0) {
+        reinterpret_cast<int *>(out)[0] = n[0];
+        reinterpret_cast<int *>(out)[1] = overflow[0];
+    }
+    float2 *op = reinterpret_cast<float2 *>(out + 16);
+    int *oa = reinterpret_cast<int *>(op + cap);
+    for (int i = tid; i < k; i += nth) {
+        op[i] = pts[i];
+        oa[i] = ages[i];
+    }
+}
+
+void launch_features_in(const uint8_t *src, size_t ages_off, int n_pts, int n_ages, int detect, float2 *feat, int *fages, int fcap,
+                        int *n_tracked, int *detect_flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(features_in_kernel, dim3(16), dim3(256), 0, stream, src, ages_off, n_pts, n_ages, detect, feat, fages, fcap,
+                       n_tracked, detect_flag);
+}
+
+void launch_features_out(const float2 *pts, const int *ages, const int *n, const int *overflow, int cap, uint8_t *out,
+                         hipStream_t stream)
+{
+    hipLaunchKernelGGL(features_out_kernel, dim3(8), dim3(256), 0, stream, pts, ages, n, overflow, cap, out);
+}
+
 void launch_frame_gather(const FrameGather &g, uint8_t *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(frame_gather_kernel, dim3(8), dim3(256), 0, stream, g, out);

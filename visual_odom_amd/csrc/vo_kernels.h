@@ -173,6 +173,13 @@ struct FrameGather {
 constexpr size_t VO_GATHER_HEADER = 512;
 inline size_t frame_gather_bytes(int cap) { return VO_GATHER_HEADER + (size_t)cap * (4 * 8 + 12 + 3 * 4); }
 void launch_frame_gather(const FrameGather &g, uint8_t *out, hipStream_t stream);
+// vo_detect_bucket's feature set in and out through page-locked host memory (post.hip)
+inline size_t features_stage_bytes(int fcap) { return (size_t)fcap * (sizeof(float2) + sizeof(int)); }
+inline size_t features_out_bytes(int cap) { return 16 + (size_t)cap * (sizeof(float2) + sizeof(int)); }
+void launch_features_in(const uint8_t *src, size_t ages_off, int n_pts, int n_ages, int detect, float2 *feat, int *fages, int fcap,
+                        int *n_tracked, int *detect_flag, hipStream_t stream);
+void launch_features_out(const float2 *pts, const int *ages, const int *n, const int *overflow, int cap, uint8_t *out,
+                         hipStream_t stream);
 void launch_compact(const float2 *pts_in, const float2 *trk, const uint8_t *status, const int *n_pts, int cap,
                     int threshold, float2 *outA, int *idxA, int *nA, float2 *outB, int *idxB, int *nB,
                     int n_frames, hipStream_t stream);

@@ -22,7 +22,7 @@ class StereoOdometry:
     pair as their t0 pair (two uploads and two pyramids per frame, as the reference keeps imageLeft_t0 / imageRight_t0,
     main.cpp:157-158); keep_pair=False hands all four images over every frame (the stateless form).  streaming=True runs the
     same loop through the batch API instead (a device-resident ring of two pairs, detection .. pose solve as one batch of one
-    frame) -- the slowest of the three since round 5 (tools/latency_mode.py: 1.16 / 0.93 / 0.86 ms per frame).  Same results."""
+    frame) -- the slowest of the three since round 5 (tools/latency_mode.py: 1.10 / 0.81 / 0.75 ms per frame).  Same results."""
 
     def __init__(self, P_l, P_r, device=0, max_w=1241, max_h=376, max_pts=4096, ctx=None, streaming=False,
                  mono_rotation=False, keep_pair=True, **detect_kw):
