@@ -56,6 +56,31 @@ def run(what, per_bucket, n):
         dt2 = time.perf_counter() - t1
         print("  track_frame %.2f ms/frame = %.0f frames/s (PCIe-inclusive, %d points); detect_bucket %.2f ms/frame"
               % (1e3 * dt / n, n / dt, len(pts[0]), 1e3 * dt2 / n))
+    elif what == "adapter":  # the three calls at the reference's own function boundaries (INTEGRATION.md's adapter)
+        ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+        K = world.K()
+
+        def frame(k):
+            cm = ctx.circular_match(L[k], R[k], L[k + 1], R[k + 1], pts[k], apply_consistency=True)
+            xyz = ctx.triangulate(P_l, P_r, cm["l0"], cm["r0"])
+            return ctx.pnp_ransac(xyz, cm["l1"], K)
+        for k in range(4):
+            frame(k)
+        tt = [0.0, 0.0, 0.0]
+        t0 = time.perf_counter()
+        for i in range(n):
+            k = i % 4
+            a = time.perf_counter()
+            cm = ctx.circular_match(L[k], R[k], L[k + 1], R[k + 1], pts[k], apply_consistency=True)
+            b = time.perf_counter()
+            xyz = ctx.triangulate(P_l, P_r, cm["l0"], cm["r0"])
+            c_ = time.perf_counter()
+            ctx.pnp_ransac(xyz, cm["l1"], K)
+            d = time.perf_counter()
+            tt[0] += b - a; tt[1] += c_ - b; tt[2] += d - c_
+        dt = time.perf_counter() - t0
+        print("  adapter calls vo_circular_match + vo_triangulate + vo_pnp_ransac: %.2f ms/frame = %.0f frames/s (%.2f + %.2f + %.2f)"
+              % (1e3 * dt / n, n / dt, 1e3 * tt[0] / n, 1e3 * tt[1] / n, 1e3 * tt[2] / n))
     elif what == "trackkept":  # the t0 pair = the previous call's t1 pair, kept on the device: two images per call
         ctx = _lib.Context(0, world.w, world.h, 4096, 1)
         ctx.track_frame(L[0], R[0], L[1], R[1], pts[0], P_l, P_r)
@@ -108,5 +133,5 @@ if __name__ == "__main__":
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
         for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default (1 per bucket)", 1)):
             print(name + ":", flush=True)
-            for what in ("track", "trackkept", "ring", "stateless", "kept", "pipelined"):
+            for what in ("track", "trackkept", "adapter", "ring", "stateless", "kept", "pipelined"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), what, str(per_bucket), str(n)], check=False)

@@ -869,29 +869,6 @@ int vo_batch_get_filtered(vo_ctx *c, int frame, float *l0, float *r0, float *l1,
 
 namespace vo_capi {
 
-// stage-A arrays (deleteUnmatchFeaturesCircle output) of one frame
-int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, float *l1, float *l0r,
-                       int32_t *keep_idx, int *n_out)
-{
-    int M = 0;
-    int rcs = sync_all(c); // the filter runs on the post stream
-    if (rcs != VO_OK)
-        return rcs;
-    VO_HIP_TRY(c, hipMemcpyAsync(&M, c->d_nA + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const size_t cap = c->cap;
-    const float2 *a = c->d_outA + (size_t)frame * 5 * cap;
-    D2H(l0, a, sizeof(float2) * M);
-    D2H(r0, a + cap, sizeof(float2) * M);
-    D2H(r1, a + 2 * cap, sizeof(float2) * M);
-    D2H(l1, a + 3 * cap, sizeof(float2) * M);
-    D2H(l0r, a + 4 * cap, sizeof(float2) * M);
-    D2H(keep_idx, c->d_idxA + (size_t)frame * cap, sizeof(int32_t) * M);
-    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *n_out = M;
-    return VO_OK;
-}
-
 // pnp_rotation: R = Rodrigues(rvec) even under mono_rotation (vo_pnp_ransac).  em_status (optional): status of the
 // essential-matrix side of the frame under mono_rotation (1 ok, 0 no model, -1 too few points), 1 otherwise.
 int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers,

@@ -89,33 +89,42 @@ int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uin
     int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
     if (rc != VO_OK)
         return rc;
-    rc = run_stages(c, VO_STAGE_PYRAMID | VO_STAGE_LK | VO_STAGE_FILTER, false);
+    // a synchronous call: every stage on the tracking stream (run_stages, `serial`), then ONE kernel that gathers whatever
+    // the caller asked for into the host-visible result buffer and one synchronisation (round 5: the batch getters cost this
+    // call ten copies and five synchronisations, ~0.17 of its 0.57 ms)
+    rc = run_stages_auto(c, VO_STAGE_PYRAMID | VO_STAGE_LK | VO_STAGE_FILTER, false, nullptr, /*sync_call*/ true);
     if (rc != VO_OK)
         return rc;
-    if (status4) {
-        rc = vo_batch_get_tracks(c, 0, nullptr, nullptr, nullptr, nullptr, status4, n);
-        if (rc != VO_OK)
-            return rc;
-    }
-    if (!apply_consistency)
-        return get_stage_a(c, 0, out_l0, out_r0, out_r1, out_l1, out_l0_ret, keep_idx, n_out);
-    // stage B drops l0_ret (removeInvalidPoints is not applied to it); fill it from stage A by index
-    int K = 0;
-    rc = vo_batch_get_filtered(c, 0, out_l0, out_r0, out_l1, out_r1, nullptr, keep_idx, &K, nullptr, nullptr);
-    if (rc != VO_OK)
-        return rc;
-    if (out_l0_ret && K > 0) {
-        std::vector<int32_t> idx((size_t)K);
-        std::vector<float> ret((size_t)2 * (n > 0 ? n : 1));
-        VO_HIP_TRY(c, hipMemcpy(idx.data(), c->pb[c->last].idxB, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
-        VO_HIP_TRY(c, hipMemcpy(ret.data(), c->d_trk2[c->trk_last] + (size_t)3 * c->cap, sizeof(float2) * n,
-                                hipMemcpyDeviceToHost));
-        for (int i = 0; i < K; i++) {
-            out_l0_ret[2 * i] = ret[2 * idx[i]];
-            out_l0_ret[2 * i + 1] = ret[2 * idx[i] + 1];
-        }
-    }
-    *n_out = K;
+    const vo_ctx::PoseBufs &pb = c->pb[c->last];
+    CircGather g;
+    g.outA = c->d_outA;
+    g.idxA = c->d_idxA;
+    g.nA = c->d_nA;
+    g.outB = pb.outB;
+    g.idxB = pb.idxB;
+    g.nB = pb.nB;
+    g.trk = c->d_trk2[c->trk_last];
+    g.status = c->d_status2[c->trk_last];
+    g.n = status4 ? n : 0;
+    g.cap = c->cap;
+    g.consistency = apply_consistency ? 1 : 0;
+    launch_circ_gather(g, c->d_gather, c->stream); // (circ_gather_bytes(cap) <= frame_gather_bytes(cap))
+    VO_HIP_TRY(c, hipGetLastError());
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint8_t *hb = c->h_gather;
+    int count = 0;
+    memcpy(&count, hb, sizeof(int));
+    const size_t cap = (size_t)c->cap;
+    float *outs[5] = {out_l0, out_r0, out_r1, out_l1, out_l0_ret};
+    for (int k = 0; k < 5; k++)
+        if (outs[k] && count > 0)
+            memcpy(outs[k], hb + 16 + (size_t)k * cap * 8, (size_t)count * 8);
+    if (keep_idx && count > 0)
+        memcpy(keep_idx, hb + 16 + 5 * cap * 8, (size_t)count * 4);
+    if (status4 && n > 0)
+        for (int hop = 0; hop < 4; hop++) // [4][n] for the caller
+            memcpy(status4 + (size_t)hop * n, hb + 16 + 5 * cap * 8 + cap * 4 + (size_t)hop * cap, (size_t)n);
+    *n_out = count;
     return VO_OK;
 }
 
@@ -134,42 +143,20 @@ int vo_triangulate(vo_ctx *c, const float *P_l, const float *P_r, const float *p
     rc = sync_all(c);
     if (rc != VO_OK)
         return rc;
-    // frame 0, stage-B rows 0 (left) and 1 (right)
+    // frame 0, stage-B rows 0 (left) and 1 (right); the points in and the result out through page-locked memory the kernels
+    // address (words_in_kernel / words_out_kernel, post.hip): one synchronisation, no copy call
     vo_ctx::PoseBufs &pb = c->pb[c->last];
-    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB, pl, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + c->cap, pr, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    memcpy(c->h_feat_stage, pl, sizeof(float2) * (size_t)n);
+    memcpy(c->h_feat_stage + sizeof(float2) * (size_t)n, pr, sizeof(float2) * (size_t)n);
+    launch_words_in(c->d_feat_stage, 2 * n, pb.outB, 2 * n, pb.outB + c->cap, pb.nB, n, c->stream);
     launch_triangulate(c->d_P, c->d_P + 12, pb.outB, pb.outB + c->cap, (size_t)4 * c->cap, pb.nB, c->cap, n, 1,
                        pb.xyz, c->stream);
+    launch_words_out(pb.xyz, 3 * n, c->d_gather, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
-    VO_HIP_TRY(c, hipMemcpyAsync(xyz_out, pb.xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(xyz_out, c->h_gather, sizeof(float) * 3 * (size_t)n);
     return VO_OK;
 }
-
-} // extern "C"
-
-namespace vo_capi {
-
-int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
-                      int *n_inliers, bool pnp_rotation)
-{
-    int status = 0, ninl = 0, em_status = 1;
-    int rc = get_pose_impl(c, 0, rvec_io, tvec_io, R_out, inliers, &ninl, &status, nullptr, pnp_rotation, &em_status);
-    if (rc != VO_OK)
-        return rc;
-    if (n_inliers)
-        *n_inliers = ninl;
-    if (status < 0)
-        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
-    if (em_status != 1) // mono_rotation and findEssentialMat found nothing: R_out was left untouched
-        return VO_NO_ESSENTIAL;
-    return status == 1 ? VO_OK : VO_NO_MODEL;
-}
-
-} // namespace vo_capi
-
-extern "C" {
 
 int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const float *K, double *rvec_io,
                   double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers)
@@ -187,18 +174,48 @@ int vo_pnp_ransac(vo_ctx *c, const float *xyz, const float *uv, int n, const flo
     pp.reproj = c->prm.ransac_reproj_error;
     pp.confidence = c->prm.ransac_confidence;
     memcpy(pp.K, K, sizeof(pp.K));
+    // the correspondences in and the pose out through page-locked memory the kernels address (the staging buffer holds
+    // 12 bytes x 4 max_pts or more, a correspondence is 20): one synchronisation per call, no copy call
     if (n > 0) {
-        VO_HIP_TRY(c, hipMemcpyAsync(pb.xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-        VO_HIP_TRY(c, hipMemcpyAsync(pb.outB + 2 * (size_t)c->cap, uv, sizeof(float2) * n, hipMemcpyHostToDevice,
-                                     c->stream));
+        memcpy(c->h_feat_stage, xyz, sizeof(float) * 3 * (size_t)n);
+        memcpy(c->h_feat_stage + sizeof(float) * 3 * (size_t)n, uv, sizeof(float2) * (size_t)n);
     }
-    VO_HIP_TRY(c, hipMemcpyAsync(pb.nB, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    launch_words_in(c->d_feat_stage, 3 * n, pb.xyz, 2 * n, pb.outB + 2 * (size_t)c->cap, pb.nB, n, c->stream);
     if (c->n_frames < 1)
         c->n_frames = 1;
     launch_pnp(pb.xyz, pb.outB + 2 * (size_t)c->cap, (size_t)4 * c->cap, pb.nB, c->cap, 1, pp, pb.subsets,
                pb.models, pb.counts, pb.rstate, pb.inliers, pb.results, standalone_waves(c), c->stream, pb.epnp_ws, 1, pb.epnp_gws, pb.rest_ws);
+    FrameGather g = {};
+    g.nA = g.nB = pb.nB;
+    g.inliers = pb.inliers;
+    g.result = pb.results;
+    g.cap = c->cap;
+    g.pose_only = 1;
+    launch_frame_gather(g, c->d_gather, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
-    return fetch_pose(c, rvec_io, tvec_io, R_out, inliers, n_inliers, /*pnp_rotation*/ true);
+    VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    PnpResult r;
+    memcpy(&r, c->h_gather + 16, sizeof(r));
+    // by the rules of get_pose_impl with pnp_rotation: R = Rodrigues(rvec) whatever vo_params.mono_rotation says
+    if (r.status == 0 && r.lm_iters < 0) { // four points, P3P without a solution: rvec / tvec stay the caller's
+        if (R_out && rvec_io)
+            rodrigues_v2m(rvec_io, R_out, nullptr);
+    } else if (r.status >= 0) {
+        if (rvec_io)
+            memcpy(rvec_io, r.rvec, sizeof(r.rvec));
+        if (tvec_io)
+            memcpy(tvec_io, r.tvec, sizeof(r.tvec));
+        if (R_out)
+            memcpy(R_out, r.R, sizeof(r.R));
+    }
+    const int ninl = r.n_inliers < c->cap ? r.n_inliers : c->cap;
+    if (inliers && ninl > 0)
+        memcpy(inliers, c->h_gather + VO_GATHER_HEADER + (size_t)c->cap * (4 * 8 + 12 + 2 * 4), sizeof(int32_t) * (size_t)ninl);
+    if (n_inliers)
+        *n_inliers = r.n_inliers;
+    if (r.status < 0)
+        return fail(c, VO_ERR_TOO_FEW, "fewer than 4 correspondences reached solvePnPRansac (CV_Assert(npoints >= 4))");
+    return r.status == 1 ? VO_OK : VO_NO_MODEL;
 }
 
 } // extern "C"

@@ -334,12 +334,10 @@ int probe_run(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry);
 int probe_candidate(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency, double *ms_per_run);
 int tune_schedule(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry, bool latency = false, bool publish = true);
 int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool sync_call = false);
-int get_stage_a(vo_ctx *c, int frame, float *l0, float *r0, float *r1, float *l1, float *l0r, int32_t *keep_idx, int *n_out);
 int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers, int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status, bool io_pose = true);
 int seq_begin_step(vo_ctx *c);
 int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode);
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h, int stride, const float *pts, int n);
-int fetch_pose(vo_ctx *c, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers, int *n_inliers, bool pnp_rotation);
 int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride);
 } // namespace vo_capi
 

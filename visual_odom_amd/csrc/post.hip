@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float *__restric
 // see FrameGather (vo_kernels.h); `out` is page-locked host memory mapped into the device's address space
 __global__ __launch_bounds__(256) void frame_gather_kernel(FrameGather g, uint8_t *__restrict__ out)
 {
-    const int K = g.nB[0], M = g.nA[0], cap = g.cap;
+    const int K = g.pose_only ? 0 : g.nB[0], M = g.pose_only ? 0 : g.nA[0], cap = g.cap; // (pose_only: vo_pnp_ransac)
     const PnpResult r = g.result[0];
     const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     if (tid == 0) {
@@ -205,6 +205,75 @@ __global__ __launch_bounds__(256) void features_out_kernel(const float2 *__restr
         op[i] = pts[i];
         oa[i] = ages[i];
     }
+}
+
+// the same for plain arrays (vo_triangulate, vo_pnp_ransac): n0 then n1 32-bit words out of page-locked host memory into two
+// device arrays, with a count; n words of a device array into page-locked host memory
+__global__ __launch_bounds__(256) void words_in_kernel(const uint32_t *__restrict__ src, int n0, uint32_t *__restrict__ dst0, int n1,
+                                                       uint32_t *__restrict__ dst1, int *__restrict__ count_dst, int count)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (int i = tid; i < n0; i += nth)
+        dst0[i] = src[i];
+    for (int i = tid; i < n1; i += nth)
+        dst1[i] = src[n0 + i];
+    if (tid == 0)
+        count_dst[0] = count;
+}
+
+__global__ __launch_bounds__(256) void words_out_kernel(const uint32_t *__restrict__ src, int n, uint32_t *__restrict__ dst)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        dst[i] = src[i];
+}
+
+// vo_circular_match's results (see CircGather, vo_kernels.h)
+__global__ __launch_bounds__(256) void circ_gather_kernel(CircGather g, uint8_t *__restrict__ out)
+{
+    const int cap = g.cap, count = g.consistency ? g.nB[0] : g.nA[0];
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid == 0)
+        reinterpret_cast<int *>(out)[0] = count;
+    float2 *o = reinterpret_cast<float2 *>(out + 16);
+    int32_t *oi = reinterpret_cast<int32_t *>(o + 5 * (size_t)cap);
+    uint8_t *os = reinterpret_cast<uint8_t *>(oi + cap);
+    for (int i = tid; i < count; i += nth) {
+        if (!g.consistency) { // stage A rows: l0, r0, r1, l1, l0_ret
+#pragma unroll
+            for (int row = 0; row < 5; row++)
+                o[(size_t)row * cap + i] = g.outA[(size_t)row * cap + i];
+            oi[i] = g.idxA[i];
+        } else { // stage B rows are l0, r0, l1, r1; it drops l0_ret (removeInvalidPoints is not applied to it): by index
+            const int k = g.idxB[i];
+            o[i] = g.outB[i];
+            o[(size_t)cap + i] = g.outB[(size_t)cap + i];
+            o[2 * (size_t)cap + i] = g.outB[3 * (size_t)cap + i];
+            o[3 * (size_t)cap + i] = g.outB[2 * (size_t)cap + i];
+            o[4 * (size_t)cap + i] = g.trk[3 * (size_t)cap + k];
+            oi[i] = k;
+        }
+    }
+    for (int i = tid; i < g.n; i += nth)
+#pragma unroll
+        for (int hop = 0; hop < 4; hop++)
+            os[(size_t)hop * cap + i] = g.status[(size_t)hop * cap + i];
+}
+
+void launch_words_in(const void *src, int n0, void *dst0, int n1, void *dst1, int *count_dst, int count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(words_in_kernel, dim3(8), dim3(256), 0, stream, static_cast<const uint32_t *>(src), n0,
+                       static_cast<uint32_t *>(dst0), n1, static_cast<uint32_t *>(dst1), count_dst, count);
+}
+
+void launch_words_out(const void *src, int n, void *dst, hipStream_t stream)
+{
+    hipLaunchKernelGGL(words_out_kernel, dim3(8), dim3(256), 0, stream, static_cast<const uint32_t *>(src), n,
+                       static_cast<uint32_t *>(dst));
+}
+
+void launch_circ_gather(const CircGather &g, uint8_t *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(circ_gather_kernel, dim3(8), dim3(256), 0, stream, g, out);
 }
 
 void launch_features_in(const uint8_t *src, size_t ages_off, int n_pts, int n_ages, int detect, float2 *feat, int *fages, int fcap,

@@ -169,10 +169,29 @@ struct FrameGather {
     const PnpResult *result;
     const EmResult *em; // null unless mono_rotation
     int cap;
+    int pose_only = 0; // no point arrays, only the PnpResult and its inliers (vo_pnp_ransac)
 };
 constexpr size_t VO_GATHER_HEADER = 512;
 inline size_t frame_gather_bytes(int cap) { return VO_GATHER_HEADER + (size_t)cap * (4 * 8 + 12 + 3 * 4); }
 void launch_frame_gather(const FrameGather &g, uint8_t *out, hipStream_t stream);
+// vo_circular_match's results in one host-visible buffer (layout: count at byte 0; from byte 16 five rows l0, r0, r1, l1, l0_ret
+// of [cap] float2, keep_idx [cap] int32, the raw LK status [4][cap] bytes): stage A (deleteUnmatchFeaturesCircle) or, with
+// `consistency`, stage B (+ checkValidMatch / removeInvalidPoints) with l0_ret picked out of the raw tracks by index
+struct CircGather {
+    const float2 *outA; // [5][cap]
+    const int32_t *idxA;
+    const int *nA;
+    const float2 *outB; // [4][cap] l0, r0, l1, r1
+    const int32_t *idxB;
+    const int *nB;
+    const float2 *trk;     // [4][cap] raw tracks (row 3 = l0_ret)
+    const uint8_t *status; // [4][cap]
+    int n, cap, consistency;
+};
+inline size_t circ_gather_bytes(int cap) { return 16 + (size_t)cap * (5 * 8 + 4 + 4); }
+void launch_circ_gather(const CircGather &g, uint8_t *out, hipStream_t stream);
+void launch_words_in(const void *src, int n0, void *dst0, int n1, void *dst1, int *count_dst, int count, hipStream_t stream);
+void launch_words_out(const void *src, int n, void *dst, hipStream_t stream);
 // vo_detect_bucket's feature set in and out through page-locked host memory (post.hip)
 inline size_t features_stage_bytes(int fcap) { return (size_t)fcap * (sizeof(float2) + sizeof(int)); }
 inline size_t features_out_bytes(int cap) { return 16 + (size_t)cap * (sizeof(float2) + sizeof(int)); }
