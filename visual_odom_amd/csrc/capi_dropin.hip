@@ -268,23 +268,24 @@ int vo_fast_detect(vo_ctx *c, const uint8_t *img, int w, int h, int stride, int 
     int rc = single_image_setup(c, img, w, h, stride);
     if (rc != VO_OK)
         return rc;
-    const int one = 1, zero = 0;
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_detect, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    VO_HIP_TRY(c, hipMemcpyAsync(c->d_ntracked, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // (no copy call: the flags by features_in_kernel, the corners and their count back through page-locked memory, one
+    // synchronisation -- see vo_detect_bucket)
+    launch_features_in(c->d_feat_stage, 0, 0, 0, /*detect*/ 1, c->d_feat, c->d_fages, c->fcap, c->d_ntracked, c->d_detect, c->stream);
     c->h_ntracked[0] = 0;
-    c->detect_uploaded = false;
+    c->h_detect[0] = 1;
+    c->detect_uploaded = true;
     threshold = threshold < 0 ? 0 : threshold > 255 ? 255 : threshold;
     launch_detect_bucket(c->d_imgs, c->quads_cur, c->d_detect, 1, w, h, threshold, nonmax, c->d_nmsmask, c->d_rowcnt, c->d_rowoff,
                          c->d_ntracked, c->d_nnew, c->fcap, c->d_feat, c->d_fages, /*bucket_size*/ 0, 1, nullptr,
                          nullptr, nullptr, 0, nullptr, nullptr, c->stream);
+    launch_features_out(c->d_feat, c->d_fages, c->d_nnew, c->d_overflow, c->fcap, c->d_feat_stage, c->stream);
     VO_HIP_TRY(c, hipGetLastError());
-    int n = 0;
-    VO_HIP_TRY(c, hipMemcpyAsync(&n, c->d_nnew, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n = reinterpret_cast<const int *>(c->h_feat_stage)[0];
     int k = n < cap ? n : cap;
     k = k < c->fcap ? k : c->fcap;
     if (k > 0)
-        VO_HIP_TRY(c, hipMemcpy(pts_out, c->d_feat, sizeof(float2) * k, hipMemcpyDeviceToHost));
+        memcpy(pts_out, c->h_feat_stage + 16, sizeof(float2) * (size_t)k);
     *n_out = n;
     if (n > c->fcap && cap > c->fcap) // the caller's buffer would have held them, the context's corner list does not
         return fail(c, VO_ERR_OVERFLOW, "vo_fast_detect: more corners than the context's corner-list capacity "

@@ -193,7 +193,7 @@ void launch_circ_gather(const CircGather &g, uint8_t *out, hipStream_t stream);
 void launch_words_in(const void *src, int n0, void *dst0, int n1, void *dst1, int *count_dst, int count, hipStream_t stream);
 void launch_words_out(const void *src, int n, void *dst, hipStream_t stream);
 // vo_detect_bucket's feature set in and out through page-locked host memory (post.hip)
-inline size_t features_stage_bytes(int fcap) { return (size_t)fcap * (sizeof(float2) + sizeof(int)); }
+inline size_t features_stage_bytes(int fcap) { return 16 + (size_t)fcap * (sizeof(float2) + sizeof(int)); } // (in: fcap points + fcap ages; out: vo_fast_detect's corners, features_out_kernel's layout)
 inline size_t features_out_bytes(int cap) { return 16 + (size_t)cap * (sizeof(float2) + sizeof(int)); }
 void launch_features_in(const uint8_t *src, size_t ages_off, int n_pts, int n_ages, int detect, float2 *feat, int *fages, int fcap,
                         int *n_tracked, int *detect_flag, hipStream_t stream);
