@@ -82,6 +82,7 @@ struct Heap {
     }
 };
 
+int g_bucket_threads = 256; // ke_set_bucket_threads: width of bucket_kernel's workgroup (256, or 1024 as in launches of <= 4 frames)
 int g_fast_big = 0; // ke_set_fast_big: tile form of the FAST kernel (0: 64 x 16, 1: 64 x 32, 2: 128 x 32)
 int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead
 
@@ -541,6 +542,7 @@ long long ke_fast_compass_pair_check()
 
 void ke_set_lk_pair(int on) { g_lk_pair = on; }
 void ke_set_fast_big(int on) { g_fast_big = on; }
+void ke_set_bucket_threads(int n) { g_bucket_threads = n; }
 
 // imgs: n_img images of w x h (contiguous).  Builds every pyramid with the emulated kernels.
 // lvl_out / der_out (optional): interior of level `want_level` of image 0 (w_l*h_l bytes / dwords).
@@ -649,7 +651,7 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
         memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);
         return n_new;
     }
-    launch(1, 1, 1, 256, [&] {
+    launch(1, 1, 1, (unsigned)g_bucket_threads, [&] {
         bucket_kernel(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
                       out_ages, &n_out, out_cap, nullptr, nullptr, nullptr);
     });

@@ -208,10 +208,13 @@ def ke_detect(lib, img, tracked=None, ages=None, threshold=20, nonmax=1, detect=
 
 @pytest.fixture(params=[0, 1, 2], ids=["tile-64x16", "tile-64x32", "tile-128x32"])
 def fast_variant(request, kemu):
-    """the FAST emulation tests run on all three tile forms of the kernel"""
+    """the FAST emulation tests run on all three tile forms of the kernel -- and, with the middle one, on the 1024-thread form
+    of bucket_kernel (launches of <= 4 frames; 256 threads otherwise)"""
     kemu.ke_set_fast_big(request.param)
+    kemu.ke_set_bucket_threads(1024 if request.param == 1 else 256)
     yield request.param
     kemu.ke_set_fast_big(0)
+    kemu.ke_set_bucket_threads(256)
 
 
 def test_emulated_fast_matches_oracle(kemu, orc, small_seq, fast_variant):

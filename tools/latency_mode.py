@@ -41,6 +41,14 @@ def run(what, per_bucket, n):
             ctx.track_frame(L[k], R[k], L[k + 1], R[k + 1], pts[k], P_l, P_r)
         print("  schedule", ctx.get_schedule(), ctx.get_probe_log())
         return
+    if what == "trackkeptonly":  # the same on the kept pair (two new images per call)
+        ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+        ctx.track_frame(L[0], R[0], L[1], R[1], pts[0], P_l, P_r)
+        for i in range(1, n):
+            a, b = ORDER[i % 8], ORDER[(i + 1) % 8]
+            ctx.detect_bucket(None, np.zeros((0, 2), np.float32), np.zeros(0, np.int32), features_per_bucket=per_bucket)
+            ctx.track_frame(None, None, L[b], R[b], pts[a], P_l, P_r)
+        return
     if what == "track":
         ctx = _lib.Context(0, world.w, world.h, 4096, 1)
         for k in range(4):

@@ -481,8 +481,11 @@ constexpr int BK_MAX_CELLS = 1024; // (rows/bucket + 1) * (cols/bucket + 1)
 constexpr int BK_MAX_FPB = 8;
 constexpr int BK_CELL_CACHE = 8192; // list entries whose cell is kept in LDS between the passes (16 KB)
 
-// one 256-thread workgroup per frame
-__global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ feat /* [B][cap] */,
+// one workgroup per frame, of 256 threads or (round 5, launches of a few frames: the kernel is on the critical path of a
+// one-sequence step and of vo_detect_bucket, 35 us per KITTI frame at 6 features per bucket) of 1024: the walks over the
+// list -- 1 + (features_per_bucket - 1) of them -- go four times as wide; the emission, 4 cells per thread, stays on the
+// first 256 threads.  Every phase is order-free (counts, minima, maxima), so the width does not change the result.
+__global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__ feat /* [B][cap] */,
                                                      const int *__restrict__ ages /* [B][cap] */,
                                                      const int *__restrict__ n_tracked,
                                                      const int *__restrict__ n_new, int cap, int rows, int cols,
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     // and every walk re-loaded point + age and re-did the two float divisions -- 70 us for ONE frame at f = 6, between the
     // pyramids and LK on the critical path of a lock-step step (gpurun_out/r4_09 timeline)
     __shared__ int16_t s_cell[BK_CELL_CACHE];
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int frame = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int bh = rows / bucket_size, bw = cols / bucket_size;
     const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
     // The list appendNewFeatures leaves (feature.cpp:255-262) is "carried features, then the new corners".  Combined
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         n_in = n_in < cap ? n_in : cap;
     }
 
-    for (int b = tid; b < nb; b += 256) {
+    for (int b = tid; b < nb; b += nthr) {
         s_cnt[b] = 0;
         s_last[b] = -1;
         for (int q = 0; q < fpb; q++)
@@ -565,13 +568,13 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         *len = (above ? __builtin_ctzll(above) : 64) - lane;
         return head && b >= 0;
     };
-    for (int base = 0; base < n_in; base += 256 * BK_PF) { // (wave-uniform trip count: the ballots need all lanes)
+    for (int base = 0; base < n_in; base += nthr * BK_PF) { // (wave-uniform trip count: the ballots need all lanes)
         const int i0 = base + tid;
         float2 pt[BK_PF];
         int ag[BK_PF];
 #pragma unroll
         for (int k = 0; k < BK_PF; k++) {
-            const int i = i0 + 256 * k;
+            const int i = i0 + nthr * k;
             if (i < n_in) {
                 pt[k] = point(i);
                 ag[k] = age(i);
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < BK_PF; k++) {
-            const int i = i0 + 256 * k; // (the wavefront's lanes hold 64 CONSECUTIVE list entries)
+            const int i = i0 + nthr * k; // (the wavefront's lanes hold 64 CONSECUTIVE list entries)
             int b = -2;                 // beyond the list: never equal to a cell or to "ignored" (-1)
             if (i < n_in) {
                 const int hidx = (int)(pt[k].y / (float)bucket_size), widx = (int)(pt[k].x / (float)bucket_size);
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
     }
     __syncthreads();
     for (int q = 1; q < fpb; q++) { // q-th eligible feature of every bucket, in list order
-        for (int base = 0; base < n_in; base += 256) {
+        for (int base = 0; base < n_in; base += nthr) {
             const int i = base + tid;
             const int b = i >= n_in ? -2 : i < BK_CELL_CACHE ? (int)s_cell[i] : cell(i);
             int len;
@@ -611,13 +614,15 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
         __syncthreads();
     }
     // emission: cells (hh, ww), hh <= bh, ww <= bw, in that order, each emits bucket hh * bw + ww
-    const int per = (nb + 255) / 256, v0 = tid * per, v1 = min(nb, v0 + per);
+    // (on the first 256 threads whatever the width of the workgroup)
+    const int per = (nb + 255) / 256, v0 = min(nb, tid * per), v1 = tid < 256 ? min(nb, v0 + per) : v0;
     int sum = 0;
     for (int v = v0; v < v1; v++) {
         const int idx = (v / (bw + 1)) * bw + (v % (bw + 1));
         sum += min(s_cnt[idx], fpb);
     }
-    s_scan[tid] = sum;
+    if (tid < 256)
+        s_scan[tid] = sum;
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const float2 *__restrict__ 
             overflow[frame] = (list_overflow ? 1 : 0) | (acc > out_cap ? 2 : 0);
     }
     __syncthreads();
-    int off = s_scan[tid];
+    int off = tid < 256 ? s_scan[tid] : 0;
     float2 *__restrict__ OP = out_pts + (size_t)frame * out_cap;
     int *__restrict__ OA = out_ages + (size_t)frame * out_cap;
     for (int v = v0; v < v1; v++) {
@@ -690,7 +695,10 @@ void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_a
 {
     if (n_frames <= 0)
         return;
-    hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(256), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
+    // 16 wavefronts per frame where the kernel is the latency of a step (a handful of frames on an otherwise idle GPU), 4 in
+    // big launches that run next to other work (the rule of launch_compact, post.hip)
+    const int threads = n_frames <= 4 ? 1024 : 256;
+    hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(threads), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
                        bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow, d_corners);
 }
 
