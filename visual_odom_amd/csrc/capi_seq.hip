@@ -2,6 +2,8 @@
 // once, state carried on the device.
 #include "capi_internal.h"
 
+#include <algorithm>
+
 namespace vo_capi {
 
 void seq_free(vo_ctx *c)
@@ -435,10 +437,23 @@ int vo_seq_step(vo_ctx *c)
                             return (double)c->probe_ms[i];
                     return -1.0;
                 };
-                // one candidate per (pose_streams, prepare) -- the two knobs the dry runs misjudge -- each with the register
-                // budget the dry runs prefer for it; the dry pick first (it stays if the loop ends before the comparison does)
+                // The dry pick first (it stays if the loop ends before the comparison does).  Where the reach of the
+                // four-kernel EPnP is a choice (5 .. 16 sequences) the dry pick with the OTHER reach comes second: dry, the two
+                // differ by a per cent or two and the probe's choice between them is a coin flip, real steps differ by 17 %
+                // at 8 sequences (0.54 against 0.65 ms per step, gpurun r5 `S=8` runs: 14.3 k or 12.0 k frames/s by that
+                // flip).  Then one candidate per other (pose_streams, prepare) pair -- the two knobs the dry runs misjudge
+                // -- each with the register budget the dry runs prefer for it, best dry time first, until four are named.
                 int n = 0;
                 c->ab_list[n++] = c->sched;
+                if (wide_knob_live(c) && !c->pin.epnp_wide_frames) {
+                    c->ab_list[n] = c->sched;
+                    c->ab_list[n].wide = c->sched.wide == VO_EPNP_WS_MAX_FRAMES ? VO_EPNP_SPLIT_DEFAULT_FRAMES : VO_EPNP_WS_MAX_FRAMES;
+                    n++;
+                }
+                struct Pair {
+                    int st, pr, bi;
+                } pairs[4];
+                int np = 0;
                 for (int st = 1; st <= 2; st++)
                     for (int pr = 1; pr >= 0; pr--) {
                         if (st == c->sched.streams && pr == c->sched.prep)
@@ -448,17 +463,18 @@ int vo_seq_step(vo_ctx *c)
                             if (c->probe_cand[i].pose_streams == st && c->probe_cand[i].prepare == pr &&
                                 (bi < 0 || c->probe_ms[i] < c->probe_ms[bi]))
                                 bi = i;
-                        if (bi >= 0 && n < 4) {
-                            c->ab_list[n].waves = c->probe_cand[bi].pose_waves;
-                            // the reach of the four-kernel EPnP the dry probe preferred at ITS winner goes to every nominee
-                            // (round 5: the probe tries the wide reach once, at the winner, instead of doubling the candidate
-                            // set; where it helped in round 4's full product it helped every (streams, prepare) pair)
-                            c->ab_list[n].wide = c->sched.wide;
-                            c->ab_list[n].streams = st;
-                            c->ab_list[n].prep = pr;
-                            n++;
-                        }
+                        if (bi >= 0)
+                            pairs[np++] = Pair{st, pr, bi};
                     }
+                std::sort(pairs, pairs + np, [&](const Pair &x, const Pair &y) { return c->probe_ms[x.bi] < c->probe_ms[y.bi]; });
+                for (int k = 0; k < np && n < 4; k++) {
+                    c->ab_list[n].waves = c->probe_cand[pairs[k].bi].pose_waves;
+                    // the reach of the four-kernel EPnP the dry probe preferred at ITS winner goes to every other nominee
+                    c->ab_list[n].wide = c->sched.wide;
+                    c->ab_list[n].streams = pairs[k].st;
+                    c->ab_list[n].prep = pairs[k].pr;
+                    n++;
+                }
                 if (n > 1) {
                     double ms = dry_ms(c->sched);
                     ms = ms > 0.02 ? ms : 0.02;
