@@ -140,8 +140,12 @@ int orc_bucketing_features(int rows, int cols, float *points, int *ages, int *n_
     (void)n_ages;
     for (int i = 0; i < np; i++) {
         /* int = float / int : float division then truncation */
-        int hidx = (int)(points[2 * i + 1] / (float)bucket_size);
-        int widx = (int)(points[2 * i] / (float)bucket_size);
+        float qy = points[2 * i + 1] / (float)bucket_size, qx = points[2 * i] / (float)bucket_size;
+        /* NaN / infinite / huge quotients: (int) of them is undefined in C (x86 gives INT_MIN), and the reference then
+         * indexes its vector out of range whatever the conversion gave -- such a feature is ignored, decided on the floats */
+        if (!(fabsf(qy) < 32768.f && fabsf(qx) < 32768.f))
+            continue;
+        int hidx = (int)qy, widx = (int)qx;
         int idx = hidx * bw + widx; /* aliasing quirk B2: stride bw, widx in [0, bw] */
         if (idx < 0 || idx >= nb)
             continue; /* the reference would index out of bounds (UB); never hit for in-image pts */

@@ -1,0 +1,278 @@
+"""Round 6 (-m gpu), VERDICT r05 item 1: VALUE-level parity at the ABI.  Every drop-in call of include/vo_hip.h gets the
+adversarial inputs of tests/adversarial.py -- non-finite / huge / denormal / negative coordinates, degenerate point sets,
+degenerate images -- and is held to the oracle with the usual bars (status, survivor indices, tracks bit-exact;
+triangulation <= 1e-5 relative; pose <= 1e-6 with identical inlier sets); a NaN in the reference is a NaN here.  Then a seeded
+hypothesis fuzz of 300 random (w, h, stride, n, parameters) cases through vo_track_frame.
+Reference: feature.cpp:96-104,136-139, visualOdometry.cpp:44-61,152-153,176-178, main.cpp:169-171."""
+import os
+
+import numpy as np
+import pytest
+
+import adversarial as adv
+from test_gpu_parity import bits, full_chain, oracle_hops, run_batch_single
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+P_L = np.array([[718.856, 0, 607.1928, 0], [0, 718.856, 185.2157, 0], [0, 0, 1, 0]], np.float32)
+P_R = P_L.copy()
+P_R[0, 3] = -386.1448
+
+
+def circle_filter(pts, trk, st):
+    """deleteUnmatchFeaturesCircle (feature.cpp:96-104) as a mask: a NaN coordinate passes the sign tests"""
+    neg = (pts < 0).any(1) | (trk[0] < 0).any(1) | (trk[1] < 0).any(1) | (trk[2] < 0).any(1)
+    return (st != 0).all(0) & ~neg
+
+
+def oracle_frame(orc, imgs, pts, P_l, P_r, K, lk=None, threshold=0, pnp=None):
+    """one frame of the reference's path from the oracle's pieces, with non-default parameters"""
+    trk, st = oracle_hops(orc, *imgs, pts, **(lk or {}))
+    trk = np.stack(trk)
+    keep = circle_filter(pts, trk, st)
+    l0, r0, r1, l1, ret = pts[keep], trk[0][keep], trk[1][keep], trk[2][keep], trk[3][keep]
+    (l0, r0, l1, r1), valid = orc.check_valid_and_remove(l0, r0, l1, r1, ret, threshold)
+    xyz = orc.triangulate(P_l, P_r, l0, r0)
+    out = dict(status4=st, trk=trk, keep_circ=np.flatnonzero(keep), keep=np.flatnonzero(keep)[valid], l0=l0, r0=r0, l1=l1,
+               r1=r1, xyz=xyz)
+    if len(l0) >= 4:
+        out["pnp"] = orc.solve_pnp_ransac(xyz, l1, K, **(pnp or {}))
+    return out
+
+
+# ------------------------------------------------------------------ LK / circularMatching
+def test_lk_nonfinite_and_edge_points(gpu_ctx, volib, orc):
+    """NaN / inf / beyond-int32 / denormal / negative start points among ordinary ones: raw status4 and tracks of all four
+    hops (lk_full_chain = 1), survivors of the default mode, and the same through vo_track_frame"""
+    from test_oracle_images import smooth_image
+    w, h = 256, 128
+    imgs = [smooth_image(w, h, seed=9), smooth_image(w, h, 3.7, -2.2, seed=9), smooth_image(w, h, 5.1, 1.4, seed=9),
+            smooth_image(w, h, -2.3, 2.8, seed=9)]
+    imgs = [imgs[0], imgs[1], imgs[3], imgs[2]]   # (l0, r0, l1, r1)
+    rng = np.random.default_rng(4)
+    ordinary = np.stack([rng.uniform(20, w - 20, 40), rng.uniform(20, h - 20, 40)], 1).astype(np.float32)
+    pts = np.vstack([adv.LK_POINTS, ordinary, adv.LK_POINTS[::-1]])
+    ref_trk, ref_st = oracle_hops(orc, *imgs, pts)
+    ref_trk = np.stack(ref_trk)
+    keep = circle_filter(pts, ref_trk, ref_st)
+    assert not ref_st[:, :adv.LK_N_HOPELESS].any() and keep[len(adv.LK_POINTS):len(adv.LK_POINTS) + 40].sum() > 30
+    with full_chain(gpu_ctx):
+        got = gpu_ctx.circular_match(*imgs, pts)
+        assert np.array_equal(got["status4"], ref_st)
+        run_batch_single(gpu_ctx, volib, imgs, pts, stages=volib.STAGE_PYRAMID | volib.STAGE_LK)
+        raw = gpu_ctx.batch_get_tracks(0, len(pts))
+    assert np.array_equal(raw["status4"], ref_st)
+    for k, name in enumerate(("r0", "r1", "l1", "l0_ret")):
+        assert np.array_equal(raw[name], ref_trk[k], equal_nan=True), name
+        assert np.array_equal(np.isnan(raw[name]), np.isnan(ref_trk[k])), name
+        fin = ~np.isnan(ref_trk[k])
+        assert np.array_equal(bits(raw[name])[fin], bits(ref_trk[k])[fin]), name
+    for mode in (1, 0):
+        gpu_ctx.set_params(lk_full_chain=mode)
+        got = gpu_ctx.circular_match(*imgs, pts)
+        assert np.array_equal(got["keep_idx"], np.flatnonzero(keep))
+        assert np.array_equal(bits(got["l0_ret"]), bits(ref_trk[3][keep])) and np.array_equal(bits(got["l1"]), bits(ref_trk[2][keep]))
+        tf = gpu_ctx.track_frame(*imgs, pts, P_L, P_R)
+        assert np.array_equal(tf["keep_idx_circ"], np.flatnonzero(keep))
+    gpu_ctx.set_params(lk_full_chain=0)
+    # nothing but hopeless points: zero survivors, the pose call reports too few points, nothing crashes
+    tf = gpu_ctx.track_frame(*imgs, adv.LK_POINTS[:adv.LK_N_HOPELESS], P_L, P_R)
+    assert len(tf["keep_idx_circ"]) == 0 and len(tf["l0"]) == 0
+
+
+@pytest.mark.parametrize("pair", [("zeros", "zeros"), ("white", "gray"), ("checker1", "checker1"), ("stripes1", "stripes1"),
+                                  ("binary", "binary"), ("noise", "noise"), ("step", "step"), ("noise", "zeros")])
+def test_lk_on_degenerate_images(gpu_ctx, volib, orc, pair):
+    """constant / saturated / 1-pixel checkerboard / stripes (aperture problem) / noise / a single step edge: min-eigenvalue
+    rejections, singular 2 x 2 systems, 30-iteration walks -- status and tracks bit for bit"""
+    h, w = 96, 160
+    d = adv.degenerate_images(h, w)
+    a, b = d[pair[0]], d[pair[1]]
+    imgs = [a, np.roll(b, 1, 1), np.roll(a, 2, 0), b]
+    rng = np.random.default_rng(7)
+    pts = np.vstack([np.stack([rng.uniform(-12, w + 12, 60), rng.uniform(-12, h + 12, 60)], 1),
+                     [[w / 2 - 0.5, 10], [w / 2, h / 2], [w / 2 + 0.5, h - 1]]]).astype(np.float32)
+    ref_trk, ref_st = oracle_hops(orc, *imgs, pts)
+    with full_chain(gpu_ctx):
+        got = gpu_ctx.circular_match(*imgs, pts)
+        run_batch_single(gpu_ctx, volib, imgs, pts, stages=volib.STAGE_PYRAMID | volib.STAGE_LK)
+        raw = gpu_ctx.batch_get_tracks(0, len(pts))
+    assert np.array_equal(got["status4"], ref_st) and np.array_equal(raw["status4"], ref_st)
+    for k, name in enumerate(("r0", "r1", "l1", "l0_ret")):
+        assert np.array_equal(bits(raw[name]), bits(ref_trk[k])), name
+    # FAST + bucketing on the same image, with a carried set the reference would index out of range with
+    corners = orc.fast_detect(a)
+    assert np.array_equal(gpu_ctx.fast_detect(a), corners)
+    for bs, fpb in ((9, 1), (9, 2), (37, 1)):
+        allp = np.vstack([adv.BUCKET_POINTS, corners])
+        alla = np.concatenate([adv.BUCKET_AGES, np.zeros(max(0, len(allp) - len(adv.BUCKET_AGES)), np.int32)])
+        op, oa = orc.bucketing_features(h, w, allp, alla, bs, fpb)
+        gp, ga = gpu_ctx.detect_bucket(a, adv.BUCKET_POINTS, adv.BUCKET_AGES, bucket_size=bs, features_per_bucket=fpb)
+        assert np.array_equal(gp, op, equal_nan=True) and np.array_equal(ga, oa), (bs, fpb)
+
+
+# ------------------------------------------------------------------ triangulation
+def test_triangulate_adversarial(gpu_ctx, orc):
+    """zero disparity (w = 0: convertPointsFromHomogeneous scales by 1), negative disparity (negative depth), NaN / inf / huge /
+    denormal coordinates: <= 1e-5 relative where finite, NaN where the reference is NaN, infinities by value"""
+    got = gpu_ctx.triangulate(P_L, P_R, adv.TRI_LEFT, adv.TRI_RIGHT)
+    ref = orc.triangulate(P_L, P_R, adv.TRI_LEFT, adv.TRI_RIGHT)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])
+    assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-5 * np.maximum(1.0, np.abs(ref[fin])))
+    assert ref[2, 2] < 0 and np.isnan(ref[3]).all()      # negative depth stays negative; NaN in -> NaN out
+    # a large ordinary set with a sprinkling of zero / negative disparities
+    rng = np.random.default_rng(2)
+    pl = np.stack([rng.uniform(0, 1241, 3000), rng.uniform(0, 376, 3000)], 1).astype(np.float32)
+    pr = pl - np.stack([rng.uniform(1, 80, 3000), rng.normal(0, 0.3, 3000)], 1).astype(np.float32)
+    pr[::50] = pl[::50]
+    pr[7::50, 0] = pl[7::50, 0] + 5
+    got, ref = gpu_ctx.triangulate(P_L, P_R, pl, pr), orc.triangulate(P_L, P_R, pl, pr)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    fin = np.isfinite(ref)
+    assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-5 * np.maximum(1.0, np.abs(ref[fin])))
+
+
+# ------------------------------------------------------------------ solvePnPRansac
+def _pnp_case_names():
+    class _O:   # the table's names do not depend on the oracle: build them from a stand-in
+        @staticmethod
+        def project_points(X, r, t, K):
+            return np.zeros((len(X), 2))
+    from test_oracle_geom import K_KITTI
+
+    def planted(orc, n, *_):
+        return np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32), np.zeros(3), np.zeros(3), None
+    return list(adv.pnp_cases(_O, planted, K_KITTI))
+
+
+@pytest.mark.parametrize("which", _pnp_case_names())
+def test_pnp_ransac_adversarial(gpu_ctx, orc, which):
+    """NaN / inf / huge / negative-depth object points, NaN / inf image points, duplicates, collinear and coplanar sets,
+    n = 4 / 5 / 6 with a duplicate, a NaN, collinear: same return code, same inliers, pose <= 1e-6 (NaN where the reference's
+    is NaN -- solvePnPRansac leaves the LAST hypothesis in rvec / tvec, and a hypothesis on a NaN point is NaN)"""
+    from test_oracle_geom import planted_problem, K_KITTI
+    X, uv, iters = adv.pnp_cases(orc, planted_problem, K_KITTI)[which]
+    gpu_ctx.set_params(ransac_iterations=iters)
+    try:
+        found, rv, tv, R, inl = gpu_ctx.pnp_ransac(X, uv, K_KITTI)
+    finally:
+        gpu_ctx.set_params(ransac_iterations=500)
+    rc, orv, otv, oinl, dbg = orc.solve_pnp_ransac(X, uv, K_KITTI, iterations=iters)
+    assert found == (rc == 1)
+    assert np.array_equal(inl, oinl)
+    assert adv.same(rv, orv, 1e-6) and adv.same(tv, otv, 1e-6), (rv, orv, tv, otv)
+    if found and np.isfinite(orv).all():
+        assert adv.same(R, orc.rodrigues(orv), 1e-6)
+
+
+# ------------------------------------------------------------------ findEssentialMat + recoverPose
+def test_essential_pose_adversarial(gpu_ctx, orc):
+    from test_gpu_parity import _em_scene
+    cases, F, PP = adv.essential_cases(_em_scene)
+    for name, (p0, p1) in cases.items():
+        found, E, Rg, tg, mask, good = gpu_ctx.essential_pose(p0, p1, F, PP)
+        ok, Eo, mo, dbg = orc.find_essential_mat(p0, p1, F, PP)
+        assert found == bool(ok), name
+        if ok:
+            go, Ro, to, m2 = orc.recover_pose(Eo, p0, p1, F, PP, mo)
+            assert adv.same(E, Eo, 1e-9) and good == go and np.array_equal(mask, m2), name
+            assert adv.same(Rg, Ro, 1e-9) and adv.same(tg, to, 1e-9), name
+
+
+# ------------------------------------------------------------------ integrateOdometryStereo
+def test_integrate_odometry_adversarial(volib, orc):
+    """the gates of main.cpp:201 / utils.cpp:80 on NaN / inf / huge motions: a NaN fails every comparison -> not integrated"""
+    rng = np.random.default_rng(3)
+    eye = np.eye(3)
+    cases = [(eye, [0, 0, np.nan]), (eye, [np.inf, 0, 0]), (eye, [0, 0, 1e30]), (eye, [0, 0, 0.05]), (eye, [0, 0, 10.0]),
+             (eye * np.nan, [0, 0, 1]), (np.full((3, 3), np.inf), [0, 0, 1]), (np.zeros((3, 3)), [0, 0, 1]),
+             (orc.rodrigues([0.0999, 0, 0]), [0, 0, 1]), (orc.rodrigues([0.1001, 0, 0]), [0, 0, 1]), (-eye, [0, 0, 1])]
+    pose0 = np.eye(4)
+    pose0[:3, 3] = rng.normal(0, 5, 3)
+    for R, t in cases:
+        e_o = orc.rotation_matrix_to_euler(R)
+        gate = bool(np.all(np.abs(e_o) < 0.1))
+        want, ok_o = orc.integrate_odometry_stereo(pose0, R, t) if gate else (pose0, False)
+        got, ok_g, e_g = volib.integrate_odometry(pose0, R, t)
+        assert ok_g == ok_o and adv.same(e_g, e_o, 0) and adv.same(got, want, 1e-12), (R, t)
+
+
+# ------------------------------------------------------------------ seeded fuzz through vo_track_frame
+@pytest.fixture(scope="module")
+def fuzz_world():
+    from visual_odom_amd import synth
+    w, h = 640, 256
+    world = synth.StereoWorld(seed=61, width=w, height=h, fx=360.0, cx=319.5, cy=127.5, bf=-190.0, tex_size=1024)
+    L, R, poses, _ = world.render_sequence(4)
+    kps = [synth.select_keypoints(L[k], bucket=16, per_bucket=3) for k in range(3)]
+    return dict(world=world, L=L, R=R, kps=kps, w=w, h=h)
+
+
+def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
+    """>= 300 random cases: an ROI of a rendered stereo sequence (so w, h are arbitrary and stride != width), n in 0 .. 500
+    points (keypoints, random positions, a few adversarial ones), random LK / consistency / RANSAC parameters -- every output of
+    vo_track_frame against the oracle's frame.  Seeded (derandomize): the same 300 cases on every run."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    fw = fuzz_world
+    seen = dict(cases=0, posed=0, empty=0)
+
+    @settings(max_examples=300, derandomize=True, deadline=None, database=None,
+              suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), k=st.integers(0, 2), w=st.integers(40, 640), h=st.integers(40, 256),
+           n_kp=st.integers(0, 400), n_rand=st.integers(0, 100), n_bad=st.integers(0, 6),
+           max_level=st.integers(0, 4), max_count=st.integers(-1, 40), eps=st.sampled_from([0.0, 0.003, 0.01, 0.05, 11.0]),
+           min_eig=st.sampled_from([0.0, 1e-4, 1e-3, 1e-2]), thr=st.integers(0, 2),
+           iters=st.sampled_from([1, 7, 64, 100, 500]), reproj=st.sampled_from([0.25, 0.5, 1.0, 3.0]),
+           conf=st.sampled_from([0.5, 0.99, float(np.float32(0.999))]))
+    def run(seed, k, w, h, n_kp, n_rand, n_bad, max_level, max_count, eps, min_eig, thr, iters, reproj, conf):
+        rng = np.random.default_rng(seed)
+        x0, y0 = int(rng.integers(0, fw["w"] - w + 1)), int(rng.integers(0, fw["h"] - h + 1))
+        roi = (slice(y0, y0 + h), slice(x0, x0 + w))
+        imgs = [fw["L"][k][roi], fw["R"][k][roi], fw["L"][k + 1][roi], fw["R"][k + 1][roi]]   # views: stride 640
+        kp = fw["kps"][k] - np.float32([x0, y0])
+        kp = kp[(kp[:, 0] >= 0) & (kp[:, 0] < w) & (kp[:, 1] >= 0) & (kp[:, 1] < h)]
+        kp = kp[rng.permutation(len(kp))[:n_kp]]
+        rnd = np.stack([rng.uniform(-15, w + 15, n_rand), rng.uniform(-15, h + 15, n_rand)], 1).astype(np.float32)
+        bad = adv.LK_POINTS[rng.integers(0, len(adv.LK_POINTS), n_bad)]
+        pts = np.vstack([kp, rnd, bad]).astype(np.float32)
+        pts = pts[rng.permutation(len(pts))]
+        P_l, P_r = fw["world"].proj_matrices()
+        P_l, P_r = P_l.copy(), P_r.copy()
+        P_l[0, 2] -= x0
+        P_l[1, 2] -= y0
+        P_r[0, 2] -= x0
+        P_r[1, 2] -= y0
+        P_r[0, 3] = P_r[0, 3]   # (the baseline term bf does not move with the ROI)
+        K = P_l[:, :3].copy()
+        gpu_ctx.set_params(lk_max_level=max_level, lk_max_count=max_count, lk_epsilon=eps, lk_min_eig_threshold=min_eig,
+                           consistency_threshold=thr, ransac_iterations=iters, ransac_reproj_error=reproj, ransac_confidence=conf)
+        got = gpu_ctx.track_frame(*imgs, pts, P_l, P_r)
+        ref = oracle_frame(orc, imgs, pts, P_l, P_r, K, lk=dict(max_level=max_level, max_count=max_count, eps=eps, min_eig=min_eig),
+                           threshold=thr, pnp=dict(iterations=iters, reproj=reproj, confidence=conf))
+        assert np.array_equal(got["keep_idx_circ"], ref["keep_circ"])
+        assert np.array_equal(got["keep_idx"], ref["keep"])
+        for name in ("l0", "r0", "l1", "r1"):
+            assert np.array_equal(bits(got[name]), bits(ref[name])), name
+        fin = np.isfinite(ref["xyz"])
+        assert np.array_equal(np.isfinite(got["xyz"]), fin)
+        assert np.all(np.abs(got["xyz"][fin] - ref["xyz"][fin]) <= 1e-5 * np.maximum(1.0, np.abs(ref["xyz"][fin])))
+        seen["cases"] += 1
+        if "pnp" not in ref:
+            assert got["rc"] == -4   # VO_ERR_TOO_FEW
+            seen["empty"] += 1
+            return
+        rc, rv, tv, inl, dbg = ref["pnp"]
+        assert (got["rc"] == 0) == (rc == 1)
+        assert np.array_equal(got["inliers"], inl)
+        assert adv.same(got["rvec"], rv, 1e-6) and adv.same(got["tvec"], tv, 1e-6)
+        seen["posed"] += rc == 1
+
+    try:
+        run()
+    finally:
+        gpu_ctx.set_params(lk_max_level=3, lk_max_count=30, lk_epsilon=0.01, lk_min_eig_threshold=1e-3, consistency_threshold=0,
+                           ransac_iterations=500, ransac_reproj_error=0.5, ransac_confidence=float(np.float32(0.999)))
+    assert seen["cases"] >= 300 and seen["posed"] >= 60, seen

@@ -194,6 +194,31 @@ def test_emulated_lk_negative_bilinear_weight(kemu, orc, lk_variant):
     assert np.array_equal(r["status"], st) and np.array_equal(bits(r["trk"]), bits(ref))
 
 
+def test_lk_nonfinite_points(kemu, orc, lk_variant):
+    """NaN / infinite / beyond-int32 / denormal / negative start points.  The emulator converts float -> int
+    like gfx950 (vo_f2i: NaN -> 0, saturating), the oracle like x86 (INT_MIN): status and positions must agree all the same
+    (a NaN position compares as NaN)."""
+    from test_oracle_images import smooth_image
+    w, h = 256, 128
+    imgs = [smooth_image(w, h, seed=9), smooth_image(w, h, 3.7, -2.2, seed=9), smooth_image(w, h, 5.1, 1.4, seed=9),
+            smooth_image(w, h, -2.3, 2.8, seed=9)]
+    from adversarial import LK_POINTS as pts, LK_N_HOPELESS
+    for full_chain in (1, 0):
+        r = ke_run(kemu, imgs, pts, full_chain=full_chain)
+        ref, st = _oracle_hops(orc, *imgs, pts)
+        if full_chain:
+            assert np.array_equal(r["status"], st)
+            assert np.array_equal(r["trk"], ref, equal_nan=True)
+            assert np.array_equal(np.isnan(r["trk"]), np.isnan(ref))
+            assert not st[:, :LK_N_HOPELESS].any() and st[:, -1].all()   # every non-finite / huge point fails every hop
+        else:
+            assert np.array_equal(r["status"][0], st[0])
+            assert np.array_equal(r["trk"][0], ref[0], equal_nan=True)
+        keep = (r["status"] != 0).all(0) & ~(pts < 0).any(1) & ~(r["trk"][:3] < 0).any(2).any(0)
+        keep_ref = (st != 0).all(0) & ~(pts < 0).any(1) & ~(ref[:3] < 0).any(2).any(0)
+        assert np.array_equal(keep, keep_ref) and keep[-1]
+
+
 def ke_detect(lib, img, tracked=None, ages=None, threshold=20, nonmax=1, detect=1, bucket_size=0, fpb=1, cap=40000):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
@@ -588,6 +613,59 @@ def test_whole_hot_path_on_the_cpu_emulator(kemu, orc, small_world, small_seq):
     assert grc == rc == 1 and np.array_equal(ginl, inl)
     assert tuple(gdbg[:4]) == tuple(int(x) for x in dbg[:4])
     assert np.abs(grv - rv).max() <= 1e-6 and np.abs(gtv - tv).max() <= 1e-6
+
+
+def test_adversarial_values_post_and_bucketing(kemu, orc):
+    """tests/adversarial.py through post.hip (filters + triangulation: zero / negative disparity, NaN, inf, huge) and through
+    bucket_kernel (carried points the reference would index its bucket vector out of range with) -- against the oracle, NaN as NaN"""
+    import adversarial as adv
+    P_l = np.array([[718.856, 0, 607.1928, 0], [0, 718.856, 185.2157, 0], [0, 0, 1, 0]], np.float32)
+    P_r = P_l.copy()
+    P_r[0, 3] = -386.1448
+    pl, pr = adv.TRI_LEFT, adv.TRI_RIGHT
+    n = len(pl)
+    trk = np.stack([pr, pr, pl, pl])
+    post = ke_post(kemu, pl, trk, np.ones((4, n), np.uint8), P_l, P_r, threshold=1 << 30)
+    keep = ~((pl < 0).any(1) | (pr < 0).any(1))              # deleteUnmatchFeaturesCircle's sign tests (NaN passes them)
+    assert np.array_equal(post["idxB"], np.flatnonzero(keep))
+    assert adv.same(post["xyz"], orc.triangulate(P_l, P_r, pl[keep], pr[keep]))
+    for name, img in adv.degenerate_images(96, 160).items():
+        for bs, fpb in ((9, 1), (9, 2), (37, 1)):
+            gp, ga = ke_detect(kemu, img, adv.BUCKET_POINTS, adv.BUCKET_AGES, bucket_size=bs, fpb=fpb)
+            corners = orc.fast_detect(img)
+            allp = np.vstack([adv.BUCKET_POINTS, corners])
+            alla = np.concatenate([adv.BUCKET_AGES, np.zeros(max(0, len(allp) - len(adv.BUCKET_AGES)), np.int32)])
+            op, oa = orc.bucketing_features(96, 160, allp, alla, bs, fpb)
+            assert np.array_equal(gp, op, equal_nan=True) and np.array_equal(ga, oa), (name, bs, fpb)
+
+
+@pytest.mark.parametrize("which", ["n=4 duplicate", "n=4 NaN", "n=5 NaN", "n=5 collinear", "all zero"])   # (the whole table: -m gpu)
+def test_adversarial_values_pose_chain(kemu, orc, which):
+    """degenerate solvePnPRansac inputs through pnp.hip on the emulator: same status, inliers and control flow as the oracle;
+    a pose that is NaN in the reference is NaN here"""
+    import adversarial as adv
+    from test_oracle_geom import planted_problem, K_KITTI
+    X, uv, iters = adv.pnp_cases(orc, planted_problem, K_KITTI)[which]
+    rc, rv, tv, inl, dbg = orc.solve_pnp_ransac(X, uv, K_KITTI, iterations=iters)
+    grc, grv, gtv, ginl, gdbg = ke_pnp(kemu, X, uv, K_KITTI, iters=iters, split=0)   # (the one-lane solver: the emulated wide SVD takes minutes on NaN)
+    assert grc == rc and np.array_equal(ginl, inl)
+    assert adv.same(grv, rv, 1e-6) and adv.same(gtv, tv, 1e-6)
+    if len(X) > 5:
+        assert tuple(gdbg[:3]) == tuple(int(x) for x in dbg[:3])
+
+
+def test_adversarial_values_essential_chain(kemu, orc):
+    import adversarial as adv
+    from test_gpu_parity import _em_scene
+    cases, F, PP = adv.essential_cases(_em_scene)
+    for name, (p0, p1) in cases.items():
+        rc, E, Rg, tg, mask, dbg = ke_essential(kemu, p0, p1, F, PP)
+        ok, Eo, mo, odbg = orc.find_essential_mat(p0, p1, F, PP)
+        assert (rc == 1) == bool(ok), name
+        if ok:
+            go, Ro, to, m2 = orc.recover_pose(Eo, p0, p1, F, PP, mo)
+            assert adv.same(E, Eo, 1e-9) and dbg[1] == go and np.array_equal(mask, m2), name
+            assert adv.same(Rg, Ro, 1e-9) and adv.same(tg, to, 1e-9), name
 
 
 def ke_essential(lib, p0, p1, focal, pp, prob=0.999, threshold=1.0, max_iters=1000):

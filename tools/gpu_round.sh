@@ -1,9 +1,11 @@
 #!/bin/bash
-# One GPU-box session: parity tests, bench (both LDS read variants), rocprofv3 kernel trace and the
-# two PMC passes.  Usage (from the authoring container):
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag>'
-# Everything lands in gpurun_out/<tag>/.
-TAG=${1:-r}
+# THE GPU session driver (one script; rounds 2-5 had one generation each).  Usage (from the authoring container):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> <part> [<part> ...]'
+# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 soak
+# Everything lands in gpurun_out/<tag>/; tools/profile_summary.py / tools/pmc_legs.py / tools/pose_pmc.py turn it into profiles/.
+TAG=${1:-r5}
+shift
+PARTS="$*"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -11,56 +13,112 @@ cd "$ROOT" || exit 1
 export TMPDIR=/tmp
 t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a "$OUT/timeline.log"; }
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+LEAN="--no-cpu-baseline --sustain 0 --no-replay-leg --no-configs"
+line() { python -c "import json,sys; b=json.loads(open('$1').read().strip().splitlines()[-1]); print('  $2 %.0f fps %.3f ms/step lk %.3f' % (b['value'], b['ms_per_step'], b['roofline']['launch_ms']), {k: round(v,2) for k,v in b['config'].get('stage_ms',{}).items()}, b['config'].get('schedule'), 'val', b.get('validated_frames'))" 2>&1 | tee -a "$OUT/summary.txt"; }
 
-stamp "pytest -m gpu"
-timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1
-rc=$?
-stamp "pytest rc=$rc"
-tail -5 "$OUT/pytest.log"
-if [ $rc -ne 0 ]; then
-    stamp "pytest failed: detailed first-contact diffs"
-    VO_PNP=1 timeout 400 python tools/dev_gpu_check.py > "$OUT/dev.log" 2>&1
-    tail -40 "$OUT/dev.log"
+if has tests; then
+    stamp "pytest -m gpu $PYTEST_K"
+    timeout 1500 python -m pytest tests -m gpu -q --durations=10 ${PYTEST_K:+-k "$PYTEST_K"} > "$OUT/pytest.log" 2>&1
+    stamp "pytest rc=$?"
+    tail -15 "$OUT/pytest.log"
 fi
-stamp "VALU issue-rate micro-benchmark"
-(cd tools/ubench && timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w valu_rate.hip -o /tmp/valu_rate && timeout 60 /tmp/valu_rate) > "$OUT/valu_rate.log" 2>&1
-cat "$OUT/valu_rate.log"
-
-stamp "latency mode of the drop-in boundary (host images, PCIe-inclusive)"
-timeout 300 python tools/latency_mode.py 40 > "$OUT/latency.log" 2>&1
-cat "$OUT/latency.log"
-stamp "bench (default)"
-timeout 600 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
-cat "$OUT/bench.json"
-stamp "bench (reference-default load, 374 points per frame)"
-timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload kitti374 > "$OUT/bench_kitti374.json" 2> "$OUT/bench_kitti374.err"
-cat "$OUT/bench_kitti374.json"
-
-stamp "bench (FAST + bucketing on the device feed LK)"
-timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages detect+full > "$OUT/bench_detect.json" 2> "$OUT/bench_detect.err"
-cat "$OUT/bench_detect.json"
-stamp "bench (mono_rotation: essential matrix + recoverPose next to the PnP solve)"
-timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --mono-rotation > "$OUT/bench_mono.json" 2> "$OUT/bench_mono.err"
-cat "$OUT/bench_mono.json"
-stamp "bench (1920x1080, 4000 points per frame)"
-timeout 400 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload hd4000 --frames 16 > "$OUT/bench_hd4000.json" 2> "$OUT/bench_hd4000.err"
-cat "$OUT/bench_hd4000.json"
-stamp "bench (pose solve serialised on the tracking stream)"
-VO_SERIAL_POSE=1 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_serial.json" 2> "$OUT/bench_serial.err"
-cat "$OUT/bench_serial.json"
-cd /tmp
-stamp "rocprofv3 kernel trace (serialised pose solve: stand-alone kernel durations)"
-VO_SERIAL_POSE=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/prof.log" 2>&1
-stamp "rocprofv3 kernel trace (overlapped, as benched)"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_overlap" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/prof_overlap.log" 2>&1
-stamp "rocprofv3 pmc FETCH_SIZE"
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-stamp "rocprofv3 pmc WRITE_SIZE"
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
-stamp "rocprofv3 pmc SQ pass A"
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sqa" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_sqa.log" 2>&1
-stamp "rocprofv3 pmc SQ pass B"
-timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d "$OUT/pmc_sqb" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_sqb.log" 2>&1
+if has latency; then
+    stamp "latency mode of the drop-in boundary"
+    timeout 300 python tools/latency_mode.py 200 > "$OUT/latency.log" 2>&1
+    cat "$OUT/latency.log"
+fi
+if has phases; then
+    stamp "pose phases (developer build time stamps)"
+    VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 300 python tools/pose_phases.py 6 14 > "$OUT/pose_phases.txt" 2>&1
+    cat "$OUT/pose_phases.txt"
+    VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so timeout 300 python tools/pose_phases.py 1 14 > "$OUT/pose_phases_340.txt" 2>&1
+    tail -3 "$OUT/pose_phases_340.txt"
+fi
+if has timeline; then
+    stamp "kernel timeline of vo_track_frame"
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tf" -- python "$ROOT/tools/latency_mode.py" trackonly 6 60 > "$OUT/tf.log" 2>&1)
+    python tools/kernel_timeline.py "$OUT/tf" 52 > "$OUT/timeline.txt" 2>&1
+    rm -rf "$OUT/tf"
+    tail -40 "$OUT/timeline.txt"
+fi
+if has bench; then
+    stamp "bench (default: headline + exact replay + configs)"
+    timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+    tail -c 600 "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+fi
+if has prof; then
+    stamp "rocprofv3 --kernel-trace --stats of the default headline (lean)"
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python "$ROOT/bench.py" --steps 20 --warmup 3 $LEAN --validate 0 > "$OUT/prof.log" 2>&1)
+    find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats_batch.csv"
+    rm -rf "$OUT/prof"
+    head -12 "$OUT/kernel_stats_batch.csv" | cut -c1-200
+fi
+if has seq; then      # the lock-step loop at the reference-default load, pairs resident in HBM, and PCIe-inclusive at 256 / 8 sequences
+    for S in 256 64 16 8 1; do
+        stamp "bench --mode sequences --seqs $S"
+        timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline ${QUADS:+--quads $QUADS} --validate $([ $S = 256 ] && echo 3 || echo 0) > "$OUT/bench_seq_${S}.json" 2> "$OUT/bench_seq_${S}.err"
+        python -c "import json; b=json.loads(open('$OUT/bench_seq_${S}.json').read().strip().splitlines()[-1]); print('  S=%-4d %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']), b['config']['schedule'])" 2>&1 | tee -a "$OUT/summary.txt"
+    done
+    for ING in pinned host; do
+        for S in 256 8; do
+            stamp "bench --mode sequences --seqs $S --ingest $ING (PCIe-inclusive)"
+            timeout 600 python bench.py --mode sequences --workload kitti374 --seqs $S --steps 40 --warmup 4 --no-cpu-baseline --validate 0 --ingest $ING > "$OUT/bench_seq_${S}_${ING}.json" 2> "$OUT/bench_seq_${S}_${ING}.err"
+            python -c "import json; b=json.loads(open('$OUT/bench_seq_${S}_${ING}.json').read().strip().splitlines()[-1]); print('  S=%-4d $ING %.0f fps %.3f ms/step' % ($S, b['value'], b['ms_per_step']))" 2>&1 | tee -a "$OUT/summary.txt"
+        done
+    done
+fi
+if has pmclegs; then  # PMC passes of every bench leg's LK launch (tools/pmc_legs.py turns them into profiles/lk_traffic.json / lk_issue.json)
+    for WL in ${PMC_WL:-kitti2000 kitti374 hd4000 hd4000l4}; do
+        FR=256; Q=""
+        case $WL in hd4000*) FR=128; Q="--quads 4";; esac
+        stamp "bench $WL x $FR (plain: the leg's line)"
+        timeout 300 python bench.py --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_$WL.json" 2> "$OUT/pmc_$WL.err"
+        for SET in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES"; do
+            NAME=${SET%%:*}; CNT=${SET#*:}
+            stamp "pmc $NAME: $WL"
+            (cd /tmp && timeout 400 rocprofv3 --pmc $CNT --output-format csv -d "$OUT/pmc_${WL}_$NAME" -- python "$ROOT/bench.py" --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_${WL}_$NAME.log" 2>&1)
+            # keep only the rows of the two kernels the summary reads (the raw files are tens of MB)
+            for f in $(find "$OUT/pmc_${WL}_$NAME" -name "*_counter_collection.csv"); do
+                (head -1 "$f"; grep -E "lk_circular_kernel|pyr_pass_kernel" "$f") > "$f.tmp" && mv "$f.tmp" "$f"
+            done
+            find "$OUT/pmc_${WL}_$NAME" -type f ! -name "*_counter_collection.csv" -delete
+        done
+    done
+    python tools/pmc_legs.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
+    cp profiles/lk_traffic.json profiles/lk_issue.json "$OUT/"
+fi
+if has posepmc; then  # counters of every kernel behind LK in the config-4 legs -> tools/pose_pmc.py -> profiles/r06_pose_pmc.md
+    for WL in ${POSE_WL:-hd4000 kitti2000}; do
+        FR=256; Q=""
+        case $WL in hd4000*) FR=128; Q="--quads 4";; esac
+        stamp "bench $WL x $FR (plain)"
+        timeout 300 python bench.py --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pose_$WL.json" 2> "$OUT/pose_$WL.err"
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pose_${WL}_trace" -- python "$ROOT/bench.py" --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pose_${WL}_trace.log" 2>&1)
+        find "$OUT/pose_${WL}_trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/pose_${WL}_kernel_stats.csv"
+        find "$OUT/pose_${WL}_trace" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/pose_pmc.py --trace {} "$OUT/pose_${WL}_resources.csv"
+        rm -rf "$OUT/pose_${WL}_trace"
+        for SET in "a:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+                   "b:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_FLAT SQ_INSTS_SMEM" \
+                   "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+            NAME=${SET%%:*}; CNT=${SET#*:}
+            stamp "pose pmc $NAME: $WL"
+            (cd /tmp && timeout 400 rocprofv3 --pmc $CNT --output-format csv -d "$OUT/posepmc_${WL}_$NAME" -- python "$ROOT/bench.py" --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/posepmc_${WL}_$NAME.log" 2>&1)
+            for f in $(find "$OUT/posepmc_${WL}_$NAME" -name "*_counter_collection.csv"); do
+                (head -1 "$f"; grep -v -E "lk_circular_kernel|pyr_pass_kernel|fast_|bucket_kernel" "$f" | tail -n +2) > "$f.tmp" && mv "$f.tmp" "$f"
+            done
+            find "$OUT/posepmc_${WL}_$NAME" -type f ! -name "*_counter_collection.csv" -delete
+        done
+    done
+    python tools/pose_pmc.py "$OUT" 2>&1 | tee "$OUT/pose_pmc.md"
+fi
+if has ranks8; then   # eight REAL ranks on this one GPU (gloo): the N > 1 code path incl. the config-5 leg
+    stamp "bench --gpus 8 on GPU 0"
+    VO_ALLOW_SHARED_GPU=1 VO_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --frames 32 --steps 3 --warmup 1 --no-cpu-baseline --sustain 0 > "$OUT/bench_ranks8.json" 2> "$OUT/bench_ranks8.err"
+    tail -c 1500 "$OUT/bench_ranks8.json"; tail -3 "$OUT/bench_ranks8.err"
+fi
+if has quads; then   # the headline against the number of distinct rendered quadruples and the world seed (one process: tools/quads_table.py)
+    stamp "quads table"
+    timeout 1500 python tools/quads_table.py ${QMAX:-128} 2> "$OUT/quads_table.err" | tee "$OUT/quads_table.txt"
+fi
 stamp "done"
-find "$OUT" -type f | head -50
-du -sh "$OUT"

@@ -1,6 +1,6 @@
 """PMC passes of the LK launch for every bench leg -> profiles/lk_traffic.json / lk_issue.json.
 
-    python tools/pmc_legs.py gpurun_out/<tag>     # written by `bash tools/gpu_r5.sh <tag> pmclegs`
+    python tools/pmc_legs.py gpurun_out/<tag>     # written by `bash tools/gpu_round.sh <tag> pmclegs`
 
 Input: gpurun_out/<tag>/pmc_<workload>_<set>/**/*_counter_collection.csv with set = fetch (FETCH_SIZE), write (WRITE_SIZE),
 sq (SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES) -- each counter

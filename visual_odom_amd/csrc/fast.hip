@@ -546,12 +546,17 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
     __syncthreads();
     // bucket of feature i, or -1 when Bucket::add_feature ignores it (age >= 10) / the reference
     // would index outside its bucket vector (undefined behaviour there; never hit by in-image points)
-    auto cell = [&](int i) {
-        const float2 p = point(i);
-        const int hidx = (int)(p.y / (float)bucket_size), widx = (int)(p.x / (float)bucket_size);
-        const int idx = hidx * bw + widx;
-        return (idx < 0 || idx >= nb || age(i) >= 10) ? -1 : idx;
+    // The quotients are float divisions truncated to int (feature.cpp:233-234).  A NaN / infinite / huge coordinate converts
+    // differently on x86 (INT_MIN) and on gfx950 (0 / saturated), and the reference then indexes its vector out of range either
+    // way: such a feature is ignored, decided on the floats so that no conversion of an unrepresentable value takes part.
+    auto cell_of = [&](float2 p, int a) {
+        const float qy = p.y / (float)bucket_size, qx = p.x / (float)bucket_size;
+        if (!(fabsf(qy) < 32768.f && fabsf(qx) < 32768.f))
+            return -1;
+        const int idx = vo_f2i(qy) * bw + vo_f2i(qx);
+        return (idx < 0 || idx >= nb || a >= 10) ? -1 : idx;
     };
+    auto cell = [&](int i) { return cell_of(point(i), age(i)); };
     // BK_PF list entries per thread at a time: their points and ages are requested before the first one is used (the walk was a
     // chain of dependent global loads -- one memory round trip per 256 features, ~14 per frame -- in a kernel that has the chip
     // to itself: one workgroup per frame).
@@ -585,9 +590,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
             const int i = i0 + nthr * k; // (the wavefront's lanes hold 64 CONSECUTIVE list entries)
             int b = -2;                 // beyond the list: never equal to a cell or to "ignored" (-1)
             if (i < n_in) {
-                const int hidx = (int)(pt[k].y / (float)bucket_size), widx = (int)(pt[k].x / (float)bucket_size);
-                const int idx = hidx * bw + widx;
-                b = (idx < 0 || idx >= nb || ag[k] >= 10) ? -1 : idx;
+                b = cell_of(pt[k], ag[k]);
                 if (i < BK_CELL_CACHE)
                     s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
             }

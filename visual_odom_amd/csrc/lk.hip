@@ -139,8 +139,11 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             prevX -= halfWin;
             prevY -= halfWin;
             const float fpx = floorf(prevX), fpy = floorf(prevY);
-            const int ipx = uni((int)fpx), ipy = uni((int)fpy);
-            if (ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih) {
+            const int ipx = uni(vo_f2i(fpx)), ipy = uni(vo_f2i(fpy));
+            // x86's cvFloor(NaN) is INT_MIN (cvttss2si), i.e. "left of the window": OpenCV rejects a NaN coordinate here.
+            // v_cvt_i32_f32(NaN) is 0, which would ADMIT it -- so NaN is rejected on the float (one
+            // v_cmp_u_f32 into a scalar pair).  +-inf and finite values beyond int32 saturate to the rejected side on both.
+            if (VO_BALLOT(__builtin_isunordered(fpx, fpy)) != 0ull || ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih) {
                 if (level == 0)
                     st = 0;
                 continue;
@@ -248,8 +251,8 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             float fnx = floorf(nextX), fny = floorf(nextY);
             bool run = prm.max_count > 0;
             while (run) {
-                const int inx = uni((int)fnx), iny = uni((int)fny);
-                if (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
+                const int inx = uni(vo_f2i(fnx)), iny = uni(vo_f2i(fny));
+                if (VO_BALLOT(__builtin_isunordered(fnx, fny)) != 0ull || inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh) {
                     if (level == 0)
                         st = 0;
                     break;
@@ -350,8 +353,10 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
             }
 
             // final in-bounds check OpenCV performs at level 0 when an err vector is requested
+            // (st == 1 here means the last cell entry was admitted and every delta since was finite: outX / outY are finite,
+            // possibly huge -- both conversions then land on a rejected side, x86's INT_MIN and gfx950's saturated INT_MAX)
             if (st && level == 0) {
-                const int fx = (int)floorf(outX - halfWin), fy = (int)floorf(outY - halfWin);
+                const int fx = vo_f2i(floorf(outX - halfWin)), fy = vo_f2i(floorf(outY - halfWin));
                 if (fx < -LK_WIN || fx >= jw || fy < -LK_WIN || fy >= jh)
                     st = 0;
             }
@@ -492,8 +497,8 @@ __global__ VO_LK_PAIR_ATTRS void lk_circular_pair_kernel(const PyrImage *__restr
             prevX -= halfWin;
             prevY -= halfWin;
             const float fpx = floorf(prevX), fpy = floorf(prevY);
-            const int ipx = (int)fpx, ipy = (int)fpy;
-            const bool in = act && !(ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih);
+            const int ipx = vo_f2i(fpx), ipy = vo_f2i(fpy);
+            const bool in = act && !(__builtin_isunordered(fpx, fpy) || ipx < -LK_WIN || ipx >= iw || ipy < -LK_WIN || ipy >= ih);
             if (act && !in && level == 0)
                 st = 0;
             if (VO_BALLOT(in) == 0ull)
@@ -586,8 +591,8 @@ __global__ VO_LK_PAIR_ATTRS void lk_circular_pair_kernel(const PyrImage *__restr
             uint32_t JtA[7], JbA[7], JtB[7], JbB[7];
             while (VO_BALLOT(run) != 0ull) {
                 if (VO_BALLOT(entry) != 0ull) {
-                    const int inx = (int)fnx, iny = (int)fny;
-                    const bool oob = entry && (inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh);
+                    const int inx = vo_f2i(fnx), iny = vo_f2i(fny);
+                    const bool oob = entry && (__builtin_isunordered(fnx, fny) || inx < -LK_WIN || inx >= jw || iny < -LK_WIN || iny >= jh);
                     if (oob) {
                         if (level == 0)
                             st = 0;
@@ -689,7 +694,7 @@ __global__ VO_LK_PAIR_ATTRS void lk_circular_pair_kernel(const PyrImage *__restr
 
             // final in-bounds check OpenCV performs at level 0 when an err vector is requested
             if (ok && st && level == 0) {
-                const int fx = (int)floorf(outX - halfWin), fy = (int)floorf(outY - halfWin);
+                const int fx = vo_f2i(floorf(outX - halfWin)), fy = vo_f2i(floorf(outY - halfWin));
                 if (fx < -LK_WIN || fx >= jw || fy < -LK_WIN || fy >= jh)
                     st = 0;
             }

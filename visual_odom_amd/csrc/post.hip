@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float2 *__restrict_
             ka = !bad;
             // int offset = max(|dx|, |dy|) truncated; keep iff offset <= threshold
             float ax = fabsf(l0.x - lr.x), ay = fabsf(l0.y - lr.y);
-            int offset = (int)(ax < ay ? ay : ax);
+            int offset = vo_f2i(ax < ay ? ay : ax); // (survivors of stage A: finite and within a window of the image)
             kb = ka && !(offset > threshold);
         }
         const unsigned long long ma = __ballot(ka), mb = __ballot(kb);

@@ -104,6 +104,38 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// float -> int32 the way gfx950 converts (v_cvt_i32_f32 / v_cvt_i32_f64): truncation towards zero, SATURATING, NaN -> 0.
+// x86 (the reference's CPU path, the oracle, and this source when g++ compiles it for the CPU emulator) converts with
+// cvttss2si / cvttsd2si, which return INT_MIN for NaN and for every value outside int32 -- so a kernel that decides on a
+// converted value can differ from the reference exactly on non-finite input (lk admitted NaN points).
+// Every value-level float -> int conversion of the kernels goes through these two: the device takes the one instruction, the
+// emulator spells the device's semantics out, so emulator == GPU on that input class and the CPU suite can hold the
+// kernels to the oracle there (tests/test_kernel_emulation.py::test_lk_nonfinite_points).
+__device__ __forceinline__ int vo_f2i(float v)
+{
+#ifdef VO_HOST_EMUL
+    if (v != v)
+        return 0;
+    if (v >= 2147483648.f)
+        return 2147483647;
+    if (v <= -2147483648.f)
+        return -2147483647 - 1;
+#endif
+    return (int)v;
+}
+__device__ __forceinline__ int vo_d2i(double v)
+{
+#ifdef VO_HOST_EMUL
+    if (v != v)
+        return 0;
+    if (v >= 2147483647.0)
+        return 2147483647;
+    if (v <= -2147483648.0)
+        return -2147483647 - 1;
+#endif
+    return (int)v;
+}
+
 __device__ __forceinline__ int uni(int v) { return VO_READFIRSTLANE(v); }
 __device__ __forceinline__ float unif(float v)
 {
