@@ -418,10 +418,12 @@ class RefFrameLoop:
     (matchingFeatures, trackingFrame2Frame, rotationMatrixToEulerAngles, integrateOdometryStereo; oracle/_ref) over the
     oracle's OpenCV-algorithm restatement.  State as in main.cpp:81-94."""
 
-    def __init__(self, fx, cx, cy, bf, mono_rotation=False, cap=65536, lib=None):
+    def __init__(self, fx, cx, cy, bf, mono_rotation=False, cap=65536, lib=None, entry="ref_frame_step"):
         # lib: another library with the same ref_frame_step entry point (tests/ref_dropin: the same reference sources
-        # over libvo_hip instead of over this oracle)
+        # over libvo_hip instead of over this oracle; its ref_frame_step_adapter also replaces main.cpp:169-171,181 by
+        # the shipped adapter's triangulate_hip / trackingFrame2Frame_hip)
         self.lib = lib if lib is not None else ref_lib()
+        self.entry = getattr(self.lib, entry)
         self.fx, self.cx, self.cy, self.bf = (float(v) for v in (fx, cx, cy, bf))
         self.mono = int(bool(mono_rotation))
         self.cap = cap
@@ -451,10 +453,10 @@ class RefFrameLoop:
         pose = np.ascontiguousarray(self.frame_pose, np.float64).copy()
         outs = [np.zeros((cap, 2), np.float32) for _ in range(4)]
         n_out, integrated = C.c_int(0), C.c_int(0)
-        rc = self.lib.ref_frame_step(_vp(l0), _vp(r0), _vp(l1), _vp(r1), w, h, C.c_float(self.fx), C.c_float(self.cx),
-                                      C.c_float(self.cy), C.c_float(self.bf), _vp(P), _vp(A), C.byref(n_p), C.byref(n_a),
-                                      cap, _vp(t), _vp(R), _vp(pose), self.mono, _vp(outs[0]), _vp(outs[1]),
-                                      _vp(outs[2]), _vp(outs[3]), C.byref(n_out), C.byref(integrated))
+        rc = self.entry(_vp(l0), _vp(r0), _vp(l1), _vp(r1), w, h, C.c_float(self.fx), C.c_float(self.cx),
+                        C.c_float(self.cy), C.c_float(self.bf), _vp(P), _vp(A), C.byref(n_p), C.byref(n_a),
+                        cap, _vp(t), _vp(R), _vp(pose), self.mono, _vp(outs[0]), _vp(outs[1]),
+                        _vp(outs[2]), _vp(outs[3]), C.byref(n_out), C.byref(integrated))
         assert rc == 0
         self.points, self.ages = P[:n_p.value].copy(), A[:n_a.value].copy()
         self.translation, self.rotation, self.frame_pose = t, R, pose

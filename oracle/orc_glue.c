@@ -10,6 +10,7 @@
  */
 #include "orc_internal.h"
 
+#include <float.h>
 #include <math.h>
 #include <string.h>
 
@@ -217,17 +218,59 @@ void orc_rotation_matrix_to_euler(const double *R, float *e)
 }
 
 /* utils.cpp:57-91: frame_pose = frame_pose * inv([R t; 0 0 0 1]) iff 0.05 < |t| < 10.
- * cv::Mat::inv() (DECOMP_LU) on a rigid transform; restated with its closed form
- * [R^T | -R^T t] -- differs from LU only in the last ulps. Returns 1 if integrated. */
+ * cv::Mat::inv() (DECOMP_LU) restated as the LU elimination cv::invert runs for n > 3 (round 6; the closed form
+ * [R^T | -R^T t] before: equal for a rotation up to the last ulps, but not what the reference does with a matrix that
+ * is no rotation -- a singular one yields the ZERO inverse and a zeroed frame_pose).  Returns 1 if integrated. */
 int orc_integrate_odometry_stereo(double *pose, const double *R, const double *t)
 {
     double scale = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
     if (!(scale > 0.05 && scale < 10))
         return 0;
-    double inv[16] = {R[0], R[3], R[6], 0, R[1], R[4], R[7], 0, R[2], R[5], R[8], 0, 0, 0, 0, 1};
-    inv[3] = -(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]);
-    inv[7] = -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]);
-    inv[11] = -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2]);
+    /* rigid_body_transformation.inv() (utils.cpp:78): cv::invert(DECOMP_LU) of a 4 x 4 CV_64F = hal::LU64f on [A | I]
+     * (LUImpl: partial pivoting, pivot < DBL_EPSILON * 100 -> singular -> the inverse is set to 0), then back substitution */
+    double A[16] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2], 0, 0, 0, 1};
+    double inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int singular = 0;
+    for (int i = 0; i < 4; i++) {
+        int k = i;
+        for (int j = i + 1; j < 4; j++)
+            if (fabs(A[j * 4 + i]) > fabs(A[k * 4 + i]))
+                k = j;
+        if (fabs(A[k * 4 + i]) < DBL_EPSILON * 100) {
+            singular = 1;
+            break;
+        }
+        if (k != i) {
+            for (int j = i; j < 4; j++) {
+                double tmp = A[i * 4 + j];
+                A[i * 4 + j] = A[k * 4 + j];
+                A[k * 4 + j] = tmp;
+            }
+            for (int j = 0; j < 4; j++) {
+                double tmp = inv[i * 4 + j];
+                inv[i * 4 + j] = inv[k * 4 + j];
+                inv[k * 4 + j] = tmp;
+            }
+        }
+        double d = -1 / A[i * 4 + i];
+        for (int j = i + 1; j < 4; j++) {
+            double alpha = A[j * 4 + i] * d;
+            for (int c = i + 1; c < 4; c++)
+                A[j * 4 + c] += alpha * A[i * 4 + c];
+            for (int c = 0; c < 4; c++)
+                inv[j * 4 + c] += alpha * inv[i * 4 + c];
+        }
+    }
+    if (singular)
+        memset(inv, 0, sizeof(inv));
+    else
+        for (int i = 3; i >= 0; i--)
+            for (int j = 0; j < 4; j++) {
+                double sum = inv[i * 4 + j];
+                for (int c = i + 1; c < 4; c++)
+                    sum -= A[i * 4 + c] * inv[c * 4 + j];
+                inv[i * 4 + j] = sum / A[i * 4 + i];
+            }
     double out[16];
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {

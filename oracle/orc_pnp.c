@@ -576,6 +576,55 @@ typedef struct {
     double epsilon;
 } LevMarq;
 
+/* STUDY SWITCH (tools/lm_cholesky_study.py; VERDICT r05 item 3, "second, gated"): 0 = cvSolve(..., CV_SVD) as CvLevMarq::step
+ * calls it -- the reference, the default, what every parity test runs; 1 = an LL^T factorisation of the same matrix with the
+ * SVD as fallback when a pivot is not safely positive.  Mode 1 exists to MEASURE how far a Cholesky-based product kernel would
+ * drift from the reference (pose, Levenberg-Marquardt iteration counts) before anyone builds one; it is not the oracle. */
+static int g_lm_solve_mode = 0;
+static long long g_lm_solves, g_lm_fallbacks;
+void orc_set_lm_solve_mode(int mode) { g_lm_solve_mode = mode; }
+void orc_lm_solve_counts(long long *solves, long long *fallbacks)
+{
+    *solves = g_lm_solves;
+    *fallbacks = g_lm_fallbacks;
+}
+int orc_cholesky6_solve(const double *A, const double *b, double *x)
+{
+    double L[36];
+    double dmax = 0;
+    for (int i = 0; i < 6; i++)
+        dmax = A[i * 6 + i] > dmax ? A[i * 6 + i] : dmax;
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; k++)
+            d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > dmax * 1e-13)) /* not safely positive definite (also NaN): the caller takes the SVD */
+            return 0;
+        d = sqrt(d);
+        L[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[i * 6 + j];
+            for (int k = 0; k < j; k++)
+                v -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = v / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+        for (int k = 0; k < i; k++)
+            v -= L[i * 6 + k] * y[k];
+        y[i] = v / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; k++)
+            v -= L[k * 6 + i] * x[k];
+        x[i] = v / L[i * 6 + i];
+    }
+    return 1;
+}
+
 static void lm_step(LevMarq *s)
 {
     const double LOG10 = log(10.);
@@ -584,6 +633,13 @@ static void lm_step(LevMarq *s)
     memcpy(JtJN, s->JtJ, sizeof(JtJN)); /* mask is all ones; err != NULL => no completeSymm */
     for (int i = 0; i < 6; i++)
         JtJN[i * 6 + i] *= 1. + lambda;
+    g_lm_solves++;
+    if (g_lm_solve_mode == 1 && orc_cholesky6_solve(JtJN, s->JtErr, x)) {
+        for (int i = 0; i < 6; i++)
+            s->param[i] = s->prevParam[i] - x[i];
+        return;
+    }
+    g_lm_fallbacks += g_lm_solve_mode == 1;
     orc_solve_svd(JtJN, 6, 6, s->JtErr, x);
     for (int i = 0; i < 6; i++)
         s->param[i] = s->prevParam[i] - x[i];

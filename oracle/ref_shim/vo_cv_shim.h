@@ -6,7 +6,7 @@
  *   * value types: cv::Point_, Size, TermCriteria, KeyPoint, Vec3f, Scalar;
  *   * a small dense cv::Mat (2-D, 8U / 32F / 64F, up to 3 channels, reference-counted storage like the real one)
  *     with exactly the members those sources use: at<>, zeros / eye, Mat_<T>(r, c) << a, b, ..., t(), inv()
- *     (Gauss-Jordan with partial pivoting), operator*, hconcat / vconcat / transpose / norm, clone, col, type, size;
+ *     (cv::invert(DECOMP_LU) restated: LU elimination with partial pivoting, zero matrix when singular), operator*, hconcat / vconcat / transpose / norm, clone, col, type, size;
  *   * drawing / window / file functions as no-ops;
  *   * the algorithm entry points (FAST, calcOpticalFlowPyrLK, triangulatePoints, convertPointsFromHomogeneous,
  *     solvePnPRansac, Rodrigues, findEssentialMat, recoverPose) as declarations only: ref_glue.cpp defines them by
@@ -176,39 +176,50 @@ public:
                 memcpy(m.data + (size_t)j * m.step + (size_t)i * es, data + (size_t)i * step + (size_t)j * es, es);
         return m;
     }
-    /* square inverse: Gauss-Jordan with partial pivoting in double (cv::Mat::inv() default is DECOMP_LU) */
+    /* square inverse as cv::invert(DECOMP_LU) forms it for n > 3: LU elimination with partial pivoting on [A | I]
+     * (hal::LU64f / LUImpl: pivot < DBL_EPSILON * 100 -> singular -> zero matrix), back substitution */
     Mat inv() const
     {
         const int n = rows;
-        std::vector<double> a((size_t)n * 2 * n, 0.0);
+        std::vector<double> A((size_t)n * n), b((size_t)n * n, 0.0);
         for (int i = 0; i < n; i++) {
             for (int j = 0; j < n; j++)
-                a[(size_t)i * 2 * n + j] = get(i, j);
-            a[(size_t)i * 2 * n + n + i] = 1.0;
+                A[(size_t)i * n + j] = get(i, j);
+            b[(size_t)i * n + i] = 1.0;
         }
-        for (int c = 0; c < n; c++) {
-            int p = c;
-            for (int r = c + 1; r < n; r++)
-                if (fabs(a[(size_t)r * 2 * n + c]) > fabs(a[(size_t)p * 2 * n + c]))
-                    p = r;
-            if (a[(size_t)p * 2 * n + c] == 0.0)
+        for (int i = 0; i < n; i++) {
+            int k = i;
+            for (int j = i + 1; j < n; j++)
+                if (fabs(A[(size_t)j * n + i]) > fabs(A[(size_t)k * n + i]))
+                    k = j;
+            if (fabs(A[(size_t)k * n + i]) < 2.220446049250313e-16 * 100)
                 return Mat::zeros(n, n, type_);
-            for (int j = 0; j < 2 * n; j++)
-                std::swap(a[(size_t)c * 2 * n + j], a[(size_t)p * 2 * n + j]);
-            const double d = a[(size_t)c * 2 * n + c];
-            for (int j = 0; j < 2 * n; j++)
-                a[(size_t)c * 2 * n + j] /= d;
-            for (int r = 0; r < n; r++)
-                if (r != c) {
-                    const double f = a[(size_t)r * 2 * n + c];
-                    for (int j = 0; j < 2 * n; j++)
-                        a[(size_t)r * 2 * n + j] -= f * a[(size_t)c * 2 * n + j];
-                }
+            if (k != i) {
+                for (int j = i; j < n; j++)
+                    std::swap(A[(size_t)i * n + j], A[(size_t)k * n + j]);
+                for (int j = 0; j < n; j++)
+                    std::swap(b[(size_t)i * n + j], b[(size_t)k * n + j]);
+            }
+            const double d = -1 / A[(size_t)i * n + i];
+            for (int j = i + 1; j < n; j++) {
+                const double alpha = A[(size_t)j * n + i] * d;
+                for (int c = i + 1; c < n; c++)
+                    A[(size_t)j * n + c] += alpha * A[(size_t)i * n + c];
+                for (int c = 0; c < n; c++)
+                    b[(size_t)j * n + c] += alpha * b[(size_t)i * n + c];
+            }
         }
+        for (int i = n - 1; i >= 0; i--)
+            for (int j = 0; j < n; j++) {
+                double s = b[(size_t)i * n + j];
+                for (int c = i + 1; c < n; c++)
+                    s -= A[(size_t)i * n + c] * b[(size_t)c * n + j];
+                b[(size_t)i * n + j] = s / A[(size_t)i * n + i];
+            }
         Mat m(n, n, type_);
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++)
-                m.set(i, j, a[(size_t)i * 2 * n + n + j]);
+                m.set(i, j, b[(size_t)i * n + j]);
         return m;
     }
 

@@ -5,8 +5,10 @@
  * sources -- src/bucket.cpp, feature.cpp, visualOdometry.cpp, utils.cpp, compiled where they lie against the
  * OpenCV stand-in oracle/ref_shim/vo_cv_shim.h -- run on top of libvo_hip.so instead of OpenCV:
  *   * visualOdometry.cpp is compiled with -DcircularMatching=circularMatching_hip, i.e. the one call site
- *     (visualOdometry.cpp:112-118) reaches the adapter below -- the adapter INTEGRATION.md gives a maintainer, same
- *     signature as feature.h:61-65 -- exactly as a USE_HIP switch next to the existing USE_CUDA one would;
+ *     (visualOdometry.cpp:112-118) reaches the SHIPPED adapter adapters/feature_hip.cpp (same signature as
+ *     feature.h:61-65) exactly as a USE_HIP switch next to the existing USE_CUDA one would;
+ *   * ref_frame_step_adapter additionally replaces main.cpp:169-171,181 by the adapter's triangulate_hip /
+ *     trackingFrame2Frame_hip, i.e. the frame loop a maintainer gets after the edits INTEGRATION.md lists;
  *   * the OpenCV entry points the other reference functions call are defined here over the C ABI:
  *     cv::FAST -> vo_fast_detect, cv::triangulatePoints (+ convertPointsFromHomogeneous) -> vo_triangulate,
  *     cv::solvePnPRansac + cv::Rodrigues -> vo_pnp_ransac, cv::findEssentialMat + cv::recoverPose -> vo_essential_pose.
@@ -27,62 +29,15 @@
 #include "visualOdometry.h"
 #include "vo_hip.h"
 
-/* ---- the adapter of INTEGRATION.md (feature_hip.cpp) ------------------------------------------------------------ */
-static vo_ctx *ctx_for(int w, int h, int n) /* one ctx per process (the reference is single-threaded) */
-{
-    static vo_ctx *c = nullptr;
-    static int cw = 0, ch = 0, cn = 0;
-    if (!c || w > cw || h > ch || n > cn) {
-        if (c)
-            vo_destroy(c);
-        cw = std::max(w, cw);
-        ch = std::max(h, ch);
-        cn = std::max(n, std::max(cn, 16384));
-        c = vo_create(/*device*/ 0, cw, ch, cn, /*max_frames*/ 1);
-        if (!c)
-            throw std::runtime_error("vo_create failed (no HIP device?)"); /* no CPU fallback */
-    }
-    return c;
-}
+/* ---- the adapter: adapters/feature_hip.cpp, compiled by the Makefile next to this file (ONE source of truth; round 5 kept a
+ * copy here).  The OpenCV stand-ins below share its context. ------------------------------------------------------------- */
+#include "feature_hip.h"
+
+static vo_ctx *ctx_for(int w, int h, int n) { return vo_adapter_context_for(w, h, n); }
 static void check(vo_ctx *c, int rc)
 {
     if (rc < 0)
         throw std::runtime_error(vo_last_error(c));
-}
-
-/* same signature as circularMatching (feature.h:61-65) */
-void circularMatching_hip(cv::Mat l0, cv::Mat r0, cv::Mat l1, cv::Mat r1, std::vector<cv::Point2f> &p_l0,
-                          std::vector<cv::Point2f> &p_r0, std::vector<cv::Point2f> &p_l1, std::vector<cv::Point2f> &p_r1,
-                          std::vector<cv::Point2f> &p_l0_ret, FeatureSet &feats)
-{
-    const int n = (int)p_l0.size();
-    vo_ctx *c = ctx_for(l0.cols, l0.rows, n);
-    std::vector<cv::Point2f> o_l0(n), o_r0(n), o_r1(n), o_l1(n), o_ret(n);
-    std::vector<int32_t> keep(n > 0 ? n : 1);
-    int m = 0;
-    /* cv::Point2f is two packed floats -> reinterpret as float* */
-    check(c, vo_circular_match(c, l0.data, r0.data, l1.data, r1.data, l0.cols, l0.rows, (int)l0.step,
-                               (const float *)p_l0.data(), n, (float *)o_l0.data(), (float *)o_r0.data(),
-                               (float *)o_r1.data(), (float *)o_l1.data(), (float *)o_ret.data(), /*status4*/ nullptr,
-                               keep.data(), &m, /*apply_consistency*/ 0));
-    /* deleteUnmatchFeaturesCircle's side effects on ages (feature.cpp:83-86,111) */
-    for (size_t i = 0; i < feats.ages.size(); i++)
-        feats.ages[i] += 1;
-    std::vector<int> ages(m);
-    for (int i = 0; i < m; i++)
-        ages[i] = feats.ages[keep[i]];
-    ages.insert(ages.end(), feats.ages.begin() + std::min<size_t>(n, feats.ages.size()), feats.ages.end()); /* quirk B3 */
-    feats.ages.swap(ages);
-    o_l0.resize(m);
-    o_r0.resize(m);
-    o_r1.resize(m);
-    o_l1.resize(m);
-    o_ret.resize(m);
-    p_l0.swap(o_l0);
-    p_r0.swap(o_r0);
-    p_r1.swap(o_r1);
-    p_l1.swap(o_l1);
-    p_l0_ret.swap(o_ret);
 }
 
 /* ---- OpenCV entry points of the remaining reference code, over the C ABI ---------------------------------------- */
@@ -255,12 +210,13 @@ static int from_points(const std::vector<cv::Point2f> &v, float *p, int cap)
     return (int)v.size();
 }
 
-/* same interface and same body as oracle/ref_shim/ref_glue.cpp::ref_frame_step (main.cpp:144-208) */
-extern "C" int ref_frame_step(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h,
+/* same interface and same body as oracle/ref_shim/ref_glue.cpp::ref_frame_step (main.cpp:144-208); adapter_tail: the
+ * triangulation and trackingFrame2Frame call sites edited as INTEGRATION.md says (triangulate_hip, trackingFrame2Frame_hip) */
+static int frame_step(const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h,
                               float fx, float cx, float cy, float bf, float *feat_pts, int *feat_ages, int *n_pts,
                               int *n_ages, int cap, double *translation, double *rotation, double *frame_pose,
                               int mono_rotation, float *out_l0, float *out_r0, float *out_l1, float *out_r1, int *n_out,
-                              int *integrated)
+                              int *integrated, bool adapter_tail)
 {
     Quiet q;
     try {
@@ -282,9 +238,14 @@ extern "C" int ref_frame_step(const uint8_t *l0, const uint8_t *r0, const uint8_
         std::vector<cv::Point2f> pl0, pr0, pl1, pr1;
         matchingFeatures(L0, R0, L1, R1, fs, pl0, pr0, pl1, pr1);
         cv::Mat points3D_t0, points4D_t0;
-        cv::triangulatePoints(projMatrl, projMatrr, pl0, pr0, points4D_t0);
-        cv::convertPointsFromHomogeneous(points4D_t0.t(), points3D_t0);
-        trackingFrame2Frame(projMatrl, projMatrr, pl0, pl1, points3D_t0, rot, trans, mono_rotation != 0);
+        if (adapter_tail) {
+            triangulate_hip(projMatrl, projMatrr, pl0, pr0, points3D_t0);
+            trackingFrame2Frame_hip(projMatrl, projMatrr, pl0, pl1, points3D_t0, rot, trans, mono_rotation != 0);
+        } else {
+            cv::triangulatePoints(projMatrl, projMatrr, pl0, pr0, points4D_t0);
+            cv::convertPointsFromHomogeneous(points4D_t0.t(), points3D_t0);
+            trackingFrame2Frame(projMatrl, projMatrr, pl0, pl1, points3D_t0, rot, trans, mono_rotation != 0);
+        }
         cv::Vec3f e = rotationMatrixToEulerAngles(rot);
         cv::Mat rigid_body_transformation;
         *integrated = 0;
@@ -315,3 +276,36 @@ extern "C" int ref_frame_step(const uint8_t *l0, const uint8_t *r0, const uint8_
         return -2;
     }
 }
+
+/* the adapter's detectAndBucket_hip (head of matchingFeatures, visualOdometry.cpp:95-108) on a caller's feature set */
+extern "C" int adapter_detect_bucket(const uint8_t *img, int w, int h, float *pts, int *ages, int *n_pts, int *n_ages, int cap)
+{
+    try {
+        cv::Mat I(h, w, CV_8UC1, (void *)img, (size_t)w);
+        FeatureSet fs;
+        fs.points = to_points(pts, *n_pts);
+        fs.ages.assign(ages, ages + *n_ages);
+        detectAndBucket_hip(I, fs);
+        if ((int)fs.points.size() > cap || (int)fs.ages.size() > cap)
+            return -1;
+        *n_pts = from_points(fs.points, pts, cap);
+        for (size_t i = 0; i < fs.ages.size(); i++)
+            ages[i] = fs.ages[i];
+        *n_ages = (int)fs.ages.size();
+        return 0;
+    } catch (const std::exception &ex) {
+        fprintf(stderr, "dropin_glue: %s\n", ex.what());
+        return -2;
+    }
+}
+
+#define VO_STEP_ARGS                                                                                                        \
+    const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h, float fx, float cx, float cy,  \
+        float bf, float *feat_pts, int *feat_ages, int *n_pts, int *n_ages, int cap, double *translation, double *rotation,  \
+        double *frame_pose, int mono_rotation, float *out_l0, float *out_r0, float *out_l1, float *out_r1, int *n_out,        \
+        int *integrated
+#define VO_STEP_PASS                                                                                                        \
+    l0, r0, l1, r1, w, h, fx, cx, cy, bf, feat_pts, feat_ages, n_pts, n_ages, cap, translation, rotation, frame_pose,        \
+        mono_rotation, out_l0, out_r0, out_l1, out_r1, n_out, integrated
+extern "C" int ref_frame_step(VO_STEP_ARGS) { return frame_step(VO_STEP_PASS, false); }
+extern "C" int ref_frame_step_adapter(VO_STEP_ARGS) { return frame_step(VO_STEP_PASS, true); }

@@ -212,3 +212,33 @@ def test_frame_loop_host_logic_of_the_kept_pair():
     for _ in range(3):
         vo2.process(img, img)
     assert all(c[1] is False for c in fake2.calls)
+
+
+def test_adapter_is_shipped_source_and_the_only_copy():
+    """adapters/feature_hip.{h,cpp} + USE_HIP.cmake are real files; the drop-in test build compiles THAT file
+    (no second copy of circularMatching_hip anywhere), INTEGRATION.md points at the files instead of pasting them; where the
+    reference tree exists, the adapter compiles on its own against the reference's feature.h (C++11, -Wall -Werror)."""
+    import subprocess
+    ad = os.path.join(ROOT, "adapters")
+    for f in ("feature_hip.h", "feature_hip.cpp", "USE_HIP.cmake"):
+        assert os.path.getsize(os.path.join(ad, f)) > 500, f
+    hdr = open(os.path.join(ad, "feature_hip.h")).read()
+    assert "__has_include(<opencv2/core.hpp>)" in hdr
+    defs = []
+    for dirpath, _, files in os.walk(ROOT):
+        if any(s in dirpath for s in ("/.git", "/gpurun_out", "/_build", "/profiles")):
+            continue
+        for f in files:
+            if f.endswith((".cpp", ".h", ".hip", ".md")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if "void circularMatching_hip(" in txt and "{" in txt.split("void circularMatching_hip(", 1)[1].split(";", 1)[0]:
+                    defs.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert defs == ["adapters/feature_hip.cpp"], defs
+    mk = open(os.path.join(ROOT, "tests", "ref_dropin", "Makefile")).read()
+    assert "adapters/feature_hip.cpp" in mk
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "adapters/feature_hip.cpp" in integ and "adapters/USE_HIP.cmake" in integ
+    if os.path.exists("/root/reference/src/feature.h"):
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "oracle", "ref_shim"),
+                               "-I/root/reference/src", "-I" + os.path.join(ROOT, "include"), "-I" + ad,
+                               os.path.join(ad, "feature_hip.cpp")])

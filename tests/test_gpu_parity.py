@@ -683,11 +683,13 @@ def test_product_frame_loop_against_the_reference_sources(gpu_ctx, orc, small_wo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mono", [False, True])
-def test_reference_sources_run_on_libvo_hip(orc, small_world, mono):
+@pytest.mark.parametrize("entry", ["ref_frame_step", "ref_frame_step_adapter"])
+def test_reference_sources_run_on_libvo_hip(orc, small_world, mono, entry):
     """THE DROP-IN: the reference's unmodified matchingFeatures() / trackingFrame2Frame() / integrateOdometryStereo()
-    (compiled where they lie; visualOdometry.cpp's circularMatching call reaches the INTEGRATION.md adapter, the OpenCV
-    entry points reach the C ABI: tests/ref_dropin) driving the MI355X, against the same reference code over the CPU
-    oracle (oracle/_ref), frame after frame"""
+    (compiled where they lie; visualOdometry.cpp's circularMatching call reaches the SHIPPED adapter adapters/feature_hip.cpp,
+    the OpenCV entry points reach the C ABI: tests/ref_dropin) driving the MI355X, against the same reference code over
+    the CPU oracle (oracle/_ref), frame after frame.  ref_frame_step_adapter: main.cpp:169-171,181 edited as INTEGRATION.md
+    says -- the adapter's triangulate_hip / trackingFrame2Frame_hip instead of the OpenCV calls."""
     import ctypes
     so = os.path.join(ROOT, "tests", "_build", "libvo_ref_dropin.so")
     if orc.ref_lib() is None or not os.path.exists(so):
@@ -698,7 +700,7 @@ def test_reference_sources_run_on_libvo_hip(orc, small_world, mono):
     P_l, P_r = small_world.proj_matrices()
     args = (P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3])
     cpu = orc.RefFrameLoop(*args, mono_rotation=mono)
-    gpu = orc.RefFrameLoop(*args, mono_rotation=mono, lib=hip)
+    gpu = orc.RefFrameLoop(*args, mono_rotation=mono, lib=hip, entry=entry)
     cpu.process(L[0], R[0])
     gpu.process(L[0], R[0])
     for k in range(1, n):

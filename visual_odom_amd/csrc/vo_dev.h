@@ -105,12 +105,12 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 // float -> int32 the way gfx950 converts (v_cvt_i32_f32 / v_cvt_i32_f64): truncation towards zero, SATURATING, NaN -> 0.
-// x86 (the reference's CPU path, the oracle, and this source when g++ compiles it for the CPU emulator) converts with
+// x86 (the reference's CPU path, the CPU checker of tests/, and this source when g++ compiles it for the CPU emulator) converts with
 // cvttss2si / cvttsd2si, which return INT_MIN for NaN and for every value outside int32 -- so a kernel that decides on a
 // converted value can differ from the reference exactly on non-finite input (lk admitted NaN points).
 // Every value-level float -> int conversion of the kernels goes through these two: the device takes the one instruction, the
 // emulator spells the device's semantics out, so emulator == GPU on that input class and the CPU suite can hold the
-// kernels to the oracle there (tests/test_kernel_emulation.py::test_lk_nonfinite_points).
+// kernels to the reference's behaviour there (tests/test_kernel_emulation.py::test_lk_nonfinite_points).
 __device__ __forceinline__ int vo_f2i(float v)
 {
 #ifdef VO_HOST_EMUL

@@ -7,6 +7,7 @@
 // on the pose; atan2 only feeds the float-rounded gate comparison.
 #pragma once
 
+#include <float.h>
 #include <math.h>
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
@@ -43,33 +44,59 @@ VO_INTEG_HD int integrate_odometry(double *pose, const double *R, const double *
     const double scale = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
     if (!(scale > 0.05 && scale < 10))
         return 0; // utils.cpp:80-90
-    // inverse of the 4x4 [R|t; 0 0 0 1] by Gauss-Jordan elimination with partial pivoting (what
-    // cv::Mat::inv() DECOMP_LU amounts to for a well-conditioned 4x4)
-    double a[4][8];
+    // inverse of the 4x4 [R|t; 0 0 0 1] as cv::Mat::inv() (DECOMP_LU) forms it for n > 3 (round 6; Gauss-Jordan before:
+    // <= 1e-12 per step away): cv::invert copies the matrix, sets dst = I and calls hal::LU64f -- LUImpl, Gaussian elimination
+    // with partial pivoting on [A | I], pivots below DBL_EPSILON * 100 are "singular", then back substitution; a singular
+    // matrix returns dst = 0, and the reference multiplies by it all the same (utils.cpp:78-84: frame_pose becomes 0).
+    // (OpenCV's LAPACK HAL declines matrices below 100 rows, so builds with and without LAPACK run this routine.)
+    double A[4][4], a[4][8]; // a[.][4 + j]: the right-hand sides (I, finally the inverse)
     for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 8; j++)
-            a[i][j] = j < 4 ? (i < 3 ? (j < 3 ? R[3 * i + j] : t[i]) : (j == 3 ? 1.0 : 0.0)) : (j - 4 == i ? 1.0 : 0.0);
-    for (int col = 0; col < 4; col++) {
-        int piv = col;
-        for (int r = col + 1; r < 4; r++)
-            if (fabs(a[r][col]) > fabs(a[piv][col]))
-                piv = r;
-        if (fabs(a[piv][col]) < 1e-300)
-            return 0;
-        if (piv != col)
-            for (int j = 0; j < 8; j++) {
-                const double tmp = a[col][j];
-                a[col][j] = a[piv][j];
-                a[piv][j] = tmp;
+        for (int j = 0; j < 4; j++) {
+            A[i][j] = i < 3 ? (j < 3 ? R[3 * i + j] : t[i]) : (j == 3 ? 1.0 : 0.0);
+            a[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    bool singular = false;
+    for (int i = 0; i < 4 && !singular; i++) {
+        int k = i;
+        for (int j = i + 1; j < 4; j++)
+            if (fabs(A[j][i]) > fabs(A[k][i]))
+                k = j;
+        if (fabs(A[k][i]) < DBL_EPSILON * 100) {
+            singular = true;
+            break;
+        }
+        if (k != i) {
+            for (int j = i; j < 4; j++) {
+                const double tmp = A[i][j];
+                A[i][j] = A[k][j];
+                A[k][j] = tmp;
             }
-        const double d = 1.0 / a[col][col];
-        for (int j = 0; j < 8; j++)
-            a[col][j] *= d;
-        for (int r = 0; r < 4; r++)
-            if (r != col) {
-                const double f = a[r][col];
-                for (int j = 0; j < 8; j++)
-                    a[r][j] -= f * a[col][j];
+            for (int j = 0; j < 4; j++) {
+                const double tmp = a[i][4 + j];
+                a[i][4 + j] = a[k][4 + j];
+                a[k][4 + j] = tmp;
+            }
+        }
+        const double d = -1 / A[i][i];
+        for (int j = i + 1; j < 4; j++) {
+            const double alpha = A[j][i] * d;
+            for (int c = i + 1; c < 4; c++)
+                A[j][c] += alpha * A[i][c];
+            for (int c = 0; c < 4; c++)
+                a[j][4 + c] += alpha * a[i][4 + c];
+        }
+    }
+    if (singular) {
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++)
+                a[i][4 + j] = 0.0;
+    } else {
+        for (int i = 3; i >= 0; i--)
+            for (int j = 0; j < 4; j++) {
+                double sum = a[i][4 + j];
+                for (int c = i + 1; c < 4; c++)
+                    sum -= A[i][c] * a[c][4 + j];
+                a[i][4 + j] = sum / A[i][i];
             }
     }
     double out[16];
