@@ -153,7 +153,12 @@ int vo_get_params(const vo_ctx *ctx, vo_params *p);
  * keep_idx (optional, [n]): input index of each survivor (the adapter compacts `ages` with it).
  * apply_consistency != 0 additionally applies checkValidMatch(thr) + removeInvalidPoints
  * (visualOdometry.cpp:44-77,119-125) so the outputs are the K points that reach triangulation.
- * img_l0 == img_r0 == NULL: the t0 pair is the previous call's t1 pair (see vo_track_frame, THE KEPT PAIR). */
+ * img_l0 == img_r0 == NULL: the t0 pair is the previous call's t1 pair (see vo_track_frame, THE KEPT PAIR).
+ * VALUES (round 6; tests/adversarial.py, tests/test_gpu_round6.py): a start point with a NaN coordinate, +-inf or a value
+ * beyond int32 fails its first hop with status 0 exactly as in calcOpticalFlowPyrLK (x86's cvFloor(NaN) is INT_MIN: "left of
+ * the window"), its reported positions are the propagated (NaN / huge) values, and deleteUnmatchFeaturesCircle drops it;
+ * denormal, negative and out-of-image coordinates take the reference's path (+-winSize admissibility window, then the sign
+ * tests of feature.cpp:96-104); constant / saturated / 1-pixel-checkerboard images fail the min-eigenvalue test as there. */
 int vo_circular_match(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
                       const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
                       float *out_l0, float *out_r0, float *out_r1, float *out_l1, float *out_l0_ret,
@@ -198,7 +203,10 @@ int vo_fast_detect(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, in
  * (feature.cpp:206-253, bucket.cpp:14-51, quirks of SURVEY.md App. B1-B3 reproduced).
  * pts_io [2 * cap] / ages_io [cap]: in: *n_pts points and *n_ages ages (n_ages >= n_pts allowed, as in
  * the reference after a consistency filter); out: the bucketed set (*n_pts == *n_ages).
- * img == NULL (also vo_fast_detect): the left image of the pair vo_track_frame kept (see there). */
+ * img == NULL (also vo_fast_detect): the left image of the pair vo_track_frame kept (see there).
+ * A carried point whose bucket index the reference would read outside its bucket vector (NaN / infinite / huge / far
+ * negative coordinates: undefined behaviour in feature.cpp:233-236) is IGNORED here (quotients beyond +-32768 or an index
+ * outside the (rows/bs + 1) x (cols/bs + 1) buckets); every in-image point takes the reference's path. */
 int vo_detect_bucket(vo_ctx *ctx, const uint8_t *img, int w, int h, int stride, const vo_detect_params *dp,
                      float *pts_io, int *n_pts, int32_t *ages_io, int *n_ages, int cap);
 
@@ -225,13 +233,21 @@ int vo_integrate_odometry(double *pose16, const double *R9, const double *t3, fl
  * with img == NULL read the kept pair's LEFT image (what matchingFeatures detects on next, visualOdometry.cpp:95-108);
  * with an image of their own they leave the kept pair alone.  VO_ERR_STATE when there is no kept pair of this size:
  * first call, another w x h, or a vo_batch_* upload / configure of another shape / vo_seq_configure since (they own the
- * image table from then on).  One NULL and one non-NULL t0 image is VO_ERR_ARG. */
+ * image table from then on).  One NULL and one non-NULL t0 image is VO_ERR_ARG.
+ * ONE CALLER PER KEPT PAIR: the pair is the context's, not the caller's -- two users of one context (two frame loops, or a
+ * loop plus direct calls) with images of the same size would read each other's t1 pair as t0 without any error.  A user who
+ * shares a context remembers vo_kept_pair_id() after its call and passes NULL only while the id is unchanged (what
+ * visual_odom_amd.odometry.StereoOdometry does); a context with a single frame loop needs none of this. */
 int vo_track_frame(vo_ctx *ctx, const uint8_t *img_l0, const uint8_t *img_r0, const uint8_t *img_l1,
                    const uint8_t *img_r1, int w, int h, int stride, const float *pts_l0_xy, int n,
                    const float *P_l, const float *P_r, float *out_l0, float *out_r0, float *out_l1,
                    float *out_r1, float *xyz_out, int32_t *keep_idx, int *n_out, int32_t *keep_idx_circ,
                    int *n_circ, double *rvec_io, double *tvec_io, double *R_out, int32_t *inliers,
                    int *n_inliers);
+
+/* identity of the kept pair: > 0 and different after every vo_track_frame / vo_circular_match that left a new t1 pair on the
+ * device; 0 = there is none (no call yet, or the batch / sequence API owns the image table) */
+int64_t vo_kept_pair_id(const vo_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------
  * Batched, device-resident API (throughput mode: many independent frames per launch so that a
@@ -252,7 +268,9 @@ int vo_batch_configure(vo_ctx *ctx, int n_images, int w, int h, int n_frames);
 int vo_batch_upload_image(vo_ctx *ctx, int image_idx, const uint8_t *host_pixels, int stride);
 /* device -> device copy (e.g. from a torch uint8 tensor's data_ptr()) */
 int vo_batch_upload_image_dev(vo_ctx *ctx, int image_idx, const void *dev_pixels, int stride);
-/* quads4 [n_frames][4] = (l0, r0, l1, r1) image indices */
+/* quads4 [n_frames][4] = (l0, r0, l1, r1) image indices.  A synchronous drop-in call (vo_track_frame, vo_circular_match,
+ * vo_fast_detect, vo_detect_bucket) runs on frame 0 with a quadruple of its own: set the quads again before the next
+ * vo_batch_run that follows one (a run without it reads what vo_batch_set_quads last uploaded, all zero after a new shape) */
 int vo_batch_set_quads(vo_ctx *ctx, const int32_t *quads4, int n_frames);
 /* Which images VO_STAGE_PYRAMID (re)builds: [first_image, first_image + n_images).  Default after
  * vo_batch_configure: all of them.  A streaming caller keeps the image table as a ring, uploads only the

@@ -316,3 +316,69 @@ def test_shipped_adapter_detect_and_bucket(orc, small_seq):
                                        C.byref(n_p), C.byref(n_a), cap)
         assert rc == 0
         assert np.array_equal(P[:n_p.value], rp) and np.array_equal(A[:n_a.value], ra), len(pts)
+
+
+# ------------------------------------------------------------------ ADVICE r05
+def test_two_frame_loops_share_one_context(volib, small_world):
+    """the kept pair belongs to the context.  Two StereoOdometry loops on ONE context with images of the
+    same size must not read each other's t1 pair as t0: each compares vo_kept_pair_id with the id it saw after its own call
+    and falls back to the four-image call -- trajectories equal those of two loops with a context each."""
+    from visual_odom_amd.odometry import StereoOdometry
+    P_l, P_r = small_world.proj_matrices()
+    L, R, _, _ = small_world.render_sequence(6)
+    L2, R2 = [np.ascontiguousarray(a[:, ::-1]) for a in R], [np.ascontiguousarray(a[:, ::-1]) for a in L]   # another "sequence", same size
+    h, w = L[0].shape
+    solo = []
+    for seqL, seqR in ((L, R), (L2, R2)):
+        vo = StereoOdometry(P_l, P_r, max_w=w, max_h=h)
+        for a, b in zip(seqL, seqR):
+            vo.process(a, b)
+        solo.append(np.array(vo.trajectory))
+        vo.close()
+    ctx = volib.Context(0, w, h, 4096, 1)
+    a, b = StereoOdometry(P_l, P_r, ctx=ctx), StereoOdometry(P_l, P_r, ctx=ctx)
+    ids = set()
+    for k in range(len(L)):
+        a.process(L[k], R[k])
+        ids.add(ctx.kept_pair_id())
+        b.process(L2[k], R2[k])
+        ids.add(ctx.kept_pair_id())
+    assert np.array_equal(np.array(a.trajectory), solo[0]) and np.array_equal(np.array(b.trajectory), solo[1])
+    assert len(ids - {0}) >= 2 * (len(L) - 1) and ctx.kept_pair_id() > 0   # every call left a new pair
+    # a single loop on the context keeps its pair: the id it stored is still the context's
+    c = StereoOdometry(P_l, P_r, ctx=ctx)
+    for k in range(3):
+        c.process(L[k], R[k])
+        assert k == 0 or c._kept_id == ctx.kept_pair_id()
+    ctx.batch_configure(4, w, h, 1)
+    ctx.batch_upload_image(0, L[0])            # the batch API takes the image table: no kept pair
+    assert ctx.kept_pair_id() == 0
+    ctx.close()
+
+
+def test_batch_run_after_a_dropin_call_reads_the_uploaded_quads(gpu_ctx, volib, small_seq):
+    """a drop-in call runs frame 0 on a constant quadruple of its own; the next batch run without a new
+    vo_batch_set_quads reads what vo_batch_set_quads last uploaded -- whatever slot pair the drop-in calls used"""
+    s = small_seq
+    imgs = [s["L"][0], s["R"][0], s["L"][1], s["R"][1]]
+    pts = s["pts"][0]
+    h, w = imgs[0].shape
+    gpu_ctx.batch_configure(4, w, h, 1)
+    for i, im in enumerate(imgs):
+        gpu_ctx.batch_upload_image(i, im)
+    gpu_ctx.batch_set_quads([[0, 1, 2, 3]])
+    gpu_ctx.batch_set_points(0, pts)
+    gpu_ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)
+    gpu_ctx.batch_sync()
+    want = gpu_ctx.batch_get_tracks(0, len(pts))
+    gpu_ctx.circular_match(*imgs, pts)                       # slots (0, 1) -> (2, 3): quadruple {0, 1, 2, 3}
+    gpu_ctx.circular_match(None, None, imgs[0], imgs[1], pts)   # kept pair (2, 3) -> new pair in (0, 1): quadruple {2, 3, 0, 1}
+    gpu_ctx.batch_configure(4, w, h, 1)                      # same shape: early return
+    for i, im in enumerate(imgs):
+        gpu_ctx.batch_upload_image(i, im)
+    gpu_ctx.batch_set_points(0, pts)
+    gpu_ctx.batch_run(volib.STAGE_PYRAMID | volib.STAGE_LK)  # no vo_batch_set_quads: {0, 1, 2, 3} as uploaded above
+    gpu_ctx.batch_sync()
+    got = gpu_ctx.batch_get_tracks(0, len(pts))
+    for k in ("r0", "r1", "l1", "l0_ret", "status4"):
+        assert np.array_equal(got[k], want[k]), k

@@ -35,7 +35,7 @@ EXPORTS = (
     "vo_batch_get_pyramid_level", "vo_model_bytes", "vo_essential_pose", "vo_batch_get_essential",
     "vo_seq_configure", "vo_seq_reset", "vo_seq_push_pair", "vo_seq_push_pair_dev", "vo_seq_push_pairs", "vo_seq_step", "vo_seq_sync",
     "vo_seq_get_state", "vo_seq_get_trajectory", "vo_set_schedule", "vo_get_schedule", "vo_get_probe_log",
-    "vo_export_schedule", "vo_import_schedule",
+    "vo_export_schedule", "vo_import_schedule", "vo_kept_pair_id",
 )
 
 
@@ -86,6 +86,8 @@ def load():
     lib.vo_default_params.restype = None
     lib.vo_default_detect_params.argtypes = [C.POINTER(VoDetectParams)]
     lib.vo_default_detect_params.restype = None
+    lib.vo_kept_pair_id.restype = C.c_int64
+    lib.vo_kept_pair_id.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -241,6 +243,11 @@ class Context:
         return {"%d,%d,%d%s%s" % (cands[i].pose_waves, cands[i].pose_streams, cands[i].prepare,
                                   ",wide%d" % cands[i].epnp_wide_frames if cands[i].epnp_wide_frames != 4 else "",
                                   " (real steps)" if real[i] else ""): float(ms[i]) for i in range(n.value)}
+
+    def kept_pair_id(self):
+        """identity of the stereo pair the last track_frame / circular_match left on the device (0: none) -- a caller that
+        shares this context passes l0 = r0 = None only while the id is the one it saw after its own call (vo_hip.h)"""
+        return int(self.lib.vo_kept_pair_id(self.h))
 
     # ---- drop-in calls ------------------------------------------------------------------
     def circular_match(self, l0, r0, l1, r1, pts_l0, apply_consistency=False):

@@ -422,6 +422,8 @@ int vo_set_params(vo_ctx *c, const vo_params *p)
     return VO_OK;
 }
 
+int64_t vo_kept_pair_id(const vo_ctx *c) { return c && c->tf_base >= 0 ? c->tf_gen : 0; }
+
 int vo_get_params(const vo_ctx *c, vo_params *p)
 {
     if (!c || !p)
@@ -450,6 +452,8 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
     if (c->n_images == n_images && c->w == w && c->h == h && c->n_frames == n_frames) {
         c->pyr_first = 0; // a (re)configure always restores "build every pyramid"
         c->pyr_count = n_images;
+        c->quads_cur = c->d_quads; // ... and "the quads are what vo_batch_set_quads last uploaded": a synchronous drop-in call
+                                   // may have left the launches reading one of its constant quadruples
         return VO_OK;
     }
     c->sched_key[0] = -1; // a new shape: the schedule is resolved again at its first run

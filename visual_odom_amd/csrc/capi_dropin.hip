@@ -38,7 +38,8 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
         return fail(c, VO_ERR_ARG, "more points than max_pts given to vo_create");
     if (stride < w) // (before anything changes: a refused call leaves the kept pair as it is)
         return fail(c, VO_ERR_ARG, "stride smaller than the width");
-    if (keep && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
+    if (keep && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h ||
+                 c->img_stale[c->tf_base] || c->img_stale[c->tf_base + 1])) // (stale: the call that uploaded the pair failed before its pyramids were built)
         return fail(c, VO_ERR_STATE, "no t0 images given, and the context does not hold the t1 pair of a previous call of this "
                                      "size (first call, another size, or the batch / sequence API used the images since)");
     int rc = vo_batch_configure(c, 4, w, h, 1);
@@ -68,6 +69,7 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
         c->pyr_count = 2;
     }
     c->tf_base = t1;
+    c->tf_gen++; // a new kept pair (vo_kept_pair_id)
     c->h_npts[0] = n;
     c->pts_on_device = false;
     c->max_pts_set = n;
@@ -108,6 +110,12 @@ int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uin
     g.n = status4 ? n : 0;
     g.cap = c->cap;
     g.consistency = apply_consistency ? 1 : 0;
+    if (!c->last_run_serial) { // (developer build, VO_SYNC_SERIAL=0: the filter ran on its own stream and this call has no
+                               // pose stage whose event would order the gather behind it -- ADVICE r05)
+        rc = sync_all(c);
+        if (rc != VO_OK)
+            return rc;
+    }
     launch_circ_gather(g, c->d_gather, c->stream); // (circ_gather_bytes(cap) <= frame_gather_bytes(cap))
     VO_HIP_TRY(c, hipGetLastError());
     VO_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -230,7 +238,8 @@ int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride)
 {
     if (img && stride < w)
         return fail(c, VO_ERR_ARG, "stride smaller than the width");
-    if (!img && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h))
+    if (!img && (c->tf_base < 0 || c->seq.on || c->n_images != 4 || c->n_frames != 1 || c->w != w || c->h != h ||
+                 c->img_stale[c->tf_base] || c->img_stale[c->tf_base + 1]))
         return fail(c, VO_ERR_STATE, "no image given, and the context does not hold the t1 pair of a previous vo_track_frame "
                                      "of this size");
     int rc = vo_batch_configure(c, 4, w, h, 1);

@@ -157,6 +157,10 @@ struct vo_ctx {
     // as its t0 pair by passing no t0 images (main.cpp:157-158: imageLeft_t0 = imageLeft_t1).  -1: no such pair (no call yet,
     // or the batch / sequence API has touched the image table since)
     int tf_base = -1;
+    // identity of that pair (vo_kept_pair_id): bumped whenever a drop-in call publishes a new t1 pair, so that a caller who
+    // shares the context with others can tell whether the pair on the device is still the one ITS last call left
+    int64_t tf_gen = 0;
+    bool last_run_serial = true; // the last run_stages put everything on the tracking stream (else: sync_all before a gather)
     bool serial_pose = false; // -DVO_DEV_VARIANTS + VO_SERIAL_POSE=1: the whole chain on the tracking stream (profiling)
     bool lk_pair = false;     // -DVO_DEV_VARIANTS + VO_LK_PAIR=1: the two-features-per-wavefront LK kernel (lk.hip)
     // pinned staging for host images: rows are repacked to the device pitch on the host and go over

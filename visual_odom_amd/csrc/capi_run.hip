@@ -183,6 +183,7 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
     if (sync_serial_env == 0 && !c->serial_pose)
         serial = false; // A/B: the synchronous call on the batch mode's streams
 #endif
+    c->last_run_serial = serial;
     hipStream_t fs = serial ? c->stream : c->stream_filter;
     const bool two_pose_streams = !serial && !c->prm.mono_rotation && c->sched.streams == 2;
     hipStream_t ps = serial ? c->stream : (two_pose_streams && (c->cur & 1)) ? c->stream_pnp2 : c->stream_pnp;

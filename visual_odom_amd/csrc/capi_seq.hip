@@ -139,6 +139,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
         ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         seq_free(c);
+        (void)select_streams(c, false); // (n_seq == 1 had moved the context onto the CU-partitioned twin: not without a loop)
         return fail(c, VO_ERR_HIP, "vo_seq_configure: allocation failed");
     }
     std::vector<Quad> tab((size_t)ring * S);

@@ -32,7 +32,7 @@ class StereoOdometry:
         self._own = ctx is None
         self.detect_kw = detect_kw
         self.streaming = streaming
-        self.keep_pair, self._kept = bool(keep_pair), False
+        self.keep_pair, self._kept, self._kept_id = bool(keep_pair), False, 0
         # trackingFrame2Frame's `mono_rotation` (visualOdometry.h:42; main.cpp:181 passes false)
         self.mono_rotation = bool(mono_rotation)
         self.ctx.set_params(mono_rotation=int(self.mono_rotation))
@@ -64,19 +64,23 @@ class StereoOdometry:
                 return None
             (l0, r0), (l1, r1) = self.prev, cur
             # matchingFeatures: appendNewFeatures + bucketingFeatures (visualOdometry.cpp:95-108)
-            pts = None
-            if self._kept:   # the previous call's t1 pair is this call's t0 pair and still on the device (main.cpp:157-158)
+            pts = out = None
+            # the previous call's t1 pair is this call's t0 pair (main.cpp:157-158) -- still on the device IF nobody else has
+            # used this context since: the pair's id must be the one this object saw after its own call (another frame loop
+            # or a direct call on a shared context leaves another id: its images would silently become our t0 pair)
+            if self._kept and self.ctx.kept_pair_id() == self._kept_id:
                 try:
                     pts, ages = self.ctx.detect_bucket(None, self.points, self.ages, **self.detect_kw)
-                    l0 = r0 = None
-                except _lib.VoError as e:   # somebody else used the context's images in between: all four again
+                    out = self.ctx.track_frame(None, None, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
+                except _lib.VoError as e:   # the context lost the pair in between (batch / sequence API, a failed call): all four again
                     if e.code != _lib.VO_ERR_STATE:
                         raise
-            if pts is None:
+                    pts = out = None
+            if out is None:
                 pts, ages = self.ctx.detect_bucket(l0, self.points, self.ages, **self.detect_kw)
-            # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
-            out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
-            self._kept = self.keep_pair
+                # circularMatching + consistency filter + triangulation + PnP (visualOdometry.cpp:110-127, main.cpp:169-181)
+                out = self.ctx.track_frame(l0, r0, l1, r1, pts, self.P_l, self.P_r, tvec=self.translation)
+            self._kept, self._kept_id = self.keep_pair, self.ctx.kept_pair_id()
         # deleteUnmatchFeaturesCircle: ages += 1, compacted with the circular-matching survivors only
         # (feature.cpp:83-86,111); the consistency filter does not touch ages (quirk B3)
         self.ages = (ages + 1)[out["keep_idx_circ"]]
