@@ -405,8 +405,14 @@ def main(argv=None):
                 "schedule": r5["config"]["schedule"], "stage_ms": r5["config"]["stage_ms"], "roofline": r5["roofline"]})
     if kept and kept[0] is not None:
         kept[0].close()
-    if rank == 0 and out is not None and world_size > 1:
-        out["config"]["host_cores_rank0"] = pin  # this rank's slice of the node's cores (replicas.pin_rank)
+    if world_size > 1:
+        # one host per GPU: every rank's slice of the node's cores (replicas.pin_rank), gathered -- the slices must be disjoint
+        slices = {k: replicas.gather_values(dist, -1 if pin.get(k) is None else pin[k])
+                  for k in ("cpus", "first_cpu", "last_cpu", "numa_node")}
+        if rank == 0 and out is not None:
+            out["config"]["host_cores_rank0"] = pin
+            out["host_cores_per_rank"] = {k: [int(v) for v in vals] for k, vals in slices.items()}
+            out["host_cores_per_rank"]["omp_num_threads_rank0"] = os.environ.get("OMP_NUM_THREADS")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

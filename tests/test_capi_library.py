@@ -175,10 +175,13 @@ def test_frame_loop_host_logic_of_the_kept_pair():
 
     class FakeCtx:
         def __init__(self):
-            self.calls, self.refuse, self.fail_code = [], False, _lib.VO_ERR_STATE
+            self.calls, self.refuse, self.fail_code, self.gen = [], False, _lib.VO_ERR_STATE, 0
 
         def set_params(self, **kw):
             pass
+
+        def kept_pair_id(self):
+            return self.gen
 
         def detect_bucket(self, image, pts, ages, **kw):
             self.calls.append(("detect", image is None))
@@ -188,6 +191,7 @@ def test_frame_loop_host_logic_of_the_kept_pair():
 
         def track_frame(self, l0, r0, l1, r1, pts, P_l, P_r, tvec=None):
             self.calls.append(("track", l0 is None, r0 is None))
+            self.gen += 1                                                  # every call leaves a new kept pair
             k = np.arange(6, dtype=np.int32)
             return dict(rc=0, l1=np.ones((6, 2), np.float32), keep_idx_circ=k, inliers=k, rvec=np.zeros(3),
                         tvec=np.array([0., 0., 0.5]), R=np.eye(3))
@@ -207,6 +211,17 @@ def test_frame_loop_host_logic_of_the_kept_pair():
     fake.refuse, fake.fail_code = True, _lib.VO_ERR_HIP
     with pytest.raises(_lib.VoError):
         vo.process(img, img)
+    # a second user of the context (another loop, a direct call) leaves ANOTHER pair there -- no error from the
+    # library, so the loop compares the pair's id with the one it saw after its own call and hands all four images over
+    fake.refuse, fake.calls = False, []
+    vo.process(img, img)                                                      # (four images after the failed call)
+    fake.calls = []
+    fake.gen += 1                                                             # somebody else's vo_track_frame
+    vo.process(img, img)
+    assert fake.calls == [("detect", False), ("track", False, False)]
+    fake.calls = []
+    vo.process(img, img)
+    assert fake.calls == [("detect", True), ("track", True, True)]
     fake2 = FakeCtx()
     vo2 = odometry.StereoOdometry(P, P, ctx=fake2, keep_pair=False)
     for _ in range(3):

@@ -382,3 +382,132 @@ def test_batch_run_after_a_dropin_call_reads_the_uploaded_quads(gpu_ctx, volib, 
     got = gpu_ctx.batch_get_tracks(0, len(pts))
     for k in ("r0", "r1", "l1", "l0_ret", "status4"):
         assert np.array_equal(got[k], want[k]), k
+
+
+# ------------------------------------------------------------------ eight real ranks on GPU 0
+def test_eight_ranks_of_bench_share_gpu_zero():
+    """the driver's N = 8 launch line with EIGHT real contexts, all on GPU 0 (VO_ALLOW_SHARED_GPU=1, gloo
+    for the barrier and the reductions): the real run_batch with per-rank validation, the real config-5 leg (one sequence per
+    rank through the lock-step loop), eight disjoint core slices in the printed line.  No scaling claim: one GPU."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VO_ALLOW_SHARED_GPU="1", VO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--frames", "32", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--sustain", "0", "--no-replay-leg", "--validate", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["ranks"] == 8 and b["n_gpus"] == 1 and b["scaling"] == "weak"
+    assert b["validated_frames"] == 2                       # the smallest of the eight ranks' counts
+    frames = b["value"] * b["ms_per_step"] * 1e-3 * b["steps"]
+    assert abs(frames - 8 * 32 * 3) < 1e-6 * frames
+    c5 = [c for c in b["configs"] if c["name"] == "config5_one_sequence_per_gpu"]
+    assert len(c5) == 1 and c5[0]["ranks"] == 8 and len(c5[0]["per_gpu_value"]) == 8 and all(v > 0 for v in c5[0]["per_gpu_value"])
+    assert c5[0]["value"] <= sum(c5[0]["per_gpu_value"]) * 1.0001 and c5[0]["validated_frames"] >= 1
+    hc = b["host_cores_per_rank"]
+    assert len(hc["cpus"]) == 8 and all(c >= 1 for c in hc["cpus"])
+    spans = sorted(zip(hc["first_cpu"], hc["last_cpu"]))
+    if (os.cpu_count() or 1) >= 8:
+        assert all(a[1] < b_[0] for a, b_ in zip(spans, spans[1:])), spans     # eight disjoint slices
+    print("eight ranks on GPU 0: batch %.0f frames/s; config 5: %.0f aggregate, per rank %s; core slices %s"
+          % (b["value"], c5[0]["value"], ["%.0f" % v for v in c5[0]["per_gpu_value"]], spans))
+
+
+# ------------------------------------------------------------------ soak + determinism
+def test_soak_5000_lockstep_steps_are_deterministic_and_leak_free(volib):
+    """VERDICT r05 item 7.  The reference's loop runs 9 000 frames (main.cpp:123); here 5 000 lock-step steps of 8 sequences
+    on a 33-pair feed, TWICE: device memory flat after warm-up, trajectories of the two runs bit-identical (the schedule
+    probe of the first ~200 steps and its pipeline drains included), a run into max_steps exhaustion (VO_ERR_STATE) and
+    vo_seq_reset mid-run, then a context created and destroyed 50 times without a leak on the device or the host."""
+    import psutil
+    import torch
+    from visual_odom_amd import synth
+    w, h, S, Q, STEPS, CHUNK = 640, 192, 8, 32, 5000, 1000
+    world = synth.StereoWorld(seed=77, width=w, height=h, fx=370.0, cx=319.5, cy=95.5, bf=-200.0, tex_size=1024)
+    lefts, rights, _, _ = world.render_sequence(Q + 1)
+    P_l, P_r = world.proj_matrices()
+    dev = torch.device("cuda", 0)
+    src = [(torch.from_numpy(np.ascontiguousarray(lefts[k])).to(dev), torch.from_numpy(np.ascontiguousarray(rights[k])).to(dev))
+           for k in range(Q + 1)]
+    torch.cuda.synchronize()
+
+    def feed(s, k):                                   # ping-pong over the 33 pairs, every sequence phase-shifted
+        j = (k + 4 * s) % (2 * Q)
+        return j if j <= Q else 2 * Q - j
+
+    def run(ctx, exhaust):
+        ctx.batch_set_detect_params()
+        ctx.seq_configure(S, w, h, ring=3, max_steps=CHUNK + 8)
+        ctx.batch_set_projection(P_l, P_r)
+        tables = [ctx.seq_pair_table(range(S), [src[feed(s, k)][0].data_ptr() for s in range(S)],
+                                     [src[feed(s, k)][1].data_ptr() for s in range(S)]) for k in range(2 * Q)]
+        rows, free_after_warmup, k = [], None, 0
+        while k < STEPS:
+            for _ in range(CHUNK):
+                ctx.seq_push_pairs(tables[k % (2 * Q)], w, 2)
+                ctx.seq_step()
+                k += 1
+                if k == 300:
+                    ctx.seq_sync()
+                    free_after_warmup = torch.cuda.mem_get_info(0)[0]
+            if exhaust and k == 2 * CHUNK:            # run into the end of the trajectory rows: the step is refused, nothing breaks
+                refused = 0
+                for extra in range(12):
+                    ctx.seq_push_pairs(tables[(k + extra) % (2 * Q)], w, 2)
+                    try:
+                        ctx.seq_step()
+                    except volib.VoError as e:
+                        assert e.code == volib.VO_ERR_STATE
+                        refused += 1
+                        break
+                assert refused == 1
+            ctx.seq_sync()
+            for s in range(S):
+                r, info = ctx.seq_get_trajectory(s)
+                rows.append((r[:CHUNK - 1].copy(), info[:CHUNK - 1].copy()))   # (the same rows in both runs, whatever the exhaustion run appended)
+            ctx.seq_reset(-1)                         # rewind: all rows available again, empty feature sets, identity pose
+        ctx.seq_sync()
+        return rows, free_after_warmup, torch.cuda.mem_get_info(0)[0]
+
+    ctx = volib.Context(0, w, h, 4096, S)
+    try:
+        rows_a, free_warm, free_end = run(ctx, exhaust=False)
+        assert free_end >= free_warm - (1 << 20), (free_warm, free_end)        # flat: not a MiB lost over 4 700 steps
+        rows_b, _, free_end_b = run(ctx, exhaust=True)
+        assert free_end_b >= free_warm - (1 << 20)
+    finally:
+        ctx.close()
+    assert len(rows_a) == len(rows_b) == S * (STEPS // CHUNK)
+    n_int = 0
+    for (ra, ia), (rb, ib) in zip(rows_a, rows_b):
+        assert ra.shape == rb.shape and ra.shape[0] == CHUNK - 1
+        assert np.array_equal(ra.view(np.uint64), rb.view(np.uint64)) and np.array_equal(ia, ib)
+        n_int += int((ia[:, 5] & 2 != 0).sum())
+    assert n_int > 0.5 * S * STEPS                                            # and it was odometry: most motions integrated
+    # create / destroy
+    proc = psutil.Process()
+    imgs = [lefts[0], rights[0], lefts[1], rights[1]]
+    pts = synth.select_keypoints(lefts[0], bucket=h // 10, per_bucket=3)
+    first = None
+    for it in range(50):
+        c = volib.Context(0, w, h, 4096, S)
+        got = c.track_frame(*imgs, pts, P_l, P_r)
+        c.seq_configure(2, w, h, ring=2, max_steps=8)
+        c.close()
+        if first is None:
+            first = got
+        assert np.array_equal(got["l1"], first["l1"]) and np.array_equal(got["tvec"], first["tvec"])
+        if it == 9:
+            torch.cuda.synchronize()
+            free10, rss10 = torch.cuda.mem_get_info(0)[0], proc.memory_info().rss
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] >= free10 - (2 << 20)
+    assert proc.memory_info().rss <= rss10 + (64 << 20), (rss10, proc.memory_info().rss)

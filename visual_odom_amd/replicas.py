@@ -50,7 +50,8 @@ def _parse_cpulist(text):
 
 
 def gpu_numa_cpus(pci_bus_id):
-    """cores of the NUMA node of the GPU at `pci_bus_id` ("0000:c1:00.0"), from sysfs; None when the kernel does not say"""
+    """(node, [cpus]) -- the NUMA node of the GPU at `pci_bus_id` ("0000:c1:00.0") and its cores, from sysfs; (None, None) when
+    the kernel does not say (no such device file, node -1)"""
     try:
         node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
         if node < 0:
