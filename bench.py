@@ -367,6 +367,20 @@ def main(argv=None):
         leg("reference_default_374", 3, kept[0], workload="kitti374", steps=20)
         if rank == 0:
             legs.append(latency_leg(kept[0], quads=min(args.quads, args.frames), seed=args.seed + rank))
+        # the exact replay with the new pairs coming from HOST memory every step: the honest ingest
+        # numbers in the driver's own run -- PCIe-inclusive, never `value`; pcie_gb_s = frames/s x 2 images x w x h bytes
+        for ing, nm in (("pinned", "host_pinned"), ("host", "host_pageable")):
+            a3 = copy.copy(args)
+            a3.mode, a3.seqs, a3.ring, a3.ingest, a3.no_cpu_baseline = "sequences", 256, 3, ing, True
+            a3.steps, a3.warmup, a3.validate = 20, 4, 2
+            r3 = run_sequences(a3, rank, world_size, local_dev, dev, dist, barrier, torch, replicas, ctx=kept[0])
+            if rank == 0 and r3 is not None:
+                legs.append({"name": "exact_replay_256_sequences_" + nm, "baseline_config": 3, "workload": r3["config"]["workload"],
+                             "stages": "detect+full", "ingest": r3["config"]["ingest"], "value": r3["value"], "unit": r3["unit"],
+                             "ms_per_step": r3["ms_per_step"], "steps": r3["steps"], "warmup": r3["warmup"], "frames_per_step": 256,
+                             "points_per_frame": r3["config"]["points_per_frame"], "validated_frames": r3["validated_frames"],
+                             "pcie_gb_s": r3["value"] * 2.0 * r3["config"]["image_bytes"] / 1e9,
+                             "schedule": r3["config"]["schedule"], "stage_ms": r3["config"]["stage_ms"], "roofline": r3["roofline"]})
         kept[0].close()
         kept[0] = None
         from visual_odom_amd import _lib
@@ -499,6 +513,7 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
     profiled_config = args.stages in ("full", "lk") and not args.mono_rotation
     out = None
     if rank == 0:
+        issue = valu_issue_frac(args.workload, B, pts_per_launch, lk_ms) if profiled_config else (None, None)
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features",
             "value": fps, "unit": "frames/s", "n_gpus": N_GPUS, "ranks": world_size, "steps": K, "warmup": args.warmup,
@@ -524,11 +539,13 @@ def run_batch(args, rank, world_size, local_dev, dev, dist, barrier, torch, repl
                          "traffic_source": ("profiles/lk_traffic.json: rocprofv3 --pmc passes of this command, imported, not "
                                             "measured in this run") if profiled_config and measured_traffic(args.workload, B)
                          else "not profiled for this configuration",
-                         # what binds the kernel: VALU issue.  valu_issue_frac = issue-cost bound / measured = (the launch's VALU
-                         # instructions -- SQ_INSTS_VALU of the imported PMC pass, per feature x this launch's features -- x the
-                         # 4.05 SIMD-cycles per wave64 instruction its opcode mix costs by the micro-benchmark table) / (1024
-                         # SIMDs x 2.4 GHz x THIS run's launch time); 1.0 = every SIMD issues a VALU instruction whenever it can
-                         "valu_issue_frac": valu_issue_frac(args.workload, B, pts_per_launch, lk_ms) if profiled_config else None,
+                         # what binds the kernel: VALU issue.  valu_issue_frac (<= 1 by construction, round 6) = the launch's VALU
+                         # instructions -- SQ_INSTS_VALU of the imported PMC pass, per feature x this launch's features -- at the
+                         # FLOOR price of their opcode classes (3.65 SIMD-cycles per wave64 instruction for this kernel's mix)
+                         # / (1024 SIMDs x 2.4 GHz x THIS run's launch time): the share of the launch that issuing this instruction
+                         # stream at the hardware's best possible rate accounts for.  valu_issue_model_ratio: the same at the
+                         # micro-benchmark's own per-opcode costs (4.05) -- a model that may exceed 1 (rounds 2-5 called THAT the frac)
+                         "valu_issue_frac": issue[0], "valu_issue_model_ratio": issue[1],
                          "valu_issue_imported": measured_issue(args.workload, B) if profiled_config else None,
                          "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
                          "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1),
@@ -624,6 +641,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     lk_ms = float(stage_ms[_lib.STAGE_NAMES.index("lk")])
     achieved = lk_bytes / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
     out = None
+    replay_key = "replay" + args.workload.replace("kitti", "")
     if rank == 0:
         out = {
             "metric": "stereo frames/sec on KITTI-00 1241x376 @ ~2000 features",
@@ -643,10 +661,17 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
                        "parallelism": "replicas x%d (%d sequences per GPU, no collective)" % (world_size, S),
                        "schedule": dict(ctx.get_schedule(), probe_ms=ctx.get_probe_log()),
                        "stage_ms": {n: float(v) for n, v in zip(_lib.STAGE_NAMES, stage_ms)},
-                       "model_bytes_per_frame": frame_bytes},
+                       "model_bytes_per_frame": frame_bytes, "image_bytes": int(w) * int(h)},
+            # traffic: the PMC passes of `bench.py --mode sequences --workload W --seqs S` (tools/gpu_round.sh pmclegs, workload
+            # key "replay2000" / "replay374"; averaged over ALL the loop's LK launches incl. its warm-up) -- round 6
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": "lk_circular_kernel", "achieved": achieved,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                         "traffic_source": "not profiled for this configuration", "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": measured_traffic(replay_key, S) if args.ingest == "device" else None,
+                         "traffic_source": ("profiles/lk_traffic.json (%s): rocprofv3 --pmc passes of the lock-step loop, imported, "
+                                            "not measured in this run" % replay_key)
+                         if args.ingest == "device" and measured_traffic(replay_key, S) else "not profiled for this configuration",
+                         "valu_issue_frac": valu_issue_frac(replay_key, S, pts_per_launch, lk_ms)[0] if args.ingest == "device" else None,
+                         "bytes_per_launch": lk_bytes, "launch_ms": lk_ms, "points_per_launch": pts_per_launch,
                          "lk_ns_per_feature": 1e6 * lk_ms / max(pts_per_launch, 1)},
         }
         if not args.no_cpu_baseline and world_size == 1:
@@ -802,21 +827,27 @@ def measured_issue(workload, frames):
 
 
 def valu_issue_frac(workload, frames, points_per_launch, launch_ms):
-    """measured / issue-bound: VALU instructions per feature and SIMD-cycles per instruction come from the committed PMC pass
-    (profiles/lk_issue.json), the launch time from THIS run's HIP events; None without a matching pass"""
+    """(frac, model_ratio).  frac = issue-FLOOR cycles of the launch's VALU instructions / the cycles THIS run's launch had:
+    instructions per feature from the committed PMC pass (profiles/lk_issue.json), each priced at the floor of its opcode
+    class (2.46 cycles for the class the micro-benchmark measures below 3, 4.0 = one wave64 pass for the rest, 8.0 for the
+    half-rate class; tools/isa_histogram.py --floor on the shipped kernel: 3.65 per instruction for the cheapest of its three
+    block groups), over 1024 SIMDs x clock x the HIP-event duration.  No issue schedule can beat that price, so frac <= 1 BY
+    CONSTRUCTION (round 6) -- it says how much of the launch is accounted for by issuing this
+    instruction stream as fast as the hardware can, NOT that the stream is minimal.  model_ratio = the same with the
+    micro-benchmark's own per-opcode costs (4.05 for the hot loop's mix): a model, a few per cent pessimistic for this mix,
+    which may exceed 1 and is reported for continuity with rounds 2-5 only.  (None, None) without a matching pass."""
     rec = measured_issue(workload, frames)
     if not rec or launch_ms <= 0:
-        return None
+        return None, None
     try:
         per_feature = float(rec["valu_instructions_per_feature"])
-        # the issue COST of the kernel's instruction mix from the micro-benchmark table (profiles/r02_valu_issue_cost.txt via
-        # tools/isa_histogram.py), not the cycles the same PMC pass measured -- that ratio would be 1 by construction
-        cyc = float(rec["issue_cost_bound_cycles_per_valu_instruction"])
+        floor = float(rec.get("issue_floor_cycles_per_valu_instruction", 3.65))
+        model = float(rec["issue_cost_bound_cycles_per_valu_instruction"])
         clock_hz = float(rec.get("shader_clock_mhz", 2400.0)) * 1e6
     except (KeyError, TypeError, ValueError):
-        return None
-    issue_s = per_feature * points_per_launch * cyc / (1024.0 * clock_hz)
-    return issue_s / (launch_ms * 1e-3)
+        return None, None
+    per_cycle = per_feature * points_per_launch / (1024.0 * clock_hz) / (launch_ms * 1e-3)
+    return min(1.0, floor * per_cycle), model * per_cycle
 
 
 def measured_pyramid_traffic(workload, n_images):

@@ -69,15 +69,17 @@ if has seq; then      # the lock-step loop at the reference-default load, pairs 
     done
 fi
 if has pmclegs; then  # PMC passes of every bench leg's LK launch (tools/pmc_legs.py turns them into profiles/lk_traffic.json / lk_issue.json)
-    for WL in ${PMC_WL:-kitti2000 kitti374 hd4000 hd4000l4}; do
+    for WL in ${PMC_WL:-kitti2000 kitti374 hd4000 hd4000l4 replay2000}; do
         FR=256; Q=""
         case $WL in hd4000*) FR=128; Q="--quads 4";; esac
+        CMD="--workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0"
+        case $WL in replay*) CMD="--mode sequences --workload kitti${WL#replay} --seqs 256 --steps 20 --warmup 4 --no-cpu-baseline --validate 0";; esac   # the exact replay (lock-step loop, pairs resident)
         stamp "bench $WL x $FR (plain: the leg's line)"
-        timeout 300 python bench.py --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_$WL.json" 2> "$OUT/pmc_$WL.err"
+        timeout 300 python bench.py $CMD > "$OUT/pmc_$WL.json" 2> "$OUT/pmc_$WL.err"
         for SET in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES"; do
             NAME=${SET%%:*}; CNT=${SET#*:}
             stamp "pmc $NAME: $WL"
-            (cd /tmp && timeout 400 rocprofv3 --pmc $CNT --output-format csv -d "$OUT/pmc_${WL}_$NAME" -- python "$ROOT/bench.py" --workload $WL --frames $FR $Q --steps 3 --warmup 1 $LEAN --validate 0 > "$OUT/pmc_${WL}_$NAME.log" 2>&1)
+            (cd /tmp && timeout 400 rocprofv3 --pmc $CNT --output-format csv -d "$OUT/pmc_${WL}_$NAME" -- python "$ROOT/bench.py" $CMD > "$OUT/pmc_${WL}_$NAME.log" 2>&1)
             # keep only the rows of the two kernels the summary reads (the raw files are tens of MB)
             for f in $(find "$OUT/pmc_${WL}_$NAME" -name "*_counter_collection.csv"); do
                 (head -1 "$f"; grep -E "lk_circular_kernel|pyr_pass_kernel" "$f") > "$f.tmp" && mv "$f.tmp" "$f"

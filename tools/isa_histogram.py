@@ -57,8 +57,18 @@ def main():
     ap.add_argument("kernel")
     ap.add_argument("--cost", default=None)
     ap.add_argument("--blocks", default=None, help="comma-separated block names to sum (e.g. LBB0_35,bb.38,LBB0_39)")
+    ap.add_argument("--floor", action="store_true",
+                    help="price every opcode at the FLOOR of its class instead of its own measured cost: 2.46 for the class the "
+                         "micro-benchmark measures below 3 cycles, 8.0 for the one it measures above 7, 4.0 (one wave64 pass of the "
+                         "16-lane SIMD) for everything else incl. unmeasured opcodes -- a sum no issue schedule can beat, which is "
+                         "what bench.py's valu_issue_frac divides by the measured cycles (round 6: <= 1 by construction)")
     args = ap.parse_args()
     cost = load_costs(args.cost)
+    if args.floor:
+        cost = {k: (2.46 if v < 3.0 else 8.0 if v > 7.0 else 4.0) for k, v in cost.items()}
+        cost["cndmask_b32"] = 4.0  # (the 23-cycle row is an artefact of a back-to-back stream of itself, r02_lk_issue_bound.md)
+        global DEFAULT_CLASS
+        DEFAULT_CLASS = 4.0
     blocks = OrderedDict()
     cur, inside = None, False
     for line in open(args.asm):

@@ -16,7 +16,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ISSUE_COST = 4.05  # SIMD-cycles per wave64 VALU instruction of the hot loop's opcode mix (profiles/r02_lk_issue_bound.md)
+ISSUE_COST = 4.05  # SIMD-cycles per wave64 VALU instruction of the hot loop's opcode mix at the micro-benchmark's own costs (profiles/r02_lk_issue_bound.md): a MODEL
+ISSUE_FLOOR = 3.65  # the same mix with every opcode at the floor of its class (2.46 / 4.0 / 8.0; tools/isa_histogram.py --floor: iteration
+                    # 3.68, cell entry 3.65, level set-up 3.77 -- the smallest of the three): no issue schedule beats it, a BOUND
 
 
 def counters(d, kernel="lk_circular_kernel"):
@@ -51,6 +53,8 @@ def main(src):
         frames = b["config"]["frames_per_step_per_gpu"]
         n_images = b["config"]["pyramids_per_step_per_gpu"]
         cmd = "python bench.py --workload %s --frames %d --steps 3 --warmup 1 --no-cpu-baseline --validate 0 --sustain 0 --no-replay-leg --no-configs" % (wl, frames)
+        if wl.startswith("replay"):  # the exact replay: the lock-step loop with the pairs resident; counters averaged over ALL its LK launches
+            cmd = "python bench.py --mode sequences --workload kitti%s --seqs %d --steps 20 --warmup 4 --no-cpu-baseline --validate 0" % (wl[6:], frames)
         fetch, _ = counters(os.path.join(src, "pmc_%s_fetch" % wl))
         write, _ = counters(os.path.join(src, "pmc_%s_write" % wl))
         sq, nsq = counters(os.path.join(src, "pmc_%s_sq" % wl))
@@ -59,7 +63,7 @@ def main(src):
             rec = {"workload": wl, "frames_per_step": frames, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
                    "hbm_bytes_per_launch": 2 * f + w, "hbm_bytes_per_launch_uncorrected": f + w,
                    "algorithmic_bytes_per_launch": b["roofline"]["bytes_per_launch"],
-                   "source": "r05 (gpurun_out/%s): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of `%s`; KB -> bytes; "
+                   "source": "r06 (gpurun_out/%s): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of `%s`; KB -> bytes; "
                              "FETCH_SIZE doubled (gfx950 correction, profiles/r01_fetch_calibration.txt); WRITE_SIZE as reported" % (tag, cmd)}
             pf, npf = pyr_counters(os.path.join(src, "pmc_%s_fetch" % wl))
             pw, npw = pyr_counters(os.path.join(src, "pmc_%s_write" % wl))
@@ -79,8 +83,9 @@ def main(src):
                                "lds_instructions_per_feature": sq["SQ_INSTS_LDS"] / waves if "SQ_INSTS_LDS" in sq else None,
                                "shader_cycles_per_launch": cyc, "simd_cycles_per_valu_instruction": per_cyc,
                                "issue_cost_bound_cycles_per_valu_instruction": ISSUE_COST, "measured_over_bound": per_cyc / ISSUE_COST,
+                               "issue_floor_cycles_per_valu_instruction": ISSUE_FLOOR,
                                "dispatches_averaged": nsq["SQ_INSTS_VALU"],
-                               "source": "r05 (gpurun_out/%s): rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU "
+                               "source": "r06 (gpurun_out/%s): rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU "
                                          "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES (its own run of `%s`), means over the lk_circular_kernel "
                                          "dispatches; the bound = the hot loop's opcode mix x measured issue costs "
                                          "(profiles/r02_lk_issue_bound.md)" % (tag, cmd)})
