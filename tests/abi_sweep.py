@@ -90,6 +90,12 @@ def main():
     expect("vo_set_params", OK, ctx, C.byref(prm))
     expect("vo_get_params", ARG, NULL, C.byref(prm))
     expect("vo_get_params", ARG, ctx, NULL)
+    # vo_kept_pair_id: an int64 id, 0 = no kept pair (NULL context, fresh context)
+    lib.vo_kept_pair_id.restype = C.c_int64
+    covered.add("vo_kept_pair_id")
+    checked[0] += 2
+    if lib.vo_kept_pair_id(NULL) != 0 or lib.vo_kept_pair_id(ctx) != 0:
+        fails.append("vo_kept_pair_id: expected 0 for a NULL / fresh context")
     sch = _lib.VoSchedule(0, 0, -1, 0)
     expect("vo_set_schedule", ARG, NULL, C.byref(sch))
     for bad in ((3, 0, -1), (4, 0, -1), (5, 0, -1), (-1, 0, -1), (0, 3, -1), (0, -1, -1), (0, 0, 2), (0, 0, -2), (0, 0, -1, 8), (0, 0, -1, -4),

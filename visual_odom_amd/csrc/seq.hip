@@ -80,35 +80,40 @@ __global__ __launch_bounds__(256) void seq_carry_kernel(const int *__restrict__ 
     }
 }
 
-// One launch moves every new stereo pair of a step into its ring slot: block (x, y) copies 4 rows of image y (2 per
-// pushed pair).  Sources are row-major 8-bit images with a byte stride, in device memory or in page-locked host
-// memory the GPU reads over PCIe directly (one kernel instead of 2 S pitched copies: at S = 256 the 512
-// hipMemcpy2DAsync calls alone cost the host 8 ms per step -- more than the step's kernels).  8 bytes per lane:
-// unaligned source loads (rows of a 1241-pixel image start anywhere), aligned destination stores.
+// One launch moves every new stereo pair of a step into its ring slot.  Sources are row-major 8-bit images with a byte
+// stride, in device memory or in page-locked host memory the GPU reads over PCIe directly (one kernel instead of 2 S
+// pitched copies: at S = 256 the 512 hipMemcpy2DAsync calls alone cost the host 8 ms per step -- more than the step's
+// kernels).  8 bytes per lane: unaligned source loads (rows of a 1241-pixel image start anywhere).
+//
+// Round 6 -- a kernel that fits in the hole LK leaves.  The transfer of step k + 1 runs under step k's LK, whose 7 waves
+// per SIMD hold 7 x 72 = 504 of the 512 registers and 7 of the 8 wave slots: a wave that needs MORE than 8 registers has to
+// wait for an LK wave to retire (and LK's next workgroup wants the same slot).  The first version (256-thread workgroups,
+// 18 -> 24 registers) therefore crawled under LK: 256 sequences at the 2 000-point load took 13.9 ms per step with
+// page-locked host pairs against 10.2 with resident ones, although the 239 MB take 6 ms of the link and the step has 10 to
+// hide them in (gpurun_out/r6_s2).  Now: ONE WAVEFRONT per image row, at most 8 VGPRs (checked in the build: the
+// static_assert-like test tests/test_capi_library.py reads the code object), row addresses on the scalar unit, the row's
+// last 8 bytes by an overlapping access instead of a byte loop -- it runs in the eighth slot of every SIMD without
+// displacing anything, and a row's three dependent PCIe round trips are hidden by the ~1 000 rows in flight.
 struct __attribute__((packed, aligned(1))) IngU2 {
     uint32_t lo, hi;
 };
 
-__global__ __launch_bounds__(256) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int w, int h, int pitch,
-                                                         uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
-                                                         size_t img_bytes)
+__global__ __launch_bounds__(64) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int w, int h, int pitch,
+                                                        uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
+                                                        size_t img_bytes)
 {
+    // (blockIdx: row, image -- everything but the lane's column offset is wave-uniform and stays in scalar registers)
     const SeqIngest e = tab[blockIdx.y >> 1];
-    const int side = blockIdx.y & 1;
-    const uint8_t *__restrict__ src = side ? e.right : e.left;
-    uint8_t *__restrict__ dst = pix0 + (size_t)(e.image0 + side) * img_bytes;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= h)
-        return;
-    const uint8_t *__restrict__ s = src + (size_t)row * e.stride;
-    uint8_t *__restrict__ d = dst + (size_t)row * pitch;
-    for (int x = lane * 8; x < w; x += 512) {
-        if (x + 8 <= w) {
-            const IngU2 v = *reinterpret_cast<const IngU2 *>(s + x);
-            *reinterpret_cast<uint2 *>(d + x) = make_uint2(v.lo, v.hi);
-        } else {
-            for (int k = x; k < w; k++)
-                d[k] = s[k];
+    const int side = blockIdx.y & 1, row = blockIdx.x;
+    const VO_GLOBAL uint8_t *__restrict__ s = (const VO_GLOBAL uint8_t *)(side ? e.right : e.left) + (size_t)row * e.stride;
+    VO_GLOBAL uint8_t *__restrict__ d = (VO_GLOBAL uint8_t *)pix0 + (size_t)(e.image0 + side) * img_bytes + (size_t)row * pitch;
+    const int last = w - 8; // (w >= 32: vo_batch_configure) the lane that would cross the row end re-reads the row's last 8 bytes
+    for (int x0 = 0; x0 < w; x0 += 512) {
+        int x = x0 + (int)threadIdx.x * 8;
+        if (x < w) {
+            x = x < last ? x : last;
+            const IngU2 v = *reinterpret_cast<const VO_GLOBAL IngU2 *>(s + (uint32_t)x);
+            *reinterpret_cast<VO_GLOBAL IngU2 *>(d + (uint32_t)x) = v;
         }
     }
 }
@@ -119,8 +124,7 @@ void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitc
 {
     if (n_pairs <= 0)
         return;
-    hipLaunchKernelGGL(seq_ingest_kernel, dim3((h + 3) / 4, 2 * n_pairs), dim3(256), 0, stream, tab, w, h, pitch, pix0,
-                       img_bytes);
+    hipLaunchKernelGGL(seq_ingest_kernel, dim3(h, 2 * n_pairs), dim3(64), 0, stream, tab, w, h, pitch, pix0, img_bytes);
 }
 
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,
