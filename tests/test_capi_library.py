@@ -257,28 +257,3 @@ def test_adapter_is_shipped_source_and_the_only_copy():
         subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "oracle", "ref_shim"),
                                "-I/root/reference/src", "-I" + os.path.join(ROOT, "include"), "-I" + ad,
                                os.path.join(ad, "feature_hip.cpp")])
-
-
-def test_ingest_kernel_fits_beside_seven_lk_waves(tmp_path):
-    """round 6: seq_ingest_kernel runs under the previous step's LK, whose 7 waves per SIMD leave 8 of the 512 registers and
-    one wave slot -- the kernel must need no more than 8 VGPRs, no LDS and single-wave workgroups, and LK must still be the
-    71-register / 7-wave kernel that leaves that hole (read from the compiler's own metadata of the shipped sources)"""
-    import re
-    import subprocess
-    csrc = os.path.join(ROOT, "visual_odom_amd", "csrc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
-             "-Wno-unused-function", "-S", "--cuda-device-only"]
-
-    def meta(src, kernel):
-        out = str(tmp_path / (src + ".s"))
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(csrc, src), "-o", out], stderr=subprocess.DEVNULL)
-        txt = open(out).read()
-        blk = [b for b in txt.split("amdhsa.kernels:")[1].split("  - .agpr_count:") if kernel in b]
-        assert blk, kernel
-        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk[0]).group(1))
-        return dict(vgpr=get("vgpr_count"), lds=get("group_segment_fixed_size"), wg=get("max_flat_workgroup_size"),
-                    scratch=get("private_segment_fixed_size"))
-    ing = meta("seq.hip", "seq_ingest_kernel")
-    assert ing["vgpr"] <= 8 and ing["lds"] == 0 and ing["wg"] == 64 and ing["scratch"] == 0, ing
-    lk = meta("lk.hip", "lk_circular_kernelE")
-    assert 64 < lk["vgpr"] <= 72 and lk["scratch"] == 0 and lk["wg"] == 64, lk      # 7 waves x 72 = 504 of 512 registers

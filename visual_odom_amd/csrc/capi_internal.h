@@ -224,6 +224,7 @@ struct vo_ctx {
         bool have_corners[VO_SEQ_MAX_RING] = {}; // d_corners of ring slot r belongs to the pair now in that slot
         SeqIngest *h_ing = nullptr, *d_ing = nullptr; // [VO_SEQ_INFLIGHT][S] pairs pushed for a step (pinned / device)
         int n_ing = 0, n_active = 0;    // pairs pushed for / sequences active in the pending step
+        bool ing_pcie = false;          // a pair of the pending step lives in host memory (launch_seq_ingest: grid size)
         // A/B of the prepare stream over REAL steps (vo_seq_step): 1 = timing the dry probe's pick, 2 = timing its
         // prepare-flipped twin, ... (ab_cnt candidates), ab_cnt + 1 = decided; ab_left counts down the phase's steps (3 untimed
         // ramp steps + ab_n timed)

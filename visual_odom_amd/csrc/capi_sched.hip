@@ -128,7 +128,7 @@ int seq_enqueue_inputs(vo_ctx *c, bool dry)
         VO_HIP_TRY(c, hipMemcpyAsync(d_tab, q.h_ing + (size_t)slot * q.S, sizeof(SeqIngest) * q.n_ing,
                                      hipMemcpyHostToDevice, q.copy));
         launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
-                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.copy);
+                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.ing_pcie, q.copy);
         if (!dry && q.staged) {
             const int g = (int)(q.step & 1);
             VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));

@@ -83,48 +83,57 @@ __global__ __launch_bounds__(256) void seq_carry_kernel(const int *__restrict__ 
 // One launch moves every new stereo pair of a step into its ring slot.  Sources are row-major 8-bit images with a byte
 // stride, in device memory or in page-locked host memory the GPU reads over PCIe directly (one kernel instead of 2 S
 // pitched copies: at S = 256 the 512 hipMemcpy2DAsync calls alone cost the host 8 ms per step -- more than the step's
-// kernels).  8 bytes per lane: unaligned source loads (rows of a 1241-pixel image start anywhere).
+// kernels -- and the copy engine moves a 1241-byte-wide pitched image at 0.1 GB/s).  8 bytes per lane: unaligned source
+// loads (rows of a 1241-pixel image start anywhere), the row's last 8 bytes by an overlapping access instead of a byte loop.
 //
-// Round 6 -- a kernel that fits in the hole LK leaves.  The transfer of step k + 1 runs under step k's LK, whose 7 waves
-// per SIMD hold 7 x 72 = 504 of the 512 registers and 7 of the 8 wave slots: a wave that needs MORE than 8 registers has to
-// wait for an LK wave to retire (and LK's next workgroup wants the same slot).  The first version (256-thread workgroups,
-// 18 -> 24 registers) therefore crawled under LK: 256 sequences at the 2 000-point load took 13.9 ms per step with
-// page-locked host pairs against 10.2 with resident ones, although the 239 MB take 6 ms of the link and the step has 10 to
-// hide them in (gpurun_out/r6_s2).  Now: ONE WAVEFRONT per image row, at most 8 VGPRs (checked in the build: the
-// static_assert-like test tests/test_capi_library.py reads the code object), row addresses on the scalar unit, the row's
-// last 8 bytes by an overlapping access instead of a byte loop -- it runs in the eighth slot of every SIMD without
-// displacing anything, and a row's three dependent PCIe round trips are hidden by the ~1 000 rows in flight.
+// Round 6 -- a PERSISTENT grid sized for the link, not for the GPU.  The transfer of step k + 1 runs under step k's kernels.
+// Rounds 2-5 launched one workgroup per four rows (48 k workgroups per step at 256 sequences): the copy kept the link's rate,
+// but everything that ran BESIDE it crawled -- with page-locked host pairs 256 sequences at the 2 000-point load took 13.9 ms
+// per step against 10.0 with resident ones (pyramids 0.5 -> 2.0 ms, detection 0.5 -> 1.9, LK 8.8 -> 9.5), at any stream
+// priority (gpurun_out/r6_ingab).  tools/ubench/ingest_under_load.hip isolates it (profiles/r06_ingest_under_load.txt): what
+// hurts the neighbour is the number of PCIe reads in flight.  Every wave parks 512 bytes of requests in the L2's queues for
+// the microseconds a host read takes; thousands of waves (the flood: as many as find a slot) hold them for ~100 us each and a
+// kernel whose waves wait for their own L2 fills -- LK -- slows from 9.8 to 13.8 ms; so do 1 024 persistent waves (13.6 ms)
+// and 4 096 (15.0), on the same CUs or on others (CU masks: 13.6).  256 waves = 128 KB in flight are what 50 GB/s x 2.5 us
+// need: the link still runs at 49.8 GB/s and the neighbour at 10.0 ms, untouched.  (The copy ENGINE would be better still --
+// 57 GB/s, no shader at all -- but only for ONE contiguous copy: 512 linear copies reach 26 GB/s, pitched ones 0.1.)
+// So: G single-wave workgroups walk over the rows, row r = blockIdx.x, + G, ...; G = 256 when any pair of the step comes
+// over PCIe, 8192 for a step of device-resident pairs (an HBM-to-HBM copy wants more loads in flight, they are short, and it
+// is over in a fraction of a millisecond).
 struct __attribute__((packed, aligned(1))) IngU2 {
     uint32_t lo, hi;
 };
 
-__global__ __launch_bounds__(64) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int w, int h, int pitch,
-                                                        uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
+__global__ __launch_bounds__(64) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int n_rows /* 2 * pairs * h */, int w,
+                                                        int h, int pitch, uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
                                                         size_t img_bytes)
 {
-    // (blockIdx: row, image -- everything but the lane's column offset is wave-uniform and stays in scalar registers)
-    const SeqIngest e = tab[blockIdx.y >> 1];
-    const int side = blockIdx.y & 1, row = blockIdx.x;
-    const VO_GLOBAL uint8_t *__restrict__ s = (const VO_GLOBAL uint8_t *)(side ? e.right : e.left) + (size_t)row * e.stride;
-    VO_GLOBAL uint8_t *__restrict__ d = (VO_GLOBAL uint8_t *)pix0 + (size_t)(e.image0 + side) * img_bytes + (size_t)row * pitch;
     const int last = w - 8; // (w >= 32: vo_batch_configure) the lane that would cross the row end re-reads the row's last 8 bytes
-    for (int x0 = 0; x0 < w; x0 += 512) {
-        int x = x0 + (int)threadIdx.x * 8;
-        if (x < w) {
-            x = x < last ? x : last;
-            const IngU2 v = *reinterpret_cast<const VO_GLOBAL IngU2 *>(s + (uint32_t)x);
-            *reinterpret_cast<VO_GLOBAL IngU2 *>(d + (uint32_t)x) = v;
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) { // (wave-uniform: image, side, row and both row addresses are scalars)
+        const int img = r / h, row = r - img * h, side = img & 1;
+        const SeqIngest e = tab[img >> 1];
+        const VO_GLOBAL uint8_t *__restrict__ s = (const VO_GLOBAL uint8_t *)(side ? e.right : e.left) + (size_t)row * e.stride;
+        VO_GLOBAL uint8_t *__restrict__ d = (VO_GLOBAL uint8_t *)pix0 + (size_t)(e.image0 + side) * img_bytes + (size_t)row * pitch;
+        for (int x0 = 0; x0 < w; x0 += 512) {
+            int x = x0 + (int)threadIdx.x * 8;
+            if (x < w) {
+                x = x < last ? x : last;
+                const IngU2 v = *reinterpret_cast<const VO_GLOBAL IngU2 *>(s + (uint32_t)x);
+                *reinterpret_cast<VO_GLOBAL IngU2 *>(d + (uint32_t)x) = v;
+            }
         }
     }
 }
 
 #ifndef VO_HOST_EMUL // (the CPU emulator of tests/host_check launches the kernels above itself)
 void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
-                       hipStream_t stream)
+                       bool over_pcie, hipStream_t stream)
 {
     if (n_pairs <= 0)
         return;
-    hipLaunchKernelGGL(seq_ingest_kernel, dim3(h, 2 * n_pairs), dim3(64), 0, stream, tab, w, h, pitch, pix0, img_bytes);
+    const int n_rows = 2 * n_pairs * h, want = over_pcie ? 256 : 8192;
+    hipLaunchKernelGGL(seq_ingest_kernel, dim3(n_rows < want ? n_rows : want), dim3(64), 0, stream, tab, n_rows, w, h, pitch, pix0,
+                       img_bytes);
 }
 
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,

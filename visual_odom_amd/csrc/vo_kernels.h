@@ -151,7 +151,7 @@ void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_a
                    const int *d_nnew, int cap, int w, int h, int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages,
                    int *d_out_n, int out_cap, const int *d_active, int *d_overflow, int n_frames, hipStream_t stream);
 void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitch, uint8_t *pix0, size_t img_bytes,
-                       hipStream_t stream);
+                       bool over_pcie, hipStream_t stream);
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,
                         const int *n_corners, int *n_new, int n_seq, hipStream_t stream);
 void launch_seq_carry(const int *active, const float2 *outB, const int *nB, const int *idxA, const int *nA,
