@@ -14,6 +14,7 @@
 //   (the pose tail -- rotationMatrixToEulerAngles + gates + integrateOdometryStereo, main.cpp:196-208, utils.cpp:57-131,
 //    one trajectory row per processed frame -- runs inside select_refine_kernel: vo_seqtail.h)
 #include "vo_kernels.h"
+#include <stdlib.h>
 
 namespace vo {
 
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void seq_carry_kernel(const int *__restrict__ 
 // and 4 096 (15.0), on the same CUs or on others (CU masks: 13.6).  256 waves = 128 KB in flight are what 50 GB/s x 2.5 us
 // need: the link still runs at 49.8 GB/s and the neighbour at 10.0 ms, untouched.  (The copy ENGINE would be better still --
 // 57 GB/s, no shader at all -- but only for ONE contiguous copy: 512 linear copies reach 26 GB/s, pitched ones 0.1.)
-// So: G single-wave workgroups walk over the rows, row r = blockIdx.x, + G, ...; G = 256 when any pair of the step comes
+// In the loop itself LK is touchier than the probe's stand-in (gpurun_out/r6_ingw, 256 sequences, page-locked pairs, 2 000 / 340
+// points per frame, k frames/s): G = 64 17.8 / 22.5, 128 23.2 / 38.3, 192 23.1 / 40.7, 256 21.7 / 37.7, 384 20.1 / 34.0,
+// 512 18.8 / 33.2 -- against 18.3 / 37.8 for the flood.
+// So: G single-wave workgroups walk over the rows, row r = blockIdx.x, + G, ...; G = 192 when any pair of the step comes
 // over PCIe, 8192 for a step of device-resident pairs (an HBM-to-HBM copy wants more loads in flight, they are short, and it
 // is over in a fraction of a millisecond).
 struct __attribute__((packed, aligned(1))) IngU2 {
@@ -131,7 +135,12 @@ void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitc
 {
     if (n_pairs <= 0)
         return;
-    const int n_rows = 2 * n_pairs * h, want = over_pcie ? 256 : 8192;
+    int want = over_pcie ? 192 : 8192;
+#ifdef VO_DEV_VARIANTS
+    if (const char *e = getenv(over_pcie ? "VO_INGEST_WAVES" : "VO_INGEST_WAVES_DEV")) // developer build: A/B of the grid size
+        want = atoi(e) > 0 ? atoi(e) : want;
+#endif
+    const int n_rows = 2 * n_pairs * h;
     hipLaunchKernelGGL(seq_ingest_kernel, dim3(n_rows < want ? n_rows : want), dim3(64), 0, stream, tab, n_rows, w, h, pitch, pix0,
                        img_bytes);
 }
