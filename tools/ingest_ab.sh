@@ -1,4 +1,6 @@
 #!/bin/bash
+# Lock-step loop, 256 / 64 / 8 sequences: page-locked / pageable / resident pairs side by side (profiles/r06_ingest_ab.txt).
+#   gpurun -- 'bash tools/ingest_ab.sh'   -> gpurun_out/<dir>/summary.txt
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6_ingab4
 timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r6_ingab4/pytest.log 2>&1; tail -4 gpurun_out/r6_ingab4/pytest.log
 for WL in kitti2000 kitti374; do for ING in pinned host; do

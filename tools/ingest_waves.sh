@@ -1,4 +1,6 @@
 #!/bin/bash
+# Sweep of the ingest kernel's persistent grid (developer build: VO_INGEST_WAVES / VO_INGEST_WAVES_DEV) in the loop itself,
+# schedule pinned (profiles/r06_experiments.md section 1).   gpurun -- 'bash tools/ingest_waves.sh'
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6_ingw
 export VO_HIP_LIB=$GRAFT_REPO_ROOT/visual_odom_amd/libvo_hip_dev.so
 for G in 64 128 192 256 384 512; do for WL in kitti2000 kitti374; do

@@ -38,10 +38,26 @@ def trace_resources(trace_csv, out_csv):
         if k not in res:
             res[k] = [r.get("VGPR_Count", ""), r.get("Accum_VGPR_Count", ""), r.get("SGPR_Count", ""), r.get("LDS_Block_Size", ""),
                       r.get("Scratch_Size", ""), r.get("Workgroup_Size_X", ""), r.get("Grid_Size_X", "")]
-    with open(out_csv, "w") as f:
-        f.write("kernel,vgpr,agpr,sgpr,lds,scratch,wg,grid\n")
+    with open(out_csv, "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "wg", "grid"])
         for k, v in res.items():
-            f.write(",".join([k] + [str(x) for x in v]) + "\n")
+            wr.writerow([k] + [str(x) for x in v])
+
+
+def read_resources(path):
+    """kernel -> row; tolerant of the first version's unquoted names (`epnp_kernel<1, false>` holds a comma): the seven numbers
+    are taken from the right"""
+    res = {}
+    if not os.path.exists(path):
+        return res
+    rows = list(csv.reader(open(path)))
+    for r in rows[1:]:
+        if len(r) < 8:
+            continue
+        name = ",".join(r[:len(r) - 7])
+        res[name] = dict(zip(["vgpr", "agpr", "sgpr", "lds", "scratch", "wg", "grid"], r[-7:]))
+    return res
 
 
 def counters(d):
@@ -58,7 +74,7 @@ def main(src):
         wl = os.path.basename(st)[5:-len("_kernel_stats.csv")]
         stats = {short(r["Name"]): r for r in csv.DictReader(open(st))}
         resf = os.path.join(src, "pose_%s_resources.csv" % wl)
-        res = {r["kernel"]: r for r in csv.DictReader(open(resf))} if os.path.exists(resf) else {}
+        res = read_resources(resf)
         c = defaultdict(dict)
         for name in ("a", "b", "fetch", "write"):
             for k, v in counters(os.path.join(src, "posepmc_%s_%s" % (wl, name))).items():

@@ -108,12 +108,12 @@ struct __attribute__((packed, aligned(1))) IngU2 {
     uint32_t lo, hi;
 };
 
-__global__ __launch_bounds__(64) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int n_rows /* 2 * pairs * h */, int w,
-                                                        int h, int pitch, uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */,
-                                                        size_t img_bytes)
+__global__ __launch_bounds__(64) void seq_ingest_kernel(const SeqIngest *__restrict__ tab, int n_rows /* 2 * pairs * h */,
+                                                        int n_waves /* = the grid */, int w, int h, int pitch,
+                                                        uint8_t *__restrict__ pix0 /* pixel (0,0) of image 0 */, size_t img_bytes)
 {
     const int last = w - 8; // (w >= 32: vo_batch_configure) the lane that would cross the row end re-reads the row's last 8 bytes
-    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) { // (wave-uniform: image, side, row and both row addresses are scalars)
+    for (int r = blockIdx.x; r < n_rows; r += n_waves) { // (wave-uniform: image, side, row and both row addresses are scalars)
         const int img = r / h, row = r - img * h, side = img & 1;
         const SeqIngest e = tab[img >> 1];
         const VO_GLOBAL uint8_t *__restrict__ s = (const VO_GLOBAL uint8_t *)(side ? e.right : e.left) + (size_t)row * e.stride;
@@ -141,8 +141,8 @@ void launch_seq_ingest(const SeqIngest *tab, int n_pairs, int w, int h, int pitc
         want = atoi(e) > 0 ? atoi(e) : want;
 #endif
     const int n_rows = 2 * n_pairs * h;
-    hipLaunchKernelGGL(seq_ingest_kernel, dim3(n_rows < want ? n_rows : want), dim3(64), 0, stream, tab, n_rows, w, h, pitch, pix0,
-                       img_bytes);
+    const int n_waves = n_rows < want ? n_rows : want;
+    hipLaunchKernelGGL(seq_ingest_kernel, dim3(n_waves), dim3(64), 0, stream, tab, n_rows, n_waves, w, h, pitch, pix0, img_bytes);
 }
 
 void launch_seq_prepare(const int *active, const int *n_tracked, int redetect_below, int *detect,
