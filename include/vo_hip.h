@@ -370,7 +370,9 @@ int vo_seq_configure(vo_ctx *ctx, int n_seq, int w, int h, int ring, int max_ste
 int vo_seq_reset(vo_ctx *ctx, int seq);
 /* the next stereo pair of sequence `seq` (8-bit gray, byte stride).  host_pinned = 0: pageable memory, staged
  * through the library's pinned buffers (the call returns when the images have been copied out of the caller's
- * memory).  host_pinned = 1: page-locked memory (hipHostMalloc / hipHostRegister / torch pin_memory) read by the
+ * memory; vo_seq_push_pairs spreads a step's copies over up to 8 host threads; from 32 sequences on, a step whose pairs
+ * are ALL pageable crosses the link as one contiguous copy-engine transfer -- the fastest way in: 256 KITTI sequences at
+ * 2 000 points per frame run at 24.9 k frames/s from pageable memory, 23.3 k from page-locked, 25.6 k resident).  host_pinned = 1: page-locked memory (hipHostMalloc / hipHostRegister / torch pin_memory) read by the
  * copy engine directly; it must stay unchanged until the step that consumes it has finished.  Either way the
  * transfer runs on a copy stream next to the previous step's kernels. */
 int vo_seq_push_pair(vo_ctx *ctx, int seq, const uint8_t *left, const uint8_t *right, int stride, int host_pinned);

@@ -168,11 +168,14 @@ static int build_pyramid(const uint8_t *img, int w, int h, int win, int max_leve
 
 /* cvRound(float): round-half-to-even (SSE cvtss2si under the default rounding mode) */
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
-/* cvFloor(float) */
+/* cvFloor(float) as OpenCV's x86 build computes it: i = (int)v is cvttss2si -- INT_MIN ("integer indefinite") for NaN and for
+ * every value outside int32 --, then i - (i > v) in two's complement (INT_MIN - 1 wraps to INT_MAX there: -1e30 "floors" to
+ * INT_MAX; either is outside every admissibility window).  Spelled out so that no C undefined behaviour takes part (round 6:
+ * the sanitizer tier runs the non-finite inputs of tests/adversarial.py through this). */
 static inline int cv_floor_f(float v)
 {
-    int i = (int)v;
-    return i - (i > v);
+    int i = (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (-2147483647 - 1);
+    return (int)((unsigned)i - (unsigned)((float)i > v));
 }
 
 #define W_BITS 14

@@ -234,6 +234,44 @@ int main()
         std::sort(th.begin(), th.end());
         printf("%-58s copy %6.2f ms = %5.1f GB/s   load %6.2f ms   (host: %.2f ms to enqueue)\n", "under load, copy engine: 512 linear hipMemcpyAsync",
                tc[3], (double)simg * n_img / 1e6 / tc[3], tl[3], th[3]);
+        {   // ONE hipMemcpyBatchAsync of the 512 images
+            std::vector<void *> dsts(n_img), srcs(n_img);
+            std::vector<size_t> sizes(n_img, simg);
+            for (int i = 0; i < n_img; i++) {
+                dsts[i] = dstage + (size_t)i * simg;
+                srcs[i] = hsrc + (size_t)i * simg;
+            }
+            bool ok = true;
+            for (int it = 0; it < 6 && ok; it++) {
+                CK(hipEventRecord(l0, s_load));
+                launch_load(s_load, iters);
+                CK(hipEventRecord(l1, s_load));
+                CK(hipEventRecord(e0, s_copy));
+                size_t fail = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                hipError_t e = hipMemcpyBatchAsync(dsts.data(), srcs.data(), sizes.data(), (size_t)n_img, nullptr, nullptr, 0, &fail, s_copy);
+                th[it] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (e != hipSuccess) {
+                    printf("hipMemcpyBatchAsync: %s (fail index %zu)\n", hipGetErrorString(e), fail);
+                    (void)hipGetLastError();
+                    ok = false;
+                }
+                CK(hipEventRecord(e1, s_copy));
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                tc[it] = ms;
+                CK(hipEventElapsedTime(&ms, l0, l1));
+                tl[it] = ms;
+            }
+            if (ok) {
+                std::sort(tc.begin(), tc.end());
+                std::sort(tl.begin(), tl.end());
+                std::sort(th.begin(), th.end());
+                printf("%-58s copy %6.2f ms = %5.1f GB/s   load %6.2f ms   (host: %.2f ms to enqueue)\n", "under load, copy engine: ONE hipMemcpyBatchAsync x 512",
+                       tc[3], (double)simg * n_img / 1e6 / tc[3], tl[3], th[3]);
+            }
+        }
         for (int it = 0; it < 6; it++) {
             CK(hipEventRecord(l0, s_load));
             launch_load(s_load, iters);

@@ -207,6 +207,11 @@ struct vo_ctx {
         bool step_pending[VO_SEQ_INFLIGHT] = {};
         // pinned staging for pageable host images: two generations of [S][2] pitched level-0 images
         uint8_t *h_stage = nullptr;
+        // (round 6) the device twin of the staging area: when EVERY sequence's pair of a step is pageable, the step's half of
+        // h_stage -- one contiguous block -- crosses the link in ONE copy-engine transfer (57 GB/s, no shader involved:
+        // nothing that runs beside it slows down) and the ingest kernel re-pitches it HBM to HBM
+        uint8_t *d_stage = nullptr;
+        int n_pageable = 0;             // pageable pairs among the pending step's n_ing
         size_t stage_img = 0;
         hipEvent_t ev_stage[2] = {};
         bool stage_busy[2] = {};

@@ -125,10 +125,26 @@ int seq_enqueue_inputs(vo_ctx *c, bool dry)
             q.slot_busy[r] = false;
         }
         SeqIngest *d_tab = q.d_ing + (size_t)slot * q.S;
-        VO_HIP_TRY(c, hipMemcpyAsync(d_tab, q.h_ing + (size_t)slot * q.S, sizeof(SeqIngest) * q.n_ing,
-                                     hipMemcpyHostToDevice, q.copy));
+        SeqIngest *h_tab = q.h_ing + (size_t)slot * q.S;
+        // Every sequence pushed a PAGEABLE pair: the step's half of the staging area is one contiguous block -- the copy engine
+        // takes it across the link in one transfer (57 GB/s against the kernel's 48, and no shader wave, no L2 queue entry beside
+        // LK: tools/ubench/ingest_under_load.hip), and the ingest kernel re-pitches it from its device twin, HBM to HBM.
+        bool over_pcie = q.ing_pcie;
+        // (from 32 sequences on: a transfer of a few megabytes is over before the copy's fixed cost is paid -- 8 sequences 0.70 ms
+        // per step through the kernel, 0.80 through the engine; 64: 1.67 / 1.63; 256: 5.20 / 4.77 and, at 2 000 points, 11.34 / 10.28)
+        if (q.d_stage && q.S >= 32 && q.n_pageable == q.S && q.n_ing == q.S) {
+            const size_t half = q.stage_img * 2 * (size_t)q.S, off = (size_t)(q.step & 1) * half;
+            VO_HIP_TRY(c, hipMemcpyAsync(q.d_stage + off, q.h_stage + off, half, hipMemcpyHostToDevice, q.copy));
+            if (!dry) // (a dry re-run finds the entries already pointing at the device twin)
+                for (int i = 0; i < q.n_ing; i++) {
+                    h_tab[i].left = q.d_stage + (h_tab[i].left - q.h_stage);
+                    h_tab[i].right = q.d_stage + (h_tab[i].right - q.h_stage);
+                }
+            over_pcie = false;
+        }
+        VO_HIP_TRY(c, hipMemcpyAsync(d_tab, h_tab, sizeof(SeqIngest) * q.n_ing, hipMemcpyHostToDevice, q.copy));
         launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
-                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, q.ing_pcie, q.copy);
+                          c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, over_pcie, q.copy);
         if (!dry && q.staged) {
             const int g = (int)(q.step & 1);
             VO_HIP_TRY(c, hipEventRecord(q.ev_stage[g], q.copy));

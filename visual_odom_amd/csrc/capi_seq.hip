@@ -25,6 +25,8 @@ void seq_free(vo_ctx *c)
         (void)hipHostFree(q.h_ing);
     if (q.h_stage)
         (void)hipHostFree(q.h_stage);
+    if (q.d_stage)
+        (void)hipFree(q.d_stage);
     hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_pyr, q.ev_stage[0], q.ev_stage[1]};
     for (auto &e : q.ev_fast)
         if (e)
@@ -283,9 +285,16 @@ static int seq_push_impl(vo_ctx *c, int seq, const void *left, const void *right
                 VO_HIP_TRY(c, hipStreamSynchronize(q.copy));
                 VO_HIP_TRY(c, hipHostFree(q.h_stage));
                 q.h_stage = nullptr;
+                if (q.d_stage)
+                    VO_HIP_TRY(c, hipFree(q.d_stage));
+                q.d_stage = nullptr;
             }
             q.stage_img = img;
             VO_HIP_TRY(c, hipHostMalloc((void **)&q.h_stage, img * 2 * 2 * (size_t)q.S, hipHostMallocDefault));
+            if (hipMalloc((void **)&q.d_stage, img * 2 * 2 * (size_t)q.S) != hipSuccess) { // (optional: without it the kernel reads h_stage over PCIe)
+                (void)hipGetLastError();
+                q.d_stage = nullptr;
+            }
         }
         if (q.stage_busy[g]) { // the ingest kernel of step - 2 still reads this half of the staging area
             VO_HIP_TRY(c, hipEventSynchronize(q.ev_stage[g]));
@@ -319,9 +328,12 @@ static int seq_push_impl(vo_ctx *c, int seq, const void *left, const void *right
         e.left = (const uint8_t *)left;
         e.right = (const uint8_t *)right;
     }
-    if (q.n_ing == 0)
+    if (q.n_ing == 0) {
         q.ing_pcie = false;
+        q.n_pageable = 0;
+    }
     q.ing_pcie = q.ing_pcie || mode != 2;
+    q.n_pageable += mode == 0;
     q.h_ing[(size_t)(q.step % VO_SEQ_INFLIGHT) * q.S + q.n_ing++] = e;
     q.pushed[seq] = 1;
     return VO_OK;
