@@ -421,7 +421,7 @@ def main(argv=None):
         kept[0].close()
     if world_size > 1:
         # one host per GPU: every rank's slice of the node's cores (replicas.pin_rank), gathered -- the slices must be disjoint
-        slices = {k: replicas.gather_values(dist, -1 if pin.get(k) is None else pin[k])
+        slices = {k: replicas.gather_values(dist, -1 if pin.get(k) is None else pin[k], dev)   # (dev: RCCL reduces device tensors)
                   for k in ("cpus", "first_cpu", "last_cpu", "numa_node")}
         if rank == 0 and out is not None:
             out["config"]["host_cores_rank0"] = pin

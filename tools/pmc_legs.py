@@ -77,10 +77,13 @@ def main(src):
         if "SQ_INSTS_VALU" in sq and "GRBM_GUI_ACTIVE" in sq and "SQ_WAVES" in sq:
             valu, waves, cyc = sq["SQ_INSTS_VALU"], sq["SQ_WAVES"], sq["GRBM_GUI_ACTIVE"] / 8.0
             per_cyc = cyc * 1024.0 / valu
+            # per FEATURE = per point of the leg's own bench line, not per launched wave: the lock-step loop sizes its grid for the
+            # largest feature set and a third of its waves leave at once (batch legs: waves == points to 1e-4)
+            feats = float(b["roofline"].get("points_per_launch") or waves)
             issue_legs.append({"workload": wl, "frames_per_step": frames, "valu_instructions_per_launch": valu, "waves_per_launch": waves,
-                               "valu_instructions_per_feature": valu / waves,
-                               "salu_instructions_per_feature": sq["SQ_INSTS_SALU"] / waves if "SQ_INSTS_SALU" in sq else None,
-                               "lds_instructions_per_feature": sq["SQ_INSTS_LDS"] / waves if "SQ_INSTS_LDS" in sq else None,
+                               "points_per_launch": feats, "valu_instructions_per_feature": valu / feats,
+                               "salu_instructions_per_feature": sq["SQ_INSTS_SALU"] / feats if "SQ_INSTS_SALU" in sq else None,
+                               "lds_instructions_per_feature": sq["SQ_INSTS_LDS"] / feats if "SQ_INSTS_LDS" in sq else None,
                                "shader_cycles_per_launch": cyc, "simd_cycles_per_valu_instruction": per_cyc,
                                "issue_cost_bound_cycles_per_valu_instruction": ISSUE_COST, "measured_over_bound": per_cyc / ISSUE_COST,
                                "issue_floor_cycles_per_valu_instruction": ISSUE_FLOOR,
