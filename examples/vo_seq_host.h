@@ -101,10 +101,19 @@ inline WorkerResult run_worker(int device, const std::vector<std::string> &dirs,
         }
         if (!pushed)
             break;
+        // pageable host memory, all pairs of the step in ONE call: the library copies them to its pinned staging area on several
+        // threads before it returns, and -- from 32 sequences on, when every sequence has a pair -- moves the step's block to
+        // the GPU in one copy-engine transfer when the step runs (vo_hip.h, vo_seq_push_pair)
+        std::vector<int32_t> ids;
+        std::vector<const void *> lp, rp;
         for (int s = 0; s < S; s++)
-            if (live[s]) // pageable host memory: copied to the library's pinned staging now, moved to the GPU when the step runs
-                if ((rc = vo_seq_push_pair(ctx, s, cur.left[s].px.data(), cur.right[s].px.data(), w, /*host_pinned*/ 0)) < 0)
-                    return fail("vo_seq_push_pair", rc);
+            if (live[s]) {
+                ids.push_back(s);
+                lp.push_back(cur.left[s].px.data());
+                rp.push_back(cur.right[s].px.data());
+            }
+        if ((rc = vo_seq_push_pairs(ctx, (int)ids.size(), ids.data(), lp.data(), rp.data(), w, /*kind: pageable*/ 0)) < 0)
+            return fail("vo_seq_push_pairs", rc);
         if ((rc = vo_seq_step(ctx)) < 0)
             return fail("vo_seq_step", rc);
         if (id + depth + 1 < max_frames) // this slot is free again: the frame `depth + 1` ahead goes into it

@@ -515,3 +515,72 @@ def test_soak_5000_lockstep_steps_are_deterministic_and_leak_free(volib):
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info(0)[0] >= free10 - (2 << 20)
     assert proc.memory_info().rss <= rss10 + (64 << 20), (rss10, proc.memory_info().rss)
+
+
+# ------------------------------------------------------------------ ingest paths (round 6: persistent grid, copy-engine block)
+def test_ingest_paths_agree_at_32_sequences(volib, small_world):
+    """32 sequences -- the size from which a step of pageable pairs crosses the link as ONE copy-engine transfer of the staging
+    half -- fed four ways: device memory, page-locked memory (192-wave persistent kernel), pageable memory through
+    vo_seq_push_pairs (threaded staging + copy engine), pageable memory pushed pair by pair with a padded stride (staging
+    repack).  Same pairs, so the trajectories and the carried feature sets must be identical bit for bit; and a step in which
+    one sequence brings a page-locked pair falls back to the kernel path with the same result."""
+    import torch
+    S, n = 32, 6
+    w, h = 480, 160
+    L, R, _, _ = small_world.render_sequence(n + 3)
+    P_l, P_r = small_world.proj_matrices()
+    dev = torch.device("cuda", 0)
+
+    def pair(s, k):                               # sequence s is the same street, three phases
+        return L[k + s % 3], R[k + s % 3]
+    results = {}
+    for mode in ("device", "pinned", "pageable", "pageable_strided", "mixed"):
+        ctx = volib.Context(0, w, h, 4096, S)
+        try:
+            ctx.batch_set_detect_params(features_per_bucket=2)
+            ctx.seq_configure(S, w, h, ring=3, max_steps=16)
+            ctx.batch_set_projection(P_l, P_r)
+            keep = []
+            for k in range(n):
+                if mode == "device":
+                    t = [(torch.from_numpy(np.ascontiguousarray(pair(s, k)[0])).to(dev), torch.from_numpy(np.ascontiguousarray(pair(s, k)[1])).to(dev)) for s in range(S)]
+                    torch.cuda.synchronize()
+                    tab = ctx.seq_pair_table(range(S), [a.data_ptr() for a, _ in t], [b.data_ptr() for _, b in t])
+                    ctx.seq_push_pairs(tab, w, 2)
+                elif mode == "pinned":
+                    t = [(torch.from_numpy(np.ascontiguousarray(pair(s, k)[0])).pin_memory(), torch.from_numpy(np.ascontiguousarray(pair(s, k)[1])).pin_memory()) for s in range(S)]
+                    tab = ctx.seq_pair_table(range(S), [a.data_ptr() for a, _ in t], [b.data_ptr() for _, b in t])
+                    ctx.seq_push_pairs(tab, w, 1)
+                elif mode == "pageable":
+                    t = [(np.ascontiguousarray(pair(s, k)[0]), np.ascontiguousarray(pair(s, k)[1])) for s in range(S)]
+                    tab = ctx.seq_pair_table(range(S), [a.ctypes.data for a, _ in t], [b.ctypes.data for _, b in t])
+                    ctx.seq_push_pairs(tab, w, 0)
+                elif mode == "pageable_strided":
+                    t = []
+                    for s in range(S):
+                        pad = np.zeros((2, h, w + 37), np.uint8)
+                        pad[0, :, :w], pad[1, :, :w] = pair(s, k)
+                        t.append(pad)
+                        ctx.seq_push_pair(s, pad[0, :, :w], pad[1, :, :w])
+                else:                             # 31 pageable pairs + one page-locked one: not a block, the kernel path
+                    t = [(np.ascontiguousarray(pair(s, k)[0]), np.ascontiguousarray(pair(s, k)[1])) for s in range(S - 1)]
+                    for s in range(S - 1):
+                        ctx.seq_push_pair(s, *t[s])
+                    p = (torch.from_numpy(np.ascontiguousarray(pair(S - 1, k)[0])).pin_memory(), torch.from_numpy(np.ascontiguousarray(pair(S - 1, k)[1])).pin_memory())
+                    ctx.seq_push_pair(S - 1, p[0].numpy(), p[1].numpy(), pinned=True)
+                    t.append(p)
+                keep.append(t)                    # (page-locked / device sources stay alive until their step has run)
+                ctx.seq_step()
+            ctx.seq_sync()
+            traj = [ctx.seq_get_trajectory(s) for s in range(S)]
+            state = [ctx.seq_get_state(s) for s in range(S)]
+            results[mode] = (traj, state)
+        finally:
+            ctx.close()
+    base_t, base_s = results["device"]
+    assert all(len(r) == n - 1 for r, _ in base_t) and sum(int((i[:, 5] & 2 != 0).sum()) for _, i in base_t) > S * (n - 1) // 2
+    for mode in ("pinned", "pageable", "pageable_strided", "mixed"):
+        traj, state = results[mode]
+        for s in range(S):
+            assert np.array_equal(traj[s][0].view(np.uint64), base_t[s][0].view(np.uint64)) and np.array_equal(traj[s][1], base_t[s][1]), (mode, s)
+            assert np.array_equal(state[s][0], base_s[s][0]) and np.array_equal(state[s][1], base_s[s][1]), (mode, s)
