@@ -214,6 +214,8 @@ struct vo_ctx {
         int n_pageable = 0;             // pageable pairs among the pending step's n_ing
         size_t stage_img = 0;
         hipEvent_t ev_stage[2] = {};
+        hipEvent_t ev_detect = nullptr; // (round 6) the latest step's detection has run: a PCIe ingest starts behind it
+        bool detect_pending = false;
         bool stage_busy[2] = {};
         // "prepare" work of a step runs on the copy stream, off the tracking stream's critical path: ingest of the new pairs,
         // their pyramids, and FAST + non-maximum suppression of their LEFT images -- the corners the NEXT step's

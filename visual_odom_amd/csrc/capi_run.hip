@@ -126,6 +126,10 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
                                  c->d_pts_det[wset], c->d_ages_det[wset], c->d_npts_det[wset], cap, seq_active,
                                  c->d_overflow, c->stream);
         }
+        if (sq.on && !prep) { // (seq_enqueue_inputs: the NEXT step's PCIe ingest waits for this)
+            VO_HIP_TRY(c, hipEventRecord(sq.ev_detect, c->stream));
+            sq.detect_pending = true;
+        }
         c->pts_sel = wset;
         // the bucketed count is only known on the device; every later grid is sized by its bound
         const int bound = cells * fpb < cap ? cells * fpb : cap;

@@ -142,6 +142,33 @@ int seq_enqueue_inputs(vo_ctx *c, bool dry)
                 }
             over_pcie = false;
         }
+        // A kernel that reads over PCIe starts behind the running step's DETECTION -- when the step can afford it.  Its host reads
+        // park in the L2's queues, and the memory-bound kernels at the head of a step (pyramid pass, FAST, bucketing) pay for that
+        // far more than LK does (256 sequences, page-locked pairs, 2 000 points: detection 0.99 ms beside the ingest against
+        // 0.42 alone).  Measured with pinned schedules (gpurun_out/r6_ingwait): +1.5 .. +8 % where LK is long against the
+        // transfer (2 000 points: 8.8 ms against 5), -3 .. -18 % where the step is the link's (340 points: 2.1 ms against 5 --
+        // there every microsecond of the window counts).  So the wait is taken iff the LK of the newest step that has certainly
+        // finished (VO_SEQ_INFLIGHT + 1 steps back, its stage events sit in the ring) lasted >= 1.6 x the transfer at 48 GB/s.
+        // A heuristic on a schedule, never on a result.  (Not with the prepare stream: there the copy stream carries the step's
+        // own pyramids.)
+        bool wait_detect = false;
+        if (over_pcie && !dry && q.step > VO_SEQ_INFLIGHT + 1) {
+            hipEvent_t *old = &c->ring[(size_t)((q.step - VO_SEQ_INFLIGHT - 1) % VO_EVENT_SLOTS) * (VO_EV_PER_RUN)];
+            float lk_ms = 0.f;
+            if (hipEventQuery(old[3]) == hipSuccess && hipEventElapsedTime(&lk_ms, old[2], old[3]) == hipSuccess)
+                wait_detect = (double)lk_ms >= 1.6 * ((double)q.n_ing * 2.0 * c->w * c->h / 48e6);
+            else
+                (void)hipGetLastError(); // (a step without an LK stage left no such events)
+        }
+#ifdef VO_DEV_VARIANTS
+        static const int wait_env = [] { const char *e = getenv("VO_INGEST_WAIT"); return e ? atoi(e) : -1; }(); // A/B: 0 / 1 force
+        if (wait_env >= 0)
+            wait_detect = wait_env != 0;
+#endif
+        if (wait_detect && over_pcie && !dry && !c->sched.prep && q.detect_pending) {
+            VO_HIP_TRY(c, hipStreamWaitEvent(q.copy, q.ev_detect, 0));
+            q.detect_pending = false;
+        }
         VO_HIP_TRY(c, hipMemcpyAsync(d_tab, h_tab, sizeof(SeqIngest) * q.n_ing, hipMemcpyHostToDevice, q.copy));
         launch_seq_ingest(d_tab, q.n_ing, c->w, c->h, c->lstride[0],
                           c->d_pix + c->loff[0] + (size_t)VO_BY * c->lstride[0] + VO_BX, c->img_bytes, over_pcie, q.copy);

@@ -27,7 +27,7 @@ void seq_free(vo_ctx *c)
         (void)hipHostFree(q.h_stage);
     if (q.d_stage)
         (void)hipFree(q.d_stage);
-    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_pyr, q.ev_stage[0], q.ev_stage[1]};
+    hipEvent_t evs[] = {q.ev_upload, q.ev_carry, q.ev_integ, q.ev_pyr, q.ev_stage[0], q.ev_stage[1], q.ev_detect};
     for (auto &e : q.ev_fast)
         if (e)
             (void)hipEventDestroy(e);
@@ -134,6 +134,7 @@ int vo_seq_configure(vo_ctx *c, int n_seq, int w, int h, int ring, int max_steps
     ok = ok && dmalloc(&q.d_rows_carry, S) == hipSuccess;
     ok = ok && dmalloc(&q.d_nages, S) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&q.ev_upload, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&q.ev_detect, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&q.ev_carry, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&q.ev_integ, hipEventDisableTiming) == hipSuccess;
     for (auto &e : q.ev_slot_free)
