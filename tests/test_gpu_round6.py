@@ -219,7 +219,11 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
     fw = fuzz_world
     seen = dict(cases=0, posed=0, empty=0, wild=0)
 
-    @settings(max_examples=300, derandomize=True, deadline=None, database=None,
+    # (VO_FUZZ_EXAMPLES / VO_FUZZ_SEED: a longer or differently seeded hunt by hand; the suite runs the same 300 cases every time)
+    n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "300"))
+    explore = os.environ.get("VO_FUZZ_SEED")
+
+    @settings(max_examples=n_examples, derandomize=explore is None, deadline=None, database=None,
               suppress_health_check=list(HealthCheck))
     # (the parameter draws lean towards values that track -- a 1-iteration, level-0-only LK on a 40-pixel crop yields a
     # handful of garbage tracks whose "pose" is chaos: still checked for status / survivors / inliers, but not a pose)
@@ -271,25 +275,32 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
         rc, rv, tv, inl, dbg = ref["pnp"]
         assert (got["rc"] == 0) == (rc == 1)
         assert np.array_equal(got["inliers"], inl)
-        # The pose bar (<= 1e-6) is a bar for a pose: when the reference's own Levenberg-Marquardt run ends nowhere -- a
-        # handful of garbage tracks (maxCount 1, level 0 only), |rvec| of 1e8 -- its last digits are chaos (seed 296 of this
-        # fuzz: 10 LM iterations in the reference's summation order, 18 in the kernel's, both "poses" ~1e9), and all that
-        # can be held is the class of the answer.  Counted, and bounded below.
-        sane = np.isfinite(rv).all() and np.isfinite(tv).all() and np.abs(rv).max() <= 2 * np.pi and np.abs(tv).max() <= 1e3
+        # The pose bar (<= 1e-6) is a bar for a pose.  When the reference's own Levenberg-Marquardt run ends nowhere -- a handful
+        # of garbage tracks (maxCount 1, level 0 only): it stops at its 20-iteration cap, or at |rvec| beyond a turn, or at a
+        # translation of kilometres -- its last digits are chaos in ANY summation order (seed 296 of this fuzz: 10 LM iterations
+        # in the reference's order, 18 in the kernel's, both "poses" ~1e9; a 3 x 2 000-case hunt with other seeds found two more
+        # of the kind: 20 iterations without convergence at |rvec| = 6.29; a converged 5-inlier frame at |t| = 84 m whose tvec
+        # differs by 7e-6 = 8e-8 of its length) and all that can be held is the class of the answer.  So: a converged run at a
+        # pose of sane size is held to 1e-6 rad and 1e-6 x max(1 m, |t|); the rest is counted, and bounded below.
+        sane = np.isfinite(rv).all() and np.isfinite(tv).all() and np.abs(rv).max() <= np.pi and np.abs(tv).max() <= 1e3 and dbg[3] < 20
         if rc == 1 and not sane:
             seen["wild"] += 1
             assert not (np.isfinite(got["rvec"]).all() and np.abs(got["rvec"]).max() <= 1e-3 and np.abs(got["tvec"]).max() <= 1e-3)
             return
-        assert adv.same(got["rvec"], rv, 1e-6) and adv.same(got["tvec"], tv, 1e-6), (got["rvec"], rv, got["tvec"], tv, dbg)
+        tol_t = 1e-6 * max(1.0, float(np.abs(tv).max())) if np.isfinite(tv).all() else 1e-6
+        assert adv.same(got["rvec"], rv, 1e-6) and adv.same(got["tvec"], tv, tol_t), (got["rvec"], rv, got["tvec"], tv, dbg)
         seen["posed"] += rc == 1
 
+    if explore is not None:
+        from hypothesis import seed as hyp_seed
+        run = hyp_seed(int(explore))(run)
     try:
         run()
     finally:
         gpu_ctx.set_params(lk_max_level=3, lk_max_count=30, lk_epsilon=0.01, lk_min_eig_threshold=1e-3, consistency_threshold=0,
                            ransac_iterations=500, ransac_reproj_error=0.5, ransac_confidence=float(np.float32(0.999)))
     print("fuzz:", seen)
-    assert seen["cases"] >= 300 and seen["posed"] >= 60 and seen["wild"] <= 0.25 * seen["cases"], seen
+    assert seen["cases"] >= min(n_examples, 300) and seen["posed"] >= 0.2 * seen["cases"] and seen["wild"] <= 0.25 * seen["cases"], seen
 
 
 # ------------------------------------------------------------------ the shipped adapter (adapters/feature_hip.cpp)
