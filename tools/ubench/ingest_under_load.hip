@@ -234,6 +234,45 @@ int main()
         std::sort(th.begin(), th.end());
         printf("%-58s copy %6.2f ms = %5.1f GB/s   load %6.2f ms   (host: %.2f ms to enqueue)\n", "under load, copy engine: 512 linear hipMemcpyAsync",
                tc[3], (double)simg * n_img / 1e6 / tc[3], tl[3], th[3]);
+        for (int ns : {2, 4, 8}) { // the 512 linear copies spread over ns streams: does the runtime use several copy engines?
+            static hipStream_t cs[8] = {};
+            static hipEvent_t ce[8] = {};
+            for (int i = 0; i < ns; i++)
+                if (!cs[i]) {
+                    CK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
+                    CK(hipEventCreateWithFlags(&ce[i], hipEventDisableTiming));
+                }
+            for (int it = 0; it < 6; it++) {
+                CK(hipEventRecord(l0, s_load));
+                launch_load(s_load, iters);
+                CK(hipEventRecord(l1, s_load));
+                CK(hipEventRecord(e0, s_copy));
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < ns; i++)
+                    CK(hipStreamWaitEvent(cs[i], e0, 0));
+                for (int i = 0; i < n_img; i++)
+                    CK(hipMemcpyAsync(dstage + (size_t)i * simg, hsrc + (size_t)i * simg, simg, hipMemcpyHostToDevice, cs[i % ns]));
+                for (int i = 0; i < ns; i++) {
+                    CK(hipEventRecord(ce[i], cs[i]));
+                    CK(hipStreamWaitEvent(s_copy, ce[i], 0));
+                }
+                th[it] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                CK(hipEventRecord(e1, s_copy));
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                tc[it] = ms;
+                CK(hipEventElapsedTime(&ms, l0, l1));
+                tl[it] = ms;
+            }
+            std::sort(tc.begin(), tc.end());
+            std::sort(tl.begin(), tl.end());
+            std::sort(th.begin(), th.end());
+            char name[96];
+            snprintf(name, sizeof(name), "under load, copy engine: 512 linear copies on %d streams", ns);
+            printf("%-58s copy %6.2f ms = %5.1f GB/s   load %6.2f ms   (host: %.2f ms to enqueue)\n", name, tc[3],
+                   (double)simg * n_img / 1e6 / tc[3], tl[3], th[3]);
+        }
         {   // ONE hipMemcpyBatchAsync of the 512 images
             std::vector<void *> dsts(n_img), srcs(n_img);
             std::vector<size_t> sizes(n_img, simg);
