@@ -657,4 +657,21 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
     });
     return n_out;
 }
+
+// seq_ingest_kernel (round 6: a persistent grid of single-wave workgroups that walk over the rows): n_pairs pairs of w x h
+// images with a byte stride -> pitched destination images (pair i: images 2 i, 2 i + 1), n_waves workgroups
+void ke_seq_ingest(const uint8_t *const *left, const uint8_t *const *right, int n_pairs, int w, int h, int stride, int pitch,
+                   uint8_t *dst /* [2 n_pairs][h][pitch] */, int n_waves)
+{
+    using namespace vo;
+    std::vector<SeqIngest> tab((size_t)n_pairs);
+    for (int i = 0; i < n_pairs; i++) {
+        tab[i].left = left[i];
+        tab[i].right = right[i];
+        tab[i].stride = stride;
+        tab[i].image0 = 2 * i;
+    }
+    const int n_rows = 2 * n_pairs * h;
+    launch((unsigned)n_waves, 1, 1, 64, [&] { seq_ingest_kernel(tab.data(), n_rows, n_waves, w, h, pitch, dst, (size_t)h * pitch); });
+}
 }

@@ -785,3 +785,23 @@ def test_pyramid_pass_workgroup_decode(kemu, shape):
     w, h, ml = shape
     for n in (0, 1, 7, 8, 9, 514):
         assert kemu.ke_pass_decode_check(w, h, ml, n) == 0, (shape, n)
+
+
+@pytest.mark.parametrize("w,h,stride,n_waves", [(1241, 13, 1241, 7), (64, 9, 80, 3), (519, 5, 519, 64), (32, 4, 32, 1), (100, 6, 131, 1000)])
+def test_emulated_seq_ingest_persistent_grid(kemu, w, h, stride, n_waves):
+    """seq_ingest_kernel (round 6): G single-wave workgroups walk over the rows of all new images; a row's last 8 bytes come
+    from an overlapping access -- every destination pixel right, nothing outside the w columns of a row touched, for widths
+    that are / are not multiples of 8 and 512, padded strides, fewer and more waves than rows (and, under the sanitizer
+    tier's exactly-sized buffers, no access outside a source row's image or a destination image)"""
+    rng = np.random.default_rng(w + h)
+    n_pairs, pitch = 3, ((w + 56 + 15) // 16) * 16
+    src = [np.ascontiguousarray(rng.integers(0, 256, (h, stride), dtype=np.uint8)) for _ in range(2 * n_pairs)]
+    views = [a[:, :w] for a in src]
+    if stride > w:                      # the last row of a strided image ends at its w-th byte: nothing may be read behind it
+        src = [np.ascontiguousarray(a.ravel()[:(h - 1) * stride + w]) for a in src]
+    dst = np.full((2 * n_pairs, h, pitch), 0xAB, np.uint8)
+    ptr = lambda arrs: (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    kemu.ke_seq_ingest(ptr(src[0::2]), ptr(src[1::2]), n_pairs, w, h, stride, pitch, vp(dst), n_waves)
+    for i in range(n_pairs):
+        assert np.array_equal(dst[2 * i, :, :w], views[2 * i]) and np.array_equal(dst[2 * i + 1, :, :w], views[2 * i + 1]), i
+    assert (dst[:, :, w:] == 0xAB).all()
