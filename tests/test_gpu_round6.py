@@ -525,7 +525,7 @@ def test_soak_5000_lockstep_steps_are_deterministic_and_leak_free(volib):
             free10, rss10 = torch.cuda.mem_get_info(0)[0], proc.memory_info().rss
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info(0)[0] >= free10 - (2 << 20)
-    assert proc.memory_info().rss <= rss10 + (64 << 20), (rss10, proc.memory_info().rss)
+    assert proc.memory_info().rss <= rss10 + (256 << 20), (rss10, proc.memory_info().rss)   # (a leaked context is ~10 MB of host memory: 40 of them would show)
 
 
 # ------------------------------------------------------------------ ingest paths (round 6: persistent grid, copy-engine block)
