@@ -141,7 +141,8 @@ struct vo_ctx {
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
     bool sync_call = false;          // the run being scheduled is a synchronous drop-in call (its own probe key: latency)
-    Schedule ab_list[4];             // lock-step loop: the candidates being timed over real steps (vo_seq_step)
+    Schedule ab_list[5];             // lock-step loop: the candidates being timed over real steps (vo_seq_step): up to four nominees
+                                     // + (round 6) the winner once more with the OTHER register budget
     long long ab_key[8] = {};
     // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
     int probe_n = 0;
@@ -236,7 +237,8 @@ struct vo_ctx {
         // prepare-flipped twin, ... (ab_cnt candidates), ab_cnt + 1 = decided; ab_left counts down the phase's steps (3 untimed
         // ramp steps + ab_n timed)
         int ab_phase = 0, ab_left = 0, ab_n = 0, ab_cnt = 0;
-        hipEvent_t ev_ab[8] = {};
+        bool ab_extra = false; // the winner's twin with the other pose_waves has been appended
+        hipEvent_t ev_ab[10] = {};
         bool ab_running() const { return ab_phase >= 1 && ab_phase <= ab_cnt; }
 
         bool begun = false, staged = false;

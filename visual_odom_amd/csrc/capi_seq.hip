@@ -555,6 +555,7 @@ int vo_seq_step(vo_ctx *c)
                     q.ab_n = (int)ceil(25.0 / ms);
                     q.ab_n = q.ab_n < 12 ? 12 : q.ab_n > 48 ? 48 : q.ab_n;
                     q.ab_cnt = n;
+                    q.ab_extra = false;
                     q.ab_phase = 1;
                     q.ab_left = 3 + q.ab_n;
                     memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
@@ -607,11 +608,36 @@ int vo_seq_step(vo_ctx *c)
             } else {
                 VO_HIP_TRY(c, hipEventSynchronize(q.ev_ab[2 * ph + 1]));
                 int best = 0;
-                float t[4] = {0, 0, 0, 0};
+                float t[5] = {0, 0, 0, 0, 0};
                 for (int i = 0; i < q.ab_cnt; i++) {
                     VO_HIP_TRY(c, hipEventElapsedTime(&t[i], q.ev_ab[2 * i], q.ev_ab[2 * i + 1]));
                     if (t[i] < t[best])
                         best = i;
+                }
+                // Round 6: every nominee ran with the register budget the DRY runs prefer for its (pose_streams, prepare) pair --
+                // and at 64 sequences of 1241 x 376 they prefer the wrong one: 2,2,1 wins the comparison at 1.42 ms per step where
+                // 1,2,1 runs 1.29 (45.2 k against 49.6 k frames/s, gpurun_out/r6_s64; the loop was bimodal by that pick).  So the
+                // winner runs once more with the other budget before anything is settled -- from 32 sequences on: below, a window
+                // of ~30 steps flatters the 256-register kernels (16 sequences: 0.76 ms per step in the window, 0.85 once the
+                // pose stream's backlog has built up; 18.7 k frames/s where the untouched pick runs 20.9 k, gpurun_out/r6_twin).
+                if (!q.ab_extra && !c->pin.pose_waves && q.ab_cnt < 5 && q.S >= 32) {
+                    vo_ctx::Schedule twin = c->ab_list[best];
+                    twin.waves = twin.waves == 1 ? 2 : 1;
+                    bool have = false;
+                    for (int i = 0; i < q.ab_cnt; i++)
+                        have = have || (c->ab_list[i].waves == twin.waves && c->ab_list[i].streams == twin.streams &&
+                                        c->ab_list[i].prep == twin.prep && c->ab_list[i].wide == twin.wide);
+                    q.ab_extra = true;
+                    if (!have) {
+                        c->ab_list[q.ab_cnt] = twin;
+                        rc = set_sched(c, twin);
+                        if (rc != VO_OK)
+                            return rc;
+                        q.ab_cnt++;
+                        q.ab_phase++;
+                        q.ab_left = 3 + q.ab_n;
+                        return VO_OK;
+                    }
                 }
                 rc = set_sched(c, c->ab_list[best]);
                 if (rc != VO_OK)
