@@ -360,3 +360,95 @@ def test_sequence_loop_guards(volib, small_world):
             ctx.seq_step()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed,S,ring,pin_sched", [(11, 5, 3, None), (12, 8, 2, (2, 1, 0)), (13, 33, 3, None), (14, 40, 2, (1, 2, 1))])
+def test_lockstep_random_feed_patterns(volib, orc, seed, S, ring, pin_sched):
+    _random_feed(volib, orc, seed, S, ring, pin_sched)
+
+
+def test_lockstep_random_feed_hunt(volib, orc):
+    """VO_FEED_HUNT=<n>: n more seeded feeds with random sizes, rings and schedules (a hunt, not part of the suite)"""
+    n = int(os.environ.get("VO_FEED_HUNT", "0"))
+    if not n:
+        pytest.skip("set VO_FEED_HUNT=<number of feeds>")
+    rng = np.random.default_rng(int(os.environ.get("VO_FEED_SEED", "1000")))
+    for k in range(n):
+        seed = int(rng.integers(1 << 30))
+        S = int(rng.choice([1, 2, 3, 7, 16, 32, 33, 48]))
+        sched = None if rng.random() < 0.5 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(0, 2)))
+        _random_feed(volib, orc, seed, S, int(rng.integers(2, 4)), sched)
+
+
+def _random_feed(volib, orc, seed, S, ring, pin_sched):
+    """A seeded random feed of the lock-step loop against one independent reference loop per sequence: every step each
+    sequence pushes its next pair from pageable, page-locked or device memory -- or pauses; now and then a sequence is
+    reset; states are pulled at random steps (a host synchronisation in the middle of steps in flight).  From 32
+    sequences on, steps in which EVERY sequence pushes a pageable pair (one copy-engine transfer into the device twin of
+    the staging area) alternate with mixed steps (the ingest kernel reads the host over PCIe); with the schedule probed
+    (dry runs + comparison over real steps, incl. the winner's twin from 32 sequences on) or pinned.  Bars as everywhere
+    in this file: feature state bit-exact, frame_pose / trajectory <= 1e-6, same number of rows."""
+    from visual_odom_amd import odometry
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref was not shipped")
+    rng = np.random.default_rng(seed)
+    N, n_worlds, max_off = 9, 3, 4
+    worlds = _worlds(n_worlds, **SMALL)
+    rendered = [w.render_sequence(N + max_off) for w in worlds]
+    P_l, P_r = worlds[0].proj_matrices()
+    src = [(s % n_worlds, (s // n_worlds) % (max_off + 1)) for s in range(S)]  # (world, first frame) of sequence s
+    ctx = volib.Context(0, 480, 160, 4096, S)
+    di = _DeviceImages()
+    try:
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, S, 480, 160, ctx=ctx, ring=ring, max_steps=32)
+        if pin_sched:
+            ctx.set_schedule(*pin_sched)
+        new_loop = lambda: orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3])
+        loops = [new_loop() for _ in range(S)]
+        fed, paused = [0] * S, [False] * S
+        kinds = np.zeros(3, int)
+        for step in range(N + 3):
+            all_pageable = S >= 32 and step % 2 == 0
+            pushed = 0
+            for s in range(S):
+                if fed[s] >= N:
+                    continue
+                a = 0 if all_pageable else rng.choice(4, p=[0.55, 0.15, 0.15, 0.15])   # pageable / page-locked / device / pause
+                if a == 3 and not (s == S - 1 and pushed == 0):
+                    paused[s] = True
+                    continue
+                a = min(a, 2)
+                wi, off = src[s]
+                L, R = rendered[wi][0][off + fed[s]], rendered[wi][1][off + fed[s]]
+                if a == 0:
+                    vo.push(s, L, R)
+                elif a == 1:
+                    vo.push(s, di.pinned(L), di.pinned(R), pinned=True)
+                else:
+                    ctx.seq_push_pair_dev(s, di.upload(L), di.upload(R), 480)
+                kinds[a] += 1
+                if paused[s]:
+                    loops[s].prev, paused[s] = None, False   # the pair from before the pause is gone (vo_hip.h, vo_seq_configure)
+                loops[s].process(L, R)
+                fed[s] += 1
+                pushed += 1
+            if pushed == 0:
+                break
+            vo.step()
+            if rng.random() < 0.3:
+                for s in rng.choice(S, size=min(S, 3), replace=False):
+                    _check_state(vo, int(s), loops[int(s)], (seed, step))
+            if rng.random() < 0.2:
+                s = int(rng.integers(S))
+                ctx.seq_reset(s)
+                loops[s], paused[s] = new_loop(), False
+        for s in range(S):
+            _check_state(vo, s, loops[s], (seed, "end"))
+            traj = vo.trajectory(s)
+            assert len(traj) == len(loops[s].trajectory), (seed, s, len(traj), len(loops[s].trajectory))
+            assert odometry.ate_rmse(traj, loops[s].trajectory) <= 1e-6, (seed, s)
+            assert all(r["overflow"] == 0 for r in vo.log(s))
+    finally:
+        ctx.set_schedule()
+        ctx.close()
+        di.free()
