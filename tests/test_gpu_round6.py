@@ -303,6 +303,75 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
     assert seen["cases"] >= min(n_examples, 300) and seen["posed"] >= 0.2 * seen["cases"] and seen["wild"] <= 0.25 * seen["cases"], seen
 
 
+def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
+    """1 000 random cases (seconds) through vo_fast_detect + vo_detect_bucket (head of matchingFeatures, visualOdometry.cpp:95-108): an ROI of
+    a rendered frame, of noise or of a checkerboard (arbitrary w, h, stride != width), any FAST threshold with and without
+    non-maximum suppression, bucket edges from 1 pixel to beyond the image, 1 .. 40 features per bucket (beyond the documented limits: VO_ERR_ARG), 0 .. 2 500 carried
+    points (a few of them the adversarial ones of tests/adversarial.py) with an ages array at least as long (quirk B3),
+    re-detection below 0 / 400 / 2 000 points -- corners, bucketed points and ages BIT-EXACT against the oracle's chain."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    fw = fuzz_world
+    rs = np.random.default_rng(5)
+    noise = rs.integers(0, 256, (fw["h"], fw["w"]), dtype=np.uint8)
+    yy, xx = np.mgrid[0:fw["h"], 0:fw["w"]]
+    board = (((xx // 5 + yy // 5) & 1) * 200 + 20).astype(np.uint8)
+    sources = [fw["L"][0], fw["R"][1], fw["L"][2], noise, board]
+    seen = dict(cases=0, redetected=0, corners=0, out=0, refused=0)
+    n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "1000"))
+    explore = os.environ.get("VO_FUZZ_SEED")
+
+    @settings(max_examples=n_examples, derandomize=explore is None, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), src=st.integers(0, 4), w=st.sampled_from([40, 64, 97, 131, 200, 320, 333, 480, 601, 640]),
+           h=st.sampled_from([40, 64, 97, 128, 160, 200, 256]), thr=st.sampled_from([0, 1, 5, 20, 20, 20, 50, 100, 254, 255]),
+           nonmax=st.integers(0, 1), bs=st.sampled_from([0, 0, 1, 3, 7, 16, 25, 50, 300]), fpb=st.sampled_from([1, 1, 2, 6, 40]),
+           n=st.sampled_from([0, 0, 1, 17, 150, 399, 400, 1999, 2000, 2500]), extra_ages=st.sampled_from([0, 0, 3, 40]),
+           n_bad=st.integers(0, 4), redetect=st.sampled_from([0, 400, 2000, 2000]))
+    def run(seed, src, w, h, thr, nonmax, bs, fpb, n, extra_ages, n_bad, redetect):
+        rng = np.random.default_rng(seed)
+        x0, y0 = int(rng.integers(0, fw["w"] - w + 1)), int(rng.integers(0, fw["h"] - h + 1))
+        img = sources[src][y0:y0 + h, x0:x0 + w]                       # a view: stride 640
+        pts = np.stack([rng.uniform(0, w - 0.01, n), rng.uniform(0, h - 0.01, n)], 1).astype(np.float32)
+        if n_bad and n:
+            pts[rng.integers(0, n, n_bad)] = adv.BUCKET_POINTS[rng.integers(0, len(adv.BUCKET_POINTS), n_bad)]
+        ages = rng.integers(-2, 14, n + extra_ages).astype(np.int32)
+        cap = 1 << 18
+        fast_o = orc.fast_detect(np.ascontiguousarray(img), thr, bool(nonmax), cap=cap)
+        if src == 3 and thr < 5 and not nonmax and w * h > 100000:
+            return                                                       # (hundreds of thousands of corners: a capacity case, test_gpu_round2)
+        fast_g = gpu_ctx.fast_detect(img, thr, bool(nonmax), cap=cap)
+        assert np.array_equal(bits(fast_g), bits(fast_o)), ("corners", len(fast_g), len(fast_o))
+        if n + len(fast_o) + extra_ages > gpu_ctx.max_pts:
+            return
+        if n < redetect:
+            allp, alla = np.vstack([pts, fast_o]), np.concatenate([ages, np.zeros(len(fast_o), np.int32)])   # feature.cpp:255-262
+            seen["redetected"] += 1
+        else:
+            allp, alla = pts, ages
+        edge = bs if bs else h // 10
+        if fpb > 8 or (h // edge + 1) * (w // edge + 1) > 1024:       # the documented limits of the device bucketing (vo_hip.h)
+            with pytest.raises(volib.VoError) as e:
+                gpu_ctx.detect_bucket(img, pts, ages, fast_threshold=thr, fast_nonmax=nonmax, redetect_below=redetect,
+                                      bucket_size=bs, features_per_bucket=fpb)
+            assert e.value.code == volib.VO_ERR_ARG
+            seen["refused"] += 1
+            return
+        want_p, want_a = orc.bucketing_features(h, w, allp, alla, edge, fpb)
+        got_p, got_a = gpu_ctx.detect_bucket(img, pts, ages, fast_threshold=thr, fast_nonmax=nonmax, redetect_below=redetect,
+                                             bucket_size=bs, features_per_bucket=fpb)
+        assert np.array_equal(bits(got_p), bits(want_p)), ("points", len(got_p), len(want_p))
+        assert np.array_equal(got_a, want_a), "ages"
+        seen["cases"] += 1
+        seen["corners"] += len(fast_o)
+        seen["out"] += len(want_p)
+
+    if explore is not None:
+        from hypothesis import seed as hyp_seed
+        run = hyp_seed(int(explore))(run)
+    run()
+    print("detect fuzz:", seen)
+    assert seen["cases"] >= 0.4 * n_examples and seen["redetected"] >= 0.3 * seen["cases"] and seen["refused"] > 0 and seen["out"] > 10 * seen["cases"], seen
+
+
 # ------------------------------------------------------------------ the shipped adapter (adapters/feature_hip.cpp)
 def test_shipped_adapter_detect_and_bucket(orc, small_seq):
     """detectAndBucket_hip (adapters/feature_hip.cpp; head of matchingFeatures, visualOdometry.cpp:95-108) against the
