@@ -128,3 +128,26 @@ def same(a, b, tol=0.0):
         return False
     d = np.abs(a[m][~inf] - b[m][~inf])
     return d.size == 0 or d.max() <= tol
+
+
+def pose_jacobian_singular_values(X, rvec, tvec, K):
+    """singular values of the 2m x 6 Jacobian of the pinhole projection of X [m, 3] with respect to (rvec, tvec), by central
+    differences in float64: how well the points determine the pose AT that pose (a flat valley of the reprojection error --
+    sigma_max / sigma_min in the thousands -- is where a Levenberg-Marquardt run stops wherever its last step happened to end)"""
+    X = np.asarray(X, np.float64)
+    K = np.asarray(K, np.float64)
+
+    def proj(p):
+        th = np.linalg.norm(p[:3])
+        k = p[:3] / th if th > 0 else np.zeros(3)
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        Y = X @ R.T + p[3:]
+        return np.stack([K[0, 0] * Y[:, 0] / Y[:, 2] + K[0, 2], K[1, 1] * Y[:, 1] / Y[:, 2] + K[1, 2]], 1).reshape(-1)
+    p = np.concatenate([np.asarray(rvec, np.float64), np.asarray(tvec, np.float64)])
+    J = np.zeros((2 * len(X), 6))
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = 1e-6
+        J[:, k] = (proj(p + d) - proj(p - d)) / 2e-6
+    return np.linalg.svd(J, compute_uv=False), J

@@ -200,6 +200,80 @@ def test_integrate_odometry_adversarial(volib, orc):
         assert ok_g == ok_o and adv.same(e_g, e_o, 0) and adv.same(got, want, 1e-12), (R, t)
 
 
+def test_pnp_ransac_fuzz(gpu_ctx, orc):
+    """500 random solvePnPRansac problems (visualOdometry.cpp:176-178) through vo_pnp_ransac: 5 .. 3 000 points, any outlier
+    rate and noise, scenes in depth, planar scenes and scenes with duplicated points, small (VO-like) and large motions,
+    several intrinsics, 1 .. 1 000 iterations, reprojection thresholds 0.25 .. 8 px, confidences 0.5 .. 0.999 -- return code
+    and inlier set IDENTICAL, pose <= 1e-6 (the bar of a converged pose of sane size, as in test_track_frame_fuzz)."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    seen = dict(cases=0, found=0, wild=0, wild_within=0, flat=0)
+    n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "500"))
+    explore = os.environ.get("VO_FUZZ_SEED")
+
+    @settings(max_examples=n_examples, derandomize=explore is None, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), n=st.sampled_from([5, 6, 7, 9, 16, 40, 64, 65, 150, 400, 1000, 3000]),
+           outliers=st.sampled_from([0.0, 0.0, 0.1, 0.3, 0.5, 0.8]), noise=st.sampled_from([0.0, 0.05, 0.2, 1.0]),
+           scene=st.sampled_from(["depth", "depth", "planar", "duplicates", "near"]), motion=st.sampled_from(["vo", "vo", "large"]),
+           fx=st.sampled_from([300.0, 718.856, 1000.0]), iters=st.sampled_from([1, 10, 100, 500, 500, 1000]),
+           reproj=st.sampled_from([0.25, 0.5, 0.5, 2.0, 8.0]), conf=st.sampled_from([0.5, 0.99, float(np.float32(0.999))]))
+    def run(seed, n, outliers, noise, scene, motion, fx, iters, reproj, conf):
+        rng = np.random.default_rng(seed)
+        K = np.array([[fx, 0, 607.19], [0, fx, 185.2], [0, 0, 1]], np.float64)
+        X = rng.uniform([-10, -2, 4], [10, 2, 50], (n, 3))
+        if scene == "planar":
+            X[:, 2] = 20.0 + 0.1 * X[:, 0]
+        elif scene == "near":
+            X[:, 2] = rng.uniform(0.5, 3.0, n)
+        elif scene == "duplicates":
+            X[n // 2:] = X[:n - n // 2]
+        X = X.astype(np.float32)
+        if motion == "vo":
+            r = np.array([0.002, -0.03, 0.001]) + rng.normal(0, 0.002, 3)
+            t = np.array([0.02, -0.01, -0.9]) + rng.normal(0, 0.02, 3)
+        else:
+            r, t = rng.normal(0, 0.25, 3), rng.normal(0, 1.5, 3)
+        uv = orc.project_points(X, r, t, K).astype(np.float64) + rng.normal(0, noise, (n, 2))
+        out = rng.random(n) < outliers
+        uv[out] += rng.uniform(-40, 40, (int(out.sum()), 2))
+        uv = uv.astype(np.float32)
+        gpu_ctx.set_params(ransac_iterations=iters, ransac_reproj_error=reproj, ransac_confidence=conf)
+        found, rv, tv, R, inl = gpu_ctx.pnp_ransac(X, uv, K)
+        rc, orv, otv, oinl, dbg = orc.solve_pnp_ransac(X, uv, K, iterations=iters, reproj=reproj, confidence=conf)
+        assert found == (rc == 1), (found, rc)
+        assert np.array_equal(inl, oinl)
+        seen["cases"] += 1
+        sane = np.isfinite(orv).all() and np.isfinite(otv).all() and np.abs(orv).max() <= np.pi and np.abs(otv).max() <= 1e3 and dbg[3] < 20
+        if rc == 1 and not sane:   # (no bar, but a count of how many of them meet the bar of a sane pose anyway)
+            seen["wild"] += 1
+            fin = np.isfinite(orv).all() and np.isfinite(otv).all()
+            seen["wild_within"] += bool(fin and adv.same(rv, orv, 1e-6) and adv.same(tv, otv, 1e-6 * max(1.0, float(np.abs(otv).max()))))
+            return
+        tol_t = 1e-6 * max(1.0, float(np.abs(otv).max())) if np.isfinite(otv).all() else 1e-6
+        if rc == 1 and not (adv.same(rv, orv, 1e-6) and adv.same(tv, otv, tol_t)):
+            # A flat valley: the inliers do not determine the pose to the bar (hunt seed 3: five coplanar inliers, singular
+            # values of the projection's Jacobian 812 ... 0.13 -- the two LM runs end 1.3e-6 apart along the flat direction,
+            # where the reprojection moves by 2e-7 px).  Accepted only when the Jacobian says so AND the two poses reproject
+            # alike to 1e-5 px; counted, and bounded below.
+            sv, J = adv.pose_jacobian_singular_values(X[oinl], orv, otv, K)
+            dp = np.concatenate([rv - orv, tv - otv])
+            assert sv[0] > 1e3 * sv[-1] and np.abs(J @ dp).max() <= 1e-5 and np.abs(dp).max() <= 1e-4, (rv, orv, tv, otv, dbg, sv)
+            seen["flat"] += 1
+            return
+        assert adv.same(rv, orv, 1e-6) and adv.same(tv, otv, tol_t), (rv, orv, tv, otv, dbg)
+        seen["found"] += rc == 1
+
+    if explore is not None:
+        from hypothesis import seed as hyp_seed
+        run = hyp_seed(int(explore))(run)
+    try:
+        run()
+    finally:
+        gpu_ctx.set_params(ransac_iterations=500, ransac_reproj_error=0.5, ransac_confidence=float(np.float32(0.999)))
+    print("pnp fuzz:", seen)
+    assert (seen["cases"] >= n_examples * 0.9 and seen["found"] >= 0.4 * seen["cases"] and seen["wild"] <= 0.1 * seen["cases"]
+            and seen["wild"] - seen["wild_within"] <= 0.01 * seen["cases"] and seen["flat"] <= 0.002 * seen["cases"] + 1), seen
+
+
 # ------------------------------------------------------------------ seeded fuzz through vo_track_frame
 @pytest.fixture(scope="module")
 def fuzz_world():
