@@ -182,6 +182,79 @@ def test_essential_pose_adversarial(gpu_ctx, orc):
             assert adv.same(Rg, Ro, 1e-9) and adv.same(tg, to, 1e-9), name
 
 
+def test_essential_pose_fuzz(gpu_ctx, orc):
+    """300 random findEssentialMat(RANSAC) + recoverPose problems (visualOdometry.cpp:152-153, mono_rotation) through
+    vo_essential_pose: 5 .. 2 000 correspondences, outlier rates to 0.7, confidences and thresholds other than the reference's --
+    found / mask / n_good IDENTICAL, E, R, t <= 1e-9 (the bars of test_gpu_parity.py::test_essential_pose_dropin)."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    from test_gpu_parity import _em_scene
+    seen = dict(cases=0, found=0)
+    n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "300"))
+    explore = os.environ.get("VO_FUZZ_SEED")
+
+    @settings(max_examples=n_examples, derandomize=explore is None, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), n=st.sampled_from([5, 6, 8, 20, 60, 300, 900, 2000]),
+           outliers=st.sampled_from([0.0, 0.0, 0.2, 0.5, 0.7]), prob=st.sampled_from([0.9, 0.999, 0.999]),
+           thr=st.sampled_from([0.5, 1.0, 1.0, 3.0]))
+    def run(seed, n, outliers, prob, thr):
+        p1, p2, R, t, F, PP = _em_scene(seed, n, outliers)
+        found, E, Rg, tg, mask, good = gpu_ctx.essential_pose(p1, p2, F, PP, prob, thr)
+        ok, Eo, mo, dbg = orc.find_essential_mat(p1, p2, F, PP, prob, thr)
+        assert found == bool(ok)
+        seen["cases"] += 1
+        if not ok:
+            return
+        go, Ro, to, m2 = orc.recover_pose(Eo, p1, p2, F, PP, mo)
+        assert good == go and np.array_equal(mask, m2)
+        assert adv.same(E, Eo, 1e-9) and adv.same(Rg, Ro, 1e-9) and adv.same(tg, to, 1e-9), (np.abs(E - Eo).max(), np.abs(Rg - Ro).max())
+        seen["found"] += 1
+
+    if explore is not None:
+        from hypothesis import seed as hyp_seed
+        run = hyp_seed(int(explore))(run)
+    run()
+    print("essential fuzz:", seen)
+    assert seen["cases"] >= 0.9 * n_examples and seen["found"] >= 0.8 * seen["cases"], seen
+
+
+def test_triangulate_fuzz(gpu_ctx, orc):
+    """300 random calls of vo_triangulate (main.cpp:169-171): rectified projection pairs of several intrinsics and baselines,
+    0 .. 3 000 point pairs with positive, zero and negative disparities, sub-pixel and far outside the image -- finite
+    where the oracle is finite, <= 1e-5 relative (the bar of test_gpu_parity.py), NaN / inf where it is."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    seen = dict(cases=0, points=0, identical=0)
+
+    @settings(max_examples=300, derandomize=True, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), n=st.sampled_from([0, 1, 2, 63, 64, 65, 500, 3000]), fx=st.sampled_from([300.0, 718.856, 1400.0]),
+           bf=st.sampled_from([-386.1448, -160.0, -30.0, 50.0]), zero=st.sampled_from([0.0, 0.0, 0.05, 0.5]))
+    def run(seed, n, fx, bf, zero):
+        rng = np.random.default_rng(seed)
+        P_l = np.array([[fx, 0, 607.19, 0], [0, fx, 185.2, 0], [0, 0, 1, 0]], np.float32)
+        P_r = P_l.copy()
+        P_r[0, 3] = bf
+        pl = np.stack([rng.uniform(-50, 1300, n), rng.uniform(-50, 430, n)], 1).astype(np.float32)
+        d = rng.uniform(-5, 120, n).astype(np.float32)
+        d[rng.random(n) < zero] = 0.0
+        pr = pl.copy()
+        pr[:, 0] -= d
+        pr[:, 1] += rng.normal(0, 0.3, n).astype(np.float32)
+        got = gpu_ctx.triangulate(P_l, P_r, pl, pr)
+        ref = orc.triangulate(P_l, P_r, pl, pr) if n else np.zeros((0, 3), np.float32)
+        assert got.shape == ref.shape
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        fin = np.isfinite(ref)
+        assert np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])
+        rowmax = np.maximum(1.0, np.abs(np.where(fin, ref, 0)).max(1, keepdims=True) if n else 1.0) * np.ones_like(ref)
+        assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-5 * rowmax[fin])
+        seen["cases"] += 1
+        seen["points"] += n
+        seen["identical"] += int((bits(got) == bits(ref)).all(1).sum()) if n else 0
+
+    run()
+    print("triangulate fuzz:", seen)
+    assert seen["cases"] >= 290 and seen["identical"] >= 0.97 * seen["points"], seen
+
+
 # ------------------------------------------------------------------ integrateOdometryStereo
 def test_integrate_odometry_adversarial(volib, orc):
     """the gates of main.cpp:201 / utils.cpp:80 on NaN / inf / huge motions: a NaN fails every comparison -> not integrated"""
