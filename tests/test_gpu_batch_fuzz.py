@@ -1,0 +1,136 @@
+"""Random batches against the synchronous call (-m gpu).  The contract of include/vo_hip.h: a frame of a vo_batch_run comes
+out BIT FOR BIT as vo_track_frame returns it for the same four images, points and parameters -- whatever the batch looks
+like around it.  The one-frame call is held to the oracle by tests/test_gpu_round6.py::test_track_frame_fuzz; this file
+holds the batch to the one-frame call, so no oracle time is spent and the batches can be many and odd: 1 .. 40 frames
+(every XCD split of lk_circular_kernel's block numbering: 1, 2, 4, 8 frames per group and the remainders), quadruples
+that share, repeat and cross their images (zero motion, time running backwards, the right image as the left), 0 .. 700
+points per frame with off-image and non-finite ones among them, random LK / RANSAC parameters, pinned and probed pose
+schedules, one run or several runs in flight."""
+import os
+
+import numpy as np
+import pytest
+
+import adversarial as adv
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+@pytest.fixture(scope="module")
+def world4():
+    from visual_odom_amd import synth
+    w, h = 640, 256
+    world = synth.StereoWorld(seed=77, width=w, height=h, fx=360.0, cx=319.5, cy=127.5, bf=-190.0, tex_size=1024)
+    L, R, poses, _ = world.render_sequence(4)
+    kps = [synth.select_keypoints(L[k], bucket=16, per_bucket=4) for k in range(4)]
+    return dict(world=world, L=L, R=R, kps=kps, w=w, h=h)
+
+
+@pytest.fixture(scope="module")
+def ctx_pair(volib):
+    batch = volib.Context(0, 640, 256, 1024, 40)
+    single = volib.Context(0, 640, 256, 1024, 1)
+    yield batch, single
+    batch.close()
+    single.close()
+
+
+def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    batch, single = ctx_pair
+    fw = world4
+    seen = dict(batches=0, frames=0, posed=0, empty=0)
+    n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "200"))
+    explore = os.environ.get("VO_FUZZ_SEED")
+
+    @settings(max_examples=n_examples, derandomize=explore is None, deadline=None, database=None, suppress_health_check=list(HealthCheck))
+    @given(seed=st.integers(0, 2 ** 31 - 1), B=st.sampled_from([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 33, 40]),
+           w=st.sampled_from([64, 131, 320, 333, 601, 640]), h=st.sampled_from([64, 97, 160, 256]),
+           max_level=st.sampled_from([0, 2, 3, 3, 3, 4]), max_count=st.sampled_from([1, 10, 30, 30]),
+           iters=st.sampled_from([7, 100, 500]), reproj=st.sampled_from([0.5, 0.5, 2.0]), thr=st.integers(0, 1),
+           sched=st.sampled_from([None, (1, 1), (1, 2), (2, 1), (2, 2)]), runs=st.sampled_from([1, 1, 2, 3]))
+    def run(seed, B, w, h, max_level, max_count, iters, reproj, thr, sched, runs):
+        rng = np.random.default_rng(seed)
+        x0, y0 = int(rng.integers(0, fw["w"] - w + 1)), int(rng.integers(0, fw["h"] - h + 1))
+        roi = (slice(y0, y0 + h), slice(x0, x0 + w))
+        imgs = []                                    # the image table: four stereo pairs, left at 2k, right at 2k + 1
+        for k in range(4):
+            imgs += [fw["L"][k][roi], fw["R"][k][roi]]
+        P_l, P_r = (m.copy() for m in fw["world"].proj_matrices())
+        for P in (P_l, P_r):
+            P[0, 2] -= x0
+            P[1, 2] -= y0
+        prm = dict(lk_max_level=max_level, lk_max_count=max_count, consistency_threshold=thr, ransac_iterations=iters,
+                   ransac_reproj_error=reproj)
+        quads, pts = [], []
+        for b in range(B):
+            kind = rng.integers(0, 10)
+            a, c = (int(v) for v in rng.choice(4, 2, replace=False))
+            if kind == 0:
+                c = a                                 # zero motion: t1 is t0
+            q = [2 * a, 2 * a + 1, 2 * c, 2 * c + 1]
+            if kind == 1:
+                q = [int(v) for v in rng.integers(0, 8, 4)]   # any four images, repeats and swapped eyes included
+            quads.append(q)
+            kp = fw["kps"][q[0] // 2] - np.float32([x0, y0])
+            kp = kp[(kp[:, 0] >= 0) & (kp[:, 0] < w) & (kp[:, 1] >= 0) & (kp[:, 1] < h)]
+            n_kp = int(rng.choice([0, 0, 5, 40, 200, 700]))
+            kp = kp[rng.permutation(len(kp))[:n_kp]]
+            n_rnd = int(rng.integers(0, 40))
+            rnd = np.stack([rng.uniform(-15, w + 15, n_rnd), rng.uniform(-15, h + 15, n_rnd)], 1).astype(np.float32)
+            bad = adv.LK_POINTS[rng.integers(0, len(adv.LK_POINTS), int(rng.integers(0, 4)))]
+            p = np.vstack([kp, rnd, bad]).astype(np.float32)
+            pts.append(p[rng.permutation(len(p))])
+        try:
+            batch.set_params(**prm)
+            single.set_params(**prm)
+            batch.set_schedule(*sched) if sched else batch.set_schedule()
+            batch.batch_configure(8, w, h, B)
+            for i, im in enumerate(imgs):
+                batch.batch_upload_image(i, im)      # views: stride 640
+            batch.batch_set_quads(quads)
+            batch.batch_set_projection(P_l, P_r)
+            for b in range(B):
+                batch.batch_set_points(b, pts[b])
+            for _ in range(runs):                    # (idempotent: several runs in flight leave one run's results)
+                batch.batch_run(volib.STAGE_ALL)
+            batch.batch_sync()
+            for b in range(B):
+                q = quads[b]
+                want = single.track_frame(imgs[q[0]], imgs[q[1]], imgs[q[2]], imgs[q[3]], pts[b], P_l, P_r)
+                got, pose = batch.batch_get_filtered(b), batch.batch_get_pose(b)
+                for name in ("keep_idx_circ", "keep_idx"):
+                    assert np.array_equal(got[name], want[name]), (b, name)
+                for name in ("l0", "r0", "l1", "r1", "xyz"):
+                    assert np.array_equal(bits(got[name]), bits(want[name])), (b, name)
+                seen["frames"] += 1
+                if want["rc"] == volib.VO_ERR_TOO_FEW:
+                    seen["empty"] += 1
+                    continue
+                assert (pose["status"] == 1) == (want["rc"] == 0), (b, pose["status"], want["rc"])
+                assert np.array_equal(pose["inliers"], want["inliers"]), b
+                if len(got["keep_idx"]) == 4 and pose["lm_iters"] < 0:
+                    continue                          # (P3P without a solution: the batch getter zeroes, the call leaves its inputs: vo_hip.h)
+                assert np.array_equal(bits(pose["rvec"]), bits(want["rvec"])) and np.array_equal(bits(pose["tvec"]), bits(want["tvec"])), \
+                    (b, pose["rvec"], want["rvec"], pose["tvec"], want["tvec"])
+                seen["posed"] += want["rc"] == 0
+            seen["batches"] += 1
+        finally:
+            batch.set_schedule()
+
+    if explore is not None:
+        from hypothesis import seed as hyp_seed
+        run = hyp_seed(int(explore))(run)
+    try:
+        run()
+    finally:
+        dflt = dict(lk_max_level=3, lk_max_count=30, consistency_threshold=0, ransac_iterations=500, ransac_reproj_error=0.5)
+        batch.set_params(**dflt)
+        single.set_params(**dflt)
+    print("batch fuzz:", seen)
+    assert seen["batches"] >= n_examples * 0.9 and seen["posed"] >= 0.2 * seen["frames"], seen
