@@ -5,7 +5,8 @@ holds the batch to the one-frame call, so no oracle time is spent and the batche
 (every XCD split of lk_circular_kernel's block numbering: 1, 2, 4, 8 frames per group and the remainders), quadruples
 that share, repeat and cross their images (zero motion, time running backwards, the right image as the left), 0 .. 700
 points per frame with off-image and non-finite ones among them, random LK / RANSAC parameters, pinned and probed pose
-schedules, one run or several runs in flight."""
+schedules, one run or several runs in flight; with VO_STAGE_DETECT in front (carried features + ages in, FAST + bucketing on
+the device feeding LK: against vo_detect_bucket + vo_track_frame) and with mono_rotation (findEssentialMat + recoverPose)."""
 import os
 
 import numpy as np
@@ -33,8 +34,8 @@ def world4():
 
 @pytest.fixture(scope="module")
 def ctx_pair(volib):
-    batch = volib.Context(0, 640, 256, 1024, 40)
-    single = volib.Context(0, 640, 256, 1024, 1)
+    batch = volib.Context(0, 640, 256, 2048, 40)
+    single = volib.Context(0, 640, 256, 2048, 1)
     yield batch, single
     batch.close()
     single.close()
@@ -44,7 +45,7 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
     from hypothesis import HealthCheck, given, settings, strategies as st
     batch, single = ctx_pair
     fw = world4
-    seen = dict(batches=0, frames=0, posed=0, empty=0)
+    seen = dict(batches=0, frames=0, posed=0, empty=0, detected=0, overflow=0)
     n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "200"))
     explore = os.environ.get("VO_FUZZ_SEED")
 
@@ -53,8 +54,10 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
            w=st.sampled_from([64, 131, 320, 333, 601, 640]), h=st.sampled_from([64, 97, 160, 256]),
            max_level=st.sampled_from([0, 2, 3, 3, 3, 4]), max_count=st.sampled_from([1, 10, 30, 30]),
            iters=st.sampled_from([7, 100, 500]), reproj=st.sampled_from([0.5, 0.5, 2.0]), thr=st.integers(0, 1),
-           sched=st.sampled_from([None, (1, 1), (1, 2), (2, 1), (2, 2)]), runs=st.sampled_from([1, 1, 2, 3]))
-    def run(seed, B, w, h, max_level, max_count, iters, reproj, thr, sched, runs):
+           sched=st.sampled_from([None, (1, 1), (1, 2), (2, 1), (2, 2)]), runs=st.sampled_from([1, 1, 2, 3]),
+           detect=st.sampled_from([0, 0, 1]), mono=st.sampled_from([0, 0, 1]), fpb=st.sampled_from([1, 2, 6]),
+           bs=st.sampled_from([0, 16, 40]), fthr=st.sampled_from([20, 45]), redetect=st.sampled_from([0, 300, 2000]))
+    def run(seed, B, w, h, max_level, max_count, iters, reproj, thr, sched, runs, detect, mono, fpb, bs, fthr, redetect):
         rng = np.random.default_rng(seed)
         x0, y0 = int(rng.integers(0, fw["w"] - w + 1)), int(rng.integers(0, fw["h"] - h + 1))
         roi = (slice(y0, y0 + h), slice(x0, x0 + w))
@@ -66,7 +69,8 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
             P[0, 2] -= x0
             P[1, 2] -= y0
         prm = dict(lk_max_level=max_level, lk_max_count=max_count, consistency_threshold=thr, ransac_iterations=iters,
-                   ransac_reproj_error=reproj)
+                   ransac_reproj_error=reproj, mono_rotation=mono)
+        dp = dict(fast_threshold=fthr, fast_nonmax=1, redetect_below=redetect, bucket_size=bs, features_per_bucket=fpb)
         quads, pts = [], []
         for b in range(B):
             kind = rng.integers(0, 10)
@@ -86,6 +90,7 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
             bad = adv.LK_POINTS[rng.integers(0, len(adv.LK_POINTS), int(rng.integers(0, 4)))]
             p = np.vstack([kp, rnd, bad]).astype(np.float32)
             pts.append(p[rng.permutation(len(p))])
+        ages = [rng.integers(0, 12, len(p) + int(rng.integers(0, 5))).astype(np.int32) for p in pts]
         try:
             batch.set_params(**prm)
             single.set_params(**prm)
@@ -95,14 +100,35 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
                 batch.batch_upload_image(i, im)      # views: stride 640
             batch.batch_set_quads(quads)
             batch.batch_set_projection(P_l, P_r)
+            if detect:
+                batch.batch_set_detect_params(**dp)
             for b in range(B):
-                batch.batch_set_points(b, pts[b])
+                batch.batch_set_features(b, pts[b], ages[b]) if detect else batch.batch_set_points(b, pts[b])
+            edge = bs if bs else h // 10
+            if detect and (h // edge + 1) * (w // edge + 1) > 1024:   # beyond the documented bucket grid (vo_hip.h): refused
+                with pytest.raises(volib.VoError) as e:
+                    batch.batch_run(volib.STAGE_ALL | volib.STAGE_DETECT)
+                assert e.value.code == volib.VO_ERR_ARG
+                return
             for _ in range(runs):                    # (idempotent: several runs in flight leave one run's results)
-                batch.batch_run(volib.STAGE_ALL)
+                batch.batch_run(volib.STAGE_ALL | (volib.STAGE_DETECT if detect else 0))
             batch.batch_sync()
             for b in range(B):
                 q = quads[b]
-                want = single.track_frame(imgs[q[0]], imgs[q[1]], imgs[q[2]], imgs[q[3]], pts[b], P_l, P_r)
+                lk_pts = pts[b]
+                if detect:                           # the bucketed set of the frame == vo_detect_bucket on its left t0 image
+                    try:
+                        lk_pts, got_ages = batch.batch_get_features(b)
+                    except volib.VoError as e:
+                        assert e.code == volib.VO_ERR_OVERFLOW
+                        with pytest.raises(volib.VoError):
+                            single.detect_bucket(imgs[q[0]], pts[b], ages[b], **dp)
+                        seen["overflow"] += 1
+                        continue
+                    want_pts, want_ages = single.detect_bucket(imgs[q[0]], pts[b], ages[b], **dp)
+                    assert np.array_equal(bits(lk_pts), bits(want_pts)) and np.array_equal(got_ages, want_ages), (b, "bucketed set")
+                    seen["detected"] += 1
+                want = single.track_frame(imgs[q[0]], imgs[q[1]], imgs[q[2]], imgs[q[3]], lk_pts, P_l, P_r)
                 got, pose = batch.batch_get_filtered(b), batch.batch_get_pose(b)
                 for name in ("keep_idx_circ", "keep_idx"):
                     assert np.array_equal(got[name], want[name]), (b, name)
@@ -112,16 +138,23 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
                 if want["rc"] == volib.VO_ERR_TOO_FEW:
                     seen["empty"] += 1
                     continue
-                assert (pose["status"] == 1) == (want["rc"] == 0), (b, pose["status"], want["rc"])
+                no_e = want["rc"] == 2               # VO_NO_ESSENTIAL (mono_rotation): the PnP model stands, R was left alone
+                # (VO_NO_ESSENTIAL outranks VO_NO_MODEL: the reference throws in recoverPose, visualOdometry.cpp:152-153, before it solves PnP)
+                assert no_e or (pose["status"] == 1) == (want["rc"] == 0), (b, pose["status"], want["rc"])
+                if mono:
+                    assert (batch.batch_get_essential(b, len(got["keep_idx"]))["status"] != 1) == no_e, (b, want["rc"])
                 assert np.array_equal(pose["inliers"], want["inliers"]), b
                 if len(got["keep_idx"]) == 4 and pose["lm_iters"] < 0:
                     continue                          # (P3P without a solution: the batch getter zeroes, the call leaves its inputs: vo_hip.h)
                 assert np.array_equal(bits(pose["rvec"]), bits(want["rvec"])) and np.array_equal(bits(pose["tvec"]), bits(want["tvec"])), \
                     (b, pose["rvec"], want["rvec"], pose["tvec"], want["tvec"])
-                seen["posed"] += want["rc"] == 0
+                if not no_e:
+                    assert np.array_equal(bits(pose["R"]), bits(want["R"])), (b, "R", mono)
+                seen["posed"] += want["rc"] in (0, 2)
             seen["batches"] += 1
         finally:
             batch.set_schedule()
+            batch.batch_set_detect_params()
 
     if explore is not None:
         from hypothesis import seed as hyp_seed
@@ -129,7 +162,7 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
     try:
         run()
     finally:
-        dflt = dict(lk_max_level=3, lk_max_count=30, consistency_threshold=0, ransac_iterations=500, ransac_reproj_error=0.5)
+        dflt = dict(lk_max_level=3, lk_max_count=30, consistency_threshold=0, ransac_iterations=500, ransac_reproj_error=0.5, mono_rotation=0)
         batch.set_params(**dflt)
         single.set_params(**dflt)
     print("batch fuzz:", seen)
