@@ -362,9 +362,10 @@ def test_sequence_loop_guards(volib, small_world):
         ctx.close()
 
 
-@pytest.mark.parametrize("seed,S,ring,pin_sched", [(11, 5, 3, None), (12, 8, 2, (2, 1, 0)), (13, 33, 3, None), (14, 40, 2, (1, 2, 1))])
-def test_lockstep_random_feed_patterns(volib, orc, seed, S, ring, pin_sched):
-    _random_feed(volib, orc, seed, S, ring, pin_sched)
+@pytest.mark.parametrize("seed,S,ring,pin_sched,mono", [(11, 5, 3, None, False), (12, 8, 2, (2, 1, 0), False), (13, 33, 3, None, False),
+                                                         (14, 40, 2, (1, 2, 1), False), (15, 6, 3, None, True)])
+def test_lockstep_random_feed_patterns(volib, orc, seed, S, ring, pin_sched, mono):
+    _random_feed(volib, orc, seed, S, ring, pin_sched, mono)
 
 
 def test_lockstep_random_feed_hunt(volib, orc):
@@ -377,10 +378,10 @@ def test_lockstep_random_feed_hunt(volib, orc):
         seed = int(rng.integers(1 << 30))
         S = int(rng.choice([1, 2, 3, 7, 16, 32, 33, 48]))
         sched = None if rng.random() < 0.5 else (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(0, 2)))
-        _random_feed(volib, orc, seed, S, int(rng.integers(2, 4)), sched)
+        _random_feed(volib, orc, seed, S, int(rng.integers(2, 4)), sched, bool(rng.random() < 0.25))
 
 
-def _random_feed(volib, orc, seed, S, ring, pin_sched):
+def _random_feed(volib, orc, seed, S, ring, pin_sched, mono=False):
     """A seeded random feed of the lock-step loop against one independent reference loop per sequence: every step each
     sequence pushes its next pair from pageable, page-locked or device memory -- or pauses; now and then a sequence is
     reset; states are pulled at random steps (a host synchronisation in the middle of steps in flight).  From 32
@@ -400,10 +401,10 @@ def _random_feed(volib, orc, seed, S, ring, pin_sched):
     ctx = volib.Context(0, 480, 160, 4096, S)
     di = _DeviceImages()
     try:
-        vo = odometry.MultiSequenceOdometry(P_l, P_r, S, 480, 160, ctx=ctx, ring=ring, max_steps=32)
+        vo = odometry.MultiSequenceOdometry(P_l, P_r, S, 480, 160, ctx=ctx, ring=ring, max_steps=32, mono_rotation=mono)
         if pin_sched:
             ctx.set_schedule(*pin_sched)
-        new_loop = lambda: orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3])
+        new_loop = lambda: orc.RefFrameLoop(P_l[0, 0], P_l[0, 2], P_l[1, 2], P_r[0, 3], mono_rotation=mono)
         loops = [new_loop() for _ in range(S)]
         fed, paused = [0] * S, [False] * S
         kinds = np.zeros(3, int)
@@ -450,5 +451,6 @@ def _random_feed(volib, orc, seed, S, ring, pin_sched):
             assert all(r["overflow"] == 0 for r in vo.log(s))
     finally:
         ctx.set_schedule()
+        ctx.set_params(mono_rotation=0)
         ctx.close()
         di.free()
