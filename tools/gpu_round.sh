@@ -1,7 +1,7 @@
 #!/bin/bash
 # THE GPU session driver (one script; rounds 2-5 had one generation each).  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> <part> [<part> ...]'
-# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 soak
+# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab
 # Everything lands in gpurun_out/<tag>/; tools/profile_summary.py / tools/pmc_legs.py / tools/pose_pmc.py turn it into profiles/.
 TAG=${1:-r5}
 shift
@@ -122,5 +122,54 @@ fi
 if has quads; then   # the headline against the number of distinct rendered quadruples and the world seed (one process: tools/quads_table.py)
     stamp "quads table"
     timeout 1500 python tools/quads_table.py ${QMAX:-128} 2> "$OUT/quads_table.err" | tee "$OUT/quads_table.txt"
+fi
+if has hunt; then    # longer, differently seeded runs of every fuzz of the GPU suite (HUNT_SEEDS, default "1 2 3")
+    for SEED in ${HUNT_SEEDS:-1 2 3}; do
+        for T in "tests/test_gpu_round6.py track_frame_fuzz 2000" "tests/test_gpu_round6.py detect_bucket_fuzz 5000" "tests/test_gpu_round6.py pnp_ransac_fuzz 5000" \
+                 "tests/test_gpu_round6.py essential_pose_fuzz 3000" "tests/test_gpu_batch_fuzz.py random_batches 2000"; do
+            set -- $T
+            stamp "hunt $2 seed $SEED x $3"
+            VO_FUZZ_EXAMPLES=$3 VO_FUZZ_SEED=$SEED timeout 900 python -m pytest $1 -m gpu -q -x -s -k "$2" > "$OUT/hunt_$2_$SEED.log" 2>&1
+            grep -E "fuzz:|passed|failed" "$OUT/hunt_$2_$SEED.log" | tee -a "$OUT/summary.txt"
+        done
+        stamp "hunt random feeds of the lock-step loop, seed $SEED x 40"
+        VO_FEED_HUNT=40 VO_FEED_SEED=$SEED timeout 900 python -m pytest tests/test_gpu_sequences.py -m gpu -q -x -k random_feed_hunt > "$OUT/hunt_feed_$SEED.log" 2>&1
+        tail -1 "$OUT/hunt_feed_$SEED.log" | tee -a "$OUT/summary.txt"
+    done
+fi
+if has ingestab; then   # lock-step loop: page-locked / pageable / resident pairs side by side (profiles/r06_ingest_ab.txt)
+    for WL in kitti2000 kitti374; do for ING in pinned host device; do
+        python bench.py --mode sequences --workload $WL --seqs 256 --steps 30 --warmup 4 --no-cpu-baseline --validate 2 --ingest $ING > "$OUT/b_${WL}_${ING}.json" 2>/dev/null
+        python -c "import json; b=json.loads(open('$OUT/b_${WL}_${ING}.json').read().strip().splitlines()[-1]); print('$WL $ING  %.0f fps %.2f ms val %d' % (b['value'], b['ms_per_step'], b['validated_frames']), {k: round(v,2) for k,v in b['config']['stage_ms'].items()}, b['config']['schedule']['prepare'])" | tee -a "$OUT/summary.txt"
+    done; done
+    for S in 8 64; do for ING in pinned host device; do
+        python bench.py --mode sequences --workload kitti374 --seqs $S --steps 60 --warmup 4 --no-cpu-baseline --validate 0 --ingest $ING > "$OUT/b_S${S}_${ING}.json" 2>/dev/null
+        python -c "import json; b=json.loads(open('$OUT/b_S${S}_${ING}.json').read().strip().splitlines()[-1]); print('kitti374 S=$S $ING  %.0f fps %.3f ms' % (b['value'], b['ms_per_step']))" | tee -a "$OUT/summary.txt"
+    done; done
+fi
+if has ingestdev; then  # developer-build A/B of the PCIe ingest inside the loop, schedule pinned (profiles/r06_experiments.md section 1):
+                        # INGEST_AB=wait: VO_INGEST_WAIT 0 / 1 (at once / behind the running step's detection); else VO_INGEST_WAVES = the persistent grid
+    devrun() { # name, env..., bench args in $ARGS
+        local name=$1; shift
+        env VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so "$@" python bench.py --mode sequences --steps 30 --warmup 4 --no-cpu-baseline --validate 0 $ARGS > "$OUT/b_$name.json" 2>/dev/null
+        python -c "import json; b=json.loads(open('$OUT/b_$name.json').read().strip().splitlines()[-1]); print('$name  %.0f fps %.3f ms' % (b['value'], b['ms_per_step']), {k: round(v,2) for k,v in b['config']['stage_ms'].items()})" | tee -a "$OUT/summary.txt"
+    }
+    if [ "$INGEST_AB" = "wait" ]; then
+        for SCH in 2,1,0 2,2,0 1,1,0; do for WL in kitti2000 kitti374; do for S in 256 64 8; do for W in 0 1; do
+            ARGS="--workload $WL --seqs $S --ingest pinned --schedule $SCH"; devrun "wait${W}_${WL}_S${S}_${SCH}" VO_INGEST_WAIT=$W
+        done; done; done; done
+    else
+        for G in 64 128 192 256 384 512; do for WL in kitti2000 kitti374; do
+            ARGS="--workload $WL --seqs 256 --ingest pinned --schedule 2,1,0"; devrun "G${G}_${WL}" VO_INGEST_WAVES=$G
+        done; done
+    fi
+fi
+if has schedab; then    # pinned schedules against the probe's pick on ONE box: SCHED_S sequences, SCHED_LIST "w,s,p ... probe", SCHED_WL, SCHED_REPS
+    S=${SCHED_S:-256}; WL=${SCHED_WL:-kitti374}
+    for rep in $(seq 1 ${SCHED_REPS:-3}); do for sc in ${SCHED_LIST:-1,2,1 2,2,1 probe}; do
+        f="$OUT/ab_${S}_${sc//,/}_$rep.json"
+        timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 60 --warmup 6 --no-cpu-baseline --validate 0 $([ "$sc" = probe ] || echo --schedule $sc) > "$f" 2> "$f.err"
+        python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); s=b['config']['schedule']; print('S=$S $WL rep $rep %-6s %8.0f fps %.3f ms/step  ran %s,%s,%s' % ('$sc', b['value'], b['ms_per_step'], s['pose_waves'], s['pose_streams'], s['prepare']))" | tee -a "$OUT/summary.txt"
+    done; done
 fi
 stamp "done"
