@@ -33,7 +33,9 @@ extern "C" {
 /* positive return codes of the pose calls: the call worked, the reference's algorithm reported a failure */
 #define VO_NO_MODEL 1        /* solvePnPRansac returned false (no consensus); rvec / tvec hold the last hypothesis */
 #define VO_NO_ESSENTIAL 2    /* mono_rotation: findEssentialMat found no model (the reference's recoverPose throws);
-                                R_out is left untouched */
+                                R_out is left untouched.  Outranks VO_NO_MODEL: the reference throws at
+                                visualOdometry.cpp:152-153, before it reaches solvePnPRansac -- rvec / tvec / inliers are
+                                filled as usual, n_inliers == 0 tells a frame whose PnP found nothing either */
 
 typedef struct vo_ctx vo_ctx;
 

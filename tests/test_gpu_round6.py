@@ -364,7 +364,7 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
     vo_track_frame against the oracle's frame.  Seeded (derandomize): the same 300 cases on every run."""
     from hypothesis import HealthCheck, given, settings, strategies as st
     fw = fuzz_world
-    seen = dict(cases=0, posed=0, empty=0, wild=0)
+    seen = dict(cases=0, posed=0, empty=0, wild=0, wild_within=0)
 
     # (VO_FUZZ_EXAMPLES / VO_FUZZ_SEED: a longer or differently seeded hunt by hand; the suite runs the same 300 cases every time)
     n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "300"))
@@ -433,6 +433,8 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
         if rc == 1 and not sane:
             seen["wild"] += 1
             assert not (np.isfinite(got["rvec"]).all() and np.abs(got["rvec"]).max() <= 1e-3 and np.abs(got["tvec"]).max() <= 1e-3)
+            fin = np.isfinite(rv).all() and np.isfinite(tv).all()   # (no bar -- but most of them meet the bar of a sane pose anyway: counted)
+            seen["wild_within"] += bool(fin and adv.same(got["rvec"], rv, 1e-6) and adv.same(got["tvec"], tv, 1e-6 * max(1.0, float(np.abs(tv).max()))))
             return
         tol_t = 1e-6 * max(1.0, float(np.abs(tv).max())) if np.isfinite(tv).all() else 1e-6
         assert adv.same(got["rvec"], rv, 1e-6) and adv.same(got["tvec"], tv, tol_t), (got["rvec"], rv, got["tvec"], tv, dbg)
@@ -447,7 +449,8 @@ def test_track_frame_fuzz(gpu_ctx, orc, fuzz_world):
         gpu_ctx.set_params(lk_max_level=3, lk_max_count=30, lk_epsilon=0.01, lk_min_eig_threshold=1e-3, consistency_threshold=0,
                            ransac_iterations=500, ransac_reproj_error=0.5, ransac_confidence=float(np.float32(0.999)))
     print("fuzz:", seen)
-    assert seen["cases"] >= min(n_examples, 300) and seen["posed"] >= 0.2 * seen["cases"] and seen["wild"] <= 0.25 * seen["cases"], seen
+    assert (seen["cases"] >= min(n_examples, 300) and seen["posed"] >= 0.2 * seen["cases"] and seen["wild"] <= 0.25 * seen["cases"]
+            and seen["wild"] - seen["wild_within"] <= 0.01 * seen["cases"]), seen   # (300 cases: 53 unconverged, 52 of them within the bar anyway)
 
 
 def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
