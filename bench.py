@@ -319,9 +319,9 @@ def main(argv=None):
         not args.mono_rotation and args.frames >= 256
     replay_leg = args.mode == "batch" and not args.no_replay_leg and args.workload.startswith("kitti") and \
         not args.mono_rotation and args.frames >= 256
-    config_legs = default_run and not args.no_configs and world_size == 1
+    config_legs = default_run and not args.no_configs and dist is None
     # N > 1: BASELINE config 5 (one sequence per GPU, exact replay) beside the weak-scaled batch headline
-    config5_leg = world_size > 1 and args.mode == "batch" and args.stages == "full" and args.workload == "kitti2000" and \
+    config5_leg = dist is not None and args.mode == "batch" and args.stages == "full" and args.workload == "kitti2000" and \
         not args.mono_rotation and not args.no_configs
     kept = [] if (replay_leg or config_legs or config5_leg) else None
     if args.mode == "sequences":
@@ -419,7 +419,7 @@ def main(argv=None):
                 "schedule": r5["config"]["schedule"], "stage_ms": r5["config"]["stage_ms"], "roofline": r5["roofline"]})
     if kept and kept[0] is not None:
         kept[0].close()
-    if world_size > 1:
+    if dist is not None:
         # one host per GPU: every rank's slice of the node's cores (replicas.pin_rank), gathered -- the slices must be disjoint
         slices = {k: replicas.gather_values(dist, -1 if pin.get(k) is None else pin[k], dev)   # (dev: RCCL reduces device tensors)
                   for k in ("cpus", "first_cpu", "last_cpu", "numa_node")}
@@ -427,6 +427,7 @@ def main(argv=None):
             out["config"]["host_cores_rank0"] = pin
             out["host_cores_per_rank"] = {k: [int(v) for v in vals] for k, vals in slices.items()}
             out["host_cores_per_rank"]["omp_num_threads_rank0"] = os.environ.get("OMP_NUM_THREADS")
+            out["dist_backend"] = dist.get_backend()   # "nccl" = RCCL on a real node; "gloo" only in the shared-GPU smoke tests
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -619,6 +619,36 @@ def test_batch_run_after_a_dropin_call_reads_the_uploaded_quads(gpu_ctx, volib, 
 
 
 # ------------------------------------------------------------------ eight real ranks on GPU 0
+def test_one_rank_over_rccl():
+    """The N > 1 code path of bench.py over the backend a real node uses: `nccl` (= RCCL) cannot put two ranks on one GPU, so
+    the shared-GPU tests run over gloo -- this one forces the process group at world size 1 (VO_DIST_FORCE=1, the driver's
+    launch line with --nproc-per-node 1): init_process_group("nccl") beside libvo_hip's own HIP runtime, barrier, the MAX / SUM
+    all_reduce and the all_gather on DEVICE tensors, the config-5 leg and the per-rank core slices."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VO_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VO_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "16", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--sustain", "0", "--no-replay-leg", "--validate", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["dist_backend"] == "nccl" and b["ranks"] == 1 and b["n_gpus"] == 1
+    frames = b["value"] * b["ms_per_step"] * 1e-3 * b["steps"]
+    assert abs(frames - 16 * 3) < 1e-6 * frames and b["validated_frames"] == 2
+    c5 = [c for c in b["configs"] if c["name"] == "config5_one_sequence_per_gpu"]
+    assert len(c5) == 1 and len(c5[0]["per_gpu_value"]) == 1 and abs(c5[0]["per_gpu_value"][0] - c5[0]["value"]) <= 1e-6 * c5[0]["value"]
+    assert len(b["host_cores_per_rank"]["cpus"]) == 1
+
+
 def test_eight_ranks_of_bench_share_gpu_zero():
     """the driver's N = 8 launch line with EIGHT real contexts, all on GPU 0 (VO_ALLOW_SHARED_GPU=1, gloo
     for the barrier and the reductions): the real run_batch with per-rank validation, the real config-5 leg (one sequence per

@@ -92,8 +92,8 @@ def pin_rank(local_rank, local_world, numa_of_local_rank=None, omp_cap=32):
 def init(backend=None):
     """process-group init for the aggregation only; returns torch.distributed or None for 1 rank"""
     rank, local_rank, world_size = rank_info()
-    if world_size <= 1:
-        return None
+    if world_size <= 1 and not (os.environ.get("VO_DIST_FORCE") == "1" and "RANK" in os.environ):
+        return None   # (VO_DIST_FORCE=1 under torchrun with ONE rank: the N > 1 code path incl. its RCCL collectives on a 1-GPU box)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
