@@ -73,9 +73,10 @@ void vo_default_params(vo_params *p);
  * (feature.cpp:43-45: FAST threshold 20, nonmaxSuppression true; visualOdometry.cpp:95: re-detect when
  *  fewer than 2000 features are carried over; :106-107: bucket_size = rows / 10 (0 here = that rule),
  *  features_per_bucket = 1).
- * LIMITS of the device bucketing (VO_ERR_ARG beyond them, nothing is computed): 1 <= features_per_bucket <= 8; at most 1024
- * buckets, counted as the reference allocates them, (rows / bucket_size + 1) * (cols / bucket_size + 1) -- KITTI at rows / 10:
- * 11 x 34 = 374, 1080p: 11 x 18 = 198; images up to 4096 pixels wide. */
+ * LIMITS of the device bucketing (VO_ERR_ARG beyond them, nothing is computed): 1 <= features_per_bucket <= 8; buckets counted
+ * as the reference allocates them, n = (rows / bucket_size + 1) * (cols / bucket_size + 1) -- KITTI at rows / 10: 11 x 34 =
+ * 374, 1080p: 11 x 18 = 198 -- n <= 1024, or (fine grids) n <= 4096 with n * features_per_bucket <= 8192; images up to 4096
+ * pixels wide. */
 typedef struct vo_detect_params {
     int fast_threshold;
     int fast_nonmax;

@@ -151,3 +151,11 @@ def pose_jacobian_singular_values(X, rvec, tvec, K):
         d[k] = 1e-6
         J[:, k] = (proj(p + d) - proj(p - d)) / 2e-6
     return np.linalg.svd(J, compute_uv=False), J
+
+
+def bucket_grid_ok(w, h, bucket_size, fpb):
+    """the documented limits of the device bucketing (include/vo_hip.h, vo_detect_params)"""
+    if bucket_size < 1 or fpb < 1 or fpb > 8:
+        return False
+    n = (h // bucket_size + 1) * (w // bucket_size + 1)
+    return n <= 1024 or (n <= 4096 and n * fpb <= 8192)

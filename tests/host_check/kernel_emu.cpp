@@ -651,9 +651,16 @@ int ke_detect(const uint8_t *img, int w, int h, int threshold, int nonmax, int d
         memcpy(out_pts, feat.data() + n_tracked, sizeof(float2) * k);
         return n_new;
     }
+    if (!bucket_grid_ok(w, h, bucket_size, fpb))
+        return -2;
+    const bool fine = (long long)(h / bucket_size + 1) * (w / bucket_size + 1) > BK_MAX_CELLS; // (launch_bucket's choice)
     launch(1, 1, 1, (unsigned)g_bucket_threads, [&] {
-        bucket_kernel(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
-                      out_ages, &n_out, out_cap, nullptr, nullptr, nullptr);
+        if (fine)
+            bucket_kernel<BK_FINE_CELLS>(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
+                                         out_ages, &n_out, out_cap, nullptr, nullptr, nullptr);
+        else
+            bucket_kernel<BK_MAX_CELLS>(feat.data(), fages.data(), &n_tracked, &n_new, fcap, h, w, bucket_size, fpb, (float2 *)out_pts,
+                                        out_ages, &n_out, out_cap, nullptr, nullptr, nullptr);
     });
     return n_out;
 }

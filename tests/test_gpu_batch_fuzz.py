@@ -105,7 +105,7 @@ def test_random_batches_equal_the_synchronous_call(volib, ctx_pair, world4):
             for b in range(B):
                 batch.batch_set_features(b, pts[b], ages[b]) if detect else batch.batch_set_points(b, pts[b])
             edge = bs if bs else h // 10
-            if detect and (h // edge + 1) * (w // edge + 1) > 1024:   # beyond the documented bucket grid (vo_hip.h): refused
+            if detect and not adv.bucket_grid_ok(w, h, edge, fpb):    # beyond the documented bucket grid (vo_hip.h): refused
                 with pytest.raises(volib.VoError) as e:
                     batch.batch_run(volib.STAGE_ALL | volib.STAGE_DETECT)
                 assert e.value.code == volib.VO_ERR_ARG

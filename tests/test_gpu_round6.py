@@ -466,7 +466,7 @@ def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
     yy, xx = np.mgrid[0:fw["h"], 0:fw["w"]]
     board = (((xx // 5 + yy // 5) & 1) * 200 + 20).astype(np.uint8)
     sources = [fw["L"][0], fw["R"][1], fw["L"][2], noise, board]
-    seen = dict(cases=0, redetected=0, corners=0, out=0, refused=0)
+    seen = dict(cases=0, redetected=0, corners=0, out=0, refused=0, fine=0)
     n_examples = int(os.environ.get("VO_FUZZ_EXAMPLES", "1000"))
     explore = os.environ.get("VO_FUZZ_SEED")
 
@@ -498,7 +498,7 @@ def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
         else:
             allp, alla = pts, ages
         edge = bs if bs else h // 10
-        if fpb > 8 or (h // edge + 1) * (w // edge + 1) > 1024:       # the documented limits of the device bucketing (vo_hip.h)
+        if not adv.bucket_grid_ok(w, h, edge, fpb):                    # the documented limits of the device bucketing (vo_hip.h)
             with pytest.raises(volib.VoError) as e:
                 gpu_ctx.detect_bucket(img, pts, ages, fast_threshold=thr, fast_nonmax=nonmax, redetect_below=redetect,
                                       bucket_size=bs, features_per_bucket=fpb)
@@ -511,6 +511,7 @@ def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
         assert np.array_equal(bits(got_p), bits(want_p)), ("points", len(got_p), len(want_p))
         assert np.array_equal(got_a, want_a), "ages"
         seen["cases"] += 1
+        seen["fine"] += (h // edge + 1) * (w // edge + 1) > 1024
         seen["corners"] += len(fast_o)
         seen["out"] += len(want_p)
 
@@ -519,7 +520,7 @@ def test_detect_bucket_fuzz(gpu_ctx, volib, orc, fuzz_world):
         run = hyp_seed(int(explore))(run)
     run()
     print("detect fuzz:", seen)
-    assert seen["cases"] >= 0.4 * n_examples and seen["redetected"] >= 0.3 * seen["cases"] and seen["refused"] > 0 and seen["out"] > 10 * seen["cases"], seen
+    assert seen["cases"] >= 0.4 * n_examples and seen["redetected"] >= 0.3 * seen["cases"] and seen["refused"] > 0 and seen["fine"] > 0 and seen["out"] > 10 * seen["cases"], seen
 
 
 # ------------------------------------------------------------------ the shipped adapter (adapters/feature_hip.cpp)

@@ -639,6 +639,39 @@ def test_adversarial_values_post_and_bucketing(kemu, orc):
             assert np.array_equal(gp, op, equal_nan=True) and np.array_equal(ga, oa), (name, bs, fpb)
 
 
+@pytest.mark.parametrize("threads", [256, 1024])
+def test_bucketing_on_fine_grids(kemu, orc, threads):
+    """bucket_kernel<4096> (round 6: grids of 1 025 .. 4 096 buckets, [q][n_buckets] table in the same LDS) against the oracle:
+    the reference's own rule rows / 10 on a wide, low image (601 x 64: 11 x 101 buckets), a 3-pixel bucket, up to as many per
+    bucket as the table holds -- and the refusal beyond the documented limits"""
+    import adversarial as adv
+    rng = np.random.default_rng(41)
+    kemu.ke_set_bucket_threads(threads)
+    try:
+        cases = ((64, 601, 6, 6), (97, 131, 3, 3), (64, 601, 6, 1), (40, 640, 4, 4))
+        for (h, w, bs, fpb) in cases[:2 if threads == 1024 else 4]:
+            n = (h // bs + 1) * (w // bs + 1)
+            assert 1024 < n <= 4096 and adv.bucket_grid_ok(w, h, bs, fpb), (h, w, bs, fpb, n)
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            img[:, : w // 2] = (img[:, : w // 2] // 64) * 64     # (fewer corners on one half: some buckets stay under their quota)
+            pts = np.stack([rng.uniform(0, w - 0.01, 300), rng.uniform(0, h - 0.01, 300)], 1).astype(np.float32)
+            pts[:len(adv.BUCKET_POINTS)] = adv.BUCKET_POINTS
+            ages = rng.integers(-2, 14, 320).astype(np.int32)
+            gp, ga = ke_detect(kemu, img, pts, ages, bucket_size=bs, fpb=fpb, cap=1 << 16)
+            corners = orc.fast_detect(img)
+            allp, alla = np.vstack([pts, corners]), np.concatenate([ages, np.zeros(len(corners), np.int32)])
+            op, oa = orc.bucketing_features(h, w, allp, alla, bs, fpb)
+            assert len(op) > n // 4, (h, w, bs, fpb, len(op))
+            assert np.array_equal(gp, op, equal_nan=True) and np.array_equal(ga, oa), (h, w, bs, fpb)
+        for (h, w, bs, fpb) in ((64, 601, 6, 8), (256, 640, 3, 1), (64, 64, 1, 2), (96, 160, 9, 9)):
+            assert not adv.bucket_grid_ok(w, h, bs, fpb)
+            img = np.zeros((h, w), np.uint8)
+            with pytest.raises(AssertionError):
+                ke_detect(kemu, img, np.zeros((0, 2), np.float32), np.zeros(0, np.int32), bucket_size=bs, fpb=fpb)
+    finally:
+        kemu.ke_set_bucket_threads(256)
+
+
 @pytest.mark.parametrize("which", ["n=4 duplicate", "n=4 NaN", "n=5 NaN", "n=5 collinear", "all zero"])   # (the whole table: -m gpu)
 def test_adversarial_values_pose_chain(kemu, orc, which):
     """degenerate solvePnPRansac inputs through pnp.hip on the emulator: same status, inliers and control flow as the oracle;

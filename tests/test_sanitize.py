@@ -23,7 +23,7 @@ import pytest
 from conftest import ROOT
 
 QUICK = ["tests/test_kernel_emulation.py", "-k",
-         "(fast or borders or pyramid_and_scharr or decode or lk_negative or small_and_odd or nonfinite or adversarial_values_post or seq_ingest) and not exhaustive "
+         "(fast or borders or pyramid_and_scharr or decode or lk_negative or small_and_odd or nonfinite or adversarial_values_post or seq_ingest or fine_grids) and not exhaustive "
          "and not row_packing",
          ]
 QUICK_ORACLE = ["tests/test_device_math_on_host.py", "tests/test_oracle_images.py", "tests/test_oracle_glue.py", "tests/test_vo_math.py",

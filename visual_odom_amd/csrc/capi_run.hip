@@ -75,8 +75,8 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
         const int cells = (c->h / bs + 1) * (c->w / bs + 1);
-        if (bs < 1 || fpb < 1 || fpb > 8 || cells > 1024)
-            return fail(c, VO_ERR_ARG, "vo_batch_run: bucket grid beyond 1024 cells / 8 features per bucket");
+        if (!bucket_grid_ok(c->w, c->h, bs, fpb))
+            return fail(c, VO_ERR_ARG, "vo_batch_run: bucket grid beyond the limits of the device bucketing (vo_hip.h, vo_detect_params)");
         if (c->w > 4096)
             return fail(c, VO_ERR_ARG, "vo_batch_run: VO_STAGE_DETECT handles images up to 4096 pixels wide");
         // appendNewFeatures only when fewer than redetect_below features were carried in (visualOdometry.cpp:95)

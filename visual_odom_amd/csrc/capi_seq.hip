@@ -419,8 +419,8 @@ int vo_seq_step(vo_ctx *c)
     {
         const int bs = c->dprm.bucket_size > 0 ? c->dprm.bucket_size : c->h / 10;
         const int fpb = c->dprm.features_per_bucket;
-        if (bs < 1 || fpb < 1 || fpb > 8 || (long long)(c->h / bs + 1) * (c->w / bs + 1) > 1024)
-            return fail(c, VO_ERR_ARG, "vo_seq_step: bucket grid beyond 1024 cells / 8 features per bucket");
+        if (!bucket_grid_ok(c->w, c->h, bs, fpb))
+            return fail(c, VO_ERR_ARG, "vo_seq_step: bucket grid beyond the limits of the device bucketing (vo_hip.h, vo_detect_params)");
         if (c->w > 4096)
             return fail(c, VO_ERR_ARG, "vo_seq_step: detection handles images up to 4096 pixels wide");
     }

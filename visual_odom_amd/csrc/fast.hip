@@ -477,14 +477,20 @@ __global__ __launch_bounds__(256) void fast_rowscan_kernel(int *__restrict__ row
     }
 }
 
-constexpr int BK_MAX_CELLS = 1024; // (rows/bucket + 1) * (cols/bucket + 1)
+constexpr int BK_MAX_CELLS = 1024; // (rows/bucket + 1) * (cols/bucket + 1) of the ordinary grid: any features_per_bucket <= 8
 constexpr int BK_MAX_FPB = 8;
 constexpr int BK_CELL_CACHE = 8192; // list entries whose cell is kept in LDS between the passes (16 KB)
+// Round 6 (the fuzz of vo_detect_bucket walked into the 1 024-bucket limit with the reference's own rule rows / 10 on a wide,
+// low image): a second instantiation for FINE grids -- up to 4 096 buckets whose "first q" table is laid out [q][n_buckets]
+// in the same 32 KB, so n_buckets x features_per_bucket <= 8 192 (a 4 096 x 376 panorama at rows / 10: 1 221 buckets, up to 6
+// per bucket; KITTI at a 20-pixel bucket: 1 197).  The ordinary instantiation is the round-5 kernel, layout and LDS unchanged.
+constexpr int BK_FINE_CELLS = 4096;
 
 // one workgroup per frame, of 256 threads or (round 5, launches of a few frames: the kernel is on the critical path of a
 // one-sequence step and of vo_detect_bucket, 35 us per KITTI frame at 6 features per bucket) of 1024: the walks over the
 // list -- 1 + (features_per_bucket - 1) of them -- go four times as wide; the emission, 4 cells per thread, stays on the
 // first 256 threads.  Every phase is order-free (counts, minima, maxima), so the width does not change the result.
+template <int CELLS>
 __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__ feat /* [B][cap] */,
                                                      const int *__restrict__ ages /* [B][cap] */,
                                                      const int *__restrict__ n_tracked,
@@ -495,8 +501,8 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
                                                      int *__restrict__ overflow /* or null */,
                                                      const float2 *__restrict__ corners /* or null: [B][cap] */)
 {
-    __shared__ int s_cnt[BK_MAX_CELLS], s_last[BK_MAX_CELLS];
-    __shared__ int s_first[BK_MAX_FPB][BK_MAX_CELLS];
+    __shared__ int s_cnt[CELLS], s_last[CELLS];
+    __shared__ int s_first_flat[BK_MAX_FPB * BK_MAX_CELLS]; // [q][BK_MAX_CELLS], or [q][nb] on a fine grid
     __shared__ int s_scan[256];
     // the cell of the first BK_CELL_CACHE list entries, computed once: with features_per_bucket = f the list is walked f times,
     // and every walk re-loaded point + age and re-did the two float divisions -- 70 us for ONE frame at f = 6, between the
@@ -505,6 +511,8 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
     const int frame = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int bh = rows / bucket_size, bw = cols / bucket_size;
     const int nb = (bh + 1) * (bw + 1); // the reference allocates this many buckets ("<=" loops)
+    const int fstride = CELLS == BK_MAX_CELLS ? BK_MAX_CELLS : nb;
+#define s_first(q, b) s_first_flat[(q) * fstride + (b)]
     // The list appendNewFeatures leaves (feature.cpp:255-262) is "carried features, then the new corners".  Combined
     // form (corners == null): both live in `feat`.  Split form: the corners were detected ahead of time into their own
     // array (lock-step loop: FAST of a frame's left image runs one step early, off the critical path), element i of the
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
         s_cnt[b] = 0;
         s_last[b] = -1;
         for (int q = 0; q < fpb; q++)
-            s_first[q][b] = INT_MAX;
+            s_first(q, b) = INT_MAX;
     }
     __syncthreads();
     // bucket of feature i, or -1 when Bucket::add_feature ignores it (age >= 10) / the reference
@@ -592,13 +600,13 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
             if (i < n_in) {
                 b = cell_of(pt[k], ag[k]);
                 if (i < BK_CELL_CACHE)
-                    s_cell[i] = (int16_t)b; // (nb <= 1024 cells: fits)
+                    s_cell[i] = (int16_t)b; // (nb <= 4 096 cells: fits)
             }
             int len;
             if (run_of(b, &len)) {
                 atomicAdd(&s_cnt[b], len);
                 atomicMax(&s_last[b], i + len - 1);
-                atomicMin(&s_first[0][b], i);
+                atomicMin(&s_first(0, b), i);
             }
         }
     }
@@ -609,9 +617,9 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
             const int b = i >= n_in ? -2 : i < BK_CELL_CACHE ? (int)s_cell[i] : cell(i);
             int len;
             if (run_of(b, &len)) { // the run's first entry behind the cell's (q - 1)-th feature, if it has one
-                const int prev = s_first[q - 1][b], cand = i > prev ? i : prev == INT_MAX ? INT_MAX : prev + 1;
+                const int prev = s_first(q - 1, b), cand = i > prev ? i : prev == INT_MAX ? INT_MAX : prev + 1;
                 if (cand <= i + len - 1)
-                    atomicMin(&s_first[q][b], cand);
+                    atomicMin(&s_first(q, b), cand);
             }
         }
         __syncthreads();
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
         const int idx = (v / (bw + 1)) * bw + (v % (bw + 1));
         const int c = s_cnt[idx], m = min(c, fpb);
         for (int q = 0; q < m; q++) {
-            const int src = q == 0 ? (c > fpb ? s_last[idx] : s_first[0][idx]) : s_first[q][idx];
+            const int src = q == 0 ? (c > fpb ? s_last[idx] : s_first(0, idx)) : s_first(q, idx);
             if (off + q < out_cap) {
                 OP[off + q] = point(src);
                 OA[off + q] = age(src);
@@ -654,6 +662,16 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const float2 *__restrict__
         }
         off += m;
     }
+#undef s_first
+}
+
+// which grids the device bucketing takes (the hosts' argument checks and launch_bucket share it)
+bool bucket_grid_ok(int w, int h, int bucket_size, int fpb)
+{
+    if (bucket_size < 1 || fpb < 1 || fpb > BK_MAX_FPB)
+        return false;
+    const long long nb = (long long)(h / bucket_size + 1) * (w / bucket_size + 1);
+    return nb <= BK_MAX_CELLS || (nb <= BK_FINE_CELLS && nb * fpb <= (long long)BK_MAX_FPB * BK_MAX_CELLS);
 }
 
 #ifndef VO_HOST_EMUL
@@ -701,8 +719,12 @@ void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_a
     // 16 wavefronts per frame where the kernel is the latency of a step (a handful of frames on an otherwise idle GPU), 4 in
     // big launches that run next to other work (the rule of launch_compact, post.hip)
     const int threads = n_frames <= 4 ? 1024 : 256;
-    hipLaunchKernelGGL(bucket_kernel, dim3(n_frames), dim3(threads), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
-                       bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow, d_corners);
+    if ((long long)(h / bucket_size + 1) * (w / bucket_size + 1) <= BK_MAX_CELLS)
+        hipLaunchKernelGGL(bucket_kernel<BK_MAX_CELLS>, dim3(n_frames), dim3(threads), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
+                           bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow, d_corners);
+    else // (bucket_grid_ok was the callers' check)
+        hipLaunchKernelGGL(bucket_kernel<BK_FINE_CELLS>, dim3(n_frames), dim3(threads), 0, stream, d_feat, d_ages, d_ntracked, d_nnew, cap, h, w,
+                           bucket_size, fpb, d_out_pts, d_out_ages, d_out_n, out_cap, d_active, d_overflow, d_corners);
 }
 
 void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w,

@@ -147,6 +147,8 @@ void launch_detect_bucket(const PyrImage *d_imgs, const Quad *d_quads, const int
 void launch_fast_corners(const PyrImage *d_imgs, const Quad *d_quads, const int *d_detect, int n_frames, int w, int h,
                          int threshold, int nonmax, unsigned long long *d_nmsmask, int *d_rowcnt, int *d_rowoff,
                          const int *d_ntracked, int *d_nnew, int cap, float2 *d_out, hipStream_t stream);
+// grids the device bucketing takes: <= 8 per bucket; <= 1 024 buckets, or <= 4 096 with buckets x per-bucket <= 8 192 (fast.hip)
+bool bucket_grid_ok(int w, int h, int bucket_size, int fpb);
 void launch_bucket(const float2 *d_feat, const float2 *d_corners, const int *d_ages, const int *d_ntracked,
                    const int *d_nnew, int cap, int w, int h, int bucket_size, int fpb, float2 *d_out_pts, int *d_out_ages,
                    int *d_out_n, int out_cap, const int *d_active, int *d_overflow, int n_frames, hipStream_t stream);
