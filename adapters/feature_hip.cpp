@@ -30,6 +30,22 @@ static void check(vo_ctx* c, int rc)
         throw std::runtime_error(vo_last_error(c));
 }
 
+// vo_adapter_keep_pair: what the previous circularMatching_hip call left on the device as its t1 pair
+static bool g_keep_pair = false;
+static long g_kept_calls = 0;
+static struct {
+    const unsigned char *l1, *r1;
+    int cols, rows;
+    size_t step;
+    int64_t id;
+} g_last = {nullptr, nullptr, 0, 0, 0, 0};
+void vo_adapter_keep_pair(bool on)
+{
+    g_keep_pair = on;
+    g_last.id = 0;
+}
+long vo_adapter_kept_calls() { return g_kept_calls; }
+
 void circularMatching_hip(cv::Mat l0, cv::Mat r0, cv::Mat l1, cv::Mat r1, std::vector<cv::Point2f>& p_l0,
                           std::vector<cv::Point2f>& p_r0, std::vector<cv::Point2f>& p_l1, std::vector<cv::Point2f>& p_r1,
                           std::vector<cv::Point2f>& p_l0_ret, FeatureSet& feats)
@@ -42,11 +58,22 @@ void circularMatching_hip(cv::Mat l0, cv::Mat r0, cv::Mat l1, cv::Mat r1, std::v
     std::vector<cv::Point2f> o_l0(n), o_r0(n), o_r1(n), o_l1(n), o_ret(n);
     std::vector<int32_t> keep(n > 0 ? n : 1);
     int m = 0;
+    // the t0 pair is the pair the previous call sent as t1 (opt-in, see feature_hip.h): name the kept pair
+    const bool kept = g_keep_pair && g_last.id != 0 && vo_kept_pair_id(c) == g_last.id && l0.data == g_last.l1 &&
+                      r0.data == g_last.r1 && l0.cols == g_last.cols && l0.rows == g_last.rows && l0.step == g_last.step;
+    g_last.id = 0;
     // cv::Point2f is two packed floats -> reinterpret as float*
-    check(c, vo_circular_match(c, l0.data, r0.data, l1.data, r1.data, l0.cols, l0.rows, (int)l0.step,
-                               (const float*)p_l0.data(), n, (float*)o_l0.data(), (float*)o_r0.data(),
+    check(c, vo_circular_match(c, kept ? nullptr : l0.data, kept ? nullptr : r0.data, l1.data, r1.data, l0.cols, l0.rows,
+                               (int)l0.step, (const float*)p_l0.data(), n, (float*)o_l0.data(), (float*)o_r0.data(),
                                (float*)o_r1.data(), (float*)o_l1.data(), (float*)o_ret.data(), /*status4*/ nullptr,
                                keep.data(), &m, /*apply_consistency*/ 0));
+    g_kept_calls += kept ? 1 : 0;
+    g_last.l1 = l1.data;
+    g_last.r1 = r1.data;
+    g_last.cols = l1.cols;
+    g_last.rows = l1.rows;
+    g_last.step = l1.step;
+    g_last.id = vo_kept_pair_id(c);
     // deleteUnmatchFeaturesCircle's side effects on ages (feature.cpp:83-86,111)
     for (size_t i = 0; i < feats.ages.size(); i++)
         feats.ages[i] += 1;

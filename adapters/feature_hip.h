@@ -44,6 +44,16 @@ void triangulate_hip(cv::Mat& projMatrl, cv::Mat& projMatrr, std::vector<cv::Poi
 // (bucket_size = rows / 10, one feature per bucket: the reference's literals)
 void detectAndBucket_hip(cv::Mat& image, FeatureSet& current_features);
 
+// OPT-IN, default off: the caller promises that the t0 pair of every circularMatching_hip call IS the t1 pair of the call
+// before it -- the reference's loop hands its frames over exactly so (main.cpp:157-158: imageLeft_t0 = imageLeft_t1 shares
+// the pixel buffer).  A call whose t0 images have the size, row step and DATA POINTERS of the previous call's t1 images then
+// names the pair libvo_hip.so kept on the device with its pyramids (vo_hip.h, THE KEPT PAIR) instead of sending it again:
+// two images cross PCIe instead of four and the first hop of the chain starts before they have arrived.  Same results bit
+// for bit as long as the promise holds; the pointers only identify the buffer, they cannot see a caller who rewrites it.
+// Anything else (first call, other buffers, another user of the context in between: vo_kept_pair_id) sends four images.
+void vo_adapter_keep_pair(bool on);
+long vo_adapter_kept_calls(); // circularMatching_hip calls that went without their t0 pair so far
+
 // the context the adapter functions share (one per process: the reference is single-threaded), grown to hold a w x h image
 // and n points; throws std::runtime_error when there is no HIP device (there is no CPU fallback)
 vo_ctx* vo_adapter_context_for(int w, int h, int n);

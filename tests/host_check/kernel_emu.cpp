@@ -84,7 +84,8 @@ struct Heap {
 
 int g_bucket_threads = 256; // ke_set_bucket_threads: width of bucket_kernel's workgroup (256, or 1024 as in launches of <= 4 frames)
 int g_fast_big = 0; // ke_set_fast_big: tile form of the FAST kernel (0: 64 x 16, 1: 64 x 32, 2: 128 x 32)
-int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead
+int g_lk_pair = 0; // ke_set_lk_pair: run the two-features-per-wavefront LK kernel instead (1) / the split chain (2)
+bool g_lk_split_fine = false;
 
 template <typename F>
 void launch(unsigned gx, unsigned gy, unsigned gz, int threads, F body)
@@ -540,7 +541,7 @@ long long ke_fast_compass_pair_check()
     return bad;
 }
 
-void ke_set_lk_pair(int on) { g_lk_pair = on; }
+void ke_set_lk_pair(int on) { g_lk_pair = on == 3 ? 2 : on; g_lk_split_fine = on == 3; } // 0: one launch, 1: pair kernel, 2: hops [0,1)+[1,4), 3: four launches
 void ke_set_fast_big(int on) { g_fast_big = on; }
 void ke_set_bucket_threads(int n) { g_bucket_threads = n; }
 
@@ -581,13 +582,28 @@ int ke_run(const uint8_t *imgs, int n_img, int w, int h, int max_level, int want
     prm.full_chain = full_chain;
     std::vector<float2> out((size_t)4 * n);
     const int cap = n, n_frames = 1, fpg = 1, parts = 8, ppp = (n + parts - 1) / parts;
-    if (g_lk_pair) {
+    if (g_lk_pair == 1) {
         const int ppp2 = ((n + 1) / 2 + parts - 1) / parts; // pairs per part
         for (unsigned b = 0; b < (unsigned)(8 * ppp2); b++) {
             emu::run_block(64, b, 0, 0, [&] {
                 lk_circular_pair_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp2, out.data(), status, prm);
             });
         }
+    } else if (g_lk_pair == 2) {
+        // the synchronous calls' split chain (lk_hops_kernel): hop 0, then hops 1 .. 3 from what hop 0 left in trk / status;
+        // ke_set_lk_pair(3): four launches of one hop each.  The outputs start as garbage the second launch must not rely on.
+        memset(status, 0xA5, (size_t)4 * n);
+        for (auto &o : out)
+            o = make_float2(123456.f, -7.f);
+        const int cuts[2][5] = {{0, 1, 4, 4, 4}, {0, 1, 2, 3, 4}};
+        const int *cut = cuts[g_lk_split_fine ? 1 : 0];
+        for (int k = 0; k < 4 && cut[k] < 4; k++)
+            for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
+                emu::run_block(64, b, 0, 0, [&] {
+                    lk_hops_kernel(d_imgs, &quad, (const float2 *)pts, &n, cap, n_frames, fpg, ppp, out.data(), status, prm, cut[k],
+                                   cut[k + 1]);
+                });
+            }
     } else {
         for (unsigned b = 0; b < (unsigned)(8 * ppp); b++) {
             emu::run_block(64, b, 0, 0, [&] {

@@ -307,5 +307,8 @@ extern "C" int adapter_detect_bucket(const uint8_t *img, int w, int h, float *pt
 #define VO_STEP_PASS                                                                                                        \
     l0, r0, l1, r1, w, h, fx, cx, cy, bf, feat_pts, feat_ages, n_pts, n_ages, cap, translation, rotation, frame_pose,        \
         mono_rotation, out_l0, out_r0, out_l1, out_r1, n_out, integrated
+/* the adapter's opt-in "t0 pair = the previous call's t1 pair" (adapters/feature_hip.h) and its count of such calls */
+extern "C" void adapter_keep_pair(int on) { vo_adapter_keep_pair(on != 0); }
+extern "C" long adapter_kept_calls(void) { return vo_adapter_kept_calls(); }
 extern "C" int ref_frame_step(VO_STEP_ARGS) { return frame_step(VO_STEP_PASS, false); }
 extern "C" int ref_frame_step_adapter(VO_STEP_ARGS) { return frame_step(VO_STEP_PASS, true); }

@@ -683,7 +683,7 @@ def test_product_frame_loop_against_the_reference_sources(gpu_ctx, orc, small_wo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mono", [False, True])
-@pytest.mark.parametrize("entry", ["ref_frame_step", "ref_frame_step_adapter"])
+@pytest.mark.parametrize("entry", ["ref_frame_step", "ref_frame_step_adapter", "ref_frame_step_adapter+keep_pair"])
 def test_reference_sources_run_on_libvo_hip(orc, small_world, mono, entry):
     """THE DROP-IN: the reference's unmodified matchingFeatures() / trackingFrame2Frame() / integrateOdometryStereo()
     (compiled where they lie; visualOdometry.cpp's circularMatching call reaches the SHIPPED adapter adapters/feature_hip.cpp,
@@ -695,6 +695,11 @@ def test_reference_sources_run_on_libvo_hip(orc, small_world, mono, entry):
     if orc.ref_lib() is None or not os.path.exists(so):
         pytest.skip("built only where /root/reference exists (make -C tests/ref_dropin) and shipped with the snapshot")
     hip = ctypes.CDLL(so)
+    keep = entry.endswith("+keep_pair")   # the adapter's opt-in: circularMatching_hip names the kept pair instead of its t0 images
+    entry = entry.split("+")[0]
+    hip.adapter_kept_calls.restype = ctypes.c_long
+    hip.adapter_keep_pair(1 if keep else 0)
+    kept0 = hip.adapter_kept_calls()
     n = 6
     L, R, poses, _ = small_world.render_sequence(n)
     P_l, P_r = small_world.proj_matrices()
@@ -711,6 +716,8 @@ def test_reference_sources_run_on_libvo_hip(orc, small_world, mono, entry):
         assert np.abs(a["tvec"] - b["tvec"]).max() <= 1e-6 and np.abs(a["R"] - b["R"]).max() <= 1e-6
         assert a["integrated"] == b["integrated"] and a["integrated"]
         assert np.abs(cpu.frame_pose - gpu.frame_pose).max() <= 1e-6
+    hip.adapter_keep_pair(0)
+    assert hip.adapter_kept_calls() - kept0 == (n - 2 if keep else 0)   # every call but the first went without its t0 pair
     T0inv = np.linalg.inv(poses[0])
     gt = [(T0inv @ T)[:3] for T in poses]
     from visual_odom_amd import odometry

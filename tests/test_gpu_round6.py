@@ -591,6 +591,76 @@ def test_two_frame_loops_share_one_context(volib, small_world):
     ctx.close()
 
 
+def test_kept_pair_split_chain_edges(volib, small_world):
+    """Round 6: on the kept pair the synchronous calls launch hop 0 of the LK chain (lk_hops_kernel) before the new pair has
+    crossed PCIe and hops 1 .. 3 behind it (capi_run.hip, vo_ctx::defer).  The ordinary cases are
+    test_gpu_round5.py::test_kept_pair_calls_equal_four_image_calls; here the edges of the new path, each against a four-image
+    call on a second context, every output bit for bit: no points, too few points (VO_ERR_TOO_FEW: the pair is kept all the
+    same), the full-chain mode with points that die in hop 0, non-reference LK parameters, mono_rotation, a new point load
+    (the schedule probe runs inside the call: the deferred pair goes the old way), vo_circular_match, 40 calls in a row."""
+    L, R, _, _ = small_world.render_sequence(6)
+    P_l, P_r = small_world.proj_matrices()
+    h, w = L[0].shape
+    from visual_odom_amd import synth
+    base = synth.select_keypoints(L[0], bucket=20, per_bucket=3).astype(np.float32)
+    rng = np.random.default_rng(66)
+    wild = np.vstack([base[:120], [[-3, 10], [w + 30, 5], [np.nan, 4], [5, np.inf], [1e30, 1], [0, 0], [w - 1, h - 1]],
+                      rng.uniform(-15, [w + 15, h + 15], (60, 2))]).astype(np.float32)
+    keys = ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ", "inliers", "rvec", "tvec", "R")
+    ctx = volib.Context(0, w, h, 2048, 1)
+    ref = volib.Context(0, w, h, 2048, 1)
+
+    def both(k0, k1, pts):
+        """kept call on ctx (its t0 pair = pair k0, left by the previous call) against the four-image call on ref"""
+        want = ref.track_frame(L[k0], R[k0], L[k1], R[k1], pts, P_l, P_r)
+        got = ctx.track_frame(None, None, L[k1], R[k1], pts, P_l, P_r)
+        assert got["rc"] == want["rc"], (k0, k1, got["rc"], want["rc"])
+        for key in keys:
+            assert np.array_equal(got[key], want[key], equal_nan=True), (k0, k1, key)
+        return got
+
+    def params(k, **kw):
+        """new parameters on both contexts; vo_set_params drops the kept pair (the pyramid plan may change), so a four-image
+        call leaves pair k again"""
+        ctx.set_params(**kw)
+        ref.set_params(**kw)
+        with pytest.raises(volib.VoError) as e:
+            ctx.track_frame(None, None, L[k], R[k], base, P_l, P_r)
+        assert e.value.code == volib.VO_ERR_STATE
+        ctx.track_frame(L[k - 1], R[k - 1], L[k], R[k], base, P_l, P_r)
+
+    try:
+        ctx.track_frame(L[0], R[0], L[1], R[1], base, P_l, P_r)              # leaves pair 1
+        assert len(both(1, 2, np.zeros((0, 2), np.float32))["l0"]) == 0      # no points (a points-only pull of nothing)
+        assert both(2, 3, base[:3])["rc"] == volib.VO_ERR_TOO_FEW            # ... and the pair of the failed call is kept:
+        g = both(3, 4, base)
+        assert g["rc"] == volib.VO_OK and len(g["inliers"]) > 20
+        params(4, lk_full_chain=1)
+        both(4, 5, wild)                                                     # dead in hop 0, carried through hops 1 .. 3
+        params(5, lk_full_chain=0)
+        both(5, 4, wild)
+        params(4, lk_max_level=2, lk_max_count=7, lk_epsilon=0.03)
+        both(4, 3, base)
+        both(3, 2, wild)
+        params(2, lk_max_level=3, lk_max_count=30, lk_epsilon=0.01, mono_rotation=1)
+        both(2, 3, base)
+        params(3, mono_rotation=0)
+        both(3, 2, base[::7])                                                # another point load: a probe inside the call
+        wantc = ref.circular_match(L[2], R[2], L[1], R[1], wild)
+        gotc = ctx.circular_match(None, None, L[1], R[1], wild)
+        for key in ("l0", "r0", "r1", "l1", "l0_ret", "status4", "keep_idx"):
+            assert np.array_equal(gotc[key], wantc[key], equal_nan=True), key
+        order = [2, 3, 4, 5, 4, 3, 2, 1, 0, 1]
+        prev = 1
+        for i in range(40):
+            k = order[i % len(order)]
+            both(prev, k, base if i % 3 else wild)
+            prev = k
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_batch_run_after_a_dropin_call_reads_the_uploaded_quads(gpu_ctx, volib, small_seq):
     """a drop-in call runs frame 0 on a constant quadruple of its own; the next batch run without a new
     vo_batch_set_quads reads what vo_batch_set_quads last uploaded -- whatever slot pair the drop-in calls used"""

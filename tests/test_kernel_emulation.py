@@ -131,9 +131,11 @@ def _oracle_hops(orc, L0, R0, L1, R1, pts, **kw):
     return np.stack([p1, p2, p3, p4]), np.stack([s1, s2, s3, s4])
 
 
-@pytest.fixture(params=[0, 1], ids=["one-feature-per-wave", "two-features-per-wave"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["one-feature-per-wave", "two-features-per-wave", "hop-0-then-hops-1-3", "four-launches"])
 def lk_variant(request, kemu):
-    """the LK emulation tests run on lk_circular_kernel and on lk_circular_pair_kernel"""
+    """the LK emulation tests run on lk_circular_kernel, on lk_circular_pair_kernel and on lk_hops_kernel (the synchronous
+    calls' split chain: hop 0, then hops 1 .. 3 from what the first launch left in the track / status arrays, which start as
+    garbage; and one launch per hop)"""
     kemu.ke_set_lk_pair(request.param)
     yield request.param
     kemu.ke_set_lk_pair(0)

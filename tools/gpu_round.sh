@@ -1,7 +1,7 @@
 #!/bin/bash
 # THE GPU session driver (one script; rounds 2-5 had one generation each).  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> <part> [<part> ...]'
-# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab
+# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab splitab
 # Everything lands in gpurun_out/<tag>/; tools/profile_summary.py / tools/pmc_legs.py / tools/pose_pmc.py turn it into profiles/.
 TAG=${1:-r5}
 shift
@@ -170,6 +170,13 @@ if has schedab; then    # pinned schedules against the probe's pick on ONE box: 
         f="$OUT/ab_${S}_${sc//,/}_$rep.json"
         timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 60 --warmup 6 --no-cpu-baseline --validate 0 $([ "$sc" = probe ] || echo --schedule $sc) > "$f" 2> "$f.err"
         python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); s=b['config']['schedule']; print('S=$S $WL rep $rep %-6s %8.0f fps %.3f ms/step  ran %s,%s,%s' % ('$sc', b['value'], b['ms_per_step'], s['pose_waves'], s['pose_streams'], s['prepare']))" | tee -a "$OUT/summary.txt"
+    done; done
+fi
+if has splitab; then    # developer-build A/B of the synchronous calls' split LK chain (hop 0 under the t1 pair's PCIe pull + pyramids): VO_SYNC_SPLIT 0 / 1
+    for rep in 1 2 3; do for SP in 0 1; do
+        VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_SYNC_SPLIT=$SP timeout 300 python tools/latency_mode.py 200 > "$OUT/latency_split${SP}_$rep.log" 2>&1
+        echo "== VO_SYNC_SPLIT=$SP rep $rep" | tee -a "$OUT/summary.txt"
+        grep -E "track_frame|adapter calls|stateless|kept pair" "$OUT/latency_split${SP}_$rep.log" | tee -a "$OUT/summary.txt"
     done; done
 fi
 stamp "done"

@@ -89,6 +89,28 @@ def run(what, per_bucket, n):
         dt = time.perf_counter() - t0
         print("  adapter calls vo_circular_match + vo_triangulate + vo_pnp_ransac: %.2f ms/frame = %.0f frames/s (%.2f + %.2f + %.2f)"
               % (1e3 * dt / n, n / dt, 1e3 * tt[0] / n, 1e3 * tt[1] / n, 1e3 * tt[2] / n))
+    elif what == "adapterkept":  # the same three calls with the adapter's opt-in (vo_adapter_keep_pair): circularMatching on the kept pair
+        ctx = _lib.Context(0, world.w, world.h, 4096, 1)
+        K = world.K()
+        ctx.circular_match(L[0], R[0], L[1], R[1], pts[0], apply_consistency=True)
+        tt = [0.0, 0.0, 0.0]
+        t0 = None
+        for i in range(1, 9 + n):
+            if i == 9:
+                t0 = time.perf_counter()
+                tt = [0.0, 0.0, 0.0]
+            a_, b_ = ORDER[i % 8], ORDER[(i + 1) % 8]
+            a = time.perf_counter()
+            cm = ctx.circular_match(None, None, L[b_], R[b_], pts[a_], apply_consistency=True)
+            b = time.perf_counter()
+            xyz = ctx.triangulate(P_l, P_r, cm["l0"], cm["r0"])
+            c_ = time.perf_counter()
+            ctx.pnp_ransac(xyz, cm["l1"], K)
+            d = time.perf_counter()
+            tt[0] += b - a; tt[1] += c_ - b; tt[2] += d - c_
+        dt = time.perf_counter() - t0
+        print("  adapter calls, circularMatching on the kept pair (vo_adapter_keep_pair): %.2f ms/frame = %.0f frames/s (%.2f + %.2f + %.2f)"
+              % (1e3 * dt / n, n / dt, 1e3 * tt[0] / n, 1e3 * tt[1] / n, 1e3 * tt[2] / n))
     elif what == "trackkept":  # the t0 pair = the previous call's t1 pair, kept on the device: two images per call
         ctx = _lib.Context(0, world.w, world.h, 4096, 1)
         ctx.track_frame(L[0], R[0], L[1], R[1], pts[0], P_l, P_r)
@@ -141,5 +163,5 @@ if __name__ == "__main__":
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
         for name, per_bucket in (("~2000 points (6 per bucket)", 6), ("reference default (1 per bucket)", 1)):
             print(name + ":", flush=True)
-            for what in ("track", "trackkept", "adapter", "ring", "stateless", "kept", "pipelined"):
+            for what in ("track", "trackkept", "adapter", "adapterkept", "ring", "stateless", "kept", "pipelined"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), what, str(per_bucket), str(n)], check=False)

@@ -237,6 +237,8 @@ void vo_destroy(vo_ctx *c)
     for (auto &ev : c->ev_trk_free)
         if (ev)
             (void)hipEventDestroy(ev);
+    if (c->ev_t1_ready)
+        (void)hipEventDestroy(c->ev_t1_ready);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
     if (c->h_gather)
@@ -283,6 +285,7 @@ vo_ctx *vo_create(int device, int max_w, int max_h, int max_pts, int max_frames)
     c->stream_em = c->streams.em;
     for (auto &ev : c->ev_trk_free)
         ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_t1_ready, hipEventDisableTiming) == hipSuccess;
 #ifdef VO_DEV_VARIANTS
     // developer build only (python -m visual_odom_amd.build --dev -> libvo_hip_dev.so): VO_SERIAL_POSE=1 enqueues the pose
     // solve on the tracking stream (no overlap), so that a kernel trace shows every kernel's stand-alone duration;
@@ -506,7 +509,8 @@ int vo_batch_configure(vo_ctx *c, int n_images, int w, int h, int n_frames)
 
 namespace vo_capi {
 
-int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle, const float *pts, int n_pts)
+int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle, const float *pts, int n_pts,
+                 hipStream_t on)
 {
     if (!c)
         return VO_ERR_ARG;
@@ -539,9 +543,9 @@ int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind 
             if (n_pts >= 0) { // the call's points (frame 0) and their count with this image
                 if (n_pts > 0)
                     memcpy(c->h_pts_stage, pts, sizeof(float2) * (size_t)n_pts);
-                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream, c->d_pts_stage, c->d_pts, n_pts, c->d_npts);
+                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, on ? on : c->stream, c->d_pts_stage, c->d_pts, n_pts, c->d_npts);
             } else {
-                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, c->stream);
+                launch_pull_image(c->d_stage + (slot - c->h_stage), dst, bytes, on ? on : c->stream);
             }
             VO_HIP_TRY(c, hipGetLastError());
         } else {

@@ -27,7 +27,7 @@ long long g_host_stamp[16];
 // a stream synchronisation, i.e. the host waited for the four uploads (~80 us for KITTI) before it launched anything (108 +
 // 21 us of the call, profiles/r04_experiments.md section 7).
 int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1,
-                              const uint8_t *r1, int w, int h, int stride, const float *pts, int n)
+                              const uint8_t *r1, int w, int h, int stride, const float *pts, int n, bool defer_t1)
 {
     // no t0 images: the t0 pair is the pair the previous call received as t1 (the reference's loop keeps it the same way,
     // main.cpp:157-158) -- it is on the device with its pyramids, two images cross the link instead of four
@@ -51,6 +51,7 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
     static_assert(VO_STAGE_SLOTS >= 4, "one staging slot per image of the call");
     VO_HOST_STAMP(1);
     c->stage_next = 0;
+    c->defer.n = 0;
     const int t0 = keep ? c->tf_base : 0, t1 = t0 ^ 2; // image slots of the two pairs
     const uint8_t *imgs[4] = {l0, r0, l1, r1};
     use_const_quad(c, t0 == 0 ? 0 : 1);
@@ -58,11 +59,34 @@ int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const ui
     // one frame: the call's points replace the whole current set, also the bucketed set a VO_STAGE_DETECT run left
     // current (nothing reads that one any more: sync_all above)
     c->pts_sel = -1;
-    for (int i = keep ? 2 : 0; i < 4; i++) { // the points travel with the last image
+    // Round 6, on the kept pair: hop 0 of the chain (l0 -> r0) reads the t0 pair only, which is on the device with its
+    // pyramids -- so only the points go now (a pull of their own) and the t1 pair is DEFERRED to run_stages, which launches
+    // hop 0 first and sends the pair on the filter stream beside it (vo_ctx::defer): 0.64 -> 0.61 ms per call at 2 039 points,
+    // 0.60 -> 0.58 at 340 (gpurun_out/r6_split1).  Not with four images: two chain launches end on their slowest feature twice
+    // (hop 0 alone 74 - 82 us, hops 1 .. 3 172 - 190, the whole chain 200 - 236) and the t0 pyramids become a launch set of their
+    // own (27 us) -- measured 0.68 -> 0.70 ms, so four images go the way they always went.
+    bool split = defer_t1 && keep;
+#ifdef VO_DEV_VARIANTS
+    static const int split_env = [] { const char *e = getenv("VO_SYNC_SPLIT"); return e ? atoi(e) : 1; }();
+    split = split && split_env != 0 && !c->lk_pair;
+#endif
+    for (int i = keep ? 2 : 0; i < (split ? 2 : 4); i++) { // the points travel with the last image
         rc = upload_image(c, (i < 2 ? t0 : t1) + (i & 1), imgs[i], stride, hipMemcpyHostToDevice, /*idle*/ true, pts, i == 3 ? n : -1);
         if (rc != VO_OK)
             return rc;
         VO_HOST_STAMP(2 + i);
+    }
+    if (split) {
+        if (n > 0)
+            memcpy(c->h_pts_stage, pts, sizeof(float2) * (size_t)n);
+        launch_pull_image(nullptr, nullptr, 0, c->stream, c->d_pts_stage, c->d_pts, n, c->d_npts);
+        VO_HIP_TRY(c, hipGetLastError());
+        c->defer.img[0] = l1;
+        c->defer.img[1] = r1;
+        c->defer.first = t1;
+        c->defer.stride = stride;
+        c->defer.n = 2;
+        c->img_stale[t1] = c->img_stale[t1 + 1] = 1; // (what is in those slots is not this call's pair until run_stages has sent it)
     }
     if (keep) {
         c->pyr_first = t1; // (vo_batch_configure above restored "every pyramid")
@@ -88,7 +112,8 @@ int vo_circular_match(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uin
 {
     if (!c || !n_out)
         return VO_ERR_ARG;
-    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    DeferGuard guard{c};
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n, /*defer_t1*/ true);
     if (rc != VO_OK)
         return rc;
     // a synchronous call: every stage on the tracking stream (run_stages, `serial`), then ONE kernel that gathers whatever
@@ -369,7 +394,8 @@ int vo_track_frame(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_
     if (!c || !P_l || !P_r)
         return VO_ERR_ARG;
     VO_HOST_STAMP(0);
-    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n);
+    DeferGuard guard{c};
+    int rc = single_frame_setup(c, l0, r0, l1, r1, w, h, stride, pts, n, /*defer_t1*/ true);
     if (rc != VO_OK)
         return rc;
     rc = vo_batch_set_projection(c, P_l, P_r);

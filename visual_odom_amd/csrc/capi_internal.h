@@ -158,6 +158,16 @@ struct vo_ctx {
     // as its t0 pair by passing no t0 images (main.cpp:157-158: imageLeft_t0 = imageLeft_t1).  -1: no such pair (no call yet,
     // or the batch / sequence API has touched the image table since)
     int tf_base = -1;
+    // (round 6) The t1 pair of a synchronous drop-in call ON THE KEPT PAIR that single_frame_setup has NOT sent yet: hop 0 of
+    // the LK chain reads the t0 pair only, so run_stages launches it first (lk_hops_kernel) and lets the t1 pair cross PCIe and
+    // get its pyramids on the filter stream beside it; hops 1 .. 3 follow behind ev_t1_ready.  Host pointers of the caller: valid
+    // inside the call that set them only -- vo_track_frame / vo_circular_match clear the record on every way out (DeferGuard).
+    struct Deferred {
+        int n = 0;                         // 2: img[0] / img[1] go to image slots first, first + 1
+        const uint8_t *img[2] = {nullptr, nullptr};
+        int first = 0, stride = 0;
+    } defer;
+    hipEvent_t ev_t1_ready = nullptr;
     // identity of that pair (vo_kept_pair_id): bumped whenever a drop-in call publishes a new t1 pair, so that a caller who
     // shares the context with others can tell whether the pair on the device is still the one ITS last call left
     int64_t tf_gen = 0;
@@ -332,7 +342,9 @@ int select_streams(vo_ctx *c, bool partitioned); // call with every stream idle
 void release_streams(int device, const StreamSet &s);
 void seq_free(vo_ctx *c);
 // idle: the caller has just drained the tracking stream (a synchronous drop-in call); pts / n_pts: the call's points ride along
-int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle = false, const float *pts = nullptr, int n_pts = -1);
+// on: the stream the pull kernel of an idle upload goes to (default: the tracking stream)
+int upload_image(vo_ctx *c, int idx, const void *src, int stride, hipMemcpyKind kind, bool idle = false, const float *pts = nullptr, int n_pts = -1,
+                 hipStream_t on = nullptr);
 int ensure_em(vo_ctx *c);
 int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr, bool dry = false);
 int sync_all(vo_ctx *c);
@@ -351,8 +363,13 @@ int run_stages_auto(vo_ctx *c, int stages, bool timed, hipEvent_t *evs = nullptr
 int get_pose_impl(vo_ctx *c, int frame, double *rvec, double *tvec, double *R, int32_t *inliers, int *n_inliers, int *status, int32_t *dbg4, bool pnp_rotation, int *em_status, bool io_pose = true);
 int seq_begin_step(vo_ctx *c);
 int seq_push(vo_ctx *c, int seq, const void *left, const void *right, int stride, int mode);
-int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h, int stride, const float *pts, int n);
+int single_frame_setup(vo_ctx *c, const uint8_t *l0, const uint8_t *r0, const uint8_t *l1, const uint8_t *r1, int w, int h, int stride, const float *pts, int n, bool defer_t1 = false);
 int single_image_setup(vo_ctx *c, const uint8_t *img, int w, int h, int stride);
+int flush_deferred(vo_ctx *c, hipStream_t on);
+struct DeferGuard { // the deferred t1 pair never outlives the call whose host pointers it holds
+    vo_ctx *c;
+    ~DeferGuard() { c->defer.n = 0; }
+};
 } // namespace vo_capi
 
 using namespace vo_capi;

@@ -4,6 +4,19 @@
 
 namespace vo_capi {
 
+// The t1 pair a synchronous drop-in call deferred (vo_ctx::defer): staged and pulled over PCIe on stream `on`.
+int flush_deferred(vo_ctx *c, hipStream_t on)
+{
+    const int n = c->defer.n;
+    c->defer.n = 0;
+    for (int k = 0; k < n; k++) {
+        int rc = upload_image(c, c->defer.first + k, c->defer.img[k], c->defer.stride, hipMemcpyHostToDevice, /*idle*/ true, nullptr, -1, on);
+        if (rc != VO_OK)
+            return rc;
+    }
+    return VO_OK;
+}
+
 // dry (lock-step loop, schedule probe): everything but the two kernels that advance a sequence's state (seq_carry,
 // seq_integrate) -- the step can then be repeated any number of times
 int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
@@ -24,10 +37,22 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
     const bool prep = sq.on && c->sched.prep; // lock-step loop: pyramids (and, from vo_seq_step, FAST) on the prepare stream
     hipStream_t pyrs = prep ? sq.copy : c->stream;
     int e = 0;
+    // A synchronous drop-in call on the kept pair that left its t1 pair in host memory (single_frame_setup): hop 0 of the LK
+    // chain reads the t0 pair only, so it starts before the t1 pair has crossed PCIe -- lk_hops_kernel [0, 1) on the tracking
+    // stream, the two pulls + the t1 pyramids on the idle filter stream beside it, lk_hops_kernel [1, 4) behind ev_t1_ready.
+    // Same bits as the one-launch chain (tests/test_kernel_emulation.py, the batch-against-call fuzz); the call gets shorter by
+    // what now hides under hop 0.  Any other run that finds a deferred pair sends it first, the old way.
+    const bool split = c->defer.n == 2 && !sq.on && B == 1 && (stages & VO_STAGE_PYRAMID) && (stages & VO_STAGE_LK) &&
+                       !(stages & VO_STAGE_DETECT) && !c->tuning;
+    if (c->defer.n && !split) {
+        int rcd = flush_deferred(c, c->stream);
+        if (rcd != VO_OK)
+            return rcd;
+    }
     if (timed)
         VO_HIP_TRY(c, hipEventRecord(evs[e], pyrs));
     e++;
-    if (stages & VO_STAGE_PYRAMID) {
+    if (!split && (stages & VO_STAGE_PYRAMID)) { // (split: the t1 pyramids follow their pixels, in the LK stage below)
         const PyrImage *tab = c->d_imgs + c->pyr_first;
         const int ni = c->pyr_count;
         if (ni > 0) {
@@ -51,7 +76,7 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
     if (prep)
         VO_HIP_TRY(c, hipEventRecord(sq.ev_pyr, pyrs));
     const int *seq_active = sq.on ? sq.d_active + (size_t)(sq.step % VO_SEQ_INFLIGHT) * sq.S : nullptr;
-    if (!sq.on && (stages & VO_STAGE_LK)) {
+    if (!sq.on && (stages & VO_STAGE_LK) && !split) { // (split: checked behind the deferred pyramids, below)
         for (int f = 0; f < B; f++) {
             const Quad &q = c->h_quads[f];
             if (c->img_stale[q.l0] | c->img_stale[q.r0] | c->img_stale[q.l1] | c->img_stale[q.r1])
@@ -151,6 +176,26 @@ int run_stages(vo_ctx *c, int stages, bool timed, hipEvent_t *evs, bool dry)
         lp.epsilon = eps * eps;
         lp.min_eig = (float)c->prm.lk_min_eig_threshold;
         lp.full_chain = c->prm.lk_full_chain;
+        if (split) {
+            const Quad &q = c->h_quads[0];
+            if (c->img_stale[q.l0] | c->img_stale[q.r0])
+                return fail(c, VO_ERR_STATE, "synchronous call: the t0 pair has no pyramids");
+            launch_lk_hops(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
+                           c->d_status2[wset], lp, 0, 1, c->stream);
+            hipStream_t side = c->stream_filter; // idle: the chain of a synchronous call stays on the tracking stream
+            const int t1 = c->defer.first;
+            int rcd = flush_deferred(c, side);
+            if (rcd != VO_OK)
+                return rcd;
+            launch_pyramid_fused(c->d_imgs + t1, 2, c->levels, c->lw, c->lh, c->lstride, side);
+            c->img_stale[t1] = c->img_stale[t1 + 1] = 0;
+            VO_HIP_TRY(c, hipEventRecord(c->ev_t1_ready, side));
+            VO_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_t1_ready, 0));
+            if (c->img_stale[q.l1] | c->img_stale[q.r1])
+                return fail(c, VO_ERR_STATE, "synchronous call: the t1 pair has no pyramids");
+            launch_lk_hops(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],
+                           c->d_status2[wset], lp, 1, 4, c->stream);
+        } else
 #ifdef VO_DEV_VARIANTS
         if (c->lk_pair)
             launch_lk_circular_pair(c->d_imgs, c->quads_cur, cur_pts(c), cur_npts(c), cap, c->max_pts_set, B, c->d_trk2[wset],

@@ -70,15 +70,17 @@ __device__ __forceinline__ void lk_weights(float a, float b, uint32_t &wt, uint3
 #ifndef VO_LK_ATTRS
 #define VO_LK_ATTRS __launch_bounds__(64, 7)
 #endif
-__global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs,
-                                                          const Quad *__restrict__ quads,
-                                                          const float2 *__restrict__ pts_in,
-                                                          const int *__restrict__ n_pts, int cap,
-                                                          int n_frames, int fpg /* 1, 2, 4 or 8 */,
-                                                          int ppp /* features per part */,
-                                                          float2 *__restrict__ trk,      // [B][4][cap]
-                                                          uint8_t *__restrict__ status,  // [B][4][cap]
-                                                          LkParams prm)
+// The body of the kernel.  SPLIT = false: the whole chain (lk_circular_kernel, every batch / lock-step launch).  SPLIT = true
+// (lk_hops_kernel, round 6, the synchronous drop-in calls only): hops hop_begin .. hop_end - 1 of the chain -- a launch that does
+// not start at hop 0 continues from what the launch before it wrote for hop_begin - 1 (position, status), with the same "this
+// feature is going to be dropped anyway" rule, so two launches [0, 1) + [1, 4) write bit for bit what one launch writes.
+template <bool SPLIT>
+__device__ __forceinline__ void lk_circular_body(const PyrImage *__restrict__ imgs, const Quad *__restrict__ quads,
+                                                 const float2 *__restrict__ pts_in, const int *__restrict__ n_pts, int cap,
+                                                 int n_frames, int fpg /* 1, 2, 4 or 8 */, int ppp /* features per part */,
+                                                 float2 *__restrict__ trk,     // [B][4][cap]
+                                                 uint8_t *__restrict__ status, // [B][4][cap]
+                                                 const LkParams prm, int hop_begin, int hop_end)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_jt[LK_JT_H * LK_JT_W];
 
@@ -106,8 +108,19 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
 
     const float2 p = pts_in[(size_t)frame * cap + f];
     float prevPtX = unif(p.x), prevPtY = unif(p.y);
+    if (SPLIT && hop_begin > 0) {
+        // the chain so far: hop_begin - 1 as the previous launch left it.  A feature that launch saw dead (see the end of the
+        // hop loop) has its remaining hops reported already.
+        const size_t o = ((size_t)frame * 4 + (hop_begin - 1)) * cap + f;
+        const float2 q0 = trk[o];
+        const bool dead0 = status[o] == 0 || q0.x < 0.f || q0.y < 0.f || (hop_begin == 1 && (p.x < 0.f || p.y < 0.f));
+        if (dead0 && !prm.full_chain)
+            return;
+        prevPtX = unif(q0.x);
+        prevPtY = unif(q0.y);
+    }
 
-    for (int hop = 0; hop < 4; hop++) {
+    for (int hop = SPLIT ? hop_begin : 0; hop < (SPLIT ? hop_end : 4); hop++) {
         // hop chain: l0 -> r0 -> r1 -> l1 -> l0
         const int pi = hop == 0 ? q.l0 : hop == 1 ? q.r0 : hop == 2 ? q.r1 : q.l1;
         const int ni = hop == 0 ? q.r0 : hop == 1 ? q.r1 : hop == 2 ? q.l1 : q.l0;
@@ -381,6 +394,29 @@ __global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs
         prevPtX = unif(outX);
         prevPtY = unif(outY);
     }
+}
+
+__global__ VO_LK_ATTRS void lk_circular_kernel(const PyrImage *__restrict__ imgs,
+                                                          const Quad *__restrict__ quads,
+                                                          const float2 *__restrict__ pts_in,
+                                                          const int *__restrict__ n_pts, int cap,
+                                                          int n_frames, int fpg /* 1, 2, 4 or 8 */,
+                                                          int ppp /* features per part */,
+                                                          float2 *__restrict__ trk,      // [B][4][cap]
+                                                          uint8_t *__restrict__ status,  // [B][4][cap]
+                                                          LkParams prm)
+{
+    lk_circular_body<false>(imgs, quads, pts_in, n_pts, cap, n_frames, fpg, ppp, trk, status, prm, 0, 4);
+}
+
+// Hops hop_begin .. hop_end - 1 only: the synchronous drop-in calls (capi_run.hip) launch hop 0 -- which reads the t0 pair
+// only -- while the t1 pair is still crossing PCIe and its pyramids are being built on another stream, then hops 1 .. 3.
+__global__ VO_LK_ATTRS void lk_hops_kernel(const PyrImage *__restrict__ imgs, const Quad *__restrict__ quads,
+                                           const float2 *__restrict__ pts_in, const int *__restrict__ n_pts, int cap,
+                                           int n_frames, int fpg, int ppp, float2 *__restrict__ trk,
+                                           uint8_t *__restrict__ status, LkParams prm, int hop_begin, int hop_end)
+{
+    lk_circular_body<true>(imgs, quads, pts_in, n_pts, cap, n_frames, fpg, ppp, trk, status, prm, hop_begin, hop_end);
 }
 
 // Developer variant: compiled into libvo_hip_dev.so (python -m visual_odom_amd.build --dev) and into the CPU emulator of
@@ -736,6 +772,20 @@ void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float
     dim3 grid((unsigned)(8 * groups * ppp));
     hipLaunchKernelGGL(lk_circular_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames,
                        fpg, ppp, d_trk, d_status, prm);
+}
+
+void launch_lk_hops(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts, int cap, int max_pts,
+                    int n_frames, float2 *d_trk, uint8_t *d_status, const LkParams &prm, int hop_begin, int hop_end,
+                    hipStream_t stream)
+{
+    if (max_pts <= 0 || n_frames <= 0 || hop_begin < 0 || hop_end > 4 || hop_begin >= hop_end)
+        return;
+    const int fpg = n_frames >= 8 ? 8 : n_frames >= 4 ? 4 : n_frames >= 2 ? 2 : 1;
+    const int parts = 8 / fpg, ppp = (max_pts + parts - 1) / parts;
+    const int groups = (n_frames + fpg - 1) / fpg;
+    dim3 grid((unsigned)(8 * groups * ppp));
+    hipLaunchKernelGGL(lk_hops_kernel, grid, dim3(64), 0, stream, d_imgs, d_quads, d_pts, d_npts, cap, n_frames, fpg, ppp,
+                       d_trk, d_status, prm, hop_begin, hop_end);
 }
 
 #ifdef VO_DEV_VARIANTS

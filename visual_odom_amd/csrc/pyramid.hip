@@ -1010,7 +1010,8 @@ void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipS
                        void *pts_dst, int n_pts, int *count_dst)
 {
     const uint32_t n16 = (uint32_t)((bytes + 15) / 16), n8 = pts_dst ? (uint32_t)n_pts : 0u;
-    hipLaunchKernelGGL(pull_image_kernel, dim3((n16 + 255) / 256 + (n8 + 255) / 256), dim3(256), 0, stream, (const uint4 *)src_pinned_dev,
+    const uint32_t blocks = (n16 + 255) / 256 + (n8 + 255) / 256; // (bytes == 0: the points and their count alone)
+    hipLaunchKernelGGL(pull_image_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, (const uint4 *)src_pinned_dev,
                        (uint4 *)dst, n16, (const uint2 *)pts_pinned_dev, (uint2 *)pts_dst, n8, count_dst, n_pts);
 }
 

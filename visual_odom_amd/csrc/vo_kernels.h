@@ -133,6 +133,10 @@ void launch_pull_image(const void *src_pinned_dev, void *dst, size_t bytes, hipS
 void launch_lk_circular(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
                         const LkParams &prm, hipStream_t stream);
+// hops hop_begin .. hop_end - 1 of the chain (lk_hops_kernel; [0, 1) + [1, 4) == launch_lk_circular bit for bit)
+void launch_lk_hops(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts, int cap, int max_pts,
+                    int n_frames, float2 *d_trk, uint8_t *d_status, const LkParams &prm, int hop_begin, int hop_end,
+                    hipStream_t stream);
 #ifdef VO_DEV_VARIANTS
 void launch_lk_circular_pair(const PyrImage *d_imgs, const Quad *d_quads, const float2 *d_pts, const int *d_npts,
                         int cap, int max_pts, int n_frames, float2 *d_trk, uint8_t *d_status,
