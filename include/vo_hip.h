@@ -236,7 +236,8 @@ int vo_integrate_odometry(double *pose16, const double *R9, const double *t3, fl
  * THE KEPT PAIR (the reference's `imageLeft_t0 = imageLeft_t1; imageRight_t0 = imageRight_t1`, main.cpp:157-158):
  * img_l0 == NULL and img_r0 == NULL name the stereo pair the previous vo_track_frame / vo_circular_match of this context
  * received as (img_l1, img_r1) -- it is still on the device with its pyramids, so only the new pair crosses the link and
- * only its pyramids are built; results are those of the call with all four images.  vo_detect_bucket / vo_fast_detect
+ * only its pyramids are built (and the chain's first hop, l0 -> r0, runs meanwhile: 0.61-0.63 ms per call); results are
+ * those of the call with all four images.  vo_detect_bucket / vo_fast_detect
  * with img == NULL read the kept pair's LEFT image (what matchingFeatures detects on next, visualOdometry.cpp:95-108);
  * with an image of their own they leave the kept pair alone.  VO_ERR_STATE when there is no kept pair of this size:
  * first call, another w x h, or a vo_batch_* upload / configure of another shape / vo_seq_configure since (they own the
