@@ -661,6 +661,85 @@ def test_kept_pair_split_chain_edges(volib, small_world):
         ref.close()
 
 
+def test_kept_pair_call_fuzz(volib, fuzz_world):
+    """Random walks of synchronous calls: one context names the kept pair whenever the call's t0 pair IS the previous call's t1
+    pair (the split LK chain of round 6: hop 0 under the new pair's PCIe pull), a second context gets all four images every
+    time -- every output of every call bit for bit.  Random ROIs of a rendered sequence (w, h arbitrary, stride 640; a new ROI
+    or a parameter change drops the kept pair: four images on both), 0 .. 500 points incl. adversarial ones, vo_track_frame and
+    vo_circular_match, detections on the kept image and on others in between, full-chain mode on and off, mono_rotation.
+    VO_FUZZ_EXAMPLES / VO_FUZZ_SEED: longer, differently seeded hunts (tools/gpu_round.sh hunt)."""
+    fw = fuzz_world
+    n_calls = int(os.environ.get("VO_FUZZ_EXAMPLES", "300"))
+    rng = np.random.default_rng(int(os.environ.get("VO_FUZZ_SEED", "20261001")))
+    P_l0, P_r0 = fw["world"].proj_matrices()
+    keys = ("l0", "r0", "l1", "r1", "xyz", "keep_idx", "keep_idx_circ", "inliers", "rvec", "tvec", "R")
+    ctx = volib.Context(0, fw["w"], fw["h"], 1024, 1)
+    ref = volib.Context(0, fw["w"], fw["h"], 1024, 1)
+    seen = dict(calls=0, kept=0, circ=0, ok=0, detect=0)
+    defaults = dict(lk_max_level=3, lk_max_count=30, lk_epsilon=0.01, lk_min_eig_threshold=1e-3, lk_full_chain=0, mono_rotation=0,
+                    consistency_threshold=0, ransac_iterations=500)
+    try:
+        roi = k_prev = None           # the pair ctx holds: frame k_prev of this ROI (None: no kept pair)
+        for _ in range(n_calls):
+            if roi is None or rng.random() < 0.07:
+                w = int(rng.choice([64, 96, 131, 200, 320, 333, 480, 601, 640]))
+                h = int(rng.choice([64, 97, 128, 160, 200, 256]))
+                x0, y0 = int(rng.integers(0, fw["w"] - w + 1)), int(rng.integers(0, fw["h"] - h + 1))
+                roi, k_prev = (slice(y0, y0 + h), slice(x0, x0 + w)), None
+                P_l, P_r = P_l0.copy(), P_r0.copy()
+                P_l[0, 2] -= x0; P_l[1, 2] -= y0; P_r[0, 2] -= x0; P_r[1, 2] -= y0
+            if rng.random() < 0.08:   # new parameters: vo_set_params drops the kept pair
+                prm = dict(defaults, lk_max_level=int(rng.choice([1, 2, 3, 3, 4])), lk_max_count=int(rng.choice([3, 10, 30, 30])),
+                           lk_full_chain=int(rng.integers(0, 2)), mono_rotation=int(rng.random() < 0.2),
+                           consistency_threshold=int(rng.integers(0, 2)), ransac_iterations=int(rng.choice([7, 100, 500])))
+                ctx.set_params(**prm)
+                ref.set_params(**prm)
+                k_prev = None
+            k0 = int(rng.integers(0, 4)) if k_prev is None else k_prev
+            k1 = k0 + 1 if k0 == 0 else k0 - 1 if k0 == 3 else k0 + int(rng.choice([-1, 1]))
+            kept = k_prev is not None and rng.random() < 0.9
+            imgs = [fw["L"][k0][roi], fw["R"][k0][roi], fw["L"][k1][roi], fw["R"][k1][roi]]
+            hh, ww = imgs[0].shape
+            if kept and rng.random() < 0.15:   # detection on the kept pair's left image / on another image: the pair stays
+                none = (np.zeros((0, 2), np.float32), np.zeros(0, np.int32))
+                a = ctx.detect_bucket(None, *none, features_per_bucket=2)
+                b = ref.detect_bucket(imgs[0], *none, features_per_bucket=2)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                if rng.random() < 0.5:
+                    assert np.array_equal(ctx.fast_detect(imgs[3]), ref.fast_detect(imgs[3]))
+                seen["detect"] += 1
+            kp = fw["kps"][min(k0, 2)] - np.float32([roi[1].start, roi[0].start])
+            kp = kp[(kp[:, 0] >= 0) & (kp[:, 0] < ww) & (kp[:, 1] >= 0) & (kp[:, 1] < hh)]
+            kp = kp[rng.permutation(len(kp))[:int(rng.integers(0, 400))]]
+            n_rand = int(rng.integers(0, 100))
+            rnd = np.stack([rng.uniform(-15, ww + 15, n_rand), rng.uniform(-15, hh + 15, n_rand)], 1).astype(np.float32)
+            bad = adv.LK_POINTS[rng.integers(0, len(adv.LK_POINTS), int(rng.integers(0, 6)))]
+            pts = np.vstack([kp, rnd, bad]).astype(np.float32)
+            pts = pts[rng.permutation(len(pts))]
+            t0 = (None, None) if kept else (imgs[0], imgs[1])
+            if rng.random() < 0.15:
+                got = ctx.circular_match(*t0, imgs[2], imgs[3], pts)
+                want = ref.circular_match(*imgs, pts)
+                for key in ("l0", "r0", "r1", "l1", "l0_ret", "status4", "keep_idx"):
+                    assert np.array_equal(got[key], want[key], equal_nan=True), (seen, key)
+                seen["circ"] += 1
+            else:
+                got = ctx.track_frame(*t0, imgs[2], imgs[3], pts, P_l, P_r)
+                want = ref.track_frame(*imgs, pts, P_l, P_r)
+                assert got["rc"] == want["rc"], (seen, got["rc"], want["rc"])
+                for key in keys:
+                    assert np.array_equal(got[key], want[key], equal_nan=True), (seen, key)
+                seen["ok"] += got["rc"] == 0
+            seen["calls"] += 1
+            seen["kept"] += kept
+            k_prev = k1
+    finally:
+        ctx.close()
+        ref.close()
+    print("kept-pair fuzz:", seen)
+    assert seen["kept"] >= 0.6 * n_calls and seen["ok"] >= 0.3 * n_calls and seen["circ"] >= 0.05 * n_calls, seen
+
+
 def test_batch_run_after_a_dropin_call_reads_the_uploaded_quads(gpu_ctx, volib, small_seq):
     """a drop-in call runs frame 0 on a constant quadruple of its own; the next batch run without a new
     vo_batch_set_quads reads what vo_batch_set_quads last uploaded -- whatever slot pair the drop-in calls used"""

@@ -126,7 +126,9 @@ fi
 if has hunt; then    # longer, differently seeded runs of every fuzz of the GPU suite (HUNT_SEEDS, default "1 2 3")
     for SEED in ${HUNT_SEEDS:-1 2 3}; do
         for T in "tests/test_gpu_round6.py track_frame_fuzz 2000" "tests/test_gpu_round6.py detect_bucket_fuzz 5000" "tests/test_gpu_round6.py pnp_ransac_fuzz 5000" \
-                 "tests/test_gpu_round6.py essential_pose_fuzz 3000" "tests/test_gpu_batch_fuzz.py random_batches 2000"; do
+                 "tests/test_gpu_round6.py essential_pose_fuzz 3000" "tests/test_gpu_batch_fuzz.py random_batches 2000" \
+                 "tests/test_gpu_round6.py kept_pair_call_fuzz 20000"; do
+            [ -n "$HUNT_ONLY" ] && [[ "$T" != *"$HUNT_ONLY"* ]] && continue
             set -- $T
             stamp "hunt $2 seed $SEED x $3"
             VO_FUZZ_EXAMPLES=$3 VO_FUZZ_SEED=$SEED timeout 900 python -m pytest $1 -m gpu -q -x -s -k "$2" > "$OUT/hunt_$2_$SEED.log" 2>&1
