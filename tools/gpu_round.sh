@@ -1,7 +1,7 @@
 #!/bin/bash
 # THE GPU session driver (one script; rounds 2-5 had one generation each).  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> <part> [<part> ...]'
-# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab splitab
+# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab splitab probereps
 # Everything lands in gpurun_out/<tag>/; tools/profile_summary.py / tools/pmc_legs.py / tools/pose_pmc.py turn it into profiles/.
 TAG=${1:-r5}
 shift
@@ -166,11 +166,11 @@ if has ingestdev; then  # developer-build A/B of the PCIe ingest inside the loop
         done; done
     fi
 fi
-if has schedab; then    # pinned schedules against the probe's pick on ONE box: SCHED_S sequences, SCHED_LIST "w,s,p ... probe", SCHED_WL, SCHED_REPS
+if has schedab; then    # pinned schedules against the probe's pick on ONE box: SCHED_S sequences, SCHED_LIST "w,s,p ... probe", SCHED_WL, SCHED_REPS, SCHED_INGEST
     S=${SCHED_S:-256}; WL=${SCHED_WL:-kitti374}
     for rep in $(seq 1 ${SCHED_REPS:-3}); do for sc in ${SCHED_LIST:-1,2,1 2,2,1 probe}; do
         f="$OUT/ab_${S}_${sc//,/}_$rep.json"
-        timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 60 --warmup 6 --no-cpu-baseline --validate 0 $([ "$sc" = probe ] || echo --schedule $sc) > "$f" 2> "$f.err"
+        timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 60 --warmup 6 --no-cpu-baseline --validate 0 ${SCHED_INGEST:+--ingest $SCHED_INGEST} $([ "$sc" = probe ] || echo --schedule $sc) > "$f" 2> "$f.err"
         python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); s=b['config']['schedule']; print('S=$S $WL rep $rep %-6s %8.0f fps %.3f ms/step  ran %s,%s,%s' % ('$sc', b['value'], b['ms_per_step'], s['pose_waves'], s['pose_streams'], s['prepare']))" | tee -a "$OUT/summary.txt"
     done; done
 fi
@@ -180,5 +180,15 @@ if has splitab; then    # developer-build A/B of the synchronous calls' split LK
         echo "== VO_SYNC_SPLIT=$SP rep $rep" | tee -a "$OUT/summary.txt"
         grep -E "track_frame|adapter calls|stateless|kept pair" "$OUT/latency_split${SP}_$rep.log" | tee -a "$OUT/summary.txt"
     done; done
+fi
+if has probereps; then   # the schedule the loop settles on, run after run on ONE box: PROBE_REPS runs of PROBE_LIST entries "S ingest workload"
+    for rep in $(seq 1 ${PROBE_REPS:-4}); do
+        while read -r S ING WL; do
+            [ -z "$S" ] && continue
+            f="$OUT/pr_${S}_${ING}_${WL}_$rep.json"
+            timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 60 --warmup 6 --no-cpu-baseline --validate 0 --ingest $ING > "$f" 2> "$f.err"
+            python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); s=b['config']['schedule']; print('S=$S $ING $WL rep $rep %8.0f fps %.3f ms/step  ran %s,%s,%s' % (b['value'], b['ms_per_step'], s['pose_waves'], s['pose_streams'], s['prepare']), {k: round(v, 2) for k, v in s.get('probe_ms', {}).items() if 'real' in k})" | tee -a "$OUT/summary.txt"
+        done <<< "${PROBE_LIST:-256 pinned kitti374}"
+    done
 fi
 stamp "done"
