@@ -577,7 +577,7 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
     ctx.set_params(lk_max_level=max_level, mono_rotation=int(args.mono_rotation))
     ctx.set_schedule(*[int(v) for v in args.schedule.split(",")]) if args.schedule else ctx.set_schedule()  # w,s,p[,wide]
     ctx.batch_set_detect_params(features_per_bucket=per_bucket)
-    ctx.seq_configure(S, w, h, args.ring, K + W + 8 + 280)
+    ctx.seq_configure(S, w, h, args.ring, K + W + 8 + 520)
     ctx.batch_set_projection(*world.proj_matrices())
 
     def feed(s, k):  # rendered pair sequence s shows at its k-th pair: same street, every sequence phase-shifted
@@ -608,10 +608,10 @@ def run_sequences(args, rank, world_size, local_dev, dev, dist, barrier, torch, 
 
     for k in range(W + 1):  # the first step of a sequence only builds pyramids (main.cpp:110-113)
         one_step(k)
-    # the library settles its schedule over the first steps of a loop (probe + up to four candidates timed over real steps,
-    # vo_schedule in vo_hip.h): warm-up goes on until that is done -- the timed steps run the settled schedule
+    # the library settles its schedule over the first steps of a loop (probe + up to eight candidates timed over real steps,
+    # 10 + 24 .. 48 steps each, vo_schedule in vo_hip.h): warm-up goes on until that is done -- the timed steps run the settled schedule
     extra = 0
-    while ctx.get_schedule()["settling"] and extra < 280:
+    while ctx.get_schedule()["settling"] and extra < 520:
         one_step(W + 1 + extra)
         extra += 1
     W += extra

@@ -121,9 +121,10 @@ int vo_set_schedule(vo_ctx *ctx, const vo_schedule *s);
  * lock-step loop is still comparing candidates over real steps (see below), 0 for defaults / pins.
  * Lock-step loop: the probe's repeated runs of a step cannot include the two kernels that advance the sequences'
  * state, and what they hide shifts the ranking by 5-25 %; so the probe only nominates -- one candidate per
- * (pose_streams, prepare), each with the pose_waves the probe prefers for it, runs for 15 .. 51 REAL steps, then the winner
- * once more with the OTHER pose_waves (round 6, from 32 sequences on: the dry runs prefer the wrong budget at some sizes), end-of-step
- * GPU timestamps decide (up to three pipeline drains in the first ~250 steps of a loop; results
+ * (pose_streams, prepare), each with the pose_waves the probe prefers for it, runs for 34 .. 58 REAL steps (10 of them an
+ * untimed ramp), then -- round 6, from 32 sequences on: the dry runs prefer the wrong budget at some sizes -- each of them
+ * once more with the OTHER pose_waves, i.e. all eight schedules; end-of-step GPU timestamps decide (a pipeline drain
+ * wherever two consecutive candidates differ in `prepare`, all within the first ~250-450 steps of a loop; results
  * never depend on any of it).  The synchronous drop-in call vo_track_frame compares its candidates by the latency of
  * a run, everything else by steady-state throughput. */
 int vo_get_schedule(const vo_ctx *ctx, vo_schedule *current, int *probed);

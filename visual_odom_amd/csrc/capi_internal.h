@@ -141,8 +141,8 @@ struct vo_ctx {
     bool sched_probed = false;       // `sched` came out of a probe (here or earlier in the process), not from defaults
     bool tuning = false;             // inside a probe: run_stages must not start another one
     bool sync_call = false;          // the run being scheduled is a synchronous drop-in call (its own probe key: latency)
-    Schedule ab_list[5];             // lock-step loop: the candidates being timed over real steps (vo_seq_step): up to four nominees
-                                     // + (round 6) the winner once more with the OTHER register budget
+    Schedule ab_list[8];             // lock-step loop: the candidates being timed over real steps (vo_seq_step): up to four nominees
+                                     // + (round 6, from 32 sequences on) every (pose_streams, prepare) pair once more with the OTHER register budget
     long long ab_key[8] = {};
     // what the last probe of this context measured: candidates and their steady-state ms per run (vo_get_probe_log)
     int probe_n = 0;
@@ -244,11 +244,11 @@ struct vo_ctx {
         int n_ing = 0, n_active = 0;    // pairs pushed for / sequences active in the pending step
         bool ing_pcie = false;          // a pair of the pending step lives in host memory (launch_seq_ingest: grid size)
         // A/B of the prepare stream over REAL steps (vo_seq_step): 1 = timing the dry probe's pick, 2 = timing its
-        // prepare-flipped twin, ... (ab_cnt candidates), ab_cnt + 1 = decided; ab_left counts down the phase's steps (3 untimed
-        // ramp steps + ab_n timed)
+        // prepare-flipped twin, ... (ab_cnt candidates), ab_cnt + 1 = decided; ab_left counts down the phase's steps (VO_AB_RAMP
+        // untimed ramp steps + ab_n timed)
         int ab_phase = 0, ab_left = 0, ab_n = 0, ab_cnt = 0;
-        bool ab_extra = false; // the winner's twin with the other pose_waves has been appended
-        hipEvent_t ev_ab[10] = {};
+        bool ab_extra = false; // the twins with the other pose_waves have been appended
+        hipEvent_t ev_ab[16] = {};
         bool ab_running() const { return ab_phase >= 1 && ab_phase <= ab_cnt; }
 
         bool begun = false, staged = false;

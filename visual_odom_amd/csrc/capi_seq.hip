@@ -404,6 +404,14 @@ int vo_seq_push_pairs(vo_ctx *c, int n, const int32_t *seq_ids, const void *cons
     return rc;
 }
 
+// The comparison of schedules over real steps: untimed ramp steps behind a switch, and the shortest timed window.  3 and 12 until
+// late in round 6 -- with 256 sequences fed from page-locked memory (a step that is the PCIe link's) such a window measured
+// 5.14 ms per step for 2,2,0, which then sustains 5.7, against 5.17 for 1,1,0, which sustains 5.15; behind 10 ramp steps a
+// 24-step window reads 5.3-5.5 against 5.05-5.2 (gpurun_out/r6_abwin): the chains of two pose streams take that long to
+// overlap as they do sustained.
+#define VO_AB_RAMP 10
+#define VO_AB_MIN 24
+
 int vo_seq_step(vo_ctx *c)
 {
     if (!c)
@@ -553,11 +561,11 @@ int vo_seq_step(vo_ctx *c)
                     double ms = dry_ms(c->sched);
                     ms = ms > 0.02 ? ms : 0.02;
                     q.ab_n = (int)ceil(25.0 / ms);
-                    q.ab_n = q.ab_n < 12 ? 12 : q.ab_n > 48 ? 48 : q.ab_n;
+                    q.ab_n = q.ab_n < VO_AB_MIN ? VO_AB_MIN : q.ab_n > 48 ? 48 : q.ab_n;
                     q.ab_cnt = n;
                     q.ab_extra = false;
                     q.ab_phase = 1;
-                    q.ab_left = 3 + q.ab_n;
+                    q.ab_left = VO_AB_RAMP + q.ab_n;
                     memcpy(c->ab_key, c->sched_key, sizeof(c->ab_key));
                     c->sched_probed = false; // "in progress" (vo_get_schedule reports 2)
                     ab_started = true;
@@ -604,11 +612,11 @@ int vo_seq_step(vo_ctx *c)
                 if (rc != VO_OK)
                     return rc;
                 q.ab_phase++;
-                q.ab_left = 3 + q.ab_n;
+                q.ab_left = VO_AB_RAMP + q.ab_n;
             } else {
                 VO_HIP_TRY(c, hipEventSynchronize(q.ev_ab[2 * ph + 1]));
                 int best = 0;
-                float t[5] = {0, 0, 0, 0, 0};
+                float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int i = 0; i < q.ab_cnt; i++) {
                     VO_HIP_TRY(c, hipEventElapsedTime(&t[i], q.ev_ab[2 * i], q.ev_ab[2 * i + 1]));
                     if (t[i] < t[best])
@@ -620,22 +628,44 @@ int vo_seq_step(vo_ctx *c)
                 // winner runs once more with the other budget before anything is settled -- from 32 sequences on: below, a window
                 // of ~30 steps flatters the 256-register kernels (16 sequences: 0.76 ms per step in the window, 0.85 once the
                 // pose stream's backlog has built up; 18.7 k frames/s where the untouched pick runs 20.9 k, gpurun_out/r6_twin).
-                if (!q.ab_extra && !c->pin.pose_waves && q.ab_cnt < 5 && q.S >= 32) {
-                    vo_ctx::Schedule twin = c->ab_list[best];
-                    twin.waves = twin.waves == 1 ? 2 : 1;
-                    bool have = false;
-                    for (int i = 0; i < q.ab_cnt; i++)
-                        have = have || (c->ab_list[i].waves == twin.waves && c->ab_list[i].streams == twin.streams &&
-                                        c->ab_list[i].prep == twin.prep && c->ab_list[i].wide == twin.wide);
+                // ... and (later in round 6) so does the nominee of every other (pose_streams, prepare) pair, fastest pair first: with
+                // 256 sequences of 340 points fed from page-locked memory the dry runs name 2,1,0 for the pair (1, 0) as often as
+                // 1,1,0 -- it sustains 41 k frames/s where 1,1,0 sustains 49.5 k and everything with two pose streams 45 k
+                // (gpurun_out/r6_pinsched), so the pair lost the comparison without its better half having run, and the loop was
+                // bimodal by that.  (Every pair, not the best two or three: 2,1,0, 2,1,1 and 1,2,1 all measure 6.3 ms there, 0.01-0.03
+                // apart -- gpurun_out/r6_ab2, r6_ab3.  From 32 sequences on the comparison is therefore exhaustive: all eight
+                // schedules over real steps, ~34 steps each.)
+                if (!q.ab_extra && !c->pin.pose_waves && q.S >= 32) {
                     q.ab_extra = true;
-                    if (!have) {
-                        c->ab_list[q.ab_cnt] = twin;
-                        rc = set_sched(c, twin);
+                    int order[8], no = 0; // best nominee of every (pose_streams, prepare) pair, fastest pair first
+                    for (int i = 0; i < q.ab_cnt; i++) {
+                        int k = 0;
+                        for (; k < no; k++)
+                            if (c->ab_list[order[k]].streams == c->ab_list[i].streams && c->ab_list[order[k]].prep == c->ab_list[i].prep)
+                                break;
+                        if (k == no)
+                            order[no++] = i;
+                        else if (t[i] < t[order[k]])
+                            order[k] = i;
+                    }
+                    std::sort(order, order + no, [&](int a, int b) { return t[a] < t[b]; });
+                    const int first_new = q.ab_cnt;
+                    for (int k = 0; k < no && q.ab_cnt < 8; k++) {
+                        vo_ctx::Schedule twin = c->ab_list[order[k]];
+                        twin.waves = twin.waves == 1 ? 2 : 1;
+                        bool have = false;
+                        for (int i = 0; i < q.ab_cnt; i++)
+                            have = have || (c->ab_list[i].waves == twin.waves && c->ab_list[i].streams == twin.streams &&
+                                            c->ab_list[i].prep == twin.prep && c->ab_list[i].wide == twin.wide);
+                        if (!have)
+                            c->ab_list[q.ab_cnt++] = twin;
+                    }
+                    if (q.ab_cnt > first_new) {
+                        rc = set_sched(c, c->ab_list[first_new]);
                         if (rc != VO_OK)
                             return rc;
-                        q.ab_cnt++;
                         q.ab_phase++;
-                        q.ab_left = 3 + q.ab_n;
+                        q.ab_left = VO_AB_RAMP + q.ab_n;
                         return VO_OK;
                     }
                 }
