@@ -392,7 +392,8 @@ int vo_seq_push_pair_dev(vo_ctx *ctx, int seq, const void *left, const void *rig
  * vo_seq_step moves all pairs of the step with one kernel on the copy stream.) */
 int vo_seq_push_pairs(vo_ctx *ctx, int n, const int32_t *seq_ids, const void *const *left, const void *const *right,
                       int stride, int kind);
-/* enqueue one step over all sequences (asynchronous; at most VO_SEQ_INFLIGHT steps run ahead of the device) */
+/* enqueue one step over all sequences (asynchronous; the host runs at most 3 steps ahead of the device, 4 when the pairs
+ * come from host memory -- a deeper queue measured 0-25 % slower, profiles/r06_experiments.md section 5) */
 int vo_seq_step(vo_ctx *ctx);
 int vo_seq_sync(vo_ctx *ctx);
 /* state of one sequence after vo_seq_sync: currentVOFeatures (points [2 * n_pts], ages [n_ages], n_ages >= n_pts)

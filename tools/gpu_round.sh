@@ -1,7 +1,7 @@
 #!/bin/bash
 # THE GPU session driver (one script; rounds 2-5 had one generation each).  Usage (from the authoring container):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> <part> [<part> ...]'
-# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab splitab probereps
+# parts: tests latency phases timeline bench prof seq pmclegs posepmc quads ranks8 hunt ingestab ingestdev schedab splitab probereps runahead
 # Everything lands in gpurun_out/<tag>/; tools/profile_summary.py / tools/pmc_legs.py / tools/pose_pmc.py turn it into profiles/.
 TAG=${1:-r5}
 shift
@@ -190,5 +190,15 @@ if has probereps; then   # the schedule the loop settles on, run after run on ON
             python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); s=b['config']['schedule']; print('S=$S $ING $WL rep $rep %8.0f fps %.3f ms/step  ran %s,%s,%s' % (b['value'], b['ms_per_step'], s['pose_waves'], s['pose_streams'], s['prepare']), {k: round(v, 2) for k, v in s.get('probe_ms', {}).items() if 'real' in k})" | tee -a "$OUT/summary.txt"
         done <<< "${PROBE_LIST:-256 pinned kitti374}"
     done
+fi
+if has runahead; then   # developer build: the host's run-ahead in the lock-step loop (VO_SEQ_RUNAHEAD steps instead of 8), schedules pinned
+    while read -r S ING WL SC; do
+        [ -z "$S" ] && continue
+        for RA in ${RUNAHEAD_LIST:-8 4 3 2}; do for rep in 1 2; do
+            f="$OUT/ra_${S}_${ING}_${WL}_${RA}_$rep.json"
+            VO_HIP_LIB=$ROOT/visual_odom_amd/libvo_hip_dev.so VO_SEQ_RUNAHEAD=$RA timeout 300 python bench.py --mode sequences --workload $WL --seqs $S --steps 80 --warmup 8 --no-cpu-baseline --validate 0 --ingest $ING --schedule $SC > "$f" 2> "$f.err"
+            python -c "import json; b=json.loads(open('$f').read().strip().splitlines()[-1]); print('S=$S $ING $WL sched $SC run-ahead $RA rep $rep %8.0f fps %.3f ms/step' % (b['value'], b['ms_per_step']))" | tee -a "$OUT/summary.txt"
+        done; done
+    done <<< "${RUNAHEAD_LOADS:-64 device kitti374 1,2,1}"
 fi
 stamp "done"

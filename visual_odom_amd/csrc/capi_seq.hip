@@ -220,6 +220,8 @@ int vo_seq_reset(vo_ctx *c, int seq)
 
 } // extern "C"
 
+#define VO_SEQ_RUNAHEAD 3 // steps the host runs ahead of the device in the lock-step loop (seq_begin_step)
+
 namespace vo_capi {
 
 // First touch of the pending step (a push or the step call itself): its slot of the pinned per-step tables must
@@ -233,6 +235,30 @@ int seq_begin_step(vo_ctx *c)
     if (q.step_pending[slot]) {
         VO_HIP_TRY(c, hipEventSynchronize(q.ev_step[slot]));
         q.step_pending[slot] = false;
+    }
+    // The host stays VO_SEQ_RUNAHEAD = 3 steps ahead of the device, not the VO_SEQ_INFLIGHT = 8 the per-step tables would allow
+    // (late in round 6).  Found through the schedule comparison: a schedule whose pose chains cannot keep up with the tracking
+    // stages fills a deep run-ahead with their backlog first and for ~50 steps reads as fast as its steps are issued (256
+    // resident sequences: 1,1,1 measured 3.36 ms per step in its window, best of eight, and sustained 3.91).  And the deep
+    // run-ahead itself costs throughput -- kernels of steps k + 2 ... k + 7 queued on every stream beside step k's: with the
+    // schedule pinned (gpurun_out/r6_ra, 340 points, frames/s at 8 / 4 / 3 / 2 steps) 16 sequences 20.4 / 24.4 / 24.7 / 20.9 k,
+    // 32: 31.8 / 35.5 / 36.2 / 29.5 k, 64: 50.0 / 49.9 / 56.9 / 41.5 k, 128: 71.5 / 71.0 / 73.6 / 55.2 k, 256: 76.0 / 76.6 / 76.3 /
+    // 71.2 k, 256 from page-locked memory 50.9 / 51.1 / 51.4 / 45.8 k, 256 at 2 000 points 25.7 / 25.7 / 25.9 / 25.5 k; 8
+    // sequences 12.7 k at 8 steps, 15.9 k at 3.  Pairs that come from HOST memory get one step more (the transfer of step k + 1
+    // has to be under way while step k runs): 64 sequences from page-locked memory 41.8 / 42.0 / 38.7 k at 8 / 4 / 3 steps,
+    // 8 sequences 12.4 / 14.6 / 14.4 k (gpurun_out/r6_ra2, r6_ra3).  (q.ing_pcie still describes the previous step here.)
+    int ahead = q.ing_pcie ? VO_SEQ_RUNAHEAD + 1 : VO_SEQ_RUNAHEAD;
+#ifdef VO_DEV_VARIANTS
+    static const int ahead_env = [] { const char *e = getenv("VO_SEQ_RUNAHEAD"); return e ? atoi(e) : 0; }(); // A/B: 1 .. 8
+    if (ahead_env > 0)
+        ahead = ahead_env;
+#endif
+    if (ahead < VO_SEQ_INFLIGHT && q.step >= ahead) {
+        const int s3 = (int)((q.step - ahead) % VO_SEQ_INFLIGHT);
+        if (q.step_pending[s3]) {
+            VO_HIP_TRY(c, hipEventSynchronize(q.ev_step[s3]));
+            q.step_pending[s3] = false;
+        }
     }
     q.n_ing = 0;
     q.begun = true;
