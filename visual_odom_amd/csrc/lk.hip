@@ -25,6 +25,8 @@
 // Grid: blocks are numbered so that (dispatcher: block b -> XCD b % 8) all features of one frame
 // run on ONE XCD, i.e. the frame's four pyramids are pulled into one L2 only, eight frames at a time.
 // Batches of fewer than 8 frames split each frame's feature list into contiguous parts over 8/fpg XCDs.
+// lk_hops_kernel (round 6): the same body for hops [begin, end) of the chain -- the synchronous drop-in calls on the kept pair
+// launch hop 0 while the new pair is still crossing PCIe (capi_run.hip); lk_circular_kernel is what every other launch runs.
 #include "vo_kernels.h"
 #include "vo_lkmath.h"
 
